@@ -1,0 +1,174 @@
+/*
+ * resdepth_hip.h -- C ABI of libresdepth_hip.so (gfx950 / MI355X).
+ *
+ * The reference (prs-eth/ResDepth) has no FFI / plugin interface: its hot path is a
+ * chain of torch.nn modules.  This header is the boundary UNDER the reference's Python
+ * surface (UNet / Trainer): every entry point replaces one implicit
+ * ATen/cuDNN kernel family the reference reaches through torch.nn, cited per function
+ * as <reference file>:<line>.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller; the library never allocates,
+ *    frees or keeps device memory; scratch comes in through (ws, ws_bytes) and the
+ *    matching rd_*_ws_bytes() query;
+ *  - activations are NHWC fp32 ("pixel-major, channel-contiguous"): index
+ *    ((n*H + y)*W + x)*C + c.  Only the network input (NCHW, few channels) and the
+ *    1-channel output / target / mask keep the reference's NCHW layout;
+ *  - H and W are powers of two (the reference validates tile_size = 2^k >= 2^(depth+2),
+ *    lib/validate_arguments.py:143-171);
+ *  - all work is enqueued on `stream` (a hipStream_t); nothing synchronises;
+ *  - return 0 on success, non-zero on error; rd_last_error_string() (thread-local)
+ *    describes the last failure of the calling thread;
+ *  - re-entrant from several host threads (forward thread + autograd thread).
+ */
+#ifndef RESDEPTH_HIP_H
+#define RESDEPTH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rd_stream_t; /* hipStream_t */
+
+#define RD_OK 0
+#define RD_ERR_ARG 1
+#define RD_ERR_WS 2
+#define RD_ERR_HIP 3
+
+int rd_version(void);
+const char* rd_last_error_string(void);
+
+/* ---- weight (re)packing: torch layouts -> GEMM operand layouts ------------------- */
+/* nn.Conv2d weight [Cout][Cin][3][3] (lib/UNet.py:4-5) ->
+ *   wf[co][tap][ci]              B operand of the forward implicit GEMM
+ *   wd[ci][tap][co] = w[co][ci][8-tap]   B operand of the data-gradient GEMM (nullable) */
+int rd_pack_conv3x3_weight(const float* w_oihw, float* wf, float* wd, int cout, int cin, rd_stream_t s);
+/* nn.ConvTranspose2d weight [Cin][Cout][2][2] (lib/UNet.py:21) ->
+ *   wtf[(a*2+b)*Cout + co][ci]   forward B operand
+ *   wtd[ci][(a*2+b)*Cout + co]   data-gradient B operand (nullable) */
+int rd_pack_convt2x2_weight(const float* w_iohw, float* wtf, float* wtd, int cin, int cout, rd_stream_t s);
+
+/* ---- 3x3 / stride 1 / pad 1 convolution, Cin % 4 == 0 (lib/UNet.py:4-5,44,65,85) - */
+/* z[N,H,W,Cout] = conv(x[N,H,W,Cin], w)          (replaces nn.Conv2d.forward, no bias) */
+int rd_conv3x3_fwd(const float* x, const float* wf, float* z, int n, int h, int w, int cin, int cout, rd_stream_t s);
+/* dx[N,H,W,Cin] = conv^T(dz)                     (autograd data gradient of the above) */
+int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int h, int w, int cin, int cout,
+                        rd_stream_t s);
+/* dw[Cout][Cin][3][3] (torch layout) = sum_p dz[p] (x) x[p+tap]   (autograd weight gradient) */
+size_t rd_conv3x3_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout);
+int rd_conv3x3_bwd_weight(const float* x, const float* dz, float* dw_oihw, int n, int h, int w, int cin, int cout,
+                          void* ws, size_t ws_bytes, rd_stream_t s);
+
+/* ---- first encoder conv: NCHW input with 1..6 channels -> NHWC (lib/UNet.py:159) -- */
+int rd_conv3x3_first_fwd(const float* x_nchw, const float* w_oihw, float* z, int n, int h, int w, int cin, int cout,
+                         rd_stream_t s);
+size_t rd_conv3x3_first_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout);
+int rd_conv3x3_first_bwd_weight(const float* x_nchw, const float* dz, float* dw_oihw, int n, int h, int w, int cin,
+                                int cout, void* ws, size_t ws_bytes, rd_stream_t s);
+
+/* ---- last conv C -> 1 (+bias) with the outer residual add fused (lib/UNet.py:184,227-244)
+ * out[N,1,H,W] = conv(s[N,H,W,C], w[1][C][3][3]) + bias[0] + x0, x0 = x_nchw[:,0] (both nullable) */
+int rd_conv3x3_last_fwd(const float* s_in, const float* w_oihw, const float* bias, const float* x_nchw, int x_channels,
+                        float* out, int n, int h, int w, int c, rd_stream_t s);
+int rd_conv3x3_last_bwd_data(const float* dout, const float* w_oihw, float* ds, int n, int h, int w, int c,
+                             rd_stream_t s);
+size_t rd_conv3x3_last_bwd_weight_ws_bytes(int n, int h, int w, int c);
+/* dw[1][C][3][3], dbias[1] (nullable) */
+int rd_conv3x3_last_bwd_weight(const float* s_in, const float* dout, float* dw_oihw, float* dbias, int n, int h, int w,
+                               int c, void* ws, size_t ws_bytes, rd_stream_t s);
+
+/* ---- ConvTranspose2d(k=2, s=2) + bias, skip ADD fused (lib/UNet.py:21,96-101,219-224)
+ * out[N,2H,2W,Cout] = convT(x[N,H,W,Cin]) + bias + skip   (skip nullable)               */
+int rd_convt2x2_fwd(const float* x, const float* wtf, const float* bias, const float* skip, float* out, int n, int h,
+                    int w, int cin, int cout, rd_stream_t s);
+/* dx[N,H,W,Cin] from dout[N,2H,2W,Cout] */
+int rd_convt2x2_bwd_data(const float* dout, const float* wtd, float* dx, int n, int h, int w, int cin, int cout,
+                         rd_stream_t s);
+size_t rd_convt2x2_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout);
+/* dw[Cin][Cout][2][2] (torch layout) */
+int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw_iohw, int n, int h, int w, int cin, int cout,
+                           void* ws, size_t ws_bytes, rd_stream_t s);
+
+/* per-channel sum over pixels: out[c] = sum_p g[p][c]   (bias gradients) */
+size_t rd_channel_sum_ws_bytes(long long pixels, int c);
+int rd_channel_sum(const float* g, float* out, long long pixels, int c, void* ws, size_t ws_bytes, rd_stream_t s);
+
+/* ---- BatchNorm2d (training statistics) (lib/UNet.py:45,66,86) ---------------------- */
+/* Phase 1: per-channel sums over z[P][C] -> sums[2*C] doubles (sum, sum of squares), so a
+ * data-parallel caller can all-reduce them (SyncBN) before phase 2. */
+size_t rd_bn_stats_ws_bytes(long long pixels, int c);
+int rd_bn_stats_partial(const float* z, double* sums, long long pixels, int c, void* ws, size_t ws_bytes,
+                        rd_stream_t s);
+/* Phase 2: mean / invstd = 1/sqrt(biased var + eps); running stats <- (1-m)*old + m*new
+ * (unbiased var); num_batches_tracked (int64, nullable) += 1.  count = pixels summed.  */
+int rd_bn_stats_finalize(const double* sums, double count, float eps, float momentum, float* mean, float* invstd,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, int c, rd_stream_t s);
+/* eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps) */
+int rd_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* invstd, int c,
+                     rd_stream_t s);
+
+/* a = act(gamma*(z-mean)*invstd + beta), act = LeakyReLU(slope) (slope 0 = ReLU, lib/UNet.py:27-33);
+ * if pooled != NULL also the 2x2/2 max-pool of a (lib/UNet.py:161,167): pooled[N,H/2,W/2,C] and
+ * idx (uint8, window position 0..3 = dy*2+dx; first maximum in row-major order, NaN wins). */
+int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       float slope, float* a, float* pooled, uint8_t* idx, int n, int h, int w, int c, rd_stream_t s);
+
+/* Backward of conv -> BN -> act [-> pool].  The gradient wrt `a` is g_full (same resolution,
+ * nullable) + unpool(g_pool via idx) (nullable).
+ * Phase 1 -> sums[3*C] doubles: sum g', sum g'*xhat (g' = gradient after the activation mask),
+ *            and sum g_full (un-masked; the bias gradient of the ConvTranspose2d feeding a skip add).
+ * Phase 2 -> dz; dgamma/dbeta are sums[C..2C) / sums[0..C) (written by rd_bn_act_bwd_apply).
+ * training=0 treats mean/invstd as constants (eval-mode BN). */
+size_t rd_bn_act_bwd_ws_bytes(int n, int h, int w, int c);
+int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                         float slope, const float* g_full, const float* g_pool, const uint8_t* idx, double* sums, int n,
+                         int h, int w, int c, void* ws, size_t ws_bytes, rd_stream_t s);
+int rd_bn_act_bwd_apply(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        float slope, const float* g_full, const float* g_pool, const uint8_t* idx, const double* sums,
+                        double count, int training, float* dz, float* dgamma, float* dbeta, int n, int h, int w, int c,
+                        rd_stream_t s);
+
+/* ---- masked, de-normalised L1 (lib/Trainer.py:87-100, lib/data_normalization.py:29-38) */
+/* sums[0] = sum over valid pixels |(yp*std_i+mean_i) - (y*std_i+mean_i)|, sums[1] = #valid.
+ * yp, y: [N,1,H,W]; mask: uint8 (torch.bool) [N,1,H,W]; mean, std: [N] fp32. */
+size_t rd_masked_l1_ws_bytes(long long numel);
+int rd_masked_l1_partial(const float* yp, const float* y, const uint8_t* mask, const float* mean, const float* std,
+                         double* sums, int n, long long pixels_per_sample, void* ws, size_t ws_bytes, rd_stream_t s);
+/* loss[0] = (float)(sums[0]/numel_total) * numel_total / sums[1];
+ * dyp = gout * std_i * sign(p-t) * mask / sums[1]     (dyp nullable; gout = *gout_dev, a DEVICE scalar so
+ * autograd's upstream gradient never has to be read on the host; NULL means 1) */
+int rd_masked_l1_finish(const float* yp, const float* y, const uint8_t* mask, const float* mean, const float* std,
+                        const double* sums, double numel_total, const float* gout_dev, float* loss, float* dyp, int n,
+                        long long pixels_per_sample, rd_stream_t s);
+
+/* ---- torch.optim.Adam step over a flat buffer (lib/utils.py:329-331) ---------------- */
+/* g += wd*p; m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps) */
+int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, float beta1, float beta2, float eps,
+                 float weight_decay, float step_size, float bc2_sqrt, float grad_scale, rd_stream_t s);
+
+/* ---- layout helpers ----------------------------------------------------------------- */
+int rd_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s);
+int rd_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s);
+
+/* ---- built-in kernel timing (HIP events on the launch stream) ----------------------- */
+/* When enabled every kernel launch is bracketed by hipEventRecord on its own stream and
+ * accumulated per kernel class; rd_prof_collect synchronises the recorded events. */
+#define RD_PROF_MAX_CLASSES 32
+typedef struct {
+    char name[48];
+    long long launches;
+    double ms;      /* summed event-to-event duration */
+    double flops;   /* summed algorithmic FLOPs declared at launch */
+    double bytes;   /* summed algorithmic HBM bytes declared at launch */
+} rd_prof_entry;
+int rd_prof_enable(int on);
+int rd_prof_reset(void);
+int rd_prof_collect(rd_prof_entry* out, int max_entries); /* returns number of classes, <0 on error */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESDEPTH_HIP_H */

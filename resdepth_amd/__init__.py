@@ -1,0 +1,10 @@
+"""resdepth_amd -- MI355X-native (gfx950) implementation of the ResDepth U-Net training hot path.
+
+Python host surface mirroring the reference (UNet / Trainer / batch dict), hand-written HIP kernels
+underneath (libresdepth_hip.so, C ABI in include/resdepth_hip.h).  No CPU fallback.
+"""
+from .unet import UNet, SkipConnection  # noqa: F401
+from .loss import MaskedL1Loss, masked_l1_loss  # noqa: F401
+from .optim import FusedAdam  # noqa: F401
+
+__all__ = ["UNet", "SkipConnection", "MaskedL1Loss", "masked_l1_loss", "FusedAdam"]

@@ -1,0 +1,158 @@
+"""ctypes binding of libresdepth_hip.so (the C ABI declared in include/resdepth_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or a tensor is not
+on a HIP device, the call raises.  Build with `resdepth_amd/csrc/build.sh` (or
+`python -c "import __graft_entry__ as g; g.build()"`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libresdepth_hip.so")
+
+_lib = None
+_lock = threading.Lock()
+
+P = C.c_void_p
+I = C.c_int
+F = C.c_float
+D = C.c_double
+LL = C.c_longlong
+SZ = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/resdepth_hip.h one to one
+SIGNATURES = {
+    "rd_version": (I, []),
+    "rd_last_error_string": (C.c_char_p, []),
+    "rd_pack_conv3x3_weight": (I, [P, P, P, I, I, P]),
+    "rd_pack_convt2x2_weight": (I, [P, P, P, I, I, P]),
+    "rd_conv3x3_fwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "rd_conv3x3_bwd_data": (I, [P, P, P, I, I, I, I, I, P]),
+    "rd_conv3x3_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
+    "rd_conv3x3_bwd_weight": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),
+    "rd_conv3x3_first_fwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "rd_conv3x3_first_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
+    "rd_conv3x3_first_bwd_weight": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),
+    "rd_conv3x3_last_fwd": (I, [P, P, P, P, I, P, I, I, I, I, P]),
+    "rd_conv3x3_last_bwd_data": (I, [P, P, P, I, I, I, I, P]),
+    "rd_conv3x3_last_bwd_weight_ws_bytes": (SZ, [I, I, I, I]),
+    "rd_conv3x3_last_bwd_weight": (I, [P, P, P, P, I, I, I, I, P, SZ, P]),
+    "rd_convt2x2_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "rd_convt2x2_bwd_data": (I, [P, P, P, I, I, I, I, I, P]),
+    "rd_convt2x2_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
+    "rd_convt2x2_bwd_weight": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),
+    "rd_channel_sum_ws_bytes": (SZ, [LL, I]),
+    "rd_channel_sum": (I, [P, P, LL, I, P, SZ, P]),
+    "rd_bn_stats_ws_bytes": (SZ, [LL, I]),
+    "rd_bn_stats_partial": (I, [P, P, LL, I, P, SZ, P]),
+    "rd_bn_stats_finalize": (I, [P, D, F, F, P, P, P, P, P, I, P]),
+    "rd_bn_eval_stats": (I, [P, P, F, P, P, I, P]),
+    "rd_bn_act_pool_fwd": (I, [P, P, P, P, P, F, P, P, P, I, I, I, I, P]),
+    "rd_bn_act_bwd_ws_bytes": (SZ, [I, I, I, I]),
+    "rd_bn_act_bwd_reduce": (I, [P, P, P, P, P, F, P, P, P, P, I, I, I, I, P, SZ, P]),
+    "rd_bn_act_bwd_apply": (I, [P, P, P, P, P, F, P, P, P, P, D, I, P, P, P, I, I, I, I, P]),
+    "rd_masked_l1_ws_bytes": (SZ, [LL]),
+    "rd_masked_l1_partial": (I, [P, P, P, P, P, P, I, LL, P, SZ, P]),
+    "rd_masked_l1_finish": (I, [P, P, P, P, P, P, D, P, P, P, I, LL, P]),
+    "rd_adam_step": (I, [P, P, P, P, LL, F, F, F, F, F, F, F, P]),
+    "rd_nchw_to_nhwc": (I, [P, P, I, I, I, I, P]),
+    "rd_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
+    "rd_prof_enable": (I, [I]),
+    "rd_prof_reset": (I, []),
+    "rd_prof_collect": (I, [P, I]),
+}
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_longlong), ("ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises RuntimeError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"resdepth_amd: HIP library not built ({LIB_PATH} missing). Run resdepth_amd/csrc/build.sh; "
+                "there is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().rd_last_error_string()
+        raise RuntimeError(f"libresdepth_hip {what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: no CPU path exists."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("resdepth_amd: tensor is not on a HIP device; the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("resdepth_amd: tensor must be contiguous")
+    return t.data_ptr()
+
+
+# ---- workspace: one growing scratch buffer per device (stream-ordered use on the current stream)
+_ws = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+# ---- parameter generation counter (bumped by in-place updates done through raw pointers) -------
+_param_gen = {}
+
+
+def bump_param_generation(flat_ptr: int):
+    _param_gen[flat_ptr] = _param_gen.get(flat_ptr, 0) + 1
+
+
+def param_generation(flat_ptr: int) -> int:
+    return _param_gen.get(flat_ptr, 0)
+
+
+# ---- profiler -----------------------------------------------------------------------------------
+def prof_enable(on: bool):
+    check(load().rd_prof_enable(1 if on else 0))
+
+
+def prof_reset():
+    check(load().rd_prof_reset())
+
+
+def prof_collect():
+    arr = (ProfEntry * 32)()
+    n = load().rd_prof_collect(C.cast(arr, C.c_void_p), 32)
+    if n < 0:
+        raise RuntimeError("rd_prof_collect failed")
+    return [{"name": arr[i].name.decode(), "launches": arr[i].launches, "ms": arr[i].ms, "flops": arr[i].flops,
+             "bytes": arr[i].bytes} for i in range(n)]

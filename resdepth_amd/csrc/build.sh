@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libresdepth_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../libresdepth_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-result"
+mkdir -p "$HERE/obj"
+pids=()
+for f in rd_runtime rd_igemm rd_elementwise; do
+  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/rd_common.h" -nt "$HERE/obj/$f.o" ] \
+     || [ "$HERE/../../include/resdepth_hip.h" -nt "$HERE/obj/$f.o" ]; then
+    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj/rd_runtime.o "$HERE"/obj/rd_igemm.o "$HERE"/obj/rd_elementwise.o
+echo "built $OUT"

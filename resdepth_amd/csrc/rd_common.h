@@ -1,0 +1,55 @@
+// Internal helpers shared by the kernel translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/resdepth_hip.h"
+
+namespace rd {
+
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+// ---- profiling (rd_prof_*) -----------------------------------------------------------
+bool prof_on();
+void prof_begin(hipStream_t s, const char* cls, double flops, double bytes);
+void prof_end(hipStream_t s);
+
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfScope(hipStream_t s_, const char* cls, double flops, double bytes) : s(s_), on(prof_on()) {
+        if (on) prof_begin(s, cls, flops, bytes);
+    }
+    ~ProfScope() {
+        if (on) prof_end(s);
+    }
+};
+
+inline int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+#define RD_REQUIRE(cond, ...)              \
+    do {                                   \
+        if (!(cond)) {                     \
+            rd::set_error(__VA_ARGS__);    \
+            return RD_ERR_ARG;             \
+        }                                  \
+    } while (0)
+
+#define RD_LAUNCH_CHECK(what)                                   \
+    do {                                                        \
+        hipError_t e__ = hipGetLastError();                     \
+        if (e__ != hipSuccess) return rd::check_hip(e__, what); \
+    } while (0)
+
+}  // namespace rd
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -1,0 +1,1014 @@
+// HBM-bound kernels of the ResDepth hot path (gfx950): BatchNorm statistics / apply (+ activation
+// + 2x2 max-pool with argmax) forward and backward, the Cin<=6 first convolution, the C->1 last
+// convolution with the outer residual add, the masked de-normalised L1 loss, the flat Adam step
+// and layout helpers.  Replaces the ATen kernels behind nn.BatchNorm2d / nn.ReLU / nn.LeakyReLU /
+// nn.MaxPool2d (lib/UNet.py:27-33, 45, 66, 86, 161, 167), the first / last nn.Conv2d
+// (lib/UNet.py:159, 184), Trainer._compute_denormalized_loss (lib/Trainer.py:87-100) and
+// torch.optim.Adam.step (lib/utils.py:329-331).
+//
+// Mapping used by every NHWC kernel here: a thread owns one float4 of channels (cq = t % CQ,
+// CQ = C/4) of one pixel row (pr = t / CQ); consecutive lanes read consecutive 16-byte chunks, so a
+// wave touches 1 KiB of contiguous HBM per load instruction.  Per-channel reductions accumulate in
+// fp64 and go through fixed-order block partials (deterministic, no float atomics).
+#include "rd_common.h"
+
+namespace rd {
+
+static inline int grid_cap(long g, int cap) {
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ float act_fn(float y, float slope) { return y > 0.f ? y : y * slope; }
+__device__ __forceinline__ float act_grad(float y, float slope) { return y > 0.f ? 1.f : slope; }
+
+// ---- block-level fixed-order reduction over the pixel-row slots of a block --------------------
+// vals[K] per thread (K = 4 * quantities); red = LDS [K][256] doubles; result valid for t < CQ.
+template <int K>
+__device__ __forceinline__ void reduce_rows(double (&vals)[K], double* red, int t, int CQ, int RP, bool active) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[k * 256 + t] = active ? vals[k] : 0.0;
+    __syncthreads();
+    if (t < CQ) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double s = 0.0;
+            for (int r = 0; r < RP; ++r) s += red[k * 256 + r * CQ + t];
+            vals[k] = s;
+        }
+    }
+    __syncthreads();
+}
+
+// sums[q*C + c] = sum_b partial[(b*Q + q)*C + c]
+__global__ void partial_reduce_kernel(const double* __restrict__ partial, double* __restrict__ sums, int nb, int QC) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= QC) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += partial[(long)b * QC + e];
+    sums[e] = s;
+}
+
+struct RowPlan {
+    int CQ, RP, nb;
+    long rows_per_block;
+};
+
+static bool plan_rows(long rows, int C, RowPlan* pl) {
+    if (C % 4 != 0 || C / 4 > 256 || C <= 0) return false;
+    pl->CQ = C / 4;
+    pl->RP = 256 / pl->CQ;
+    long rpb = (rows + 1023) / 1024;
+    const long minr = (long)pl->RP * 8;
+    if (rpb < minr) rpb = minr;
+    rpb = (rpb + pl->RP - 1) / pl->RP * pl->RP;
+    pl->rows_per_block = rpb;
+    pl->nb = (int)((rows + rpb - 1) / rpb);
+    if (pl->nb < 1) pl->nb = 1;
+    return true;
+}
+
+// ---- per-channel sum / sum of squares ---------------------------------------------------------
+template <bool SQ>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ z, double* __restrict__ partial,
+                                                            long P, int C, int CQ, int RP, long rows_per_block) {
+    __shared__ double red[8 * 256];
+    const int t = threadIdx.x, cq = t % CQ, pr = t / CQ;
+    const bool active = pr < RP;
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0.0;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > P) r1 = P;
+    if (active) {
+        for (long r = r0 + pr; r < r1; r += RP) {
+            const float4 x = *reinterpret_cast<const float4*>(z + r * C + cq * 4);
+            v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+            if (SQ) {
+                v[4] += (double)x.x * x.x; v[5] += (double)x.y * x.y;
+                v[6] += (double)x.z * x.z; v[7] += (double)x.w * x.w;
+            }
+        }
+    }
+    reduce_rows<8>(v, red, t, CQ, RP, active);
+    if (t < CQ) {
+        const int Q = SQ ? 2 : 1;
+        double* out = partial + (long)blockIdx.x * Q * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            out[cq * 4 + k] = v[k];
+            if (SQ) out[C + cq * 4 + k] = v[4 + k];
+        }
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, int64_t* nbt, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const double m = sums[c] / count;
+    double var = sums[C + c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    if (rvar) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                     float* __restrict__ mean, float* __restrict__ invstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rmean[c];
+    invstd[c] = 1.f / sqrtf(rvar[c] + eps);
+}
+
+// ---- BN apply + activation (+ 2x2 max-pool with argmax) ---------------------------------------
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float slope,
+                                                              float* __restrict__ a, float* __restrict__ pooled,
+                                                              uint8_t* __restrict__ idx, long rows, int H, int W, int C,
+                                                              int CQ) {
+    // rows = pooled pixels (POOL) or pixels; one thread per (row, cq)
+    const long total = rows * CQ;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(e % CQ);
+        const long row = e / CQ;
+        const float4 mu = *reinterpret_cast<const float4*>(mean + cq * 4);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + cq * 4);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + cq * 4);
+        const float4 be = *reinterpret_cast<const float4*>(beta + cq * 4);
+        const float sc[4] = {is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w};
+        const float sh[4] = {be.x - mu.x * sc[0], be.y - mu.y * sc[1], be.z - mu.z * sc[2], be.w - mu.w * sc[3]};
+        if (!POOL) {
+            const float4 x = *reinterpret_cast<const float4*>(z + row * C + cq * 4);
+            float4 y;
+            y.x = act_fn(fmaf(x.x, sc[0], sh[0]), slope);
+            y.y = act_fn(fmaf(x.y, sc[1], sh[1]), slope);
+            y.z = act_fn(fmaf(x.z, sc[2], sh[2]), slope);
+            y.w = act_fn(fmaf(x.w, sc[3], sh[3]), slope);
+            *reinterpret_cast<float4*>(a + row * C + cq * 4) = y;
+        } else {
+            const int W2 = W >> 1, H2 = H >> 1;
+            const int j = (int)(row % W2);
+            const int i = (int)((row / W2) % H2);
+            const long img = row / ((long)W2 * H2);
+            const long base = (img * H + 2 * i) * W + 2 * j;
+            float m[4];
+            int mi[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long pix = base + (k >> 1) * W + (k & 1);
+                const float4 x = *reinterpret_cast<const float4*>(z + pix * C + cq * 4);
+                float y[4];
+                y[0] = act_fn(fmaf(x.x, sc[0], sh[0]), slope);
+                y[1] = act_fn(fmaf(x.y, sc[1], sh[1]), slope);
+                y[2] = act_fn(fmaf(x.z, sc[2], sh[2]), slope);
+                y[3] = act_fn(fmaf(x.w, sc[3], sh[3]), slope);
+                *reinterpret_cast<float4*>(a + pix * C + cq * 4) = make_float4(y[0], y[1], y[2], y[3]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // torch max_pool2d: (val > maxval) || isnan(val) replaces -> first max wins, NaN wins
+                    if (k == 0 || y[q] > m[q] || y[q] != y[q]) {
+                        m[q] = y[q];
+                        mi[q] = k;
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(pooled + row * C + cq * 4) = make_float4(m[0], m[1], m[2], m[3]);
+            *reinterpret_cast<uchar4*>(idx + row * C + cq * 4) =
+                make_uchar4((unsigned char)mi[0], (unsigned char)mi[1], (unsigned char)mi[2], (unsigned char)mi[3]);
+        }
+    }
+}
+
+// ---- BN + activation (+ pool) backward ---------------------------------------------------------
+// g(a) = g_full (nullable) + unpool(g_pool) (nullable).  POOL: rows are pooled pixels, each thread
+// visits the 2x2 window; otherwise rows are pixels.
+template <bool POOL, bool APPLY>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float slope, const float* __restrict__ g_full,
+                                                         const float* __restrict__ g_pool,
+                                                         const uint8_t* __restrict__ idx, double* __restrict__ partial,
+                                                         const double* __restrict__ sums, double count, int training,
+                                                         float* __restrict__ dz, long rows, int H, int W, int C, int CQ,
+                                                         int RP, long rows_per_block) {
+    __shared__ double red[APPLY ? 1 : 12 * 256];
+    const int t = threadIdx.x, cq = t % CQ, pr = t / CQ;
+    const bool active = pr < RP;
+    double acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+    float sc[4], sh[4], mu[4], is[4], k1[4] = {0, 0, 0, 0}, k2[4] = {0, 0, 0, 0};
+    {
+        const float4 m4 = *reinterpret_cast<const float4*>(mean + cq * 4);
+        const float4 i4 = *reinterpret_cast<const float4*>(invstd + cq * 4);
+        const float4 g4 = *reinterpret_cast<const float4*>(gamma + cq * 4);
+        const float4 b4 = *reinterpret_cast<const float4*>(beta + cq * 4);
+        mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+        is[0] = i4.x; is[1] = i4.y; is[2] = i4.z; is[3] = i4.w;
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc[q] = is[q] * gg[q];
+            sh[q] = bb[q] - mu[q] * sc[q];
+            if (APPLY && training) {
+                k1[q] = (float)(sums[cq * 4 + q] / count);
+                k2[q] = (float)(sums[C + cq * 4 + q] / count);
+            }
+        }
+    }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    if (active) {
+        for (long row = r0 + pr; row < r1; row += RP) {
+            long base = row;
+            float gp[4] = {0, 0, 0, 0};
+            int pi[4] = {-1, -1, -1, -1};
+            if (POOL) {
+                const int W2 = W >> 1, H2 = H >> 1;
+                const int j = (int)(row % W2);
+                const int i = (int)((row / W2) % H2);
+                const long img = row / ((long)W2 * H2);
+                base = (img * H + 2 * i) * W + 2 * j;
+                if (g_pool) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(g_pool + row * C + cq * 4);
+                    const uchar4 i4 = *reinterpret_cast<const uchar4*>(idx + row * C + cq * 4);
+                    gp[0] = g4.x; gp[1] = g4.y; gp[2] = g4.z; gp[3] = g4.w;
+                    pi[0] = i4.x; pi[1] = i4.y; pi[2] = i4.z; pi[3] = i4.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < (POOL ? 4 : 1); ++k) {
+                const long pix = POOL ? base + (k >> 1) * W + (k & 1) : base;
+                const float4 x4 = *reinterpret_cast<const float4*>(z + pix * C + cq * 4);
+                float4 f4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g_full) f4 = *reinterpret_cast<const float4*>(g_full + pix * C + cq * 4);
+                const float x[4] = {x4.x, x4.y, x4.z, x4.w}, gf[4] = {f4.x, f4.y, f4.z, f4.w};
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float y = fmaf(x[q], sc[q], sh[q]);
+                    float g = gf[q];
+                    if (POOL && pi[q] == k) g += gp[q];
+                    const float gm = g * act_grad(y, slope);
+                    const float xh = (x[q] - mu[q]) * is[q];
+                    if (!APPLY) {
+                        acc[q] += gm;
+                        acc[4 + q] += (double)gm * xh;
+                        acc[8 + q] += gf[q];
+                    } else {
+                        o[q] = training ? sc[q] * (gm - k1[q] - xh * k2[q]) : sc[q] * gm;
+                    }
+                }
+                if (APPLY) *reinterpret_cast<float4*>(dz + pix * C + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    if (!APPLY) {
+        reduce_rows<12>(acc, red, t, CQ, RP, active);
+        if (t < CQ) {
+            double* out = partial + (long)blockIdx.x * 3 * C;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                out[cq * 4 + q] = acc[q];
+                out[C + cq * 4 + q] = acc[4 + q];
+                out[2 * C + cq * 4 + q] = acc[8 + q];
+            }
+        }
+    }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] = (float)sums[c];
+    if (dgamma) dgamma[c] = (float)sums[C + c];
+}
+
+// ---- first encoder convolution (NCHW input, CIN <= 6) ----------------------------------------
+constexpr int FT_H = 8, FT_W = 32;
+
+template <int CIN, bool WGRAD>
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ z_or_null, const float* __restrict__ dz,
+                                                         float* __restrict__ partial, int N, int H, int W, int Cout,
+                                                         int CQ, int PS, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int TW2 = FT_W + 2, TH2 = FT_H + 2, NT = 9 * CIN;
+    __shared__ float tile[TH2 * TW2 * CIN];
+    __shared__ float red[WGRAD ? 256 * 4 : 1];
+    const int t = threadIdx.x, cq = t % CQ, ps = t / CQ;
+    const bool active = ps < PS;
+    float wreg[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tap = j / CIN, ci = j % CIN;
+            wreg[j][k] = WGRAD ? 0.f : (active ? w[((long)(cq * 4 + k) * CIN + ci) * 9 + tap] : 0.f);
+        }
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+        const int y0 = ty * FT_H, x0 = tx * FT_W;
+        __syncthreads();
+        for (int e = t; e < TH2 * TW2 * CIN; e += 256) {
+            const int ci = e / (TH2 * TW2), rem = e % (TH2 * TW2), yy = rem / TW2, xx = rem % TW2;
+            const int gy = y0 + yy - 1, gx = x0 + xx - 1;
+            float v = 0.f;
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = x[(((long)n * CIN + ci) * H + gy) * W + gx];
+            tile[(yy * TW2 + xx) * CIN + ci] = v;
+        }
+        __syncthreads();
+        if (active) {
+            for (int pix = ps; pix < FT_H * FT_W; pix += PS) {
+                const int py = pix / FT_W, px = pix % FT_W;
+                const int gy = y0 + py, gx = x0 + px;
+                if (gy >= H || gx >= W) continue;
+                const long o = (((long)n * H + gy) * W + gx) * Cout + cq * 4;
+                if (!WGRAD) {
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int tap = j / CIN, ci = j % CIN;
+                        const float xv = tile[((py + tap / 3) * TW2 + px + tap % 3) * CIN + ci];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[k] = fmaf(xv, wreg[j][k], acc[k]);
+                    }
+                    *reinterpret_cast<float4*>(z_or_null + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                } else {
+                    const float4 d4 = *reinterpret_cast<const float4*>(dz + o);
+                    const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int tap = j / CIN, ci = j % CIN;
+                        const float xv = tile[((py + tap / 3) * TW2 + px + tap % 3) * CIN + ci];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) wreg[j][k] = fmaf(xv, d[k], wreg[j][k]);
+                    }
+                }
+            }
+        }
+    }
+    if (WGRAD) {
+        // fixed-order reduction over the pixel slots, one (tap,ci) row at a time
+        float* out = partial + (long)blockIdx.x * NT * Cout;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[t * 4 + k] = active ? wreg[j][k] : 0.f;
+            __syncthreads();
+            if (t < CQ) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float s = 0.f;
+                    for (int r = 0; r < PS; ++r) s += red[(r * CQ + t) * 4 + k];
+                    out[(long)j * Cout + t * 4 + k] = s;
+                }
+            }
+        }
+    }
+}
+
+// dw[(co*CIN + ci)*9 + tap] = sum_b partial[b][tap*CIN + ci][co]
+__global__ void first_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nb, int CIN,
+                                          int Cout) {
+    const int NT = 9 * CIN;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NT * Cout) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += (double)partial[(long)b * NT * Cout + e];
+    const int j = e / Cout, co = e % Cout, tap = j / CIN, ci = j % CIN;
+    dw[((long)co * CIN + ci) * 9 + tap] = (float)s;
+}
+
+// ---- last convolution C -> 1 (+bias, + x0) ----------------------------------------------------
+constexpr int LT_H = 8, LT_W = 32, LT_CH = 16, LT_STRIDE = LT_CH + 4;
+
+__global__ __launch_bounds__(256) void conv_last_fwd_kernel(const float* __restrict__ s_in, const float* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ x_nchw, int xc,
+                                                            float* __restrict__ out, int N, int H, int W, int C,
+                                                            int tiles_x, int tiles_y) {
+    constexpr int TW2 = LT_W + 2, TH2 = LT_H + 2;
+    __shared__ __attribute__((aligned(16))) float tile[TH2 * TW2 * LT_STRIDE];
+    const int t = threadIdx.x;
+    const int tl = blockIdx.x;
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+    const int y0 = ty * LT_H, x0 = tx * LT_W;
+    const int py = t / LT_W, px = t % LT_W;
+    float acc = 0.f;
+    for (int c0 = 0; c0 < C; c0 += LT_CH) {
+        const int nq = (C - c0 < LT_CH ? C - c0 : LT_CH) / 4;  // float4 per pixel in this chunk
+        __syncthreads();
+        for (int e = t; e < TH2 * TW2 * nq; e += 256) {
+            const int q = e % nq, pp = e / nq, yy = pp / TW2, xx = pp % TW2;
+            const int gy = y0 + yy - 1, gx = x0 + xx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                v = *reinterpret_cast<const float4*>(s_in + (((long)n * H + gy) * W + gx) * C + c0 + q * 4);
+            *reinterpret_cast<float4*>(&tile[pp * LT_STRIDE + q * 4]) = v;
+        }
+        __syncthreads();
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* tp = &tile[((py + tap / 3) * TW2 + px + tap % 3) * LT_STRIDE];
+            for (int q = 0; q < nq; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(tp + q * 4);
+                const int c = c0 + q * 4;
+                acc = fmaf(v.x, w[(c + 0) * 9 + tap], acc);
+                acc = fmaf(v.y, w[(c + 1) * 9 + tap], acc);
+                acc = fmaf(v.z, w[(c + 2) * 9 + tap], acc);
+                acc = fmaf(v.w, w[(c + 3) * 9 + tap], acc);
+            }
+        }
+    }
+    const int gy = y0 + py, gx = x0 + px;
+    if (gy < H && gx < W) {
+        float v = acc;
+        if (bias) v += bias[0];
+        if (x_nchw) v = x_nchw[(((long)n * xc) * H + gy) * W + gx] + v;
+        out[((long)n * H + gy) * W + gx] = v;
+    }
+}
+
+// ds[q][ci] = sum_tap dout[q - tap] * w[ci][tap]
+__global__ __launch_bounds__(256) void conv_last_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                              float* __restrict__ ds, long P, int H, int W, int C, int CQ,
+                                                              int RP, long rows_per_block) {
+    const int t = threadIdx.x, cq = t % CQ, pr = t / CQ;
+    if (pr >= RP) return;
+    float wr[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wr[tap][k] = w[(cq * 4 + k) * 9 + tap];
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > P) r1 = P;
+    for (long p = r0 + pr; p < r1; p += RP) {
+        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int sy = yy - dy, sx = xx - dx;
+            float d = 0.f;
+            if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) d = dout[p - dy * W - dx];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(d, wr[tap][k], acc[k]);
+        }
+        *reinterpret_cast<float4*>(ds + p * C + cq * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// dw[ci][tap] = sum_q s[q][ci] * dout[q - tap];  db = sum dout
+__global__ __launch_bounds__(256) void conv_last_wgrad_kernel(const float* __restrict__ s_in,
+                                                              const float* __restrict__ dout,
+                                                              double* __restrict__ partial, long P, int H, int W, int C,
+                                                              int CQ, int RP, long rows_per_block) {
+    __shared__ double red[4 * 256];
+    const int t = threadIdx.x, cq = t % CQ, pr = t / CQ;
+    const bool active = pr < RP;
+    float acc[9][4];
+    float accb = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[tap][k] = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > P) r1 = P;
+    if (active) {
+        for (long p = r0 + pr; p < r1; p += RP) {
+            const int xx = (int)(p % W), yy = (int)((p / W) % H);
+            const float4 s4 = *reinterpret_cast<const float4*>(s_in + p * C + cq * 4);
+            const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const int sy = yy - dy, sx = xx - dx;
+                float d = 0.f;
+                if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) d = dout[p - dy * W - dx];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[tap][k] = fmaf(sv[k], d, acc[tap][k]);
+                if (tap == 4 && cq == 0) accb += d;
+            }
+        }
+    }
+    // partial layout per block: [9][C] then [1] (bias)
+    double* out = partial + (long)blockIdx.x * (9 * C + 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = acc[tap][k];
+        reduce_rows<4>(v, red, t, CQ, RP, active);
+        if (t < CQ) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[tap * C + cq * 4 + k] = v[k];
+        }
+    }
+    double vb[4] = {(double)accb, 0.0, 0.0, 0.0};
+    reduce_rows<4>(vb, red, t, CQ, RP, active);
+    if (t == 0) out[9 * C] = vb[0];
+}
+
+// dw[ci*9 + tap] = sum_b partial[b][tap*C + ci]; dbias = sum_b partial[b][9*C]
+__global__ void last_wgrad_reduce_kernel(const double* __restrict__ partial, float* __restrict__ dw,
+                                         float* __restrict__ dbias, int nb, int C) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tot = 9 * C + 1;
+    if (e >= tot) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += partial[(long)b * tot + e];
+    if (e == 9 * C) {
+        if (dbias) dbias[0] = (float)s;
+    } else {
+        const int tap = e / C, ci = e % C;
+        dw[ci * 9 + tap] = (float)s;
+    }
+}
+
+// ---- masked de-normalised L1 ---------------------------------------------------------------------
+__device__ __forceinline__ float denorm(float v, float sd, float mu) { return __fadd_rn(__fmul_rn(v, sd), mu); }
+
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ yp, const float* __restrict__ y,
+                                                         const uint8_t* __restrict__ mask, const float* __restrict__ mean,
+                                                         const float* __restrict__ stdv, double* __restrict__ partial,
+                                                         long total, long pps) {
+    __shared__ double red[2 * 256];
+    double s = 0.0, c = 0.0;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        if (mask[e]) {
+            const int n = (int)(e / pps);
+            const float sd = stdv[n], mu = mean[n];
+            s += (double)fabsf(denorm(yp[e], sd, mu) - denorm(y[e], sd, mu));
+            c += 1.0;
+        }
+    }
+    red[threadIdx.x] = s;
+    red[256 + threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[threadIdx.x] += red[threadIdx.x + off];
+            red[256 + threadIdx.x] += red[256 + threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 2] = red[0];
+        partial[blockIdx.x * 2 + 1] = red[256];
+    }
+}
+
+__global__ void l1_reduce_kernel(const double* __restrict__ partial, double* __restrict__ sums, int nb) {
+    if (threadIdx.x < 2 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += partial[b * 2 + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void l1_finish_kernel(const float* __restrict__ yp, const float* __restrict__ y,
+                                                        const uint8_t* __restrict__ mask, const float* __restrict__ mean,
+                                                        const float* __restrict__ stdv, const double* __restrict__ sums,
+                                                        double numel_total, const float* __restrict__ gout_dev,
+                                                        float* __restrict__ loss, float* __restrict__ dyp, long total,
+                                                        long pps) {
+    const float cnt = (float)sums[1], numel = (float)numel_total;
+    const float gout = gout_dev ? gout_dev[0] : 1.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss) {
+        float l = (float)(sums[0] / numel_total);  // L1Loss(mean) over all elements
+        l = l * numel;                             // * loss_mask.numel()
+        loss[0] = l / cnt;                         // / loss_mask.sum()
+    }
+    if (!dyp) return;
+    // autograd of the reference expression: ((gout / cnt) * numel) / numel * sign(p - t) * std_i, 0 where masked
+    const float g = ((gout / cnt) * numel) / numel;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        float o = 0.f;
+        if (mask[e]) {
+            const int n = (int)(e / pps);
+            const float sd = stdv[n], mu = mean[n];
+            const float d = denorm(yp[e], sd, mu) - denorm(y[e], sd, mu);
+            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            o = g * sg * sd;
+        }
+        dyp[e] = o;
+    }
+}
+
+// ---- Adam -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float b1,
+                                                   float b2, float eps, float wd, float step_size, float bc2_sqrt,
+                                                   float gscale) {
+    const float w1 = 1.f - b1, w2 = 1.f - b2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const float pe = p[e];
+        float ge = g[e] * gscale;
+        ge = fmaf(wd, pe, ge);
+        float me = m[e], ve = v[e];
+        me = me + w1 * (ge - me);
+        ve = fmaf(w2 * ge, ge, ve * b2);
+        const float denom = sqrtf(ve) / bc2_sqrt + eps;
+        p[e] = pe - step_size * (me / denom);
+        m[e] = me;
+        v[e] = ve;
+    }
+}
+
+// ---- layout ---------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW) {
+    const long total = (long)N * C * HW;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const long pix = e / C;
+        const long n = pix / HW, hw = pix % HW;
+        dst[e] = src[(n * C + c) * HW + hw];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW) {
+    const long total = (long)N * C * HW;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long hw = e % HW;
+        const int c = (int)((e / HW) % C);
+        const long n = e / ((long)HW * C);
+        dst[e] = src[(n * HW + hw) * C + c];
+    }
+}
+
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" {
+
+size_t rd_channel_sum_ws_bytes(long long pixels, int c) {
+    RowPlan pl;
+    if (!plan_rows(pixels, c, &pl)) return 0;
+    return (size_t)pl.nb * c * sizeof(double) + (size_t)c * sizeof(double);
+}
+
+int rd_channel_sum(const float* g, float* out, long long pixels, int c, void* ws, size_t ws_bytes, rd_stream_t s) {
+    // result returned as float; internally doubles.  out may alias nothing in ws.
+    RowPlan pl;
+    RD_REQUIRE(plan_rows(pixels, c, &pl), "rd_channel_sum: C must be a multiple of 4 and <= 1024 (got %d)", c);
+    const size_t need = (size_t)pl.nb * c * sizeof(double) + (size_t)c * sizeof(double);
+    if (!ws || ws_bytes < need) {
+        set_error("rd_channel_sum: workspace too small (%zu < %zu)", ws_bytes, need);
+        return RD_ERR_WS;
+    }
+    ProfScope ps((hipStream_t)s, "channel_sum", 0, 4.0 * pixels * c);
+    double* partial = (double*)ws;
+    double* sums = partial + (size_t)pl.nb * c;
+    hipLaunchKernelGGL((channel_stats_kernel<false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, g, partial,
+                       (long)pixels, c, pl.CQ, pl.RP, pl.rows_per_block);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, partial, sums, pl.nb, c);
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, (float*)nullptr,
+                       out, c);
+    RD_LAUNCH_CHECK("channel_sum");
+    return RD_OK;
+}
+
+size_t rd_bn_stats_ws_bytes(long long pixels, int c) {
+    RowPlan pl;
+    if (!plan_rows(pixels, c, &pl)) return 0;
+    return (size_t)pl.nb * 2 * c * sizeof(double);
+}
+
+int rd_bn_stats_partial(const float* z, double* sums, long long pixels, int c, void* ws, size_t ws_bytes,
+                        rd_stream_t s) {
+    RowPlan pl;
+    RD_REQUIRE(z && sums, "rd_bn_stats_partial: null pointer");
+    RD_REQUIRE(plan_rows(pixels, c, &pl), "rd_bn_stats_partial: C must be a multiple of 4 and <= 1024 (got %d)", c);
+    const size_t need = (size_t)pl.nb * 2 * c * sizeof(double);
+    if (!ws || ws_bytes < need) {
+        set_error("rd_bn_stats_partial: workspace too small (%zu < %zu)", ws_bytes, need);
+        return RD_ERR_WS;
+    }
+    ProfScope ps((hipStream_t)s, "bn_stats", 0, 4.0 * pixels * c);
+    hipLaunchKernelGGL((channel_stats_kernel<true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, (double*)ws,
+                       (long)pixels, c, pl.CQ, pl.RP, pl.rows_per_block);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(2 * c, 256)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
+                       sums, pl.nb, 2 * c);
+    RD_LAUNCH_CHECK("bn_stats");
+    return RD_OK;
+}
+
+int rd_bn_stats_finalize(const double* sums, double count, float eps, float momentum, float* mean, float* invstd,
+                         float* running_mean, float* running_var, int64_t* nbt, int c, rd_stream_t s) {
+    RD_REQUIRE(sums && mean && invstd && c > 0 && count > 0, "rd_bn_stats_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, count, eps, momentum,
+                       mean, invstd, running_mean, running_var, nbt, c);
+    RD_LAUNCH_CHECK("bn_finalize");
+    return RD_OK;
+}
+
+int rd_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* invstd, int c,
+                     rd_stream_t s) {
+    RD_REQUIRE(running_mean && running_var && mean && invstd && c > 0, "rd_bn_eval_stats: bad arguments");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, running_mean,
+                       running_var, eps, mean, invstd, c);
+    RD_LAUNCH_CHECK("bn_eval_stats");
+    return RD_OK;
+}
+
+int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       float slope, float* a, float* pooled, uint8_t* idx, int n, int h, int w, int c, rd_stream_t s) {
+    RD_REQUIRE(z && mean && invstd && gamma && beta && a, "rd_bn_act_pool_fwd: null pointer");
+    RD_REQUIRE(c % 4 == 0 && c > 0, "rd_bn_act_pool_fwd: C must be a multiple of 4 (got %d)", c);
+    const int CQ = c / 4;
+    const long pixels = (long)n * h * w;
+    if (pooled) {
+        RD_REQUIRE(idx && h % 2 == 0 && w % 2 == 0, "rd_bn_act_pool_fwd: pooling needs idx and even H, W");
+        const long rows = pixels / 4;
+        ProfScope ps((hipStream_t)s, "bn_act_pool_fwd", 0, 4.0 * pixels * c * 2.25 + 0.25 * pixels * c);
+        hipLaunchKernelGGL((bn_act_pool_fwd_kernel<true>), dim3(grid_cap((rows * CQ + 255) / 256, 8192)), dim3(256), 0,
+                           (hipStream_t)s, z, mean, invstd, gamma, beta, slope, a, pooled, idx, rows, h, w, c, CQ);
+    } else {
+        ProfScope ps((hipStream_t)s, "bn_act_fwd", 0, 8.0 * pixels * c);
+        hipLaunchKernelGGL((bn_act_pool_fwd_kernel<false>), dim3(grid_cap((pixels * CQ + 255) / 256, 8192)), dim3(256),
+                           0, (hipStream_t)s, z, mean, invstd, gamma, beta, slope, a, (float*)nullptr,
+                           (uint8_t*)nullptr, pixels, h, w, c, CQ);
+    }
+    RD_LAUNCH_CHECK("bn_act_pool_fwd");
+    return RD_OK;
+}
+
+size_t rd_bn_act_bwd_ws_bytes(int n, int h, int w, int c) {
+    RowPlan pl;
+    if (!plan_rows((long)n * h * w, c, &pl)) return 0;
+    return (size_t)pl.nb * 3 * c * sizeof(double);  // upper bound (pooled variant uses fewer rows)
+}
+
+int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                         float slope, const float* g_full, const float* g_pool, const uint8_t* idx, double* sums, int n,
+                         int h, int w, int c, void* ws, size_t ws_bytes, rd_stream_t s) {
+    RD_REQUIRE(z && mean && invstd && gamma && beta && sums, "rd_bn_act_bwd_reduce: null pointer");
+    RD_REQUIRE(g_full || g_pool, "rd_bn_act_bwd_reduce: no gradient source");
+    RD_REQUIRE(!g_pool || idx, "rd_bn_act_bwd_reduce: g_pool needs idx");
+    const bool pool = g_pool != nullptr;
+    const long pixels = (long)n * h * w;
+    const long rows = pool ? pixels / 4 : pixels;
+    RowPlan pl;
+    RD_REQUIRE(plan_rows(rows, c, &pl), "rd_bn_act_bwd_reduce: C must be a multiple of 4 and <= 1024 (got %d)", c);
+    const size_t need = (size_t)pl.nb * 3 * c * sizeof(double);
+    if (!ws || ws_bytes < need) {
+        set_error("rd_bn_act_bwd_reduce: workspace too small (%zu < %zu)", ws_bytes, need);
+        return RD_ERR_WS;
+    }
+    ProfScope ps((hipStream_t)s, "bn_act_bwd_reduce", 0, 4.0 * pixels * c * (1 + (g_full ? 1 : 0) + (pool ? 0.3 : 0)));
+    if (pool)
+        hipLaunchKernelGGL((bn_act_bwd_kernel<true, false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean, invstd,
+                           gamma, beta, slope, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
+                           (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
+    else
+        hipLaunchKernelGGL((bn_act_bwd_kernel<false, false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
+                           invstd, gamma, beta, slope, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
+                           (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(3 * c, 256)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
+                       sums, pl.nb, 3 * c);
+    RD_LAUNCH_CHECK("bn_act_bwd_reduce");
+    return RD_OK;
+}
+
+int rd_bn_act_bwd_apply(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        float slope, const float* g_full, const float* g_pool, const uint8_t* idx, const double* sums,
+                        double count, int training, float* dz, float* dgamma, float* dbeta, int n, int h, int w, int c,
+                        rd_stream_t s) {
+    RD_REQUIRE(z && mean && invstd && gamma && beta && sums && dz, "rd_bn_act_bwd_apply: null pointer");
+    RD_REQUIRE(g_full || g_pool, "rd_bn_act_bwd_apply: no gradient source");
+    RD_REQUIRE(!g_pool || idx, "rd_bn_act_bwd_apply: g_pool needs idx");
+    RD_REQUIRE(count > 0, "rd_bn_act_bwd_apply: count must be positive");
+    const bool pool = g_pool != nullptr;
+    const long pixels = (long)n * h * w;
+    const long rows = pool ? pixels / 4 : pixels;
+    RowPlan pl;
+    RD_REQUIRE(plan_rows(rows, c, &pl), "rd_bn_act_bwd_apply: C must be a multiple of 4 and <= 1024 (got %d)", c);
+    {
+        ProfScope ps((hipStream_t)s, "bn_act_bwd_apply", 0,
+                     4.0 * pixels * c * (2 + (g_full ? 1 : 0) + (pool ? 0.3 : 0)));
+        if (pool)
+            hipLaunchKernelGGL((bn_act_bwd_kernel<true, true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
+                               invstd, gamma, beta, slope, g_full, g_pool, idx, (double*)nullptr, sums, count, training,
+                               dz, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
+        else
+            hipLaunchKernelGGL((bn_act_bwd_kernel<false, true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
+                               invstd, gamma, beta, slope, g_full, g_pool, idx, (double*)nullptr, sums, count, training,
+                               dz, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
+    }
+    if (dgamma || dbeta)
+        hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, dgamma, dbeta,
+                           c);
+    RD_LAUNCH_CHECK("bn_act_bwd_apply");
+    return RD_OK;
+}
+
+}  // extern "C"
+
+// ---- first conv ------------------------------------------------------------------------------------
+static int first_grid(int n, int h, int w, int* tiles_x, int* tiles_y, int* ntiles) {
+    *tiles_x = cdiv(w, FT_W);
+    *tiles_y = cdiv(h, FT_H);
+    *ntiles = n * (*tiles_x) * (*tiles_y);
+    return *ntiles < 1024 ? *ntiles : 1024;
+}
+
+template <bool WGRAD>
+static int launch_first(const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h, int w,
+                        int cin, int cout, int grid, int tiles_x, int tiles_y, int ntiles, hipStream_t s) {
+    const int CQ = cout / 4, PS = 256 / CQ;
+#define RD_FIRST_CASE(CI)                                                                                              \
+    case CI:                                                                                                           \
+        hipLaunchKernelGGL((conv_first_kernel<CI, WGRAD>), dim3(grid), dim3(256), 0, s, x, wt, z, dz, partial, n, h, w, \
+                           cout, CQ, PS, tiles_x, tiles_y, ntiles);                                                    \
+        break;
+    switch (cin) {
+        RD_FIRST_CASE(1)
+        RD_FIRST_CASE(2)
+        RD_FIRST_CASE(3)
+        RD_FIRST_CASE(4)
+        RD_FIRST_CASE(5)
+        RD_FIRST_CASE(6)
+        default:
+            set_error("first conv supports 1..6 input channels (got %d)", cin);
+            return RD_ERR_ARG;
+    }
+#undef RD_FIRST_CASE
+    return RD_OK;
+}
+
+extern "C" {
+
+int rd_conv3x3_first_fwd(const float* x, const float* wt, float* z, int n, int h, int w, int cin, int cout,
+                         rd_stream_t s) {
+    RD_REQUIRE(x && wt && z, "rd_conv3x3_first_fwd: null pointer");
+    RD_REQUIRE(cout % 4 == 0 && cout / 4 <= 256 && cout > 0, "rd_conv3x3_first_fwd: Cout must be a multiple of 4, <= 1024");
+    int tx, ty, nt;
+    const int grid = first_grid(n, h, w, &tx, &ty, &nt);
+    ProfScope ps((hipStream_t)s, "conv_first_fwd", 2.0 * n * h * w * cout * 9.0 * cin,
+                 4.0 * n * h * w * (double)(cin + cout));
+    if (int e = launch_first<false>(x, wt, z, nullptr, nullptr, n, h, w, cin, cout, grid, tx, ty, nt, (hipStream_t)s))
+        return e;
+    RD_LAUNCH_CHECK("conv_first_fwd");
+    return RD_OK;
+}
+
+size_t rd_conv3x3_first_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout) {
+    int tx, ty, nt;
+    const int grid = first_grid(n, h, w, &tx, &ty, &nt);
+    return (size_t)grid * 9 * cin * cout * sizeof(float);
+}
+
+int rd_conv3x3_first_bwd_weight(const float* x, const float* dz, float* dw, int n, int h, int w, int cin, int cout,
+                                void* ws, size_t ws_bytes, rd_stream_t s) {
+    RD_REQUIRE(x && dz && dw, "rd_conv3x3_first_bwd_weight: null pointer");
+    RD_REQUIRE(cout % 4 == 0 && cout / 4 <= 256 && cout > 0,
+               "rd_conv3x3_first_bwd_weight: Cout must be a multiple of 4, <= 1024");
+    int tx, ty, nt;
+    const int grid = first_grid(n, h, w, &tx, &ty, &nt);
+    const size_t need = (size_t)grid * 9 * cin * cout * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        set_error("rd_conv3x3_first_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
+        return RD_ERR_WS;
+    }
+    ProfScope ps((hipStream_t)s, "conv_first_wgrad", 2.0 * n * h * w * cout * 9.0 * cin,
+                 4.0 * n * h * w * (double)(cin + cout));
+    if (int e = launch_first<true>(x, nullptr, nullptr, dz, (float*)ws, n, h, w, cin, cout, grid, tx, ty, nt,
+                                   (hipStream_t)s))
+        return e;
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 256)), dim3(256), 0, (hipStream_t)s,
+                       (const float*)ws, dw, grid, cin, cout);
+    RD_LAUNCH_CHECK("conv_first_wgrad");
+    return RD_OK;
+}
+
+// ---- last conv -------------------------------------------------------------------------------------
+int rd_conv3x3_last_fwd(const float* s_in, const float* wt, const float* bias, const float* x_nchw, int x_channels,
+                        float* out, int n, int h, int w, int c, rd_stream_t s) {
+    RD_REQUIRE(s_in && wt && out, "rd_conv3x3_last_fwd: null pointer");
+    RD_REQUIRE(c % 4 == 0 && c > 0, "rd_conv3x3_last_fwd: C must be a multiple of 4 (got %d)", c);
+    const int tx = cdiv(w, LT_W), ty = cdiv(h, LT_H);
+    ProfScope ps((hipStream_t)s, "conv_last_fwd", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(c + 2));
+    hipLaunchKernelGGL(conv_last_fwd_kernel, dim3(n * tx * ty), dim3(256), 0, (hipStream_t)s, s_in, wt, bias, x_nchw,
+                       x_channels, out, n, h, w, c, tx, ty);
+    RD_LAUNCH_CHECK("conv_last_fwd");
+    return RD_OK;
+}
+
+int rd_conv3x3_last_bwd_data(const float* dout, const float* wt, float* ds, int n, int h, int w, int c, rd_stream_t s) {
+    RD_REQUIRE(dout && wt && ds, "rd_conv3x3_last_bwd_data: null pointer");
+    RowPlan pl;
+    RD_REQUIRE(plan_rows((long)n * h * w, c, &pl), "rd_conv3x3_last_bwd_data: C must be a multiple of 4, <= 1024");
+    ProfScope ps((hipStream_t)s, "conv_last_dgrad", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(c + 1));
+    hipLaunchKernelGGL(conv_last_dgrad_kernel, dim3(pl.nb), dim3(256), 0, (hipStream_t)s, dout, wt, ds, (long)n * h * w,
+                       h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
+    RD_LAUNCH_CHECK("conv_last_dgrad");
+    return RD_OK;
+}
+
+size_t rd_conv3x3_last_bwd_weight_ws_bytes(int n, int h, int w, int c) {
+    RowPlan pl;
+    if (!plan_rows((long)n * h * w, c, &pl)) return 0;
+    return (size_t)pl.nb * (9 * c + 1) * sizeof(double);
+}
+
+int rd_conv3x3_last_bwd_weight(const float* s_in, const float* dout, float* dw, float* dbias, int n, int h, int w,
+                               int c, void* ws, size_t ws_bytes, rd_stream_t s) {
+    RD_REQUIRE(s_in && dout && dw, "rd_conv3x3_last_bwd_weight: null pointer");
+    RowPlan pl;
+    RD_REQUIRE(plan_rows((long)n * h * w, c, &pl), "rd_conv3x3_last_bwd_weight: C must be a multiple of 4, <= 1024");
+    const size_t need = (size_t)pl.nb * (9 * c + 1) * sizeof(double);
+    if (!ws || ws_bytes < need) {
+        set_error("rd_conv3x3_last_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
+        return RD_ERR_WS;
+    }
+    ProfScope ps((hipStream_t)s, "conv_last_wgrad", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(c + 1));
+    hipLaunchKernelGGL(conv_last_wgrad_kernel, dim3(pl.nb), dim3(256), 0, (hipStream_t)s, s_in, dout, (double*)ws,
+                       (long)n * h * w, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
+    hipLaunchKernelGGL(last_wgrad_reduce_kernel, dim3(cdiv(9 * c + 1, 256)), dim3(256), 0, (hipStream_t)s,
+                       (const double*)ws, dw, dbias, pl.nb, c);
+    RD_LAUNCH_CHECK("conv_last_wgrad");
+    return RD_OK;
+}
+
+// ---- loss ------------------------------------------------------------------------------------------
+static int l1_grid(long total) { return grid_cap((total + 255) / 256, 1024); }
+
+size_t rd_masked_l1_ws_bytes(long long numel) { return (size_t)l1_grid(numel) * 2 * sizeof(double); }
+
+int rd_masked_l1_partial(const float* yp, const float* y, const uint8_t* mask, const float* mean, const float* stdv,
+                         double* sums, int n, long long pps, void* ws, size_t ws_bytes, rd_stream_t s) {
+    RD_REQUIRE(yp && y && mask && mean && stdv && sums && n > 0 && pps > 0, "rd_masked_l1_partial: bad arguments");
+    const long total = (long)n * pps;
+    const int nb = l1_grid(total);
+    if (!ws || ws_bytes < (size_t)nb * 2 * sizeof(double)) {
+        set_error("rd_masked_l1_partial: workspace too small");
+        return RD_ERR_WS;
+    }
+    ProfScope ps((hipStream_t)s, "masked_l1", 0, 9.0 * total);
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, yp, y, mask, mean, stdv, (double*)ws,
+                       total, (long)pps);
+    hipLaunchKernelGGL(l1_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const double*)ws, sums, nb);
+    RD_LAUNCH_CHECK("masked_l1_partial");
+    return RD_OK;
+}
+
+int rd_masked_l1_finish(const float* yp, const float* y, const uint8_t* mask, const float* mean, const float* stdv,
+                        const double* sums, double numel_total, const float* gout, float* loss, float* dyp, int n,
+                        long long pps, rd_stream_t s) {
+    RD_REQUIRE(yp && y && mask && mean && stdv && sums && n > 0 && pps > 0, "rd_masked_l1_finish: bad arguments");
+    const long total = (long)n * pps;
+    ProfScope ps((hipStream_t)s, "masked_l1", 0, 13.0 * total);
+    hipLaunchKernelGGL(l1_finish_kernel, dim3(dyp ? l1_grid(total) : 1), dim3(256), 0, (hipStream_t)s, yp, y, mask, mean,
+                       stdv, sums, numel_total, gout, loss, dyp, total, (long)pps);
+    RD_LAUNCH_CHECK("masked_l1_finish");
+    return RD_OK;
+}
+
+// ---- Adam ------------------------------------------------------------------------------------------
+int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, float beta1, float beta2, float eps,
+                 float weight_decay, float step_size, float bc2_sqrt, float grad_scale, rd_stream_t s) {
+    RD_REQUIRE(p && g && m && v && numel > 0, "rd_adam_step: bad arguments");
+    ProfScope ps((hipStream_t)s, "adam", 0, 28.0 * numel);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_cap((numel + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v,
+                       (long)numel, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale);
+    RD_LAUNCH_CHECK("adam");
+    return RD_OK;
+}
+
+int rd_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s) {
+    RD_REQUIRE(src && dst, "rd_nchw_to_nhwc: null pointer");
+    const long total = (long)n * c * h * w;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_cap((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, src,
+                       dst, n, c, h * w);
+    RD_LAUNCH_CHECK("nchw_to_nhwc");
+    return RD_OK;
+}
+
+int rd_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s) {
+    RD_REQUIRE(src && dst, "rd_nhwc_to_nchw: null pointer");
+    const long total = (long)n * c * h * w;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_cap((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, src,
+                       dst, n, c, h * w);
+    RD_LAUNCH_CHECK("nhwc_to_nchw");
+    return RD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,605 @@
+// Implicit-GEMM convolution kernels on the exact-f32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak).
+//
+//  NT kernel  C[M][N] = A[M][K] * B[N][K]^T      M = pixels, K = taps*Cin (im2col on the fly)
+//      conv3x3 forward        A = x   (3x3 taps, zero padding),   B = wf[co][tap][ci]
+//      conv3x3 data-gradient  A = dz  (3x3 taps),                 B = wd[ci][tap][co] (flipped)
+//      convT2x2 forward       A = x   (1 tap),                    B = wtf[(ab,co)][ci], scatter epilogue
+//      convT2x2 data-gradient A = dout(4 taps on the fine grid),  B = wtd[ci][(ab,co)]
+//  TN kernel  C[M][N] = sum_p A[p][M] * B[p][N]   reduction over pixels, split-K slabs
+//      conv3x3 weight-gradient   A = dz[p][co],         B = x[p+tap][ci]   -> [co][(tap,ci)]
+//      convT2x2 weight-gradient  A = dout[fine(p,ab)][co], B = x[p][ci]    -> [(ab,co)][ci]
+//
+// Replaces the ATen/cuDNN kernels behind nn.Conv2d / nn.ConvTranspose2d forward and autograd
+// (reference call sites lib/UNet.py:4-5, 21, 44, 63-65, 85, 181).
+//
+// Tiling: 256 threads = 4 waves (one per SIMD), block tile BMxBN, K-step 32, each wave a
+// (BM/WM)x(BN/WN) sub-tile of 32x32 MFMA accumulators.  Operands are staged global -> VGPR
+// (prefetched one K-step ahead) -> LDS.  NT LDS rows are padded to 36 floats so the b128
+// fragment reads are bank-conflict free (MI355X guide, LDS table); the MFMA k-pairing is
+// permuted so that one b128 read feeds four consecutive MFMA k-steps.
+#include "rd_common.h"
+
+namespace rd {
+
+enum { A_CONV3 = 0, A_PLAIN = 1, A_UP2 = 2 };
+enum { EPI_STORE = 0, EPI_CONVT = 1 };
+
+struct NtParams {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* skip;
+    int M, N, K;
+    int Cin;  // channels per tap (A row length)
+    int H, W, logH, logW;
+    int Cout;  // EPI_CONVT: channels per (a,b) quadrant
+    int chunks, nk;
+    int tiles_n;
+};
+
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    // blocks are dispatched round-robin over the 8 XCDs; give every XCD a contiguous range of
+    // logical tiles so neighbouring tiles (which share A rows / B panels) share one L2.
+    const int q = nb >> 3, r = nb & 7, x = b & 7, within = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + within;
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
+    constexpr int BK = 32, LS = BK + 4;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AI = BM / 32, BI = BN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LS];
+    float* As = smem;
+    float* Bs = smem + BM * LS;
+
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int c4 = t & 7, r0 = t >> 3;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[AI], rb[BI];
+    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+
+    auto load_tile = [&](int kt) {
+        const int tap = kt / p.chunks;
+        const int c0 = (kt - tap * p.chunks) * BK + c4 * 4;
+        const bool cok = c0 < p.Cin;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int m = m0 + r0 + 32 * i;
+            bool ok = cok && (m < p.M);
+            long src;
+            if (AMODE == A_CONV3) {
+                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                const int y = (m >> logW) & (H - 1), x = m & (W - 1);
+                ok = ok && ((unsigned)(y + dy) < (unsigned)H) && ((unsigned)(x + dx) < (unsigned)W);
+                src = (long)m + dy * W + dx;
+            } else if (AMODE == A_PLAIN) {
+                src = m;
+            } else {
+                const int a = tap >> 1, b = tap & 1;
+                const int j = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+                src = ((long)img * (2 * H) + 2 * ii + a) * (2 * W) + 2 * j + b;
+            }
+            ra[i] = ok ? *reinterpret_cast<const float4*>(p.A + src * p.Cin + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int n = n0 + r0 + 32 * i;
+            const bool ok = cok && (n < p.N);
+            rb[i] = ok ? *reinterpret_cast<const float4*>(p.B + (long)n * p.K + (long)tap * p.Cin + c0)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LS + c4 * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LS + c4 * 4]) = rb[i];
+    };
+
+    const int lrow = lane & 31, half = lane >> 5;
+    const float* a_base = As + (wm * TM * 32 + lrow) * LS + half * 4;
+    const float* b_base = Bs + (wn * TN * 32 + lrow) * LS + half * 4;
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < p.nk; ++kt) {
+        const bool more = kt + 1 < p.nk;
+        if (more) load_tile(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * LS + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * LS + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float av = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float bv = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: D[i][j], lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * TN * 32 + j * 32 + lrow;
+            if (n >= p.N) continue;
+            int co = n, qa = 0, qb = 0;
+            float bv = 0.f;
+            if (EPI == EPI_CONVT) {
+                const int ab = n / p.Cout;
+                co = n - ab * p.Cout;
+                qa = ab >> 1;
+                qb = ab & 1;
+                bv = p.bias ? p.bias[co] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= p.M) continue;
+                if (EPI == EPI_STORE) {
+                    p.C[(long)m * p.N + n] = acc[i][j][r];
+                } else {
+                    const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+                    const long opix = ((long)img * (2 * H) + 2 * ii + qa) * (2 * W) + 2 * jj + qb;
+                    const long o = opix * p.Cout + co;
+                    float v = acc[i][j][r] + bv;
+                    if (p.skip) v = p.skip[o] + v;
+                    p.C[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int AMODE, int EPI>
+static int launch_nt(NtParams p, hipStream_t s, const char* cls) {
+    const long flops = 2L * p.M * p.N * p.K;
+    const double bytes = 4.0 * ((double)p.M * p.Cin * (AMODE == A_UP2 ? 4 : 1) + (double)p.N * p.K + (double)p.M * p.N);
+    ProfScope ps(s, cls, (double)flops, bytes);
+    p.chunks = cdiv(p.Cin, 32);
+    const int taps = p.K / p.Cin;
+    p.nk = taps * p.chunks;
+    const int tiles128 = cdiv(p.M, 128) * cdiv(p.N, p.N > 64 ? 128 : 64);
+    if (tiles128 < 200 || p.M < 128) {
+        p.tiles_n = cdiv(p.N, 64);
+        const int grid = cdiv(p.M, 64) * p.tiles_n;
+        hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+    } else if (p.N > 64) {
+        p.tiles_n = cdiv(p.N, 128);
+        const int grid = cdiv(p.M, 128) * p.tiles_n;
+        hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+    } else {
+        p.tiles_n = cdiv(p.N, 64);
+        const int grid = cdiv(p.M, 128) * p.tiles_n;
+        hipLaunchKernelGGL((igemm_nt_kernel<128, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+    }
+    RD_LAUNCH_CHECK(cls);
+    return RD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+//  TN split-K kernel (weight gradients)
+// ------------------------------------------------------------------------------------------
+enum { WA_PLAIN = 0, WA_UP2 = 1 };
+enum { WB_PLAIN = 0, WB_CONV3 = 1 };
+
+struct TnParams {
+    const float* A;
+    const float* B;
+    float* slab;  // [splits][M][N]
+    int M, N;
+    long Kp;       // pixels reduced over
+    int lda, ldb;  // channels per pixel of the A / B source tensors
+    int H, W, logH, logW;
+    int Cout;  // WA_UP2: channels per (a,b) quadrant of the A columns
+    int Cin;   // WB_CONV3: channels per tap of the B columns
+    int kchunk;  // pixels per split, multiple of 32
+    int tiles_n, tiles_mn;
+};
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(TnParams p) {
+    constexpr int BK = 32;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AQ = BM / 4, BQ = BN / 4;          // float4 per row
+    constexpr int AR = 256 / AQ, BR = 256 / BQ;      // rows per pass
+    constexpr int AP = BK / AR, BP = BK / BR;        // passes
+    __shared__ __attribute__((aligned(16))) float smem[BK * (BM + BN)];
+    float* As = smem;
+    float* Bs = smem + BK * BM;
+
+    const int nb_mn = p.tiles_mn;
+    const int split = blockIdx.x / nb_mn;
+    const int lb = blockIdx.x - split * nb_mn;
+    const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+
+    // per-thread fixed column descriptors
+    const int ca = t % AQ, ra0 = t / AQ;
+    const int cb = t % BQ, rb0 = t / BQ;
+    const int ma = m0 + ca * 4, nbcol = n0 + cb * 4;
+    const bool a_ok = ma < p.M, b_ok = nbcol < p.N;
+    int a_col = ma, a_qa = 0, a_qb = 0;
+    if (AMODE == WA_UP2) {
+        const int ab = ma / p.Cout;
+        a_col = ma - ab * p.Cout;
+        a_qa = ab >> 1;
+        a_qb = ab & 1;
+    }
+    int b_col = nbcol, b_dy = 0, b_dx = 0;
+    if (BMODE == WB_CONV3) {
+        const int tap = nbcol / p.Cin;
+        b_col = nbcol - tap * p.Cin;
+        b_dy = tap / 3 - 1;
+        b_dx = tap - (tap / 3) * 3 - 1;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[AP], rb[BP];
+    const long k_begin = (long)split * p.kchunk;
+    long k_end = k_begin + p.kchunk;
+    if (k_end > p.Kp) k_end = p.Kp;
+
+    auto load_tile = [&](long kbase) {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const long pp = kbase + ra0 + AR * i;
+            bool ok = a_ok && pp < k_end;
+            long src = pp;
+            if (AMODE == WA_UP2) {
+                const int m = (int)pp;
+                const int j = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+                src = ((long)img * (2 * H) + 2 * ii + a_qa) * (2 * W) + 2 * j + a_qb;
+            }
+            ra[i] = ok ? *reinterpret_cast<const float4*>(p.A + src * p.lda + a_col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const long pp = kbase + rb0 + BR * i;
+            bool ok = b_ok && pp < k_end;
+            long src = pp;
+            if (BMODE == WB_CONV3) {
+                const int m = (int)pp;
+                const int y = (m >> logW) & (H - 1), x = m & (W - 1);
+                ok = ok && ((unsigned)(y + b_dy) < (unsigned)H) && ((unsigned)(x + b_dx) < (unsigned)W);
+                src = pp + b_dy * W + b_dx;
+            }
+            rb[i] = ok ? *reinterpret_cast<const float4*>(p.B + src * p.ldb + b_col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AP; ++i) *reinterpret_cast<float4*>(&As[(ra0 + AR * i) * BM + ca * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BP; ++i) *reinterpret_cast<float4*>(&Bs[(rb0 + BR * i) * BN + cb * 4]) = rb[i];
+    };
+
+    const int lrow = lane & 31, half = lane >> 5;
+    const float* a_base = As + half * BM + wm * TM * 32 + lrow;
+    const float* b_base = Bs + half * BN + wn * TN * 32 + lrow;
+
+    if (k_begin < k_end) {
+        load_tile(k_begin);
+        store_tile();
+        __syncthreads();
+        for (long kb = k_begin; kb < k_end; kb += BK) {
+            const bool more = kb + BK < k_end;
+            if (more) load_tile(kb + BK);
+#pragma unroll
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                float af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = a_base[ks * 2 * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = b_base[ks * 2 * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                store_tile();
+                __syncthreads();
+            }
+        }
+    }
+
+    float* out = p.slab + (long)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * TN * 32 + j * 32 + lrow;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.M) out[(long)m * p.N + n] = acc[i][j][r];
+            }
+        }
+}
+
+struct TnPlan {
+    int bm, bn, tiles_m, tiles_n, splits, kchunk;
+};
+
+static TnPlan plan_tn(int M, int N, long Kp) {
+    TnPlan pl;
+    pl.bm = M > 64 ? 128 : 64;
+    pl.bn = N > 64 ? 128 : 64;
+    pl.tiles_m = cdiv(M, pl.bm);
+    pl.tiles_n = cdiv(N, pl.bn);
+    const int tiles = pl.tiles_m * pl.tiles_n;
+    long ktiles = (Kp + 31) / 32;
+    long want = (1024 + tiles - 1) / tiles;       // ~4 blocks per CU in flight
+    long maxs = ktiles / 8 > 0 ? ktiles / 8 : 1;  // at least 8 K-steps per split
+    long s = want < maxs ? want : maxs;
+    if (s < 1) s = 1;
+    if (s > 512) s = 512;
+    long per = (ktiles + s - 1) / s;
+    pl.kchunk = (int)(per * 32);
+    pl.splits = (int)((ktiles + per - 1) / per);
+    return pl;
+}
+
+template <int AMODE, int BMODE>
+static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cls) {
+    ProfScope ps(s, cls, 2.0 * p.M * p.N * (double)p.Kp,
+                 4.0 * ((double)p.Kp * p.lda * (AMODE == WA_UP2 ? 4 : 1) + (double)p.Kp * p.ldb + (double)p.M * p.N));
+    p.kchunk = pl.kchunk;
+    p.tiles_n = pl.tiles_n;
+    p.tiles_mn = pl.tiles_m * pl.tiles_n;
+    const int grid = p.tiles_mn * pl.splits;
+    if (pl.bm == 128 && pl.bn == 128)
+        hipLaunchKernelGGL((wgrad_tn_kernel<128, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+    else if (pl.bm == 128)
+        hipLaunchKernelGGL((wgrad_tn_kernel<128, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+    else if (pl.bn == 128)
+        hipLaunchKernelGGL((wgrad_tn_kernel<64, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((wgrad_tn_kernel<64, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+    RD_LAUNCH_CHECK(cls);
+    return RD_OK;
+}
+
+// slab[s][m][n] summed over s and scattered into the torch weight layout.
+//  mode 0 (conv3x3): m = co, n = tap*Cin + ci  ->  dw[(co*Cin + ci)*9 + tap]
+//  mode 1 (convT)  : m = ab*Cout + co, n = ci  ->  dw[(ci*Cout + co)*4 + ab]
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M, int N, int splits,
+                                   int mode, int Cin, int Cout) {
+    const long total = (long)M * N;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int s = 0; s < splits; ++s) acc += (double)slab[(long)s * total + e];
+        const int m = (int)(e / N), n = (int)(e - (long)m * N);
+        long o;
+        if (mode == 0) {
+            const int tap = n / Cin, ci = n - tap * Cin;
+            o = ((long)m * Cin + ci) * 9 + tap;
+        } else {
+            const int ab = m / Cout, co = m - ab * Cout;
+            o = ((long)n * Cout + co) * 4 + ab;
+        }
+        dw[o] = (float)acc;
+    }
+}
+
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd,
+                                    int cout, int cin) {
+    const long total = (long)cout * cin * 9;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        // e indexes wf[co][tap][ci]
+        const int ci = (int)(e % cin);
+        const int tap = (int)((e / cin) % 9);
+        const int co = (int)(e / ((long)cin * 9));
+        const float v = w[((long)co * cin + ci) * 9 + tap];
+        wf[e] = v;
+        if (wd) wd[((long)ci * 9 + (8 - tap)) * cout + co] = v;
+    }
+}
+
+__global__ void pack_convt_kernel(const float* __restrict__ w, float* __restrict__ wtf, float* __restrict__ wtd,
+                                  int cin, int cout) {
+    const long total = (long)cin * cout * 4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        // e indexes wtf[(ab*Cout + co)][ci]
+        const int ci = (int)(e % cin);
+        const int co = (int)((e / cin) % cout);
+        const int ab = (int)(e / ((long)cin * cout));
+        const float v = w[((long)ci * cout + co) * 4 + ab];
+        wtf[e] = v;
+        if (wtd) wtd[(long)ci * 4 * cout + (long)ab * cout + co] = v;
+    }
+}
+
+static int grid_for(long total, int block = 256, int cap = 4096) {
+    long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static int check_conv_args(int n, int h, int w, int cin, int cout) {
+    RD_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad conv shape n=%d h=%d w=%d cin=%d cout=%d", n, h, w,
+               cin, cout);
+    RD_REQUIRE(ilog2_exact(h) >= 0 && ilog2_exact(w) >= 0, "H and W must be powers of two (got %dx%d)", h, w);
+    RD_REQUIRE((long)n * h * w * 4L < (1L << 31), "pixel count too large for 32-bit tile indices");
+    return RD_OK;
+}
+
+}  // namespace rd
+
+using namespace rd;
+
+extern "C" {
+
+int rd_pack_conv3x3_weight(const float* w, float* wf, float* wd, int cout, int cin, rd_stream_t s) {
+    RD_REQUIRE(w && wf && cout > 0 && cin > 0, "rd_pack_conv3x3_weight: bad arguments");
+    ProfScope ps((hipStream_t)s, "pack_weights", 0, 12.0 * cout * cin * 9);
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for((long)cout * cin * 9)), dim3(256), 0, (hipStream_t)s, w, wf,
+                       wd, cout, cin);
+    RD_LAUNCH_CHECK("pack_conv3x3");
+    return RD_OK;
+}
+
+int rd_pack_convt2x2_weight(const float* w, float* wtf, float* wtd, int cin, int cout, rd_stream_t s) {
+    RD_REQUIRE(w && wtf && cout > 0 && cin > 0, "rd_pack_convt2x2_weight: bad arguments");
+    ProfScope ps((hipStream_t)s, "pack_weights", 0, 12.0 * cout * cin * 4);
+    hipLaunchKernelGGL(pack_convt_kernel, dim3(grid_for((long)cout * cin * 4)), dim3(256), 0, (hipStream_t)s, w, wtf,
+                       wtd, cin, cout);
+    RD_LAUNCH_CHECK("pack_convt");
+    return RD_OK;
+}
+
+int rd_conv3x3_fwd(const float* x, const float* wf, float* z, int n, int h, int w, int cin, int cout, rd_stream_t s) {
+    if (int e = check_conv_args(n, h, w, cin, cout)) return e;
+    RD_REQUIRE(x && wf && z, "rd_conv3x3_fwd: null pointer");
+    RD_REQUIRE(cin % 4 == 0, "rd_conv3x3_fwd: Cin must be a multiple of 4 (got %d); use rd_conv3x3_first_fwd", cin);
+    NtParams p = {};
+    p.A = x; p.B = wf; p.C = z;
+    p.M = n * h * w; p.N = cout; p.K = 9 * cin; p.Cin = cin;
+    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    return launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_fwd");
+}
+
+int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int h, int w, int cin, int cout,
+                        rd_stream_t s) {
+    if (int e = check_conv_args(n, h, w, cin, cout)) return e;
+    RD_REQUIRE(dz && wd && dx, "rd_conv3x3_bwd_data: null pointer");
+    RD_REQUIRE(cout % 4 == 0, "rd_conv3x3_bwd_data: Cout must be a multiple of 4 (got %d)", cout);
+    NtParams p = {};
+    p.A = dz; p.B = wd; p.C = dx;
+    p.M = n * h * w; p.N = cin; p.K = 9 * cout; p.Cin = cout;
+    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    return launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_dgrad");
+}
+
+size_t rd_conv3x3_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout) {
+    TnPlan pl = plan_tn(cout, 9 * cin, (long)n * h * w);
+    return (size_t)pl.splits * cout * 9 * cin * sizeof(float);
+}
+
+int rd_conv3x3_bwd_weight(const float* x, const float* dz, float* dw, int n, int h, int w, int cin, int cout, void* ws,
+                          size_t ws_bytes, rd_stream_t s) {
+    if (int e = check_conv_args(n, h, w, cin, cout)) return e;
+    RD_REQUIRE(x && dz && dw, "rd_conv3x3_bwd_weight: null pointer");
+    RD_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "rd_conv3x3_bwd_weight: channels must be multiples of 4 (%d, %d)", cin,
+               cout);
+    const size_t need = rd_conv3x3_bwd_weight_ws_bytes(n, h, w, cin, cout);
+    if (ws_bytes < need || !ws) {
+        set_error("rd_conv3x3_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
+        return RD_ERR_WS;
+    }
+    TnPlan pl = plan_tn(cout, 9 * cin, (long)n * h * w);
+    TnParams p = {};
+    p.A = dz; p.B = x; p.slab = (float*)ws;
+    p.M = cout; p.N = 9 * cin; p.Kp = (long)n * h * w;
+    p.lda = cout; p.ldb = cin; p.Cin = cin; p.Cout = cout;
+    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    if (int e = launch_tn<WA_PLAIN, WB_CONV3>(p, pl, (hipStream_t)s, "conv3x3_wgrad")) return e;
+    ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N)), dim3(256), 0, (hipStream_t)s,
+                       (const float*)ws, dw, p.M, p.N, pl.splits, 0, cin, cout);
+    RD_LAUNCH_CHECK("slab_reduce");
+    return RD_OK;
+}
+
+int rd_convt2x2_fwd(const float* x, const float* wtf, const float* bias, const float* skip, float* out, int n, int h,
+                    int w, int cin, int cout, rd_stream_t s) {
+    if (int e = check_conv_args(n, h, w, cin, cout)) return e;
+    RD_REQUIRE(x && wtf && out, "rd_convt2x2_fwd: null pointer");
+    RD_REQUIRE(cin % 4 == 0, "rd_convt2x2_fwd: Cin must be a multiple of 4 (got %d)", cin);
+    NtParams p = {};
+    p.A = x; p.B = wtf; p.C = out; p.bias = bias; p.skip = skip;
+    p.M = n * h * w; p.N = 4 * cout; p.K = cin; p.Cin = cin; p.Cout = cout;
+    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    return launch_nt<A_PLAIN, EPI_CONVT>(p, (hipStream_t)s, "convt2x2_fwd");
+}
+
+int rd_convt2x2_bwd_data(const float* dout, const float* wtd, float* dx, int n, int h, int w, int cin, int cout,
+                         rd_stream_t s) {
+    if (int e = check_conv_args(n, h, w, cin, cout)) return e;
+    RD_REQUIRE(dout && wtd && dx, "rd_convt2x2_bwd_data: null pointer");
+    RD_REQUIRE(cout % 4 == 0, "rd_convt2x2_bwd_data: Cout must be a multiple of 4 (got %d)", cout);
+    NtParams p = {};
+    p.A = dout; p.B = wtd; p.C = dx;
+    p.M = n * h * w; p.N = cin; p.K = 4 * cout; p.Cin = cout;
+    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    return launch_nt<A_UP2, EPI_STORE>(p, (hipStream_t)s, "convt2x2_dgrad");
+}
+
+size_t rd_convt2x2_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout) {
+    TnPlan pl = plan_tn(4 * cout, cin, (long)n * h * w);
+    return (size_t)pl.splits * 4 * cout * cin * sizeof(float);
+}
+
+int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw, int n, int h, int w, int cin, int cout,
+                           void* ws, size_t ws_bytes, rd_stream_t s) {
+    if (int e = check_conv_args(n, h, w, cin, cout)) return e;
+    RD_REQUIRE(x && dout && dw, "rd_convt2x2_bwd_weight: null pointer");
+    RD_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "rd_convt2x2_bwd_weight: channels must be multiples of 4 (%d, %d)", cin,
+               cout);
+    const size_t need = rd_convt2x2_bwd_weight_ws_bytes(n, h, w, cin, cout);
+    if (ws_bytes < need || !ws) {
+        set_error("rd_convt2x2_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
+        return RD_ERR_WS;
+    }
+    TnPlan pl = plan_tn(4 * cout, cin, (long)n * h * w);
+    TnParams p = {};
+    p.A = dout; p.B = x; p.slab = (float*)ws;
+    p.M = 4 * cout; p.N = cin; p.Kp = (long)n * h * w;
+    p.lda = cout; p.ldb = cin; p.Cin = cin; p.Cout = cout;
+    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    if (int e = launch_tn<WA_UP2, WB_PLAIN>(p, pl, (hipStream_t)s, "convt2x2_wgrad")) return e;
+    ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N)), dim3(256), 0, (hipStream_t)s,
+                       (const float*)ws, dw, p.M, p.N, pl.splits, 1, cin, cout);
+    RD_LAUNCH_CHECK("slab_reduce");
+    return RD_OK;
+}
+
+}  // extern "C"

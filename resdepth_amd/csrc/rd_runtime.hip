@@ -1,0 +1,144 @@
+// Error reporting, version and the event-based kernel profiler of libresdepth_hip.so.
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rd_common.h"
+
+namespace rd {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return RD_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return RD_ERR_HIP;
+}
+
+// ---- profiler ---------------------------------------------------------------------------
+struct ProfRec {
+    int cls;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+struct ProfClass {
+    std::string name;
+    long long launches = 0;
+    double ms = 0, flops = 0, bytes = 0;
+};
+static std::mutex g_mu;
+static volatile bool g_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<ProfClass> g_cls;
+static std::vector<hipEvent_t> g_free_events;
+static thread_local int t_open = -1;
+
+bool prof_on() { return g_on; }
+
+static hipEvent_t get_event() {
+    if (!g_free_events.empty()) {
+        hipEvent_t e = g_free_events.back();
+        g_free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void prof_begin(hipStream_t s, const char* cls, double flops, double bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int ci = -1;
+    for (size_t i = 0; i < g_cls.size(); ++i)
+        if (g_cls[i].name == cls) ci = (int)i;
+    if (ci < 0) {
+        if (g_cls.size() >= RD_PROF_MAX_CLASSES) return;
+        g_cls.push_back(ProfClass());
+        g_cls.back().name = cls;
+        ci = (int)g_cls.size() - 1;
+    }
+    ProfRec r;
+    r.cls = ci;
+    r.e0 = get_event();
+    r.e1 = get_event();
+    r.flops = flops;
+    r.bytes = bytes;
+    if (!r.e0 || !r.e1) return;
+    (void)hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+    t_open = (int)g_recs.size() - 1;
+}
+
+void prof_end(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (t_open < 0 || t_open >= (int)g_recs.size()) return;
+    (void)hipEventRecord(g_recs[t_open].e1, s);
+    t_open = -1;
+}
+
+static void drain_locked() {
+    for (auto& r : g_recs) {
+        (void)hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            ProfClass& c = g_cls[r.cls];
+            c.launches += 1;
+            c.ms += ms;
+            c.flops += r.flops;
+            c.bytes += r.bytes;
+        }
+        g_free_events.push_back(r.e0);
+        g_free_events.push_back(r.e1);
+    }
+    g_recs.clear();
+}
+
+}  // namespace rd
+
+extern "C" {
+
+int rd_version(void) { return 100; }
+
+const char* rd_last_error_string(void) { return rd::g_err; }
+
+int rd_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(rd::g_mu);
+    rd::g_on = on != 0;
+    return RD_OK;
+}
+
+int rd_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(rd::g_mu);
+    rd::drain_locked();
+    rd::g_cls.clear();
+    return RD_OK;
+}
+
+int rd_prof_collect(rd_prof_entry* out, int max_entries) {
+    std::lock_guard<std::mutex> lk(rd::g_mu);
+    rd::drain_locked();
+    int n = 0;
+    for (auto& c : rd::g_cls) {
+        if (n >= max_entries) break;
+        memset(&out[n], 0, sizeof(rd_prof_entry));
+        strncpy(out[n].name, c.name.c_str(), sizeof(out[n].name) - 1);
+        out[n].launches = c.launches;
+        out[n].ms = c.ms;
+        out[n].flops = c.flops;
+        out[n].bytes = c.bytes;
+        ++n;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/resdepth_hip.h).
+
+Activations are NHWC fp32 tensors shaped [N, H, W, C]; weights keep the torch layouts of the
+reference's modules (nn.Conv2d [Cout,Cin,3,3], nn.ConvTranspose2d [Cin,Cout,2,2],
+lib/UNet.py:4-5,21) and are re-packed into GEMM operand layouts by `pack_*`.
+Every call enqueues on torch's current HIP stream and never synchronises.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, load, ptr, stream_ptr, workspace
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t
+
+
+def pack_conv3x3_weight(w, need_dgrad=True):
+    cout, cin = w.shape[0], w.shape[1]
+    wf = torch.empty(cout, 9, cin, device=w.device, dtype=torch.float32)
+    wd = torch.empty(cin, 9, cout, device=w.device, dtype=torch.float32) if need_dgrad else None
+    check(load().rd_pack_conv3x3_weight(ptr(w.detach()), ptr(wf), ptr(wd), cout, cin, stream_ptr()), "pack_conv3x3")
+    return wf, wd
+
+
+def pack_convt2x2_weight(w, need_dgrad=True):
+    cin, cout = w.shape[0], w.shape[1]
+    wtf = torch.empty(4 * cout, cin, device=w.device, dtype=torch.float32)
+    wtd = torch.empty(cin, 4 * cout, device=w.device, dtype=torch.float32) if need_dgrad else None
+    check(load().rd_pack_convt2x2_weight(ptr(w.detach()), ptr(wtf), ptr(wtd), cin, cout, stream_ptr()), "pack_convt")
+    return wtf, wtd
+
+
+def conv3x3_fwd(x, wf):
+    n, h, w, cin = x.shape
+    cout = wf.shape[0]
+    z = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
+    check(load().rd_conv3x3_fwd(ptr(_f32(x, "x")), ptr(wf), ptr(z), n, h, w, cin, cout, stream_ptr()), "conv3x3_fwd")
+    return z
+
+
+def conv3x3_bwd_data(dz, wd):
+    n, h, w, cout = dz.shape
+    cin = wd.shape[0]
+    dx = torch.empty(n, h, w, cin, device=dz.device, dtype=torch.float32)
+    check(load().rd_conv3x3_bwd_data(ptr(dz), ptr(wd), ptr(dx), n, h, w, cin, cout, stream_ptr()), "conv3x3_bwd_data")
+    return dx
+
+
+def conv3x3_bwd_weight(x, dz, out=None):
+    n, h, w, cin = x.shape
+    cout = dz.shape[3]
+    if out is None:
+        out = torch.empty(cout, cin, 3, 3, device=x.device, dtype=torch.float32)
+    nb = load().rd_conv3x3_bwd_weight_ws_bytes(n, h, w, cin, cout)
+    ws = workspace(nb, x.device)
+    check(load().rd_conv3x3_bwd_weight(ptr(x), ptr(dz), ptr(out), n, h, w, cin, cout, ws.data_ptr(), ws.numel(),
+                                       stream_ptr()), "conv3x3_bwd_weight")
+    return out
+
+
+def conv3x3_first_fwd(x_nchw, w):
+    n, cin, h, wd_ = x_nchw.shape
+    cout = w.shape[0]
+    z = torch.empty(n, h, wd_, cout, device=x_nchw.device, dtype=torch.float32)
+    check(load().rd_conv3x3_first_fwd(ptr(_f32(x_nchw, "x")), ptr(w.detach()), ptr(z), n, h, wd_, cin, cout,
+                                      stream_ptr()), "conv3x3_first_fwd")
+    return z
+
+
+def conv3x3_first_bwd_weight(x_nchw, dz, out=None):
+    n, cin, h, wd_ = x_nchw.shape
+    cout = dz.shape[3]
+    if out is None:
+        out = torch.empty(cout, cin, 3, 3, device=dz.device, dtype=torch.float32)
+    nb = load().rd_conv3x3_first_bwd_weight_ws_bytes(n, h, wd_, cin, cout)
+    ws = workspace(nb, dz.device)
+    check(load().rd_conv3x3_first_bwd_weight(ptr(x_nchw), ptr(dz), ptr(out), n, h, wd_, cin, cout, ws.data_ptr(),
+                                             ws.numel(), stream_ptr()), "conv3x3_first_bwd_weight")
+    return out
+
+
+def conv3x3_last_fwd(s, w, bias, x_nchw):
+    n, h, wd_, c = s.shape
+    out = torch.empty(n, 1, h, wd_, device=s.device, dtype=torch.float32)
+    xc = x_nchw.shape[1] if x_nchw is not None else 0
+    check(load().rd_conv3x3_last_fwd(ptr(s), ptr(w.detach()), ptr(bias.detach() if bias is not None else None),
+                                     ptr(x_nchw), xc, ptr(out), n, h, wd_, c, stream_ptr()), "conv3x3_last_fwd")
+    return out
+
+
+def conv3x3_last_bwd_data(dout, w, c):
+    n, _, h, wd_ = dout.shape
+    ds = torch.empty(n, h, wd_, c, device=dout.device, dtype=torch.float32)
+    check(load().rd_conv3x3_last_bwd_data(ptr(dout), ptr(w.detach()), ptr(ds), n, h, wd_, c, stream_ptr()),
+          "conv3x3_last_bwd_data")
+    return ds
+
+
+def conv3x3_last_bwd_weight(s, dout, dw=None, dbias=None, want_bias=True):
+    n, h, wd_, c = s.shape
+    if dw is None:
+        dw = torch.empty(1, c, 3, 3, device=s.device, dtype=torch.float32)
+    if dbias is None and want_bias:
+        dbias = torch.empty(1, device=s.device, dtype=torch.float32)
+    nb = load().rd_conv3x3_last_bwd_weight_ws_bytes(n, h, wd_, c)
+    ws = workspace(nb, s.device)
+    check(load().rd_conv3x3_last_bwd_weight(ptr(s), ptr(dout), ptr(dw), ptr(dbias), n, h, wd_, c, ws.data_ptr(),
+                                            ws.numel(), stream_ptr()), "conv3x3_last_bwd_weight")
+    return dw, dbias
+
+
+def convt2x2_fwd(x, wtf, bias, skip):
+    n, h, w, cin = x.shape
+    cout = wtf.shape[0] // 4
+    out = torch.empty(n, 2 * h, 2 * w, cout, device=x.device, dtype=torch.float32)
+    check(load().rd_convt2x2_fwd(ptr(x), ptr(wtf), ptr(bias.detach() if bias is not None else None), ptr(skip),
+                                 ptr(out), n, h, w, cin, cout, stream_ptr()), "convt2x2_fwd")
+    return out
+
+
+def convt2x2_bwd_data(dout, wtd):
+    n, h2, w2, cout = dout.shape
+    cin = wtd.shape[0]
+    dx = torch.empty(n, h2 // 2, w2 // 2, cin, device=dout.device, dtype=torch.float32)
+    check(load().rd_convt2x2_bwd_data(ptr(dout), ptr(wtd), ptr(dx), n, h2 // 2, w2 // 2, cin, cout, stream_ptr()),
+          "convt2x2_bwd_data")
+    return dx
+
+
+def convt2x2_bwd_weight(x, dout, out=None):
+    n, h, w, cin = x.shape
+    cout = dout.shape[3]
+    if out is None:
+        out = torch.empty(cin, cout, 2, 2, device=x.device, dtype=torch.float32)
+    nb = load().rd_convt2x2_bwd_weight_ws_bytes(n, h, w, cin, cout)
+    ws = workspace(nb, x.device)
+    check(load().rd_convt2x2_bwd_weight(ptr(x), ptr(dout), ptr(out), n, h, w, cin, cout, ws.data_ptr(), ws.numel(),
+                                        stream_ptr()), "convt2x2_bwd_weight")
+    return out
+
+
+def channel_sum(g, out=None):
+    c = g.shape[-1]
+    pixels = g.numel() // c
+    if out is None:
+        out = torch.empty(c, device=g.device, dtype=torch.float32)
+    nb = load().rd_channel_sum_ws_bytes(pixels, c)
+    ws = workspace(nb, g.device)
+    check(load().rd_channel_sum(ptr(g), ptr(out), pixels, c, ws.data_ptr(), ws.numel(), stream_ptr()), "channel_sum")
+    return out
+
+
+def bn_stats_partial(z):
+    """-> sums [2*C] float64 (sum, sum of squares) over the pixels of z[N,H,W,C]."""
+    c = z.shape[-1]
+    pixels = z.numel() // c
+    sums = torch.empty(2 * c, device=z.device, dtype=torch.float64)
+    nb = load().rd_bn_stats_ws_bytes(pixels, c)
+    ws = workspace(nb, z.device)
+    check(load().rd_bn_stats_partial(ptr(z), ptr(sums), pixels, c, ws.data_ptr(), ws.numel(), stream_ptr()),
+          "bn_stats_partial")
+    return sums
+
+
+def bn_stats_finalize(sums, count, running_mean, running_var, num_batches_tracked, eps=BN_EPS, momentum=BN_MOMENTUM):
+    c = sums.numel() // 2
+    mean = torch.empty(c, device=sums.device, dtype=torch.float32)
+    invstd = torch.empty(c, device=sums.device, dtype=torch.float32)
+    check(load().rd_bn_stats_finalize(ptr(sums), float(count), eps, momentum, ptr(mean), ptr(invstd),
+                                      ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), c, stream_ptr()),
+          "bn_stats_finalize")
+    return mean, invstd
+
+
+def bn_eval_stats(running_mean, running_var, eps=BN_EPS):
+    c = running_mean.numel()
+    mean = torch.empty(c, device=running_mean.device, dtype=torch.float32)
+    invstd = torch.empty(c, device=running_mean.device, dtype=torch.float32)
+    check(load().rd_bn_eval_stats(ptr(running_mean), ptr(running_var), eps, ptr(mean), ptr(invstd), c, stream_ptr()),
+          "bn_eval_stats")
+    return mean, invstd
+
+
+def bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, pool):
+    n, h, w, c = z.shape
+    a = torch.empty_like(z)
+    pooled = idx = None
+    if pool:
+        pooled = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.float32)
+        idx = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.uint8)
+    check(load().rd_bn_act_pool_fwd(ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
+                                    float(slope), ptr(a), ptr(pooled), ptr(idx), n, h, w, c, stream_ptr()),
+          "bn_act_pool_fwd")
+    return a, pooled, idx
+
+
+def bn_act_bwd_reduce(z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx):
+    """-> sums [3*C] float64: sum g', sum g'*xhat, sum g_full."""
+    n, h, w, c = z.shape
+    sums = torch.empty(3 * c, device=z.device, dtype=torch.float64)
+    nb = load().rd_bn_act_bwd_ws_bytes(n, h, w, c)
+    ws = workspace(nb, z.device)
+    check(load().rd_bn_act_bwd_reduce(ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
+                                      float(slope), ptr(g_full), ptr(g_pool), ptr(idx), ptr(sums), n, h, w, c,
+                                      ws.data_ptr(), ws.numel(), stream_ptr()), "bn_act_bwd_reduce")
+    return sums
+
+
+def bn_act_bwd_apply(z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx, sums, count, training=True,
+                     dgamma=None, dbeta=None):
+    n, h, w, c = z.shape
+    dz = torch.empty_like(z)
+    check(load().rd_bn_act_bwd_apply(ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
+                                     float(slope), ptr(g_full), ptr(g_pool), ptr(idx), ptr(sums), float(count),
+                                     1 if training else 0, ptr(dz), ptr(dgamma), ptr(dbeta), n, h, w, c, stream_ptr()),
+          "bn_act_bwd_apply")
+    return dz
+
+
+def masked_l1_partial(yp, y, mask, mean, std):
+    """-> sums [2] float64 on device: (sum |p - t| over valid pixels, #valid)."""
+    n = yp.shape[0]
+    pps = yp.numel() // n
+    sums = torch.empty(2, device=yp.device, dtype=torch.float64)
+    nb = load().rd_masked_l1_ws_bytes(yp.numel())
+    ws = workspace(nb, yp.device)
+    check(load().rd_masked_l1_partial(ptr(yp), ptr(y), ptr(mask), ptr(mean), ptr(std), ptr(sums), n, pps,
+                                      ws.data_ptr(), ws.numel(), stream_ptr()), "masked_l1_partial")
+    return sums
+
+
+def masked_l1_finish(yp, y, mask, mean, std, sums, numel_total, gout=None, want_loss=True, want_grad=True):
+    """gout: optional 0-dim fp32 DEVICE tensor (upstream gradient); None means 1."""
+    n = yp.shape[0]
+    pps = yp.numel() // n
+    loss = torch.empty(1, device=yp.device, dtype=torch.float32) if want_loss else None
+    dyp = torch.empty_like(yp) if want_grad else None
+    check(load().rd_masked_l1_finish(ptr(yp), ptr(y), ptr(mask), ptr(mean), ptr(std), ptr(sums), float(numel_total),
+                                     ptr(gout), ptr(loss), ptr(dyp), n, pps, stream_ptr()), "masked_l1_finish")
+    return loss, dyp
+
+
+def adam_step(p, g, m, v, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale=1.0):
+    check(load().rd_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), beta1, beta2, eps, weight_decay, step_size,
+                              bc2_sqrt, grad_scale, stream_ptr()), "adam_step")
+
+
+def nchw_to_nhwc(x):
+    n, c, h, w = x.shape
+    out = torch.empty(n, h, w, c, device=x.device, dtype=torch.float32)
+    check(load().rd_nchw_to_nhwc(ptr(x), ptr(out), n, c, h, w, stream_ptr()), "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x):
+    n, h, w, c = x.shape
+    out = torch.empty(n, c, h, w, device=x.device, dtype=torch.float32)
+    check(load().rd_nhwc_to_nchw(ptr(x), ptr(out), n, c, h, w, stream_ptr()), "nhwc_to_nchw")
+    return out

@@ -1,0 +1,141 @@
+"""Fused Adam over the model's flat parameter buffer (torch.optim.Adam as configured by
+lib/utils.py:329-331: coupled L2 weight decay, betas (0.9, 0.999), eps 1e-8).
+
+`FusedAdam` is a torch.optim.Optimizer with torch.optim.Adam's param_group keys and per-parameter
+state ('step', 'exp_avg', 'exp_avg_sq'), so optimizer state_dicts are interchangeable with the
+reference's checkpoints (lib/Trainer.py:145-157).  When all parameters (and their .grad) are views
+into one flat buffer -- which resdepth_amd.UNet arranges -- the whole step is ONE kernel launch;
+otherwise it falls back to one launch per tensor (still the HIP kernel, never torch math).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib, ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
+            raise ValueError("invalid Adam hyper-parameter")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        self._flat_state = {}      # group index -> (flat_ptr, m, v)
+        self.grad_scale = 1.0
+
+    @staticmethod
+    def _flat_range(tensors):
+        """(base_ptr, numel) if the tensors tile one contiguous fp32 range in order, else None."""
+        base = tensors[0].data_ptr()
+        off = 0
+        for t in tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() != base + 4 * off:
+                return None
+            off += t.numel()
+        return base, off
+
+    def _ensure_state(self, group, gi):
+        params = [p for p in group["params"]]
+        fr = self._flat_range([p.data for p in params])
+        dev = params[0].device
+        have = self._flat_state.get(gi)
+        if fr is not None:
+            total = fr[1]
+            if have is None or have[0] != fr[0] or have[1].numel() != total:
+                m = torch.zeros(total, device=dev, dtype=torch.float32)
+                v = torch.zeros(total, device=dev, dtype=torch.float32)
+                off = 0
+                for p in params:
+                    st = self.state[p]
+                    n = p.numel()
+                    if "exp_avg" in st:          # e.g. after load_state_dict
+                        m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                        v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    st["exp_avg"] = m[off:off + n].view(p.shape)
+                    st["exp_avg_sq"] = v[off:off + n].view(p.shape)
+                    st.setdefault("step", torch.tensor(0.0))
+                    off += n
+                self._flat_state[gi] = (fr[0], m, v)
+            return self._flat_state[gi]
+        for p in params:
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p.data)
+                st["exp_avg_sq"] = torch.zeros_like(p.data)
+        return None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"]]
+            if not params:
+                continue
+            if any(not p.is_cuda for p in params):
+                raise RuntimeError("resdepth_amd.FusedAdam: parameters must live on a HIP device (no CPU fallback)")
+            if group.get("amsgrad") or group.get("maximize"):
+                raise NotImplementedError("FusedAdam: amsgrad / maximize are not implemented")
+            if any(p.grad is None for p in params):
+                # torch.optim.Adam skips parameters without gradient; the flat kernel cannot
+                active = [p for p in params if p.grad is not None]
+                flat = None
+            else:
+                active = params
+                flat = self._ensure_state(group, gi)
+            b1, b2 = group["betas"]
+            lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
+            if flat is not None:
+                gr = self._flat_range([p.grad for p in params])
+            else:
+                gr = None
+                self._ensure_state_per_tensor(active)
+            # step counter (python float tensors like torch.optim.Adam's default path)
+            for p in active:
+                self.state[p]["step"] += 1
+            if not active:
+                continue
+            t = float(self.state[active[0]]["step"])
+            bc1 = 1.0 - b1 ** t
+            bc2 = 1.0 - b2 ** t
+            step_size = lr / bc1
+            bc2_sqrt = math.sqrt(bc2)
+            if flat is not None and gr is not None and gr[1] == flat[1].numel():
+                total = gr[1]
+                pflat = _as_flat(params[0].data, total)
+                gflat = _as_flat(params[0].grad, total)
+                ops.adam_step(pflat, gflat, flat[1], flat[2], b1, b2, eps, wd, step_size, bc2_sqrt, self.grad_scale)
+                _lib.bump_param_generation(flat[0])
+            else:
+                for p in active:
+                    st = self.state[p]
+                    g = p.grad.contiguous()
+                    ops.adam_step(p.data.view(-1) if p.data.is_contiguous() else p.data, g.view(-1),
+                                  st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1), b1, b2, eps, wd, step_size,
+                                  bc2_sqrt, self.grad_scale)
+                    p.data.add_(0)  # bump the version counter so packed-weight caches notice
+        return loss
+
+    def _ensure_state_per_tensor(self, params):
+        for p in params:
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p.data)
+                st["exp_avg_sq"] = torch.zeros_like(p.data)
+
+
+def _as_flat(first: torch.Tensor, total: int) -> torch.Tensor:
+    """A 1-D view of `total` fp32 elements starting at `first`'s storage position."""
+    return torch.as_strided(first, (total,), (1,), first.storage_offset()) if first.storage_offset() + total <= \
+        first.untyped_storage().nbytes() // 4 else _raise("flat range exceeds storage")
+
+
+def _raise(msg):
+    raise RuntimeError(msg)

@@ -1,0 +1,402 @@
+"""UNet(nn.Module) with the reference's constructor, module tree and state_dict keys
+(lib/UNet.py:104-246), executed by hand-written gfx950 kernels through libresdepth_hip.so.
+
+The sub-modules (nn.Conv2d / nn.BatchNorm2d / nn.ConvTranspose2d ...) are kept ONLY as
+parameter containers so that `state_dict()` / `load_state_dict()` / `parameters()` /
+`.to(device)` / `.train()` / `.eval()` behave exactly like the reference's module and
+published `.pth` checkpoints load unchanged.  `forward()` never calls them: it runs the whole
+network as one autograd.Function over NHWC fp32 activations:
+
+    encoder level i : conv3x3 -> BN stats -> BN-apply+act+maxpool(+argmax)      (lib/UNet.py:201-207)
+    bottleneck      : conv3x3 -> BN stats -> BN-apply+act                       (lib/UNet.py:210)
+    decoder level i : convT2x2 (+bias, +skip ADD fused) -> conv3x3 -> BN -> act (lib/UNet.py:213-224)
+    head            : conv3x3 C->1 (+bias) + x[:,0:1]                           (lib/UNet.py:227-244)
+
+There is no CPU fallback: inputs must live on a HIP device.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+_SLOPES = {"relu": 0.0, "lrelu": 0.01}
+
+
+def _check_valid_activation(choice):
+    # same message / exception type as lib/UNet.py:12-14
+    if choice not in ["relu", "lrelu", "prelu"]:
+        raise ValueError(f"'{choice}' is not a valid activation function. Choose among ['relu', 'lrelu', 'prelu'].\n")
+
+
+def _make_activation(choice):
+    # the reference builds all three and returns one (lib/UNet.py:27-33); none of them draws random numbers
+    return {"relu": nn.ReLU(inplace=True), "lrelu": nn.LeakyReLU(inplace=True), "prelu": nn.PReLU()}[choice]
+
+
+def _conv3x3(cin, cout, bias):
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1, bias=bias)
+
+
+def _upconv(c, mode):
+    # RNG-order contract: the reference's upconv() constructs the bilinear branch's
+    # conv1x1 (weight + bias draws) BEFORE the ConvTranspose2d and discards it (lib/UNet.py:17-24).
+    discarded = nn.Conv2d(c, c, kernel_size=1, stride=1)
+    up = nn.ConvTranspose2d(c, c, kernel_size=2, stride=2)
+    if mode == "bilinear":
+        return nn.Sequential(nn.Upsample(mode="bilinear", scale_factor=2), discarded)
+    return up
+
+
+def _block(cin, cout, act, do_bn):
+    if do_bn:
+        return nn.Sequential(_conv3x3(cin, cout, False), nn.BatchNorm2d(cout), _make_activation(act))
+    return nn.Sequential(_conv3x3(cin, cout, True), _make_activation(act))
+
+
+class SkipConnection(nn.Module):
+    """Parameter-free marker kept for module-tree parity (lib/UNet.py:96-101); the ADD itself is fused
+    into the transposed-convolution epilogue."""
+
+    def forward(self, x_skip, x_up):
+        return x_skip + x_up
+
+
+class UNet(nn.Module):
+    def __init__(self, n_input_channels=1, start_kernel=64, max_filter_depth=512, depth=8,
+                 act_fn_encoder="relu", act_fn_decoder="relu", act_fn_bottleneck="relu", up_mode="transpose",
+                 do_BN=True, bias_conv_layer=False, outer_skip=True, outer_skip_BN=False):
+        super().__init__()
+        _check_valid_activation(act_fn_encoder)
+        _check_valid_activation(act_fn_decoder)
+        _check_valid_activation(act_fn_bottleneck)
+        if up_mode not in ["transpose", "bilinear"]:
+            raise ValueError(f"'{up_mode}' is not a valid mode for upsampling. Choose among ['transpose', 'bilinear'] "
+                             "to specify 'up_mode'.\n")
+        self.n_input_channels = n_input_channels
+        self.start_kernel = start_kernel
+        self.depth = depth
+        self.act_fn_encoder = act_fn_encoder
+        self.act_fn_decoder = act_fn_decoder
+        self.act_fn_bottleneck = act_fn_bottleneck
+        self.up_mode = up_mode
+        self.max_filter_depth = max_filter_depth
+        self.do_BN = do_BN
+        self.bias_conv_layer = bias_conv_layer
+        self.do_outer_skip = outer_skip
+        self.do_outer_skip_BN = outer_skip_BN
+        self.filter_depths = [min(start_kernel * (2 ** i), max_filter_depth) for i in range(depth)]
+        fd = self.filter_depths
+
+        # module tree: same names, same construction (= RNG draw) order as lib/UNet.py:157-194
+        self.encoder = nn.ModuleList()
+        cin = n_input_channels
+        for c in fd:
+            self.encoder.append(nn.Sequential(_block(cin, c, act_fn_encoder, do_BN), nn.MaxPool2d(kernel_size=2, stride=2)))
+            cin = c
+        self.bottleneck = _block(fd[-1], fd[-1], act_fn_bottleneck, do_BN)
+        self.decoder = nn.ModuleList()
+        self.filter_depths_up = list(reversed(fd))
+        for ci, co in zip(self.filter_depths_up[:-1], self.filter_depths_up[1:]):
+            self.decoder.append(nn.Sequential(_upconv(ci, up_mode), _block(ci, co, act_fn_decoder, do_BN)))
+        self.decoder.append(_upconv(self.filter_depths_up[-1], up_mode))
+        self.last_layer = _conv3x3(start_kernel, 1, bias_conv_layer)
+        self.skipconnect = SkipConnection()
+        if self.do_outer_skip:
+            self.layer_outer_skip = nn.ModuleList()
+            if self.do_outer_skip_BN:
+                self.layer_outer_skip.append(nn.BatchNorm2d(1))
+            self.layer_outer_skip.append(SkipConnection())
+
+        # ---- engine state (not part of the state_dict) ----
+        self._flat_param = None      # flat fp32 buffer holding every parameter (views are the nn.Parameters)
+        self._flat_grad = None       # flat fp32 buffer the backward writes gradients into
+        self._offsets = None
+        self._pack_cache = None
+        self._pack_key = None
+        self.grad_sync = None        # optional resdepth_amd.dp.GradSync (data-parallel hooks)
+        self.sync_bn = False
+
+    # ------------------------------------------------------------------------------------------
+    def _unsupported(self) -> Optional[str]:
+        if not self.do_BN:
+            return "do_BN=False"
+        if self.up_mode != "transpose":
+            return "up_mode='bilinear'"
+        for a in (self.act_fn_encoder, self.act_fn_decoder, self.act_fn_bottleneck):
+            if a == "prelu":
+                return "activation 'prelu'"
+        if self.do_outer_skip and self.do_outer_skip_BN:
+            return "outer_skip_BN=True"
+        if self.start_kernel % 4 != 0:
+            return "start_kernel not a multiple of 4"
+        if not 1 <= self.n_input_channels <= 6:
+            return "n_input_channels outside 1..6"
+        return None
+
+    def _param_list(self) -> List[nn.Parameter]:
+        return list(self.parameters())
+
+    def flatten_parameters(self):
+        """Re-home every parameter into one flat fp32 buffer (same values, same Parameter objects) so the
+        gradient all-reduce and the fused Adam step run over one contiguous range."""
+        params = self._param_list()
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, device=dev, dtype=torch.float32)
+        offs = []
+        o = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                flat[o:o + n].copy_(p.data.reshape(-1))
+                p.data = flat[o:o + n].view(p.shape)
+                offs.append(o)
+                o += n
+        self._flat_param = flat
+        self._flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self._offsets = offs
+        self._pack_key = None
+        return flat
+
+    def _ensure_flat(self):
+        params = self._param_list()
+        ok = self._flat_param is not None and self._flat_param.device == params[0].device
+        if ok:
+            base = self._flat_param.data_ptr()
+            for p, o in zip(params, self._offsets):
+                if p.data_ptr() != base + 4 * o:
+                    ok = False
+                    break
+        if not ok:
+            self.flatten_parameters()
+
+    def grad_view(self, index: int, shape):
+        o = self._offsets[index]
+        n = 1
+        for s in shape:
+            n *= s
+        return self._flat_grad[o:o + n].view(shape)
+
+    # ------------------------------------------------------------------------------------------
+    def _packed(self):
+        """GEMM-layout copies of the conv / convT weights, rebuilt whenever a parameter changed."""
+        params = self._param_list()
+        key = (self._flat_param.data_ptr(), _lib.param_generation(self._flat_param.data_ptr()),
+               tuple(p._version for p in params))
+        if self._pack_key == key and self._pack_cache is not None:
+            return self._pack_cache
+        d = self.depth
+        pk = {"enc": [], "dec_t": [], "dec_c": []}
+        for i in range(1, d):
+            pk["enc"].append(ops.pack_conv3x3_weight(self.encoder[i][0][0].weight))
+        pk["bott"] = ops.pack_conv3x3_weight(self.bottleneck[0].weight)
+        for i in range(d):
+            up = self.decoder[i][0] if i < d - 1 else self.decoder[i]
+            pk["dec_t"].append(ops.pack_convt2x2_weight(up.weight))
+            if i < d - 1:
+                pk["dec_c"].append(ops.pack_conv3x3_weight(self.decoder[i][1][0].weight))
+        self._pack_cache, self._pack_key = pk, key
+        return pk
+
+    # ------------------------------------------------------------------------------------------
+    def _bn_forward(self, z, bn: nn.BatchNorm2d, slope, pool, training):
+        c = z.shape[-1]
+        if training:
+            sums = ops.bn_stats_partial(z)
+            count = z.numel() // c
+            if self.sync_bn and self.grad_sync is not None:
+                count = self.grad_sync.allreduce_stats(sums, count)
+            mean, invstd = ops.bn_stats_finalize(sums, count, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                                 eps=bn.eps, momentum=bn.momentum)
+        else:
+            mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, eps=bn.eps)
+            count = z.numel() // c
+        a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, bn.weight, bn.bias, slope, pool)
+        return a, p, idx, mean, invstd, count
+
+    def _engine_forward(self, x, training: bool, save: bool):
+        d = self.depth
+        pk = self._packed()
+        se, sb, sd_ = _SLOPES[self.act_fn_encoder], _SLOPES[self.act_fn_bottleneck], _SLOPES[self.act_fn_decoder]
+        S = {"x": x, "enc": [], "dec": [], "training": training} if save else None
+        skips = []
+        cur = None
+        for i in range(d):
+            blk = self.encoder[i][0]
+            if i == 0:
+                z = ops.conv3x3_first_fwd(x, blk[0].weight)
+            else:
+                z = ops.conv3x3_fwd(cur, pk["enc"][i - 1][0])
+            a, p, idx, mean, invstd, count = self._bn_forward(z, blk[1], se, True, training)
+            skips.append(a)
+            if save:
+                S["enc"].append({"z": z, "idx": idx, "mean": mean, "invstd": invstd, "count": count, "p": p})
+            cur = p
+        zb = ops.conv3x3_fwd(cur, pk["bott"][0])
+        ab, _, _, mean, invstd, count = self._bn_forward(zb, self.bottleneck[1], sb, False, training)
+        if save:
+            S["bott"] = {"z": zb, "mean": mean, "invstd": invstd, "count": count, "a": ab}
+        cur = ab
+        for i in range(d):
+            up = self.decoder[i][0] if i < d - 1 else self.decoder[i]
+            s = ops.convt2x2_fwd(cur, pk["dec_t"][i][0], up.bias, skips[d - 1 - i])
+            skips[d - 1 - i] = None          # the skip tensor is not needed by the backward pass
+            rec = {"s": s}
+            if i < d - 1:
+                blk = self.decoder[i][1]
+                zd = ops.conv3x3_fwd(s, pk["dec_c"][i][0])
+                ad, _, _, mean, invstd, count = self._bn_forward(zd, blk[1], sd_, False, training)
+                rec.update(z=zd, mean=mean, invstd=invstd, count=count, a=ad)
+                cur = ad
+            else:
+                cur = s
+            if save:
+                S["dec"].append(rec)
+        out = ops.conv3x3_last_fwd(cur, self.last_layer.weight, self.last_layer.bias,
+                                   x if self.do_outer_skip else None)
+        return out, S
+
+    def _engine_backward(self, S, dout):
+        """Writes every parameter gradient into a flat gradient buffer; returns the list of views
+        (state_dict / parameters() order).  Order of production: head, decoder levels d-1..0 + bottleneck,
+        encoder levels d-1..0 -- i.e. from the END of the flat buffer towards its start, which is what the
+        data-parallel bucketing in resdepth_amd.dp relies on for overlap."""
+        d = self.depth
+        pk = self._packed()
+        se, sb, sd_ = _SLOPES[self.act_fn_encoder], _SLOPES[self.act_fn_bottleneck], _SLOPES[self.act_fn_decoder]
+        training = S["training"]
+        params = self._param_list()
+        index = {id(p): i for i, p in enumerate(params)}
+        grads = [None] * len(params)
+        # autograd ACCUMULATES into an existing .grad; if the caller kept gradients from a previous step
+        # (the reference sets them to None, lib/Trainer.py:221-222) they may alias the persistent flat
+        # buffer, so write this step's gradients somewhere else.
+        flat = self._flat_grad
+        if any(p.grad is not None for p in params):
+            flat = torch.empty_like(self._flat_grad)
+        sync = self.grad_sync if flat is self._flat_grad else None
+        sync_bn = self.sync_bn and self.grad_sync is not None and training
+
+        def gv(p):
+            i = index[id(p)]
+            o = self._offsets[i]
+            g = flat[o:o + p.numel()].view(p.shape)
+            grads[i] = g
+            return g
+
+        def done(*ps):
+            if sync is not None:
+                sync.params_ready(self, [index[id(p)] for p in ps if p is not None])
+
+        def bn_backward(rec, bn, slope, g_full, g_pool, idx, extra_bias=None):
+            c = rec["z"].shape[-1]
+            sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
+                                         g_pool, idx)
+            if extra_bias is not None:
+                gv(extra_bias).copy_(sums[2 * c:3 * c])
+            if sync_bn:
+                local = sums[:2 * c].clone()
+                self.grad_sync.allreduce_sums(sums)
+                gv(bn.weight).copy_(local[c:2 * c])
+                gv(bn.bias).copy_(local[:c])
+                dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
+                                          g_pool, idx, sums, rec["count"], training)
+            else:
+                dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
+                                          g_pool, idx, sums, rec["count"], training, dgamma=gv(bn.weight),
+                                          dbeta=gv(bn.bias))
+            done(bn.weight, bn.bias, extra_bias)
+            return dz
+
+        dout = dout.contiguous()
+        c0 = self.filter_depths[0]
+        # head (lib/UNet.py:227-244): the outer residual add passes dout straight through to x (not needed)
+        ll = self.last_layer
+        ops.conv3x3_last_bwd_weight(S["dec"][d - 1]["s"], dout, gv(ll.weight),
+                                    gv(ll.bias) if ll.bias is not None else None, want_bias=ll.bias is not None)
+        done(ll.weight, ll.bias)
+        g = ops.conv3x3_last_bwd_data(dout, ll.weight, c0)
+        skipgrad = [None] * d
+        gp = None
+        for i in reversed(range(d)):
+            up = self.decoder[i][0] if i < d - 1 else self.decoder[i]
+            src = S["dec"][i - 1] if i > 0 else S["bott"]
+            ops.convt2x2_bwd_weight(src["a"], g, gv(up.weight))
+            done(up.weight)
+            dprev = ops.convt2x2_bwd_data(g, pk["dec_t"][i][1])
+            skipgrad[d - 1 - i] = g       # gradient wrt the encoder skip a_{d-1-i} (SkipConnection is an ADD)
+            if i > 0:
+                blk = self.decoder[i - 1][1]
+                dz = bn_backward(src, blk[1], sd_, dprev, None, None)
+                ops.conv3x3_bwd_weight(S["dec"][i - 1]["s"], dz, gv(blk[0].weight))
+                done(blk[0].weight)
+                g = ops.conv3x3_bwd_data(dz, pk["dec_c"][i - 1][1])
+            else:
+                dz = bn_backward(src, self.bottleneck[1], sb, dprev, None, None)
+                ops.conv3x3_bwd_weight(S["enc"][d - 1]["p"], dz, gv(self.bottleneck[0].weight))
+                done(self.bottleneck[0].weight)
+                gp = ops.conv3x3_bwd_data(dz, pk["bott"][1])
+        for i in reversed(range(d)):
+            e = S["enc"][i]
+            blk = self.encoder[i][0]
+            # third reduction output = per-channel sum of the skip gradient = bias gradient of the
+            # ConvTranspose2d whose output was added to this skip (decoder level d-1-i)
+            j = d - 1 - i
+            up = self.decoder[j][0] if j < d - 1 else self.decoder[j]
+            dz = bn_backward(e, blk[1], se, skipgrad[i], gp, e["idx"], extra_bias=up.bias)
+            skipgrad[i] = None
+            if i > 0:
+                ops.conv3x3_bwd_weight(S["enc"][i - 1]["p"], dz, gv(blk[0].weight))
+                gp = ops.conv3x3_bwd_data(dz, pk["enc"][i - 1][1])
+            else:
+                ops.conv3x3_first_bwd_weight(S["x"], dz, gv(blk[0].weight))
+            done(blk[0].weight)
+        if sync is not None:
+            sync.finish(self)
+        elif self.grad_sync is not None:
+            self.grad_sync.allreduce_unbucketed(flat)
+        return grads
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, x):
+        why = self._unsupported()
+        if why is not None:
+            raise NotImplementedError(f"resdepth_amd.UNet: {why} is not implemented by the HIP engine yet")
+        if not x.is_cuda:
+            raise RuntimeError("resdepth_amd.UNet runs on MI355X only: move the model and the input to a HIP device "
+                               "(there is no CPU fallback)")
+        if x.dim() != 4 or x.shape[1] != self.n_input_channels:
+            raise ValueError(f"expected input [N, {self.n_input_channels}, T, T], got {tuple(x.shape)}")
+        t = x.shape[2]
+        if x.shape[3] != t or (t & (t - 1)) != 0 or t < 2 ** self.depth:
+            raise ValueError(f"tile size must be a power of two >= 2^depth = {2 ** self.depth} (got {tuple(x.shape[2:])})")
+        x = x.contiguous().float()
+        self._ensure_flat()
+        params = self._param_list()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if not need_grad:
+            out, _ = self._engine_forward(x, self.training, save=False)
+            return out
+        return _UNetFunction.apply(x, self, *params)
+
+
+class _UNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        out, saved = model._engine_forward(x, model.training, save=True)
+        ctx.model = model
+        ctx.saved = saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, S = ctx.model, ctx.saved
+        if S is None:
+            raise RuntimeError("resdepth_amd.UNet: backward called twice (activations were released)")
+        grads = model._engine_backward(S, dout)
+        ctx.saved = None
+        return (None, None, *grads)

@@ -1,0 +1,82 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, the module tree /
+state_dict / RNG-order contract holds, and the product path refuses to run without a GPU."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, load_npz
+from oracle import unet_oracle as O
+
+
+def test_library_exports_every_declared_symbol():
+    from resdepth_amd import _lib
+    lib = _lib.load()            # raises if the .so is missing or a symbol is absent
+    hdr = open(os.path.join(ROOT, "include", "resdepth_hip.h")).read()
+    declared = set(re.findall(r"\b(rd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rd_version() >= 100
+
+
+@pytest.mark.parametrize("c,sk,d,bias", [(3, 64, 5, True), (1, 8, 3, False), (2, 16, 4, True)])
+def test_module_tree_matches_reference_layout(c, sk, d, bias):
+    from resdepth_amd import UNet
+    spec = O.Spec(n_input_channels=c, start_kernel=sk, depth=d, bias_conv_layer=bias)
+    torch.manual_seed(3)
+    m = UNet(n_input_channels=c, start_kernel=sk, depth=d, bias_conv_layer=bias)
+    sd = m.state_dict()
+    layout = O.param_layout(spec)
+    assert list(sd.keys()) == [k for k, _, _ in layout]
+    for k, shape, _ in layout:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    ref = O.init_state_dict(spec, 3)              # same seed -> identical weights (RNG draw order)
+    for k in sd:
+        assert torch.equal(sd[k], ref[k]), k
+    assert [n for n, _ in m.named_parameters()] == O.param_keys(spec)
+
+
+def test_golden_state_dict_loads():
+    import json
+    from resdepth_amd import UNet
+    g = load_npz("g1_tiny3.npz")
+    kwargs = json.loads(str(g["kwargs_json"]))
+    m = UNet(**kwargs)
+    sd = {k[len("init/"):]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("init/")}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+def test_constructor_errors_match_reference():
+    from resdepth_amd import UNet
+    with pytest.raises(ValueError, match="not a valid activation function"):
+        UNet(act_fn_encoder="gelu")
+    with pytest.raises(ValueError, match="not a valid mode for upsampling"):
+        UNet(up_mode="nearest")
+
+
+def test_no_cpu_fallback():
+    from resdepth_amd import UNet, masked_l1_loss, FusedAdam
+    m = UNet(n_input_channels=1, start_kernel=4, depth=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        masked_l1_loss(torch.zeros(1, 1, 4, 4), torch.zeros(1, 1, 4, 4), torch.ones(1, 1, 4, 4, dtype=torch.bool),
+                       torch.zeros(1), torch.ones(1))
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "resdepth_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

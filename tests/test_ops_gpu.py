@@ -1,0 +1,305 @@
+"""Per-kernel parity (-m gpu): every C-ABI entry point against the torch-CPU op the reference calls
+(the oracle's arithmetic), on seeded inputs, plus the committed known-answer fixtures (g4_ops.npz).
+
+Tolerances: fp32 accumulation-order noise only -- rel-L2 <= 2e-6 for GEMM-like ops, max-abs scaled
+<= 1e-5; integer outputs (pool indices) bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def nhwc(t):      # NCHW cpu -> NHWC gpu
+    return t.permute(0, 2, 3, 1).contiguous().to(dev())
+
+
+def nchw(t):      # NHWC gpu -> NCHW cpu
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def close(a, b, tol=2e-6, name=""):
+    r = rel_l2(a, b)
+    assert r <= tol, f"{name}: rel-L2 {r:.3e} > {tol}"
+    scale = float(b.abs().max()) + 1e-30
+    m = float((a.double() - b.double()).abs().max()) / scale
+    assert m <= 50 * tol, f"{name}: max-abs/scale {m:.3e}"
+
+
+CONV_SHAPES = [  # n, h, w, cin, cout
+    (2, 8, 16, 8, 24),        # ragged channels, 64x64 tile path, edge predication
+    (1, 4, 4, 4, 4),          # minimum
+    (8, 64, 64, 32, 128),     # 128x128 tiles
+    (8, 64, 64, 64, 64),      # 128x64 tiles
+    (2, 16, 16, 128, 256),    # multi K-chunk per tap, 64x64 path
+    (3, 32, 32, 20, 36),      # non-power-of-two channels
+]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", CONV_SHAPES)
+def test_conv3x3_fwd_dgrad_wgrad(n, h, w, cin, cout):
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(n * 1000 + cin)
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).requires_grad_(True)
+    gy = torch.randn(n, cout, h, w, generator=g)
+    y = F.conv2d(x, wt, None, 1, 1)
+    y.backward(gy)
+    wf, wd = ops.pack_conv3x3_weight(wt.detach().to(dev()))
+    z = ops.conv3x3_fwd(nhwc(x.detach()), wf)
+    close(nchw(z), y.detach(), name="fwd")
+    dx = ops.conv3x3_bwd_data(nhwc(gy), wd)
+    close(nchw(dx), x.grad, name="dgrad")
+    dw = ops.conv3x3_bwd_weight(nhwc(x.detach()), nhwc(gy))
+    close(dw.cpu(), wt.grad, name="wgrad")
+
+
+CONVT_SHAPES = [(2, 4, 8, 8, 12), (1, 2, 2, 4, 4), (4, 16, 16, 128, 128), (8, 32, 32, 64, 64), (2, 8, 8, 256, 256)]
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", CONVT_SHAPES)
+def test_convt2x2_fwd_dgrad_wgrad(n, h, w, cin, cout):
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(n * 77 + cin)
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cin, cout, 2, 2, generator=g) / cin ** 0.5).requires_grad_(True)
+    b = torch.randn(cout, generator=g, requires_grad=True)
+    skip = torch.randn(n, cout, 2 * h, 2 * w, generator=g)
+    gy = torch.randn(n, cout, 2 * h, 2 * w, generator=g)
+    y = skip + F.conv_transpose2d(x, wt, b, stride=2)
+    y.backward(gy)
+    wtf, wtd = ops.pack_convt2x2_weight(wt.detach().to(dev()))
+    out = ops.convt2x2_fwd(nhwc(x.detach()), wtf, b.detach().to(dev()), nhwc(skip))
+    close(nchw(out), y.detach(), name="fwd")
+    out2 = ops.convt2x2_fwd(nhwc(x.detach()), wtf, None, None)
+    close(nchw(out2), F.conv_transpose2d(x.detach(), wt.detach(), None, stride=2), name="fwd-nobias")
+    dx = ops.convt2x2_bwd_data(nhwc(gy), wtd)
+    close(nchw(dx), x.grad, name="dgrad")
+    dw = ops.convt2x2_bwd_weight(nhwc(x.detach()), nhwc(gy))
+    close(dw.cpu(), wt.grad, name="wgrad")
+    db = ops.channel_sum(nhwc(gy))
+    close(db.cpu(), b.grad, name="dbias")
+
+
+def test_convt_known_answer(g4):
+    from resdepth_amd import ops
+    t = lambda k: torch.from_numpy(g4["convt/" + k].copy())
+    wtf, wtd = ops.pack_convt2x2_weight(t("w").to(dev()))
+    # fixture has cin=4, cout=6 (cout not a multiple of 4 -> only the forward and wgrad-free parts apply)
+    out = ops.convt2x2_fwd(nhwc(t("x")), wtf, t("b").to(dev()), None)
+    close(nchw(out), t("y"), name="convt KA fwd")
+
+
+def test_conv_known_answer(g4):
+    from resdepth_amd import ops
+    t = lambda k: torch.from_numpy(g4["conv/" + k].copy())
+    wf, wd = ops.pack_conv3x3_weight(t("w").to(dev()))
+    close(nchw(ops.conv3x3_fwd(nhwc(t("x")), wf)), t("y"), name="conv KA fwd")
+    close(nchw(ops.conv3x3_bwd_data(nhwc(t("gy")), wd)), t("gx"), name="conv KA dgrad")
+    close(ops.conv3x3_bwd_weight(nhwc(t("x")), nhwc(t("gy"))).cpu(), t("gw"), name="conv KA wgrad")
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 32, 32, 3, 8), (1, 16, 16, 1, 4), (3, 8, 64, 2, 64), (2, 64, 64, 3, 64),
+                                            (1, 16, 16, 6, 12)])
+def test_first_conv(n, h, w, cin, cout):
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(cin * 10 + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / 3).requires_grad_(True)
+    gy = torch.randn(n, cout, h, w, generator=g)
+    y = F.conv2d(x, wt, None, 1, 1)
+    y.backward(gy)
+    z = ops.conv3x3_first_fwd(x.to(dev()), wt.detach().to(dev()))
+    close(nchw(z), y.detach(), name="first fwd")
+    dw = ops.conv3x3_first_bwd_weight(x.to(dev()), nhwc(gy))
+    close(dw.cpu(), wt.grad, tol=5e-6, name="first wgrad")
+
+
+@pytest.mark.parametrize("n,h,w,c,xc,bias", [(2, 32, 32, 8, 3, True), (1, 16, 16, 4, 1, False), (2, 64, 64, 64, 3, True),
+                                             (3, 8, 8, 20, 2, True)])
+def test_last_conv(n, h, w, c, xc, bias):
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(c)
+    s = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(1, c, 3, 3, generator=g) / (3 * c ** 0.5)).requires_grad_(True)
+    b = torch.randn(1, generator=g, requires_grad=True) if bias else None
+    x = torch.randn(n, xc, h, w, generator=g)
+    gy = torch.randn(n, 1, h, w, generator=g)
+    y = x[:, 0:1] + F.conv2d(s, wt, b, 1, 1)
+    y.backward(gy)
+    out = ops.conv3x3_last_fwd(nhwc(s.detach()), wt.detach().to(dev()), b.detach().to(dev()) if bias else None,
+                               x.to(dev()))
+    close(out.cpu(), y.detach(), name="last fwd")
+    ds = ops.conv3x3_last_bwd_data(gy.to(dev()), wt.detach().to(dev()), c)
+    close(nchw(ds), s.grad, name="last dgrad")
+    dw, db = ops.conv3x3_last_bwd_weight(nhwc(s.detach()), gy.to(dev()), want_bias=bias)
+    close(dw.cpu(), wt.grad, tol=5e-6, name="last wgrad")
+    if bias:
+        close(db.cpu(), b.grad, tol=5e-6, name="last dbias")
+
+
+@pytest.mark.parametrize("n,h,w,c,slope,pool", [(3, 8, 8, 8, 0.0, True), (2, 16, 32, 64, 0.0, True),
+                                                (2, 16, 16, 12, 0.01, True), (4, 8, 8, 512, 0.0, False),
+                                                (2, 4, 4, 32, 0.01, False)])
+def test_bn_act_pool_forward_backward(n, h, w, c, slope, pool):
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(c + n)
+    x = (torch.randn(n, c, h, w, generator=g) * 1.7 + 0.6).requires_grad_(True)
+    gam = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
+    bet = (torch.randn(c, generator=g) * 0.3).requires_grad_(True)
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    y = F.batch_norm(x, rm, rv, gam, bet, True, 0.1, 1e-5)
+    a = F.leaky_relu(y, slope) if slope else F.relu(y)
+    if pool:
+        p, idx = F.max_pool2d(a, 2, 2, return_indices=True)
+        g_pool = torch.randn(p.shape, generator=g)
+        g_full = torch.randn(a.shape, generator=g)
+        (p * g_pool).sum().add((a * g_full).sum()).backward()
+    else:
+        g_full = torch.randn(a.shape, generator=g)
+        (a * g_full).sum().backward()
+    z = nhwc(x.detach())
+    drm, drv = rm0.to(dev()), rv0.to(dev())
+    nbt = torch.zeros((), dtype=torch.long, device=dev())
+    sums = ops.bn_stats_partial(z)
+    mean, invstd = ops.bn_stats_finalize(sums, n * h * w, drm, drv, nbt)
+    assert int(nbt) == 1
+    np.testing.assert_allclose(drm.cpu().numpy(), rm.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(drv.cpu().numpy(), rv.numpy(), rtol=1e-5, atol=1e-6)
+    ga, be = gam.detach().to(dev()), bet.detach().to(dev())
+    da, dp, didx = ops.bn_act_pool_fwd(z, mean, invstd, ga, be, slope, pool)
+    close(nchw(da), a.detach(), tol=2e-6, name="bn act")
+    if pool:
+        # bit-exact pooling given identical inputs: pool OUR activation with torch and compare
+        p2, idx2 = F.max_pool2d(nchw(da), 2, 2, return_indices=True)
+        assert torch.equal(nchw(dp), p2)
+        iy, ix = idx2 // w, idx2 % w
+        pos = (iy % 2) * 2 + (ix % 2)
+        assert torch.equal(nchw(didx).long(), pos)
+    gf = nhwc(g_full)
+    gp = nhwc(g_pool) if pool else None
+    bs = ops.bn_act_bwd_reduce(z, mean, invstd, ga, be, slope, gf, gp, didx)
+    dgam = torch.empty(c, device=dev())
+    dbet = torch.empty(c, device=dev())
+    dz = ops.bn_act_bwd_apply(z, mean, invstd, ga, be, slope, gf, gp, didx, bs, n * h * w, True, dgam, dbet)
+    close(nchw(dz), x.grad, tol=2e-5, name="bn dz")
+    close(dgam.cpu(), gam.grad, tol=1e-5, name="dgamma")
+    close(dbet.cpu(), bet.grad, tol=1e-5, name="dbeta")
+    close(bs[2 * c:].float().cpu(), g_full.sum((0, 2, 3)), tol=1e-5, name="sum g_full")
+    # eval mode: running statistics, constants in the backward
+    emean, einv = ops.bn_eval_stats(drm, drv)
+    ea, _, _ = ops.bn_act_pool_fwd(z, emean, einv, ga, be, slope, False)
+    ye = F.batch_norm(x.detach(), rm, rv, gam.detach(), bet.detach(), False, 0.1, 1e-5)
+    close(nchw(ea), F.leaky_relu(ye, slope) if slope else F.relu(ye), tol=2e-6, name="bn eval")
+
+
+def test_pool_ties_and_nan_known_answer(g4):
+    """first maximum in row-major window order; NaN wins (golden from torch's MaxPool2d)."""
+    from resdepth_amd import ops
+    x = torch.from_numpy(g4["pool/x"].copy())              # [1,1,4,8]
+    xx = x.repeat(1, 4, 1, 1)                              # 4 channels (kernels want C % 4 == 0)
+    z = nhwc(xx)
+    one, zero = torch.ones(4, device=dev()), torch.zeros(4, device=dev())
+    a, p, idx = ops.bn_act_pool_fwd(z, zero, one, one, zero, 1.0, True)   # slope 1 => identity activation
+    ref_p = torch.from_numpy(g4["pool/y"])
+    ref_i = torch.from_numpy(g4["pool/idx"]).long()
+    pos = ((ref_i // 8) % 2) * 2 + (ref_i % 8) % 2
+    got_p = nchw(p)[:, 0:1]
+    assert torch.equal(torch.isnan(got_p), torch.isnan(ref_p))
+    assert torch.equal(torch.nan_to_num(got_p, nan=7.0), torch.nan_to_num(ref_p, nan=7.0))
+    assert torch.equal(nchw(idx)[:, 0:1].long(), pos)
+    # backward routing on the random relu case
+    x2 = torch.from_numpy(g4["pool2/x"].copy())            # [2,5,8,8]
+    x2 = torch.cat([x2, x2[:, :3]], 1)                     # 8 channels
+    gy = torch.from_numpy(g4["pool2/gy"].copy())
+    gy = torch.cat([gy, gy[:, :3]], 1)
+    gx = torch.from_numpy(g4["pool2/gx"].copy())
+    gx = torch.cat([gx, gx[:, :3]], 1)
+    one, zero = torch.ones(8, device=dev()), torch.zeros(8, device=dev())
+    z2 = nhwc(x2)
+    a, p, idx = ops.bn_act_pool_fwd(z2, zero, one, one, zero, 1.0, True)
+    sums = ops.bn_act_bwd_reduce(z2, zero, one, one, zero, 1.0, None, nhwc(gy), idx)
+    dz = ops.bn_act_bwd_apply(z2, zero, one, one, zero, 1.0, None, nhwc(gy), idx, sums, 1.0, False)
+    assert torch.equal(nchw(dz), gx)
+
+
+def test_masked_l1_known_answers(g4):
+    from resdepth_amd import masked_l1_loss
+    t = lambda k: torch.from_numpy(g4["l1/" + k].copy())
+    yp = t("yp").to(dev()).requires_grad_(True)
+    loss = masked_l1_loss(yp, t("yt"), t("mask"), t("mean"), t("std"))
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(g4["l1/loss"]), rtol=2e-6)
+    np.testing.assert_allclose(yp.grad.cpu().numpy(), g4["l1/gyp"], rtol=2e-6, atol=0)
+    yp2 = t("yp").to(dev()).requires_grad_(True)
+    loss0 = masked_l1_loss(yp2, t("yt"), torch.zeros_like(t("mask")), t("mean"), t("std"))
+    loss0.backward()
+    assert np.isnan(float(loss0)) and np.isnan(float(g4["l1/loss_allmasked"]))
+    np.testing.assert_array_equal(yp2.grad.cpu().numpy(), g4["l1/gyp_allmasked"])
+
+
+def test_masked_l1_random_vs_oracle():
+    from oracle import unet_oracle as O
+    from resdepth_amd import masked_l1_loss
+    b = O.synthetic_batch(5, 1, 64, seed=11)
+    g = torch.Generator().manual_seed(5)
+    yp = (b["target"] + 0.2 * torch.randn(b["target"].shape, generator=g)).requires_grad_(True)
+    std = torch.rand(5, generator=g) * 3 + 0.5
+    ref = O.masked_l1_loss(yp, b["target"], b["loss_mask"], b["dsm_mean"], std)
+    ref.backward()
+    ypd = yp.detach().to(dev()).requires_grad_(True)
+    loss = masked_l1_loss(ypd, b["target"], b["loss_mask"], b["dsm_mean"], std)
+    (loss * 2.5).backward()
+    np.testing.assert_allclose(float(loss), float(ref), rtol=2e-6)
+    np.testing.assert_allclose(ypd.grad.cpu().numpy(), 2.5 * yp.grad.numpy(), rtol=3e-6, atol=0)
+
+
+def test_adam_known_answers(g4):
+    from resdepth_amd import FusedAdam
+    p = torch.nn.Parameter(torch.from_numpy(g4["adam/p0"].copy()).to(dev()))
+    opt = FusedAdam([p], lr=2e-4, weight_decay=1e-5)
+    gs = torch.from_numpy(g4["adam/g"].copy()).to(dev())
+    p.grad = gs[0].clone()
+    opt.step()
+    np.testing.assert_allclose(p.detach().cpu().numpy(), g4["adam/p1"], rtol=2e-6, atol=1e-8)
+    opt.state[p]["step"] = torch.tensor(999.0)
+    p.grad = gs[1].clone()
+    opt.step()
+    np.testing.assert_allclose(p.detach().cpu().numpy(), g4["adam/p1000"], rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(opt.state[p]["exp_avg"].cpu().numpy(), g4["adam/m1000"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(opt.state[p]["exp_avg_sq"].cpu().numpy(), g4["adam/v1000"], rtol=2e-6, atol=1e-12)
+    # state_dict interchangeable with torch.optim.Adam
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(257))], lr=2e-4, weight_decay=1e-5)
+    sd = opt.state_dict()
+    sd["state"] = {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()}
+    ref.load_state_dict(sd)
+    assert float(ref.state[ref.param_groups[0]["params"][0]]["step"]) == 1000.0
+
+
+def test_layout_roundtrip():
+    from resdepth_amd import ops
+    x = torch.randn(3, 5, 8, 4).to(dev())
+    y = ops.nchw_to_nhwc(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw(y), x)
+
+
+def test_errors_are_reported():
+    from resdepth_amd import ops
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        ops.conv3x3_fwd(torch.zeros(1, 4, 4, 3, device=dev()), torch.zeros(8, 9, 3, device=dev()))
+    with pytest.raises(RuntimeError, match="powers of two"):
+        ops.conv3x3_fwd(torch.zeros(1, 6, 4, 4, device=dev()), torch.zeros(8, 9, 4, device=dev()))
