@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""ResDepth hot-path benchmark: DSM tiles/s, forward + backward + Adam (+ DP gradient sync) on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1] (cfg-S): config_ResDepth-stereo, 3-channel 256x256 tiles, depth-5 U-Net,
+batch 32 per GPU (weak scaling: 8 GPUs = global batch 256), fp32, synthetic tiles already resident in HBM,
+default-initialised weights.  One "step" = the reference's training iteration (lib/Trainer.py:159-222):
+forward, masked de-normalised L1, backward, Adam step, gradients cleared -- with the scalar loss kept on the
+device and read back after the timed region (the reference's per-step loss.item() would only add a host sync).
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel class, timed with HIP events on the
+launch stream over the timed region (rd_prof_*, include/resdepth_hip.h); `cpu_baseline` is the oracle
+(torch-CPU restatement of the reference step) on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_TILE = 59.33e9        # fwd+bwd, cfg-S (SURVEY.md 8d / BASELINE.md section 2)
+PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+MFMA_CLASSES = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "convt2x2_fwd", "convt2x2_dgrad", "convt2x2_wgrad")
+
+
+def cpu_baseline(batch=4, timed=2):
+    """The oracle's train step (same module graph / loss / Adam as the reference) on the host CPU."""
+    from oracle import unet_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    spec = O.Spec(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True)
+    sd = O.init_state_dict(spec, 0)
+    b = O.synthetic_batch(batch, 3, 256, seed=1234)
+    state = {}
+    O.train_step(sd, b, spec, state)                      # warm-up
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        O.train_step(sd, b, spec, state)
+    dt = (time.perf_counter() - t0) / timed
+    return {"value": round(batch / dt, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{timed} timed + 1 warm-up train steps (fwd+bwd+Adam) of batch {batch}, 3-ch 256x256 depth-5, "
+                      f"torch-CPU oracle, {dt * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="tiles per GPU")
+    ap.add_argument("--sync-bn", action="store_true", help="SyncBN (single-device-equivalent statistics)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
+              f"(WORLD_SIZE={world})", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from resdepth_amd import UNet, FusedAdam, masked_l1_loss, _lib, dp
+    from oracle import unet_oracle as O   # synthetic batch generator + cpu_baseline only (never the measured path)
+    _lib.load()
+
+    gs = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(0)
+    model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).train()
+    if world > 1:
+        gs = dp.attach(model, sync_bn=args.sync_bn)
+        dp.broadcast_parameters(model, 0)
+    opt = FusedAdam(model.parameters(), lr=2e-4, weight_decay=1e-5)
+
+    n = args.batch
+    b = O.synthetic_batch(n, 3, 256, seed=1234 + rank)
+    x = b["input"].to(dev)
+    y = b["target"].to(dev)
+    mask = b["loss_mask"].to(dev)
+    mean, std = b["dsm_mean"].to(torch.float32).to(dev), b["dsm_std"].to(dev)
+    params = list(model.parameters())
+    losses = []
+
+    def step():
+        y_pred = model(x)
+        loss = masked_l1_loss(y_pred, y, mask, mean, std, grad_sync=gs)
+        loss.backward()
+        opt.step()
+        for p in params:
+            p.grad = None                     # lib/Trainer.py:221-222
+        losses.append(loss.detach())
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    prof = not args.no_prof
+    if prof:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+    losses.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if prof:
+        _lib.prof_enable(False)
+        kern = _lib.prof_collect()
+    else:
+        kern = []
+    loss_vals = [float(v) for v in losses]
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        tiles_s = n * world * args.steps / dt
+        kernels = []
+        for k in sorted(kern, key=lambda e: -e["ms"]):
+            if k["launches"] == 0:
+                continue
+            e = {"name": k["name"], "launches_per_step": k["launches"] / args.steps,
+                 "ms_per_step": round(k["ms"] / args.steps, 4)}
+            if k["flops"] > 0:
+                e["tflops"] = round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2)
+            if k["bytes"] > 0:
+                e["alg_gbs"] = round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1)
+            kernels.append(e)
+        roof = None
+        mf = [k for k in kern if k["name"] in MFMA_CLASSES and k["launches"] > 0]
+        if mf:
+            dom = max(mf, key=lambda e: e["ms"])
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roof = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                    "alg_flop_per_launch": dom["flops"] / dom["launches"],
+                    "launches_per_step": dom["launches"] / args.steps}
+        out = {
+            "metric": "DSM tiles/sec fwd+bwd (256x256, 3-ch, depth-5 U-Net)", "value": round(tiles_s, 2),
+            "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (randn tiles resident in HBM, default-initialised weights)",
+            "config": {"workload": "config_ResDepth-stereo (cfg-S): 3-ch 256x256 tiles, depth-5 U-Net, fwd+loss+bwd+Adam",
+                       "tiles_per_gpu": n, "global_batch": n * world,
+                       "parallelism": f"dp{world}" + ("+syncbn" if args.sync_bn else "")},
+            "e2e": {"tflops": round(tiles_s / world * FLOP_PER_TILE / 1e12, 2),
+                    "frac_f32_peak": round(tiles_s / world * FLOP_PER_TILE / 1e12 / PEAK_F32_TFLOPS, 4)},
+            "roofline": roof,
+            "kernels": kernels,
+            "loss_first_last": [round(loss_vals[0], 6), round(loss_vals[-1], 6)] if loss_vals else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -206,7 +206,7 @@ def op_cases():
     out["pool2/x"], out["pool2/y"], out["pool2/idx"] = xr.detach().numpy(), p.detach().numpy(), idx.numpy().astype(np.int32)
     out["pool2/gy"], out["pool2/gx"] = gy.numpy(), xr.grad.numpy()
     # transposed conv k2 s2 (+bias) index mapping (lib/UNet.py:21)
-    x = torch.randn(2, 4, 3, 5, generator=g, requires_grad=True)
+    x = torch.randn(2, 4, 4, 8, generator=g, requires_grad=True)
     w = torch.randn(4, 6, 2, 2, generator=g, requires_grad=True)
     b = torch.randn(6, generator=g, requires_grad=True)
     y = F.conv_transpose2d(x, w, b, stride=2)
@@ -215,7 +215,7 @@ def op_cases():
     for k, v in dict(x=x, w=w, b=b, y=y, gy=gy, gx=x.grad, gw=w.grad, gb=b.grad).items():
         out["convt/" + k] = v.detach().numpy()
     # conv3x3 pad 1 (lib/UNet.py:4-5)
-    x = torch.randn(2, 4, 6, 6, generator=g, requires_grad=True)
+    x = torch.randn(2, 4, 8, 4, generator=g, requires_grad=True)
     w = torch.randn(8, 4, 3, 3, generator=g, requires_grad=True)
     y = F.conv2d(x, w, None, 1, 1)
     gy = torch.randn(y.shape, generator=g)

