@@ -36,7 +36,9 @@ MFMA_CLASSES = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "convt2x2_fwd",
 def cpu_baseline(batch=4, timed=2):
     """The oracle's train step (same module graph / loss / Adam as the reference) on the host CPU."""
     from oracle import unet_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # thread count: best of a measured sweep on the 2 x 64-core EPYC 9575F host of the MI355X box
+    # (8: 0.59, 16: 0.54, 32: 0.62, 64: 1.10 s/step at batch 4; all 256 hardware threads: 62 s/step)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     spec = O.Spec(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True)
     sd = O.init_state_dict(spec, 0)
     b = O.synthetic_batch(batch, 3, 256, seed=1234)

@@ -146,7 +146,8 @@ int rd_masked_l1_finish(const float* yp, const float* y, const uint8_t* mask, co
 
 /* ---- torch.optim.Adam step over a flat buffer (lib/utils.py:329-331) ---------------- */
 /* g += wd*p; m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps) */
-int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, float beta1, float beta2, float eps,
+/* beta1/beta2 are doubles so that (1-beta) is formed from the host's double scalars exactly like torch does */
+int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, double beta1, double beta2, float eps,
                  float weight_decay, float step_size, float bc2_sqrt, float grad_scale, rd_stream_t s);
 
 /* ---- layout helpers ----------------------------------------------------------------- */

@@ -41,13 +41,40 @@ __device__ __forceinline__ void reduce_rows(double (&vals)[K], double* red, int 
     __syncthreads();
 }
 
-// sums[q*C + c] = sum_b partial[(b*Q + q)*C + c]
-__global__ void partial_reduce_kernel(const double* __restrict__ partial, double* __restrict__ sums, int nb, int QC) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= QC) return;
+// Second-stage reduction helper: one block = 16 columns x 16 slices of the partial rows; every thread sums its
+// slice with four loads in flight, the 16 slice sums are combined in fixed order (deterministic).  Result valid
+// for threadIdx.x < 16 (column = blockIdx.x*16 + threadIdx.x).
+template <typename T>
+__device__ __forceinline__ double sliced_column_sum(const T* __restrict__ partial, int nb, long stride, int ncols,
+                                                    double* red) {
+    const int t = threadIdx.x, slice = t >> 4, col = blockIdx.x * 16 + (t & 15);
     double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += partial[(long)b * QC + e];
-    sums[e] = s;
+    if (col < ncols) {
+        int b = slice;
+        for (; b + 48 < nb; b += 64) {
+            const T v0 = partial[(long)b * stride + col], v1 = partial[(long)(b + 16) * stride + col];
+            const T v2 = partial[(long)(b + 32) * stride + col], v3 = partial[(long)(b + 48) * stride + col];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; b < nb; b += 16) s += (double)partial[(long)b * stride + col];
+    }
+    red[t] = s;
+    __syncthreads();
+    double r = 0.0;
+    if (t < 16) {
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) r += red[sl * 16 + t];
+    }
+    return r;
+}
+
+// sums[q*C + c] = sum_b partial[(b*Q + q)*C + c]
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const double* __restrict__ partial,
+                                                             double* __restrict__ sums, int nb, int QC) {
+    __shared__ double red[256];
+    const double r = sliced_column_sum<double>(partial, nb, QC, QC, red);
+    const int col = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x < 16 && col < QC) sums[col] = r;
 }
 
 struct RowPlan {
@@ -59,7 +86,7 @@ static bool plan_rows(long rows, int C, RowPlan* pl) {
     if (C % 4 != 0 || C / 4 > 256 || C <= 0) return false;
     pl->CQ = C / 4;
     pl->RP = 256 / pl->CQ;
-    long rpb = (rows + 1023) / 1024;
+    long rpb = (rows + 511) / 512;          // <= 512 first-stage blocks; the row loops are unrolled for MLP
     const long minr = (long)pl->RP * 8;
     if (rpb < minr) rpb = minr;
     rpb = (rpb + pl->RP - 1) / pl->RP * pl->RP;
@@ -83,13 +110,25 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
     long r1 = r0 + rows_per_block;
     if (r1 > P) r1 = P;
     if (active) {
-        for (long r = r0 + pr; r < r1; r += RP) {
-            const float4 x = *reinterpret_cast<const float4*>(z + r * C + cq * 4);
-            v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
-            if (SQ) {
-                v[4] += (double)x.x * x.x; v[5] += (double)x.y * x.y;
-                v[6] += (double)x.z * x.z; v[7] += (double)x.w * x.w;
+        // 8 independent 16-byte loads in flight per lane; fp32 partials over 8 rows, fp64 across groups
+        for (long r = r0 + pr; r < r1; r += 8L * RP) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long rr = r + (long)u * RP;
+                x[u] = rr < r1 ? *reinterpret_cast<const float4*>(z + rr * C + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s0 += x[u].x; s1 += x[u].y; s2 += x[u].z; s3 += x[u].w;
+                if (SQ) {
+                    q0 = fmaf(x[u].x, x[u].x, q0); q1 = fmaf(x[u].y, x[u].y, q1);
+                    q2 = fmaf(x[u].z, x[u].z, q2); q3 = fmaf(x[u].w, x[u].w, q3);
+                }
+            }
+            v[0] += s0; v[1] += s1; v[2] += s2; v[3] += s3;
+            if (SQ) { v[4] += q0; v[5] += q1; v[6] += q2; v[7] += q3; }
         }
     }
     reduce_rows<8>(v, red, t, CQ, RP, active);
@@ -234,6 +273,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
     long r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
     if (active) {
+#pragma unroll 2
         for (long row = r0 + pr; row < r1; row += RP) {
             long base = row;
             float gp[4] = {0, 0, 0, 0};
@@ -251,6 +291,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
                     pi[0] = i4.x; pi[1] = i4.y; pi[2] = i4.z; pi[3] = i4.w;
                 }
             }
+            float pacc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < (POOL ? 4 : 1); ++k) {
                 const long pix = POOL ? base + (k >> 1) * W + (k & 1) : base;
@@ -267,14 +308,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
                     const float gm = g * act_grad(y, slope);
                     const float xh = (x[q] - mu[q]) * is[q];
                     if (!APPLY) {
-                        acc[q] += gm;
-                        acc[4 + q] += (double)gm * xh;
-                        acc[8 + q] += gf[q];
+                        pacc[q] += gm;
+                        pacc[4 + q] = fmaf(gm, xh, pacc[4 + q]);
+                        pacc[8 + q] += gf[q];
                     } else {
                         o[q] = training ? sc[q] * (gm - k1[q] - xh * k2[q]) : sc[q] * gm;
                     }
                 }
                 if (APPLY) *reinterpret_cast<float4*>(dz + pix * C + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            if (!APPLY) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) acc[q] += (double)pacc[q];
             }
         }
     }
@@ -385,15 +430,16 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 }
 
 // dw[(co*CIN + ci)*9 + tap] = sum_b partial[b][tap*CIN + ci][co]
-__global__ void first_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nb, int CIN,
-                                          int Cout) {
-    const int NT = 9 * CIN;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= NT * Cout) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += (double)partial[(long)b * NT * Cout + e];
-    const int j = e / Cout, co = e % Cout, tap = j / CIN, ci = j % CIN;
-    dw[((long)co * CIN + ci) * 9 + tap] = (float)s;
+__global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                                 float* __restrict__ dw, int nb, int CIN, int Cout) {
+    __shared__ double red[256];
+    const int NT = 9 * CIN, tot = NT * Cout;
+    const double r = sliced_column_sum<float>(partial, nb, tot, tot, red);
+    const int e = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x < 16 && e < tot) {
+        const int j = e / Cout, co = e % Cout, tap = j / CIN, ci = j % CIN;
+        dw[((long)co * CIN + ci) * 9 + tap] = (float)r;
+    }
 }
 
 // ---- last convolution C -> 1 (+bias, + x0) ----------------------------------------------------
@@ -528,18 +574,20 @@ __global__ __launch_bounds__(256) void conv_last_wgrad_kernel(const float* __res
 }
 
 // dw[ci*9 + tap] = sum_b partial[b][tap*C + ci]; dbias = sum_b partial[b][9*C]
-__global__ void last_wgrad_reduce_kernel(const double* __restrict__ partial, float* __restrict__ dw,
-                                         float* __restrict__ dbias, int nb, int C) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void last_wgrad_reduce_kernel(const double* __restrict__ partial,
+                                                                float* __restrict__ dw, float* __restrict__ dbias,
+                                                                int nb, int C) {
+    __shared__ double red[256];
     const int tot = 9 * C + 1;
-    if (e >= tot) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += partial[(long)b * tot + e];
-    if (e == 9 * C) {
-        if (dbias) dbias[0] = (float)s;
-    } else {
-        const int tap = e / C, ci = e % C;
-        dw[ci * 9 + tap] = (float)s;
+    const double r = sliced_column_sum<double>(partial, nb, tot, tot, red);
+    const int e = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x < 16 && e < tot) {
+        if (e == 9 * C) {
+            if (dbias) dbias[0] = (float)r;
+        } else {
+            const int tap = e / C, ci = e % C;
+            dw[ci * 9 + tap] = (float)r;
+        }
     }
 }
 
@@ -576,11 +624,27 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict
     }
 }
 
-__global__ void l1_reduce_kernel(const double* __restrict__ partial, double* __restrict__ sums, int nb) {
-    if (threadIdx.x < 2 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < nb; ++b) s += partial[b * 2 + threadIdx.x];
-        sums[threadIdx.x] = s;
+__global__ __launch_bounds__(256) void l1_reduce_kernel(const double* __restrict__ partial, double* __restrict__ sums,
+                                                        int nb) {
+    __shared__ double red[2 * 256];
+    double s = 0.0, c = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        s += partial[b * 2];
+        c += partial[b * 2 + 1];
+    }
+    red[threadIdx.x] = s;
+    red[256 + threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[threadIdx.x] += red[threadIdx.x + off];
+            red[256 + threadIdx.x] += red[256 + threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sums[0] = red[0];
+        sums[1] = red[256];
     }
 }
 
@@ -615,10 +679,9 @@ __global__ __launch_bounds__(256) void l1_finish_kernel(const float* __restrict_
 
 // ---- Adam -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, long n, float b1,
-                                                   float b2, float eps, float wd, float step_size, float bc2_sqrt,
-                                                   float gscale) {
-    const float w1 = 1.f - b1, w2 = 1.f - b2;
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float w1,
+                                                   float b2, float w2, float eps, float wd, float step_size,
+                                                   float bc2_sqrt, float gscale) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const float pe = p[e];
         float ge = g[e] * gscale;
@@ -679,7 +742,7 @@ int rd_channel_sum(const float* g, float* out, long long pixels, int c, void* ws
     double* sums = partial + (size_t)pl.nb * c;
     hipLaunchKernelGGL((channel_stats_kernel<false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, g, partial,
                        (long)pixels, c, pl.CQ, pl.RP, pl.rows_per_block);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, partial, sums, pl.nb, c);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(c, 16)), dim3(256), 0, (hipStream_t)s, partial, sums, pl.nb, c);
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, (float*)nullptr,
                        out, c);
     RD_LAUNCH_CHECK("channel_sum");
@@ -705,7 +768,7 @@ int rd_bn_stats_partial(const float* z, double* sums, long long pixels, int c, v
     ProfScope ps((hipStream_t)s, "bn_stats", 0, 4.0 * pixels * c);
     hipLaunchKernelGGL((channel_stats_kernel<true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, (double*)ws,
                        (long)pixels, c, pl.CQ, pl.RP, pl.rows_per_block);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(2 * c, 256)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(2 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
                        sums, pl.nb, 2 * c);
     RD_LAUNCH_CHECK("bn_stats");
     return RD_OK;
@@ -782,7 +845,7 @@ int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd,
         hipLaunchKernelGGL((bn_act_bwd_kernel<false, false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
                            invstd, gamma, beta, slope, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
                            (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(3 * c, 256)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(3 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
                        sums, pl.nb, 3 * c);
     RD_LAUNCH_CHECK("bn_act_bwd_reduce");
     return RD_OK;
@@ -827,7 +890,7 @@ static int first_grid(int n, int h, int w, int* tiles_x, int* tiles_y, int* ntil
     *tiles_x = cdiv(w, FT_W);
     *tiles_y = cdiv(h, FT_H);
     *ntiles = n * (*tiles_x) * (*tiles_y);
-    return *ntiles < 1024 ? *ntiles : 1024;
+    return *ntiles < 512 ? *ntiles : 512;
 }
 
 template <bool WGRAD>
@@ -893,7 +956,7 @@ int rd_conv3x3_first_bwd_weight(const float* x, const float* dz, float* dw, int 
     if (int e = launch_first<true>(x, nullptr, nullptr, dz, (float*)ws, n, h, w, cin, cout, grid, tx, ty, nt,
                                    (hipStream_t)s))
         return e;
-    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 256)), dim3(256), 0, (hipStream_t)s,
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 16)), dim3(256), 0, (hipStream_t)s,
                        (const float*)ws, dw, grid, cin, cout);
     RD_LAUNCH_CHECK("conv_first_wgrad");
     return RD_OK;
@@ -942,7 +1005,7 @@ int rd_conv3x3_last_bwd_weight(const float* s_in, const float* dout, float* dw, 
     ProfScope ps((hipStream_t)s, "conv_last_wgrad", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(c + 1));
     hipLaunchKernelGGL(conv_last_wgrad_kernel, dim3(pl.nb), dim3(256), 0, (hipStream_t)s, s_in, dout, (double*)ws,
                        (long)n * h * w, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
-    hipLaunchKernelGGL(last_wgrad_reduce_kernel, dim3(cdiv(9 * c + 1, 256)), dim3(256), 0, (hipStream_t)s,
+    hipLaunchKernelGGL(last_wgrad_reduce_kernel, dim3(cdiv(9 * c + 1, 16)), dim3(256), 0, (hipStream_t)s,
                        (const double*)ws, dw, dbias, pl.nb, c);
     RD_LAUNCH_CHECK("conv_last_wgrad");
     return RD_OK;
@@ -965,7 +1028,7 @@ int rd_masked_l1_partial(const float* yp, const float* y, const uint8_t* mask, c
     ProfScope ps((hipStream_t)s, "masked_l1", 0, 9.0 * total);
     hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, yp, y, mask, mean, stdv, (double*)ws,
                        total, (long)pps);
-    hipLaunchKernelGGL(l1_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const double*)ws, sums, nb);
+    hipLaunchKernelGGL(l1_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, (const double*)ws, sums, nb);
     RD_LAUNCH_CHECK("masked_l1_partial");
     return RD_OK;
 }
@@ -983,12 +1046,13 @@ int rd_masked_l1_finish(const float* yp, const float* y, const uint8_t* mask, co
 }
 
 // ---- Adam ------------------------------------------------------------------------------------------
-int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, float beta1, float beta2, float eps,
+int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, double beta1, double beta2, float eps,
                  float weight_decay, float step_size, float bc2_sqrt, float grad_scale, rd_stream_t s) {
     RD_REQUIRE(p && g && m && v && numel > 0, "rd_adam_step: bad arguments");
     ProfScope ps((hipStream_t)s, "adam", 0, 28.0 * numel);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_cap((numel + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v,
-                       (long)numel, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, grad_scale);
+                       (long)numel, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, step_size, bc2_sqrt,
+                       grad_scale);
     RD_LAUNCH_CHECK("adam");
     return RD_OK;
 }

@@ -18,6 +18,8 @@
 // (prefetched one K-step ahead) -> LDS.  NT LDS rows are padded to 36 floats so the b128
 // fragment reads are bank-conflict free (MI355X guide, LDS table); the MFMA k-pairing is
 // permuted so that one b128 read feeds four consecutive MFMA k-steps.
+#include <stdlib.h>
+
 #include "rd_common.h"
 
 namespace rd {
@@ -37,6 +39,7 @@ struct NtParams {
     int Cout;  // EPI_CONVT: channels per (a,b) quadrant
     int chunks, nk;
     int tiles_n;
+    int vec;  // epilogue may use 16-byte accesses (N % 4 == 0 and, for the transposed conv, Cout % 4 == 0)
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
@@ -148,33 +151,62 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
         }
     }
 
-    // epilogue: D[i][j], lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  D[i][j]: lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5).  The accumulators
+    // are staged through LDS (one row-band of BM/WM rows per pass) so that HBM sees 16 B per lane and whole
+    // contiguous rows per wave; bias / skip-add of the transposed convolution ride the same pass.
+    constexpr int CS = BN + 4, ROWS = BM / WM, Q = BN / 4;
+    static_assert(ROWS * CS <= (BM + BN) * LS, "epilogue staging must fit the operand buffers");
+    float* Cs = smem;
+    for (int pass = 0; pass < WM; ++pass) {
+        __syncthreads();
+        if (wm == pass) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * TN * 32 + j * 32 + lrow;
-            if (n >= p.N) continue;
-            int co = n, qa = 0, qb = 0;
-            float bv = 0.f;
-            if (EPI == EPI_CONVT) {
-                const int ab = n / p.Cout;
-                co = n - ab * p.Cout;
-                qa = ab >> 1;
-                qb = ab & 1;
-                bv = p.bias ? p.bias[co] : 0.f;
-            }
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m >= p.M) continue;
+                    for (int r = 0; r < 16; ++r)
+                        Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CS + wn * TN * 32 + j * 32 + lrow] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (p.vec) {
+            for (int e = t; e < ROWS * Q; e += 256) {
+                const int row = e / Q, q4 = e - row * Q;
+                const int m = m0 + pass * ROWS + row, n = n0 + q4 * 4;
+                if (m >= p.M || n >= p.N) continue;
+                float4 v = *reinterpret_cast<const float4*>(&Cs[row * CS + q4 * 4]);
                 if (EPI == EPI_STORE) {
-                    p.C[(long)m * p.N + n] = acc[i][j][r];
+                    *reinterpret_cast<float4*>(p.C + (long)m * p.N + n) = v;
                 } else {
+                    const int ab = n / p.Cout, co = n - ab * p.Cout;
                     const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
-                    const long opix = ((long)img * (2 * H) + 2 * ii + qa) * (2 * W) + 2 * jj + qb;
+                    const long opix = ((long)img * (2 * H) + 2 * ii + (ab >> 1)) * (2 * W) + 2 * jj + (ab & 1);
                     const long o = opix * p.Cout + co;
-                    float v = acc[i][j][r] + bv;
+                    if (p.bias) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co);
+                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                    }
+                    if (p.skip) {
+                        const float4 s4 = *reinterpret_cast<const float4*>(p.skip + o);
+                        v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w;
+                    }
+                    *reinterpret_cast<float4*>(p.C + o) = v;
+                }
+            }
+        } else {
+            for (int e = t; e < ROWS * BN; e += 256) {
+                const int row = e / BN, c = e - row * BN;
+                const int m = m0 + pass * ROWS + row, n = n0 + c;
+                if (m >= p.M || n >= p.N) continue;
+                float v = Cs[row * CS + c];
+                if (EPI == EPI_STORE) {
+                    p.C[(long)m * p.N + n] = v;
+                } else {
+                    const int ab = n / p.Cout, co = n - ab * p.Cout;
+                    const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+                    const long opix = ((long)img * (2 * H) + 2 * ii + (ab >> 1)) * (2 * W) + 2 * jj + (ab & 1);
+                    const long o = opix * p.Cout + co;
+                    if (p.bias) v += p.bias[co];
                     if (p.skip) v = p.skip[o] + v;
                     p.C[o] = v;
                 }
@@ -189,14 +221,18 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls) {
     const double bytes = 4.0 * ((double)p.M * p.Cin * (AMODE == A_UP2 ? 4 : 1) + (double)p.N * p.K + (double)p.M * p.N);
     ProfScope ps(s, cls, (double)flops, bytes);
     p.chunks = cdiv(p.Cin, 32);
+    p.vec = (p.N % 4 == 0) && (EPI != EPI_CONVT || p.Cout % 4 == 0);
     const int taps = p.K / p.Cin;
     p.nk = taps * p.chunks;
     const int tiles128 = cdiv(p.M, 128) * cdiv(p.N, p.N > 64 ? 128 : 64);
-    if (tiles128 < 200 || p.M < 128) {
+    static const int force = getenv("RD_NT_TILE") ? atoi(getenv("RD_NT_TILE")) : -1;   // tuning override
+    int cfg = (tiles128 < 200 || p.M < 128) ? 2 : (p.N > 64 ? 0 : 1);
+    if (force >= 0 && force <= 2 && !(force == 0 && p.N <= 64)) cfg = force;
+    if (cfg == 2) {
         p.tiles_n = cdiv(p.N, 64);
         const int grid = cdiv(p.M, 64) * p.tiles_n;
         hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
-    } else if (p.N > 64) {
+    } else if (cfg == 0) {
         p.tiles_n = cdiv(p.N, 128);
         const int grid = cdiv(p.M, 128) * p.tiles_n;
         hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
@@ -375,7 +411,9 @@ static TnPlan plan_tn(int M, int N, long Kp) {
     pl.tiles_n = cdiv(N, pl.bn);
     const int tiles = pl.tiles_m * pl.tiles_n;
     long ktiles = (Kp + 31) / 32;
-    long want = (1024 + tiles - 1) / tiles;       // ~4 blocks per CU in flight
+    static const int target = getenv("RD_TN_BLOCKS") ? atoi(getenv("RD_TN_BLOCKS")) : 1024;   // tuning override
+    long want = target / tiles;                   // whole rounds of resident blocks
+    if (want < 1) want = 1;
     long maxs = ktiles / 8 > 0 ? ktiles / 8 : 1;  // at least 8 K-steps per split
     long s = want < maxs ? want : maxs;
     if (s < 1) s = 1;

@@ -1,0 +1,58 @@
+"""Per-layer timing of the MFMA kernels at the cfg-S shapes (N=32). Tuning aid; env RD_NT_TILE / RD_TN_BLOCKS
+override the tile / split heuristics (read once per process)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from resdepth_amd import ops, _lib
+
+N = int(os.environ.get("BL_N", "32"))
+dev = "cuda:0"
+layers = [  # name, H, Cin, Cout
+    ("enc1", 128, 64, 128), ("enc2", 64, 128, 256), ("enc3", 32, 256, 512), ("enc4", 16, 512, 512),
+    ("bott", 8, 512, 512), ("dec0", 16, 512, 512), ("dec1", 32, 512, 256), ("dec2", 64, 256, 128), ("dec3", 128, 128, 64)]
+convt = [("up0", 8, 512), ("up1", 16, 512), ("up2", 32, 256), ("up3", 64, 128), ("up4", 128, 64)]
+which = os.environ.get("BL_WHICH", "fwd,dgrad,wgrad,convt").split(",")
+reps = 5
+
+
+def timed(fn):
+    fn(); torch.cuda.synchronize()
+    _lib.prof_reset(); _lib.prof_enable(True)
+    for _ in range(reps):
+        fn()
+    _lib.prof_enable(False)
+    r = [e for e in _lib.prof_collect() if e["flops"] > 0]
+    ms = sum(e["ms"] for e in r) / reps
+    fl = sum(e["flops"] for e in r) / reps
+    return ms, fl / (ms * 1e-3) / 1e12
+
+
+tot = {}
+print(f"cfg RD_NT_TILE={os.environ.get('RD_NT_TILE')} RD_TN_BLOCKS={os.environ.get('RD_TN_BLOCKS')} N={N}")
+for name, h, cin, cout in layers:
+    x = torch.randn(N, h, h, cin, device=dev)
+    dz = torch.randn(N, h, h, cout, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    wf, wd = ops.pack_conv3x3_weight(w)
+    row = f"{name:5s} M={N*h*h:7d} Cin={cin:3d} Cout={cout:3d} "
+    if "fwd" in which:
+        ms, tf = timed(lambda: ops.conv3x3_fwd(x, wf)); row += f"| fwd {ms:6.3f} ms {tf:6.1f} TF "; tot["fwd"] = tot.get("fwd", 0) + ms
+    if "dgrad" in which:
+        ms, tf = timed(lambda: ops.conv3x3_bwd_data(dz, wd)); row += f"| dgrad {ms:6.3f} ms {tf:6.1f} TF "; tot["dgrad"] = tot.get("dgrad", 0) + ms
+    if "wgrad" in which:
+        ms, tf = timed(lambda: ops.conv3x3_bwd_weight(x, dz)); row += f"| wgrad {ms:6.3f} ms {tf:6.1f} TF "; tot["wgrad"] = tot.get("wgrad", 0) + ms
+    print(row)
+if "convt" in which:
+    for name, h, c in convt:
+        x = torch.randn(N, h, h, c, device=dev)
+        do = torch.randn(N, 2 * h, 2 * h, c, device=dev)
+        skip = torch.randn(N, 2 * h, 2 * h, c, device=dev)
+        w = torch.randn(c, c, 2, 2, device=dev) * 0.05
+        b = torch.randn(c, device=dev)
+        wtf, wtd = ops.pack_convt2x2_weight(w)
+        row = f"{name:5s} M={N*h*h:7d} C={c:3d}          "
+        ms, tf = timed(lambda: ops.convt2x2_fwd(x, wtf, b, skip)); row += f"| fwd {ms:6.3f} ms {tf:6.1f} TF "; tot["tfwd"] = tot.get("tfwd", 0) + ms
+        ms, tf = timed(lambda: ops.convt2x2_bwd_data(do, wtd)); row += f"| dgrad {ms:6.3f} ms {tf:6.1f} TF "; tot["tdgrad"] = tot.get("tdgrad", 0) + ms
+        ms, tf = timed(lambda: ops.convt2x2_bwd_weight(x, do)); row += f"| wgrad {ms:6.3f} ms {tf:6.1f} TF "; tot["twgrad"] = tot.get("twgrad", 0) + ms
+        print(row)
+print("totals ms:", {k: round(v, 3) for k, v in tot.items()})
