@@ -148,8 +148,12 @@ def init_state_dict(spec: Spec, seed: int) -> Dict[str, torch.Tensor]:
     return {k: sd[k] for k, _, _ in param_layout(spec)}
 
 
-def _bn_act(z, sd, prefix, slope, training, update_running):
-    """conv output -> BatchNorm2d -> (Leaky)ReLU   (lib/UNet.py:44-47, 65-68, 85-87)."""
+def _bn_act(z, sd, prefix, slope, training, update_running, mask=None):
+    """conv output -> BatchNorm2d -> (Leaky)ReLU   (lib/UNet.py:44-47, 65-68, 85-87).
+
+    `mask` (bool, optional) imposes the activation's branch decision (True = positive branch) instead of
+    deriving it from the sign of the BN output: used by the parity tests to compare gradients under
+    IDENTICAL discrete decisions (one flipped ReLU in a 10^6-element layer moves rel-L2 by 1e-3)."""
     rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
     if training and not update_running:
         rm, rv = rm.clone(), rv.clone()
@@ -157,31 +161,41 @@ def _bn_act(z, sd, prefix, slope, training, update_running):
                      training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
     if training and update_running:
         sd[prefix + ".num_batches_tracked"] += 1
+    if mask is not None:
+        return torch.where(mask, y, y * slope)
     return F.leaky_relu(y, slope) if slope != 0.0 else F.relu(y)
 
 
 def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, spec: Spec, training: bool = True,
-            update_running: bool = True, keep: Optional[dict] = None) -> torch.Tensor:
+            update_running: bool = True, keep: Optional[dict] = None,
+            decisions: Optional[dict] = None) -> torch.Tensor:
     """UNet.forward (lib/UNet.py:196-246) as a flat functional graph.
 
+    `decisions` (optional) imposes discrete choices: mask_e{i} / mask_b / mask_d{i} (bool activations masks)
+    and idx{i} (pool arg-max, flat indices) -- see _bn_act.
     `keep`, if given, receives every intermediate (NCHW): z{i} conv outputs, a{i}
     post-activation skips, p{i}/idx{i} pooled values and flat argmax indices, zb/ab
     bottleneck, u{i}/s{i} up-conv output / skip sum, zd{i}/ad{i} decoder conv blocks,
     'res' last conv output.
     """
     k = keep if keep is not None else {}
+    dec = decisions if decisions is not None else {}
     d = spec.depth
     se, sb, sdec = _slope(spec.act_fn_encoder), _slope(spec.act_fn_bottleneck), _slope(spec.act_fn_decoder)
     skips = []
     out = x
     for i in range(d):                                            # lib/UNet.py:201-207
         z = F.conv2d(out, sd[f"encoder.{i}.0.0.weight"], None, 1, 1)
-        a = _bn_act(z, sd, f"encoder.{i}.0.1", se, training, update_running)
+        a = _bn_act(z, sd, f"encoder.{i}.0.1", se, training, update_running, dec.get(f"mask_e{i}"))
         skips.append(a)
-        out, idx = F.max_pool2d(a, 2, 2, return_indices=True)
+        if f"idx{i}" in dec:          # imposed arg-max (flat H*W indices, as torch returns them)
+            idx = dec[f"idx{i}"]
+            out = a.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+        else:
+            out, idx = F.max_pool2d(a, 2, 2, return_indices=True)
         k[f"z{i}"], k[f"a{i}"], k[f"p{i}"], k[f"idx{i}"] = z, a, out, idx
     z = F.conv2d(out, sd["bottleneck.0.weight"], None, 1, 1)       # lib/UNet.py:210
-    out = _bn_act(z, sd, "bottleneck.1", sb, training, update_running)
+    out = _bn_act(z, sd, "bottleneck.1", sb, training, update_running, dec.get("mask_b"))
     k["zb"], k["ab"] = z, out
     for i in range(d):                                            # lib/UNet.py:213-224
         pre = f"decoder.{i}.0" if i < d - 1 else f"decoder.{i}"
@@ -190,7 +204,7 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, spec: Spec, training: 
         k[f"u{i}"], k[f"s{i}"] = u, s
         if i < d - 1:
             z = F.conv2d(s, sd[f"decoder.{i}.1.0.weight"], None, 1, 1)
-            out = _bn_act(z, sd, f"decoder.{i}.1.1", sdec, training, update_running)
+            out = _bn_act(z, sd, f"decoder.{i}.1.1", sdec, training, update_running, dec.get(f"mask_d{i}"))
             k[f"zd{i}"], k[f"ad{i}"] = z, out
         else:
             out = s

@@ -4,7 +4,9 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../libresdepth_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-result"
+# -amdgpu-mfma-vgpr-form: accumulators stay in arch VGPRs (gfx950 has a unified file); without it hipcc shuttles all 64
+# accumulator registers AGPR<->VGPR around every K-step of the weight-gradient kernel (128 extra VALU per 64 MFMA)
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form"
 mkdir -p "$HERE/obj"
 pids=()
 for f in rd_runtime rd_igemm rd_elementwise; do

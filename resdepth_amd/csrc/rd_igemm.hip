@@ -37,10 +37,24 @@ struct NtParams {
     int Cin;  // channels per tap (A row length)
     int H, W, logH, logW;
     int Cout;  // EPI_CONVT: channels per (a,b) quadrant
-    int chunks, nk;
+    int chunks, nk, taps;
     int tiles_n;
     int vec;  // epilogue may use 16-byte accesses (N % 4 == 0 and, for the transposed conv, Cout % 4 == 0)
+    int ablate;  // tuning only (RD_ABLATE): 1 = no global reloads, 2 = no LDS restores, 4 = no barriers (wrong results)
+    unsigned a_bytes, b_bytes;  // extents of the A / B tensors for the buffer descriptors
 };
+
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOOB = 0xFFFFFF00u;  // voffset beyond any descriptor extent: the hardware returns zeros
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
 
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
     // blocks are dispatched round-robin over the 8 XCDs; give every XCD a contiguous range of
@@ -76,36 +90,59 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
     float4 ra[AI], rb[BI];
     const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
 
+    // ---- operand addressing, hoisted out of the K loop.  Loads are raw buffer loads: every lane carries a
+    // 32-bit byte offset, lanes that must read zero (image border taps, rows/columns beyond M/N/Cin) carry an
+    // out-of-range offset and the hardware returns 0 -- no exec-mask branches, no 64-bit pointer math.
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+    unsigned a_off[AI], a_val[AI], b_off[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const bool inm = m < p.M;
+        unsigned val = 0;
+        long pix = m;
+        if (AMODE == A_CONV3) {
+            const int y = (m >> logW) & (H - 1), x = m & (W - 1);
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+                if (((unsigned)(y + dy) < (unsigned)H) && ((unsigned)(x + dx) < (unsigned)W)) val |= 1u << t9;
+            }
+        } else if (AMODE == A_PLAIN) {
+            val = 1u;
+        } else {
+            const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+            pix = ((long)img * (2 * H) + 2 * ii) * (2 * W) + 2 * jj;
+            val = 0xFu;
+        }
+        a_val[i] = inm ? val : 0u;
+        a_off[i] = (unsigned)((pix * p.Cin + c4 * 4) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        b_off[i] = n < p.N ? (unsigned)(((long)n * p.K + c4 * 4) * 4) : kOOB;
+    }
+
     auto load_tile = [&](int kt) {
-        const int tap = kt / p.chunks;
-        const int c0 = (kt - tap * p.chunks) * BK + c4 * 4;
-        const bool cok = c0 < p.Cin;
+        // K order = channel-chunk outer, tap inner: the taps re-touch the same 128-byte row segments of
+        // neighbouring pixels within consecutive K-steps (L1/L2 hits)
+        const int chunk = kt / p.taps;
+        const int tap = kt - chunk * p.taps;
+        int shift;  // pixel shift of this tap, in A pixels
+        if (AMODE == A_CONV3) shift = (tap / 3 - 1) * W + (tap - (tap / 3) * 3 - 1);
+        else if (AMODE == A_PLAIN) shift = 0;
+        else shift = (tap >> 1) * (2 * W) + (tap & 1);
+        const unsigned toff = (unsigned)((shift * p.Cin + chunk * BK) * 4);
+        const unsigned koff = (unsigned)((tap * p.Cin + chunk * BK) * 4);
+        const bool cok = chunk * BK + c4 * 4 < p.Cin;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int m = m0 + r0 + 32 * i;
-            bool ok = cok && (m < p.M);
-            long src;
-            if (AMODE == A_CONV3) {
-                const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-                const int y = (m >> logW) & (H - 1), x = m & (W - 1);
-                ok = ok && ((unsigned)(y + dy) < (unsigned)H) && ((unsigned)(x + dx) < (unsigned)W);
-                src = (long)m + dy * W + dx;
-            } else if (AMODE == A_PLAIN) {
-                src = m;
-            } else {
-                const int a = tap >> 1, b = tap & 1;
-                const int j = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
-                src = ((long)img * (2 * H) + 2 * ii + a) * (2 * W) + 2 * j + b;
-            }
-            ra[i] = ok ? *reinterpret_cast<const float4*>(p.A + src * p.Cin + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = cok && ((a_val[i] >> tap) & 1u);
+            ra[i] = buf_load4(rsA, ok ? a_off[i] + toff : kOOB, 0);
         }
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int n = n0 + r0 + 32 * i;
-            const bool ok = cok && (n < p.N);
-            rb[i] = ok ? *reinterpret_cast<const float4*>(p.B + (long)n * p.K + (long)tap * p.Cin + c0)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < BI; ++i) rb[i] = buf_load4(rsB, cok ? b_off[i] : kOOB, koff);
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -123,7 +160,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
     __syncthreads();
     for (int kt = 0; kt < p.nk; ++kt) {
         const bool more = kt + 1 < p.nk;
-        if (more) load_tile(kt + 1);
+        if (more && !(p.ablate & 1)) load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float4 af[TM], bf[TN];
@@ -144,10 +181,10 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
                 }
             }
         }
-        __syncthreads();
-        if (more) {
+        if (!(p.ablate & 4)) __syncthreads();
+        if (more && !(p.ablate & 2)) {
             store_tile();
-            __syncthreads();
+            if (!(p.ablate & 4)) __syncthreads();
         }
     }
 
@@ -222,11 +259,28 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls) {
     ProfScope ps(s, cls, (double)flops, bytes);
     p.chunks = cdiv(p.Cin, 32);
     p.vec = (p.N % 4 == 0) && (EPI != EPI_CONVT || p.Cout % 4 == 0);
+    static const int ablate = getenv("RD_ABLATE") ? atoi(getenv("RD_ABLATE")) : 0;
+    p.ablate = ablate;
+    const double a_bytes = 4.0 * p.M * p.Cin * (AMODE == A_UP2 ? 4 : 1), b_bytes = 4.0 * p.N * p.K;
+    if (a_bytes >= 4294967040.0 || b_bytes >= 4294967040.0) {
+        set_error("%s: operand larger than the 4 GiB buffer-descriptor range (A %.0f B, B %.0f B)", cls, a_bytes, b_bytes);
+        return RD_ERR_ARG;
+    }
+    p.a_bytes = (unsigned)a_bytes;
+    p.b_bytes = (unsigned)b_bytes;
     const int taps = p.K / p.Cin;
+    p.taps = taps;
     p.nk = taps * p.chunks;
-    const int tiles128 = cdiv(p.M, 128) * cdiv(p.N, p.N > 64 ? 128 : 64);
+    // Tile choice (measured per layer on MI355X, scripts/bench_layers.py): with the lean buffer-load loader the
+    // launch BALANCE matters more than per-block efficiency -- 1024 tiles of 128x128 at 3 resident blocks/CU run
+    // 1.33 rounds (~105 TF) where 2048 tiles of 128x64 run 130+ TF.  128x128 only pays for short-K problems
+    // (few K-steps per tile -> amortise the epilogue over a bigger tile); tiny grids take 64x64.
     static const int force = getenv("RD_NT_TILE") ? atoi(getenv("RD_NT_TILE")) : -1;   // tuning override
-    int cfg = (tiles128 < 200 || p.M < 128) ? 2 : (p.N > 64 ? 0 : 1);
+    const int tiles_128x64 = cdiv(p.M, 128) * cdiv(p.N, 64);
+    int cfg;
+    if (p.M < 128 || tiles_128x64 < 1024) cfg = 2;
+    else if (p.N >= 128 && p.K <= 640 && cdiv(p.M, 128) * cdiv(p.N, 128) >= 1536) cfg = 0;
+    else cfg = 1;
     if (force >= 0 && force <= 2 && !(force == 0 && p.N <= 64)) cfg = force;
     if (cfg == 2) {
         p.tiles_n = cdiv(p.N, 64);
@@ -263,6 +317,7 @@ struct TnParams {
     int Cin;   // WB_CONV3: channels per tap of the B columns
     int kchunk;  // pixels per split, multiple of 32
     int tiles_n, tiles_mn;
+    unsigned a_bytes, b_bytes;
 };
 
 template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
@@ -277,8 +332,9 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnParams p) {
     float* Bs = smem + BK * BM;
 
     const int nb_mn = p.tiles_mn;
-    const int split = blockIdx.x / nb_mn;
-    const int lb = blockIdx.x - split * nb_mn;
+    const int gb = xcd_remap(blockIdx.x, gridDim.x);   // the (tap, ci) tiles of one pixel chunk share an XCD's L2
+    const int split = gb / nb_mn;
+    const int lb = gb - split * nb_mn;
     const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -318,31 +374,41 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnParams p) {
     long k_end = k_begin + p.kchunk;
     if (k_end > p.Kp) k_end = p.Kp;
 
+    // raw buffer loads: 32-bit byte offsets, out-of-range offset => the hardware returns zeros (see NT kernel)
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+    const int b_shift = b_dy * W + b_dx;
     auto load_tile = [&](long kbase) {
+        const int rem = (int)(k_end - kbase);   // rows of this K-step that exist (>= 32 except at the very end)
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            const long pp = kbase + ra0 + AR * i;
-            bool ok = a_ok && pp < k_end;
-            long src = pp;
+            const int row = ra0 + AR * i;
+            const bool ok = a_ok && row < rem;
+            unsigned voff;
             if (AMODE == WA_UP2) {
-                const int m = (int)pp;
+                const int m = (int)kbase + row;
                 const int j = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
-                src = ((long)img * (2 * H) + 2 * ii + a_qa) * (2 * W) + 2 * j + a_qb;
+                const long src = ((long)img * (2 * H) + 2 * ii + a_qa) * (2 * W) + 2 * j + a_qb;
+                voff = (unsigned)((src * p.lda + a_col) * 4);
+                ra[i] = buf_load4(rsA, ok ? voff : kOOB, 0);
+            } else {
+                voff = (unsigned)((row * p.lda + a_col) * 4);
+                ra[i] = buf_load4(rsA, ok ? voff : kOOB, (unsigned)(kbase * p.lda * 4));
             }
-            ra[i] = ok ? *reinterpret_cast<const float4*>(p.A + src * p.lda + a_col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
-            const long pp = kbase + rb0 + BR * i;
-            bool ok = b_ok && pp < k_end;
-            long src = pp;
+            const int row = rb0 + BR * i;
+            bool ok = b_ok && row < rem;
             if (BMODE == WB_CONV3) {
-                const int m = (int)pp;
+                const int m = (int)kbase + row;
                 const int y = (m >> logW) & (H - 1), x = m & (W - 1);
                 ok = ok && ((unsigned)(y + b_dy) < (unsigned)H) && ((unsigned)(x + b_dx) < (unsigned)W);
-                src = pp + b_dy * W + b_dx;
+                const unsigned voff = (unsigned)((((long)m + b_shift) * p.ldb + b_col) * 4);
+                rb[i] = buf_load4(rsB, ok ? voff : kOOB, 0);
+            } else {
+                const unsigned voff = (unsigned)((row * p.ldb + b_col) * 4);
+                rb[i] = buf_load4(rsB, ok ? voff : kOOB, (unsigned)(kbase * p.ldb * 4));
             }
-            rb[i] = ok ? *reinterpret_cast<const float4*>(p.B + src * p.ldb + b_col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_tile = [&]() {
@@ -428,6 +494,13 @@ template <int AMODE, int BMODE>
 static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cls) {
     ProfScope ps(s, cls, 2.0 * p.M * p.N * (double)p.Kp,
                  4.0 * ((double)p.Kp * p.lda * (AMODE == WA_UP2 ? 4 : 1) + (double)p.Kp * p.ldb + (double)p.M * p.N));
+    const double a_bytes = 4.0 * (double)p.Kp * p.lda * (AMODE == WA_UP2 ? 4 : 1), b_bytes = 4.0 * (double)p.Kp * p.ldb;
+    if (a_bytes >= 4294967040.0 || b_bytes >= 4294967040.0) {
+        set_error("%s: operand larger than the 4 GiB buffer-descriptor range", cls);
+        return RD_ERR_ARG;
+    }
+    p.a_bytes = (unsigned)a_bytes;
+    p.b_bytes = (unsigned)b_bytes;
     p.kchunk = pl.kchunk;
     p.tiles_n = pl.tiles_n;
     p.tiles_mn = pl.tiles_m * pl.tiles_n;

@@ -218,7 +218,7 @@ class UNet(nn.Module):
         a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, bn.weight, bn.bias, slope, pool)
         return a, p, idx, mean, invstd, count
 
-    def _engine_forward(self, x, training: bool, save: bool):
+    def _engine_forward(self, x, training: bool, save: bool, keep_skips: bool = False):
         d = self.depth
         pk = self._packed()
         se, sb, sd_ = _SLOPES[self.act_fn_encoder], _SLOPES[self.act_fn_bottleneck], _SLOPES[self.act_fn_decoder]
@@ -235,6 +235,8 @@ class UNet(nn.Module):
             skips.append(a)
             if save:
                 S["enc"].append({"z": z, "idx": idx, "mean": mean, "invstd": invstd, "count": count, "p": p})
+                if keep_skips:               # tests only: the backward never needs the skip activations
+                    S["enc"][-1]["a"] = a
             cur = p
         zb = ops.conv3x3_fwd(cur, pk["bott"][0])
         ab, _, _, mean, invstd, count = self._bn_forward(zb, self.bottleneck[1], sb, False, training)

@@ -111,6 +111,7 @@ def test_full_size_against_oracle_and_reference_digest():
     yp = model(x.to(DEV))
     loss = masked_l1_loss(yp, y, mask, mean, std)
     loss.backward()
+    sd1 = {k: v.detach().clone() for k, v in model.state_dict().items()}   # BN buffers after exactly one step
     # (1) reference digest
     assert abs(float(loss) - d["loss"]) <= 1e-5 * abs(d["loss"])
     ypc = yp.detach().cpu()
@@ -125,25 +126,55 @@ def test_full_size_against_oracle_and_reference_digest():
     work = dict(sd0)
     work.update(leaves)
     yo = O.forward(work, x, spec, training=True)
+    work_first = {k: v.detach().clone() for k, v in work.items()}
     lo = O.masked_l1_loss(yo, y, mask, mean, std)
     go = torch.autograd.grad(lo, list(leaves.values()))
     assert float((ypc - yo.detach()).abs().max()) <= 1e-4
     dev_m = float(((ypc - yo.detach()).abs() * std.view(-1, 1, 1, 1)).max())
     assert dev_m <= 3e-4, f"residual-height deviation {dev_m} m"
-    # ReLU masks / pool argmax are discrete: ONE flipped decision in a 10^6-element layer moves the rel-L2 of
-    # everything upstream by ~1e-3 (measured: 0-1 flips per layer between this path and torch-CPU, and torch
-    # fp32 vs fp64 shows the same 1e-4..1e-3 jumps) -- so the ReLU net gets a flip-aware bound here and the
-    # arithmetic itself is pinned tightly on the smooth surrogate below.
+    # ReLU masks / pool arg-max are discrete: ONE flipped decision in a 10^6-element layer moves the rel-L2 of
+    # everything upstream by ~1e-3 (measured: 0-1 flips per layer between this path and torch-CPU; torch fp32 vs
+    # fp64 shows the same jumps).  So (a) the decisions themselves must agree up to a vanishing fraction, and
+    # (b) gradients are compared under IDENTICAL decisions: the oracle re-runs with the HIP path's masks / arg-max
+    # imposed, which leaves pure fp32 arithmetic differences.
     for (k, p), gr in zip(model.named_parameters(), go):
-        r = rel_l2(p.grad, gr)
-        assert r <= 1e-2, (k, r)
         cos = float(torch.dot(p.grad.flatten().cpu().double(), gr.flatten().double()) /
                     (p.grad.double().norm().cpu() * gr.double().norm() + 1e-300))
-        assert cos >= 1 - 1e-4, (k, cos)
-    sd1 = model.state_dict()
+        assert cos >= 1 - 1e-3, (k, cos)
+    with torch.no_grad():
+        _, S = model._engine_forward(x.to(DEV), True, save=True, keep_skips=True)
+    keep = {}
+    O.forward(dict(sd0), x, spec, training=True, update_running=False, keep=keep)
+    dec, total, flips = {}, 0, 0
+    nchw = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()
+    for i, e in enumerate(S["enc"]):
+        m = nchw(e["a"]) > 0
+        pos = nchw(e["idx"]).long()
+        H2, W2 = pos.shape[2], pos.shape[3]
+        ii = torch.arange(H2).view(1, 1, H2, 1)
+        jj = torch.arange(W2).view(1, 1, 1, W2)
+        idx = (2 * ii + pos // 2) * (2 * W2) + 2 * jj + pos % 2
+        dec[f"mask_e{i}"], dec[f"idx{i}"] = m, idx
+        flips += int((m != (keep[f"a{i}"] > 0)).sum()) + int((idx != keep[f"idx{i}"]).sum())
+        total += m.numel() + idx.numel()
+    dec["mask_b"] = nchw(S["bott"]["a"]) > 0
+    flips += int((dec["mask_b"] != (keep["ab"] > 0)).sum())
+    for i in range(spec.depth - 1):
+        dec[f"mask_d{i}"] = nchw(S["dec"][i]["a"]) > 0
+        flips += int((dec[f"mask_d{i}"] != (keep[f"ad{i}"] > 0)).sum())
+        total += dec[f"mask_d{i}"].numel()
+    assert flips <= 1e-5 * total, (flips, total)
+    leaves = {k: sd0[k].clone().requires_grad_(True) for k in O.param_keys(spec)}
+    work = dict(sd0)
+    work.update(leaves)
+    yo2 = O.forward(work, x, spec, training=True, update_running=False, decisions=dec)
+    go2 = torch.autograd.grad(O.masked_l1_loss(yo2, y, mask, mean, std), list(leaves.values()))
+    for (k, p), gr in zip(model.named_parameters(), go2):
+        r = rel_l2(p.grad, gr)
+        assert r <= 1e-4, (k, r)
     for k in sd1:
         if "running" in k:
-            np.testing.assert_allclose(sd1[k].cpu().numpy(), work[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+            np.testing.assert_allclose(sd1[k].cpu().numpy(), work_first[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
 
 
 def test_determinism_and_tile_independence_at_full_batch():
