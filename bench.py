@@ -146,21 +146,37 @@ def main():
         for k in sorted(kern, key=lambda e: -e["ms"]):
             if k["launches"] == 0:
                 continue
-            e = {"name": k["name"], "launches_per_step": k["launches"] / args.steps,
+            op, _, sym = k["name"].partition("|")
+            e = {"name": op, "launches_per_step": k["launches"] / args.steps,
                  "ms_per_step": round(k["ms"] / args.steps, 4)}
+            if sym:
+                e["kernel"] = sym
             if k["flops"] > 0:
                 e["tflops"] = round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2)
             if k["bytes"] > 0:
                 e["alg_gbs"] = round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1)
             kernels.append(e)
+        # roofline of the dominant KERNEL (= one kernel symbol as rocprofv3 reports it; e.g. the conv3x3 forward
+        # and data-gradient launches are the same igemm_nt instantiation)
         roof = None
-        mf = [k for k in kern if k["name"] in MFMA_CLASSES and k["launches"] > 0]
-        if mf:
-            dom = max(mf, key=lambda e: e["ms"])
+        by_sym = {}
+        for k in kern:
+            op, _, sym = k["name"].partition("|")
+            if op in MFMA_CLASSES and k["launches"] > 0:
+                g = by_sym.setdefault(sym or op, {"ms": 0.0, "flops": 0.0, "launches": 0, "ops": set()})
+                g["ms"] += k["ms"]; g["flops"] += k["flops"]; g["launches"] += k["launches"]; g["ops"].add(op)
+        if by_sym:
+            sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            roof = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
-                    "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+            traffic = None
+            try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (scripts/summarize_prof.py)
+                with open(os.path.join(ROOT, "profiles", "r01_summary.json")) as f:
+                    traffic = json.load(f)["kernels"][sym]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+            roof = {"kernel": sym, "ops": sorted(dom["ops"]), "bound": "mfma", "achieved": round(ach, 2),
+                    "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
+                    "traffic": traffic, "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                     "alg_flop_per_launch": dom["flops"] / dom["launches"],
                     "launches_per_step": dom["launches"] / args.steps}
         out = {

@@ -157,9 +157,9 @@ int rd_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, rd
 /* ---- built-in kernel timing (HIP events on the launch stream) ----------------------- */
 /* When enabled every kernel launch is bracketed by hipEventRecord on its own stream and
  * accumulated per kernel class; rd_prof_collect synchronises the recorded events. */
-#define RD_PROF_MAX_CLASSES 32
+#define RD_PROF_MAX_CLASSES 64
 typedef struct {
-    char name[48];
+    char name[64];   /* "<operation>|<kernel symbol / tile>" */
     long long launches;
     double ms;      /* summed event-to-event duration */
     double flops;   /* summed algorithmic FLOPs declared at launch */

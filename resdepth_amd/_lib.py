@@ -69,7 +69,7 @@ SIGNATURES = {
 
 
 class ProfEntry(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_longlong), ("ms", C.c_double),
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_longlong), ("ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double)]
 
 
@@ -150,8 +150,8 @@ def prof_reset():
 
 
 def prof_collect():
-    arr = (ProfEntry * 32)()
-    n = load().rd_prof_collect(C.cast(arr, C.c_void_p), 32)
+    arr = (ProfEntry * 64)()
+    n = load().rd_prof_collect(C.cast(arr, C.c_void_p), 64)
     if n < 0:
         raise RuntimeError("rd_prof_collect failed")
     return [{"name": arr[i].name.decode(), "launches": arr[i].launches, "ms": arr[i].ms, "flops": arr[i].flops,

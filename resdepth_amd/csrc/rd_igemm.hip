@@ -256,7 +256,6 @@ template <int AMODE, int EPI>
 static int launch_nt(NtParams p, hipStream_t s, const char* cls) {
     const long flops = 2L * p.M * p.N * p.K;
     const double bytes = 4.0 * ((double)p.M * p.Cin * (AMODE == A_UP2 ? 4 : 1) + (double)p.N * p.K + (double)p.M * p.N);
-    ProfScope ps(s, cls, (double)flops, bytes);
     p.chunks = cdiv(p.Cin, 32);
     p.vec = (p.N % 4 == 0) && (EPI != EPI_CONVT || p.Cout % 4 == 0);
     static const int ablate = getenv("RD_ABLATE") ? atoi(getenv("RD_ABLATE")) : 0;
@@ -282,6 +281,10 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls) {
     else if (p.N >= 128 && p.K <= 640 && cdiv(p.M, 128) * cdiv(p.N, 128) >= 1536) cfg = 0;
     else cfg = 1;
     if (force >= 0 && force <= 2 && !(force == 0 && p.N <= 64)) cfg = force;
+    char pcls[64];   // "<operation>|<kernel symbol>": the kernel symbol is what rocprofv3 reports
+    snprintf(pcls, sizeof(pcls), "%s|igemm_nt<%s,%d,%d>", cls, cfg == 0 ? "128,128" : cfg == 1 ? "128,64" : "64,64",
+             AMODE, EPI);
+    ProfScope ps(s, pcls, (double)flops, bytes);
     if (cfg == 2) {
         p.tiles_n = cdiv(p.N, 64);
         const int grid = cdiv(p.M, 64) * p.tiles_n;
@@ -492,7 +495,9 @@ static TnPlan plan_tn(int M, int N, long Kp) {
 
 template <int AMODE, int BMODE>
 static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cls) {
-    ProfScope ps(s, cls, 2.0 * p.M * p.N * (double)p.Kp,
+    char pcls[64];
+    snprintf(pcls, sizeof(pcls), "%s|wgrad_tn<%d,%d,%d,%d>", cls, pl.bm, pl.bn, AMODE, BMODE);
+    ProfScope ps(s, pcls, 2.0 * p.M * p.N * (double)p.Kp,
                  4.0 * ((double)p.Kp * p.lda * (AMODE == WA_UP2 ? 4 : 1) + (double)p.Kp * p.ldb + (double)p.M * p.N));
     const double a_bytes = 4.0 * (double)p.Kp * p.lda * (AMODE == WA_UP2 ? 4 : 1), b_bytes = 4.0 * (double)p.Kp * p.ldb;
     if (a_bytes >= 4294967040.0 || b_bytes >= 4294967040.0) {
