@@ -6,5 +6,8 @@ underneath (libresdepth_hip.so, C ABI in include/resdepth_hip.h).  No CPU fallba
 from .unet import UNet, SkipConnection  # noqa: F401
 from .loss import MaskedL1Loss, masked_l1_loss  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
+from .trainer import Trainer, AverageMeter  # noqa: F401
+from .data import SyntheticDsmOrthoDataset  # noqa: F401
 
-__all__ = ["UNet", "SkipConnection", "MaskedL1Loss", "masked_l1_loss", "FusedAdam"]
+__all__ = ["UNet", "SkipConnection", "MaskedL1Loss", "masked_l1_loss", "FusedAdam", "Trainer", "AverageMeter",
+           "SyntheticDsmOrthoDataset"]

@@ -1,0 +1,298 @@
+"""Trainer with the reference's surface (lib/Trainer.py): `Trainer(args)` where `args` carries
+model, optimizer, scheduler, criterion, trainloader, valloader, n_epochs, evaluate_rate, save_model_rate,
+freq_average_train_loss, save_dir, log_file, checkpoint_dir, tboard_log_dir, pretrained_path
+(lib/utils.py:395-439); methods `train()`, `inference_one_epoch(epoch, phase)`,
+`inference_one_batch(batch, phase) -> {'MAE_metric': float}`; checkpoints
+{'epoch','model_state_dict','optimizer_state_dict','loss_train','loss_val'[,'scheduler_state_dict']} written as
+Model_best.pth / Model_last.pth / Model_after_{k}_epochs.pth (lib/Trainer.py:145-157,283-317).
+
+What is different underneath:
+  * forward/backward run on the HIP engine; the criterion + de-normalisation pair (lib/Trainer.py:87-100) is the
+    fused `masked_l1_loss` (the `criterion` argument must be an nn.L1Loss(reduction='mean'), the only loss the
+    reference offers, lib/utils.py:285);
+  * the epoch loop keeps the per-step loss on the device and reads it back only when a value is logged
+    (every `freq_average_train_loss` iterations and at epoch end) instead of one host sync per step
+    (lib/Trainer.py:197); `inference_one_batch` still returns a python float as the reference does;
+  * data parallel: with a torch.distributed process group initialised every rank trains on its own loader
+    shard; gradients, the loss normaliser (and optionally BN statistics) are exchanged by resdepth_amd.dp;
+    rank 0 alone logs and writes checkpoints;
+  * tensorboard is optional (a no-op writer is used when the package is absent).
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+import time
+
+import torch
+
+from .loss import masked_l1_loss
+
+
+def _get(args, name, default=None):
+    if isinstance(args, dict):
+        return args.get(name, default)
+    return getattr(args, name, default)
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+    def add_hparams(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+
+def _make_writer(log_dir):
+    try:
+        from torch.utils.tensorboard import SummaryWriter  # noqa: WPS433
+        return SummaryWriter(log_dir=log_dir)
+    except Exception:  # tensorboard not installed
+        return _NullWriter()
+
+
+class AverageMeter:
+    """Running mean of a scalar (same fields as lib/AverageMeter.py: val, avg, sum, count)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = 0.0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+class _DeviceMeter:
+    """Accumulates device scalars without synchronising; `flush_into(meter)` does one read-back."""
+
+    def __init__(self):
+        self.pending = []
+
+    def add(self, t):
+        self.pending.append(t.detach().reshape(()))
+
+    def flush_into(self, meter: AverageMeter):
+        if self.pending:
+            vals = torch.stack(self.pending).double().cpu().tolist()
+            self.pending = []
+            for v in vals:
+                meter.update(float(v))
+
+
+class Trainer:
+    def __init__(self, args):
+        self.config = args
+        self.save_dir = _get(args, "save_dir")
+        self.checkpoint_dir = _get(args, "checkpoint_dir")
+        self.tboard_log_dir = _get(args, "tboard_log_dir")
+        self.pretrained_path = _get(args, "pretrained_path")
+        self.log_file = _get(args, "log_file")
+        self.is_dist = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.rank = torch.distributed.get_rank() if self.is_dist else 0
+        self.is_main = self.rank == 0
+        for d in (self.save_dir, self.checkpoint_dir):
+            if d and self.is_main:
+                os.makedirs(d, exist_ok=True)
+        self.path_model_best = os.path.join(self.checkpoint_dir, "Model_best.pth")
+        self.path_model_last = os.path.join(self.checkpoint_dir, "Model_last.pth")
+        self.writer = _make_writer(self.tboard_log_dir) if self.is_main else _NullWriter()
+        self.logger = self._setup_logger()
+
+        self.start_epoch = 0
+        self.n_epochs = _get(args, "n_epochs")
+        if torch.cuda.is_available():
+            local = int(os.environ.get("LOCAL_RANK", "0")) if self.is_dist else 0
+            self.device = torch.device("cuda", local)
+        else:
+            self.device = torch.device("cpu")
+        self.model = _get(args, "model")
+        self.optimizer = _get(args, "optimizer")
+        self.scheduler = _get(args, "scheduler")
+        self.criterion = _get(args, "criterion")
+        if self.criterion is not None and not (isinstance(self.criterion, torch.nn.L1Loss)
+                                                and self.criterion.reduction == "mean"):
+            raise NotImplementedError("resdepth_amd.Trainer implements the reference's L1 (mean) criterion only")
+        self.evaluate_rate = _get(args, "evaluate_rate", 1)
+        self.save_model_rate = _get(args, "save_model_rate", 10 ** 9)
+        self.freq_average_train_loss = _get(args, "freq_average_train_loss", 20)
+        self.best_loss = math.inf
+        self.index_best_loss = math.inf
+        self.grad_sync = getattr(self.model, "grad_sync", None)
+
+        if self.pretrained_path is not None:
+            self._load_pretrain(self.pretrained_path)
+        else:
+            self.logger.info("\nStart training from scratch.\n")
+            self.model = self.model.to(self.device)
+        self.loader = {"train": _get(args, "trainloader"), "val": _get(args, "valloader")}
+
+        first = next(iter(self.loader["train"]))          # the reference also draws one batch here (lib/Trainer.py:61-64)
+        self.batch_size = first["input"].shape[0]
+        self.hparams = {"batch_size": self.batch_size, "lr_initial": self._get_lr(),
+                        "optimizer": type(self.optimizer).__name__, "scheduler": "None", "patience": -1, "step_size": -1}
+        if self.scheduler is not None:
+            self.hparams["scheduler"] = type(self.scheduler).__name__
+            if self.hparams["scheduler"] == "ReduceLROnPlateau":
+                self.hparams["patience"] = self.scheduler.patience
+            elif self.hparams["scheduler"] == "StepLR":
+                self.hparams["step_size"] = self.scheduler.step_size
+
+    # ------------------------------------------------------------------------------------------
+    def _setup_logger(self):
+        logger = logging.getLogger(f"resdepth_amd.train.{id(self)}")
+        logger.setLevel(logging.INFO)
+        logger.propagate = False
+        if self.is_main:
+            logger.addHandler(logging.StreamHandler())
+            if self.log_file:
+                os.makedirs(os.path.dirname(self.log_file) or ".", exist_ok=True)
+                logger.addHandler(logging.FileHandler(self.log_file))
+        else:
+            logger.addHandler(logging.NullHandler())
+        return logger
+
+    def _get_lr(self, group=0):
+        return self.optimizer.param_groups[group]["lr"]
+
+    @staticmethod
+    def _extract_inputs_outputs_loss_masks(batch):
+        return batch["input"], batch["target"], batch["loss_mask"]
+
+    def _load_pretrain(self, resume):
+        if not os.path.isfile(resume):
+            raise ValueError(f"No checkpoint found at '{resume}.\n'")
+        ckpt = torch.load(resume, map_location="cpu", weights_only=False)
+        self.model.load_state_dict(ckpt["model_state_dict"])
+        self.model = self.model.to(self.device)          # model first, then the optimizer state (lib/Trainer.py:122-126)
+        self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+        if "scheduler_state_dict" in ckpt and self.scheduler is not None:
+            self.scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+        self.start_epoch = ckpt["epoch"] + 1
+        self.n_epochs += self.start_epoch
+        self.best_loss = ckpt["loss_val"]
+        self.index_best_loss = ckpt["epoch"]
+        self.logger.info(f"\n\nRestoring the pretrained model from epoch {self.start_epoch}.")
+        self.logger.info(f"Successfully load pretrained model from {resume}!\n")
+        self.logger.info(f"Current best loss {self.best_loss}\n")
+
+    def _save_checkpoint(self, epoch, loss_train, loss_val, filepath):
+        if not self.is_main:
+            return
+        state = {"epoch": epoch, "model_state_dict": self.model.state_dict(),
+                 "optimizer_state_dict": self.optimizer.state_dict(), "loss_train": loss_train, "loss_val": loss_val}
+        if self.scheduler is not None:
+            state["scheduler_state_dict"] = self.scheduler.state_dict()
+        torch.save(state, filepath)
+
+    # ------------------------------------------------------------------------------------------
+    def _loss_on_device(self, batch, train: bool):
+        """forward (+ backward when training); returns the 0-dim device loss (no host sync)."""
+        x, y, loss_mask = self._extract_inputs_outputs_loss_masks(batch)
+        x = x.to(self.device, non_blocking=True)
+        y = y.to(self.device, non_blocking=True)
+        loss_mask = loss_mask.to(self.device, non_blocking=True)
+        mean = torch.flatten(batch["dsm_mean"])
+        std = torch.flatten(batch["dsm_std"])
+        if train:
+            self.model.train()
+            y_pred = self.model(x)
+            loss = masked_l1_loss(y_pred, y, loss_mask, mean, std, grad_sync=self.grad_sync)
+            loss.backward()
+        else:
+            self.model.eval()
+            with torch.no_grad():
+                y_pred = self.model(x)
+                loss = masked_l1_loss(y_pred, y, loss_mask, mean, std, grad_sync=self.grad_sync)
+        return loss.detach()
+
+    def inference_one_batch(self, batch, phase):
+        assert phase in ["train", "val"]
+        loss = self._loss_on_device(batch, phase == "train")
+        return {"MAE_metric": float(loss.item())}
+
+    @staticmethod
+    def stats_dict():
+        return {"MAE_metric": 0.0}
+
+    def stats_meter(self):
+        return {k: AverageMeter() for k in self.stats_dict()}
+
+    def inference_one_epoch(self, epoch, phase):
+        assert phase in ["train", "val"]
+        meters = self.stats_meter()
+        dev = _DeviceMeter()
+        loader = self.loader[phase]
+        num_iter = len(loader)
+        params = list(self.model.parameters())
+        for p in params:
+            p.grad = None
+        for c_iter, batch in enumerate(loader):
+            dev.add(self._loss_on_device(batch, phase == "train"))
+            if phase == "train":
+                self.optimizer.step()
+                for p in params:
+                    p.grad = None
+                if (c_iter + 1) % self.freq_average_train_loss == 0:
+                    dev.flush_into(meters["MAE_metric"])
+                    curr_iter = num_iter * epoch + (c_iter + 1)
+                    message = f"{phase}:\tEpoch: {epoch} [{c_iter + 1}/{num_iter}]\t"
+                    for key, value in meters.items():
+                        self.writer.add_scalar(f"train/{key}", value.avg, curr_iter)
+                        message += f"{key}: {value.avg:.6f}\t"
+                        value.reset()
+                    self.logger.info(message)
+                    self.writer.add_scalar("train/learning_rate", self._get_lr(), curr_iter)
+        dev.flush_into(meters["MAE_metric"])
+        return meters
+
+    def train(self):
+        self.logger.info("Start training...\n")
+        t0 = time.time()
+        train_meter = val_meter = None
+        epoch = self.start_epoch - 1
+        for epoch in range(self.start_epoch, self.n_epochs):
+            head = f"Epoch {epoch}/{self.n_epochs - 1}"
+            self.logger.info("\n{}\n{}\n".format(head, "-" * len(head)))
+            train_meter = self.inference_one_epoch(epoch, "train")
+            if (epoch + 1) % self.evaluate_rate == 0:
+                val_meter = self.inference_one_epoch(epoch, "val")
+                message = f"\nval:\tEpoch: {epoch}\t\t"
+                for key, value in val_meter.items():
+                    self.writer.add_scalar(f"val/{key}", value.avg, epoch)
+                    message += f"{key}: {value.avg:.6f}\t"
+                self.logger.info(message + "\n")
+                self.writer.add_scalar("val/learning_rate", self._get_lr(), epoch)
+                v = val_meter["MAE_metric"].avg
+                if v < self.best_loss:
+                    self.best_loss, self.index_best_loss = v, epoch
+                    self._save_checkpoint(epoch, train_meter["MAE_metric"].avg, v, self.path_model_best)
+                    self.writer.add_hparams(hparam_dict=self.hparams, metric_dict={"hparam/MAE_metric": v},
+                                            run_name=self.tboard_log_dir)
+                if self.scheduler is not None:
+                    if type(self.scheduler).__name__ == "ReduceLROnPlateau":
+                        self.scheduler.step(v)
+                    else:
+                        self.scheduler.step()
+            if (epoch + 1) % self.save_model_rate == 0 and epoch > self.evaluate_rate and val_meter is not None:
+                name = "Model_after_" + str(epoch + 1) + "_epochs.pth"
+                self._save_checkpoint(epoch, train_meter["MAE_metric"].avg, val_meter["MAE_metric"].avg,
+                                      os.path.join(self.checkpoint_dir, name))
+        elapsed = time.strftime("%H:%M:%S", time.gmtime(time.time() - t0))
+        self.logger.info(f"\n\nTraining finished!\nTraining time: {elapsed}")
+        self.logger.info(f"\nBest model at epoch: {self.index_best_loss}")
+        self.logger.info("Validation loss of the best model: {:.6f}".format(self.best_loss))
+        self.writer.close()
+        if train_meter is not None:
+            self._save_checkpoint(epoch, train_meter["MAE_metric"].avg,
+                                  val_meter["MAE_metric"].avg if val_meter is not None else math.inf,
+                                  self.path_model_last)
