@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="SyncBN (single-device-equivalent statistics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the data-parallel code path (RCCL process group, bucketed all-reduce) even at world size 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,12 +82,15 @@ def main():
     _lib.load()
 
     gs = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:          # --force-dist without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(0)
     model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).train()
-    if world > 1:
+    if use_dist:
         gs = dp.attach(model, sync_bn=args.sync_bn)
         dp.broadcast_parameters(model, 0)
     opt = FusedAdam(model.parameters(), lr=2e-4, weight_decay=1e-5)
@@ -109,7 +114,7 @@ def main():
         losses.append(loss.detach())
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -133,7 +138,7 @@ def main():
     else:
         kern = []
     loss_vals = [float(v) for v in losses]
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -196,7 +201,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

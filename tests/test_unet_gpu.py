@@ -266,3 +266,29 @@ def test_full_size_smooth_surrogate_gradients(monkeypatch):
     # ... and everything else is bounded at flip level
     bad = {k: v for k, v in errs.items() if v > 5e-3}
     assert not bad, bad
+
+
+def test_data_parallel_code_path_on_rccl_world1():
+    """The DP path (RCCL process group via torch.distributed.run, bucketed async all-reduce, global loss
+    normaliser, SyncBN collectives) on the one GPU we have: world size 1 must reproduce the plain path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+            "127.0.0.1", "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
+            "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--force-dist"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = []
+    for extra in ([], ["--sync-bn"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    plain = json.loads(r.stdout.strip().splitlines()[-1])
+    for o in outs:
+        assert o["n_gpus"] == 1 and o["value"] > 0
+        assert o["loss_first_last"] == plain["loss_first_last"], (o["loss_first_last"], plain["loss_first_last"])
