@@ -150,6 +150,14 @@ int rd_masked_l1_finish(const float* yp, const float* y, const uint8_t* mask, co
 int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, double beta1, double beta2, float eps,
                  float weight_decay, float step_size, float bc2_sqrt, float grad_scale, rd_stream_t s);
 
+/* ---- tiled inference: linear blend of overlapping tiles (lib/evaluation.py:460-567) ----------- */
+/* For every tile i (in order, one launch each => deterministic fp64 accumulation order, no atomics):
+ *   raster[y_i + r][x_i + c] += (double)(float)(pred[i][r][c] * std[i] + mean[i]) * w_i(r, c)
+ * with w_i = the reference's _get_blend_weights(tile_size, stride, ulx, uly, lrx, lry) (separable linear ramps,
+ * np.linspace(0,1,overlap)).  pos = int32 [n][2] (offset_y, offset_x); reg = int32 [n][4] (uly, ulx, lry, lrx). */
+int rd_blend_accumulate(const float* pred, const float* mean, const float* std, const int* pos, const int* reg, int n,
+                        int tile_size, int stride, double* raster, int rows, int cols, rd_stream_t s);
+
 /* ---- layout helpers ----------------------------------------------------------------- */
 int rd_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s);
 int rd_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s);

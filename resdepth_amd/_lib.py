@@ -60,6 +60,7 @@ SIGNATURES = {
     "rd_masked_l1_partial": (I, [P, P, P, P, P, P, I, LL, P, SZ, P]),
     "rd_masked_l1_finish": (I, [P, P, P, P, P, P, D, P, P, P, I, LL, P]),
     "rd_adam_step": (I, [P, P, P, P, LL, D, D, F, F, F, F, F, P]),
+    "rd_blend_accumulate": (I, [P, P, P, P, P, I, I, I, P, I, I, P]),
     "rd_nchw_to_nhwc": (I, [P, P, I, I, I, I, P]),
     "rd_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
     "rd_prof_enable": (I, [I]),

@@ -696,6 +696,42 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// ---- tiled inference: linear blend --------------------------------------------------------------
+__device__ __forceinline__ double blend_axis(int c, int lo, int hi, int T, int overlap, double step) {
+    // np.linspace(0, 1, overlap): ramp[i] = i * step, last element exactly 1
+    double w = 1.0;
+    if (lo > 0) {
+        if (c < lo - overlap) return 0.0;
+        if (c < lo) {
+            const int i = c - (lo - overlap);
+            w *= (i == overlap - 1 && overlap > 1) ? 1.0 : i * step;
+        }
+    }
+    if (hi < T - 1 && c > hi) {
+        const int i = overlap - 1 - (c - hi - 1);
+        w *= (i < 0) ? 0.0 : ((i == overlap - 1 && overlap > 1) ? 1.0 : i * step);
+    }
+    return w;
+}
+
+__global__ __launch_bounds__(256) void blend_tile_kernel(const float* __restrict__ pred, const float* __restrict__ mean,
+                                                         const float* __restrict__ stdv, const int* __restrict__ pos,
+                                                         const int* __restrict__ reg, int tile, int T, int stride,
+                                                         double* __restrict__ raster, int rows, int cols) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= T * T) return;
+    const int r = e / T, c = e - r * T;
+    const int y0 = pos[tile * 2], x0 = pos[tile * 2 + 1];
+    const int uly = reg[tile * 4], ulx = reg[tile * 4 + 1], lry = reg[tile * 4 + 2], lrx = reg[tile * 4 + 3];
+    const int y = y0 + r, x = x0 + c;
+    if ((unsigned)y >= (unsigned)rows || (unsigned)x >= (unsigned)cols) return;
+    const int overlap = T - stride;
+    const double step = overlap > 1 ? 1.0 / (double)(overlap - 1) : 0.0;
+    const double w = blend_axis(r, uly, lry, T, overlap, step) * blend_axis(c, ulx, lrx, T, overlap, step);
+    const float den = __fadd_rn(__fmul_rn(pred[(long)tile * T * T + e], stdv[tile]), mean[tile]);
+    raster[(long)y * cols + x] += (double)den * w;
+}
+
 // ---- layout ---------------------------------------------------------------------------------------
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW) {
     const long total = (long)N * C * HW;
@@ -1054,6 +1090,20 @@ int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, 
                        (long)numel, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, step_size, bc2_sqrt,
                        grad_scale);
     RD_LAUNCH_CHECK("adam");
+    return RD_OK;
+}
+
+int rd_blend_accumulate(const float* pred, const float* mean, const float* stdv, const int* pos, const int* reg, int n,
+                        int tile_size, int stride, double* raster, int rows, int cols, rd_stream_t s) {
+    RD_REQUIRE(pred && mean && stdv && pos && reg && raster, "rd_blend_accumulate: null pointer");
+    RD_REQUIRE(n > 0 && tile_size > 0 && stride > 0 && stride <= tile_size && rows > 0 && cols > 0,
+               "rd_blend_accumulate: bad shape (n=%d tile=%d stride=%d raster=%dx%d)", n, tile_size, stride, rows, cols);
+    ProfScope ps((hipStream_t)s, "blend_accumulate", 0, 20.0 * n * tile_size * tile_size);
+    const int blocks = cdiv((long)tile_size * tile_size, 256);
+    for (int i = 0; i < n; ++i)   // one launch per tile, in order: overlapping tiles never race, order is fixed
+        hipLaunchKernelGGL(blend_tile_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, pred, mean, stdv, pos, reg, i,
+                           tile_size, stride, raster, rows, cols);
+    RD_LAUNCH_CHECK("blend_accumulate");
     return RD_OK;
 }
 

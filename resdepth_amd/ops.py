@@ -265,3 +265,14 @@ def nhwc_to_nchw(x):
     out = torch.empty(n, c, h, w, device=x.device, dtype=torch.float32)
     check(load().rd_nhwc_to_nchw(ptr(x), ptr(out), n, c, h, w, stream_ptr()), "nhwc_to_nchw")
     return out
+
+
+def blend_accumulate(pred, mean, std, pos, reg, tile_size, stride, raster):
+    """raster (float64 [rows, cols], device) += blend-weighted de-normalised tiles; pos/reg int32 device tensors."""
+    n = pred.shape[0]
+    rows, cols = raster.shape
+    if raster.dtype != torch.float64 or pos.dtype != torch.int32 or reg.dtype != torch.int32:
+        raise TypeError("blend_accumulate: raster must be float64, pos/reg int32")
+    check(load().rd_blend_accumulate(ptr(_f32(pred, "pred")), ptr(mean), ptr(std), ptr(pos), ptr(reg), n, tile_size,
+                                     stride, ptr(raster), rows, cols, stream_ptr()), "blend_accumulate")
+    return raster

@@ -1,0 +1,73 @@
+"""Tiled inference on the GPU (-m gpu): the accumulate kernel against the oracle / the reference fixture, and the whole
+predict_linear_blend sweep (HIP U-Net in eval mode) against the oracle pipeline."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+from conftest import load_npz
+from oracle import blend_oracle as B
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_accumulate_kernel_against_reference_fixture():
+    from resdepth_amd import ops
+    g = load_npz("g6_blend.npz")
+    rows, cols, t, s = [int(v) for v in g["blend/shape"]]
+    x = torch.from_numpy(g["blend/tiles"])
+    pred = (x[:, 0:1] * 0.5 + 0.25 * x[:, 1:2] * x[:, 1:2]).contiguous()
+    raster = torch.zeros(rows, cols, dtype=torch.float64, device=DEV)
+    pos = torch.from_numpy(g["blend/pos"]).to(torch.int32).to(DEV)
+    reg = torch.from_numpy(g["blend/reg"]).to(torch.int32).to(DEV)
+    mean = torch.from_numpy(g["blend/means"]).float().to(DEV)
+    std = torch.from_numpy(g["blend/stds"]).to(DEV)
+    for lo in range(0, pred.shape[0], 7):                      # ragged batches, same result
+        hi = min(lo + 7, pred.shape[0])
+        ops.blend_accumulate(pred[lo:hi].to(DEV), mean[lo:hi].contiguous(), std[lo:hi].contiguous(),
+                             pos[lo:hi].contiguous(), reg[lo:hi].contiguous(), t, s, raster)
+    np.testing.assert_allclose(raster.cpu().numpy(), g["blend/raster"], rtol=1e-13, atol=1e-10)
+
+
+def test_constant_prediction_blends_to_constant():
+    """Partition of unity at a realistic size (T=256, stride 128, 1000x1300 raster)."""
+    from resdepth_amd import ops, tiling
+    rows, cols, t, s = 1000, 1300, 256, 128
+    pos, reg = tiling.regular_grid([(0, cols - 1)], [(0, rows - 1)], t, s)
+    n = len(pos)
+    raster = torch.zeros(rows, cols, dtype=torch.float64, device=DEV)
+    pred = torch.zeros(n, 1, t, t, device=DEV)
+    ops.blend_accumulate(pred, torch.full((n,), 412.5, device=DEV), torch.ones(n, device=DEV),
+                         torch.tensor(pos, dtype=torch.int32, device=DEV), torch.tensor(reg, dtype=torch.int32, device=DEV),
+                         t, s, raster)
+    np.testing.assert_allclose(raster.cpu().numpy(), 412.5, rtol=0, atol=1e-9)
+
+
+def test_predict_linear_blend_against_oracle_pipeline():
+    from resdepth_amd import UNet, SyntheticRasterTiles, predict_linear_blend
+    kw = dict(n_input_channels=2, start_kernel=8, depth=2, bias_conv_layer=True)
+    spec = O.Spec(**kw)
+    torch.manual_seed(3)
+    model = UNet(**kw)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    for k in sd:                                             # non-trivial running statistics for eval-mode BN
+        if k.endswith("running_mean"):
+            sd[k] = torch.linspace(-0.1, 0.1, sd[k].numel())
+        if k.endswith("running_var"):
+            sd[k] = torch.linspace(0.8, 1.3, sd[k].numel())
+    model.load_state_dict(sd)
+    ds = SyntheticRasterTiles(150, 203, 2, tile_size=64, seed=5)
+    out = predict_linear_blend(DataLoader(ds, batch_size=5, shuffle=False), model)
+    assert out.shape == (150, 203) and out.dtype == np.float64
+    ref = np.zeros((150, 203))
+    for i in range(len(ds)):
+        smp = ds[i]
+        with torch.no_grad():
+            yp = O.forward(dict(sd), smp["input"][None], spec, training=False)
+        B.accumulate(ref, yp.numpy(), [float(smp["dsm_mean"])], [float(smp["dsm_std"])], [ds.pos[i]], [ds.reg[i]],
+                     64, 32)
+    assert np.abs(out - ref).max() <= 1e-4                   # metres; forward noise (~1e-6) x std
+    again = predict_linear_blend(DataLoader(ds, batch_size=3, shuffle=False), model)
+    assert np.abs(out - again).max() <= 1e-9                 # batch size does not matter
