@@ -54,6 +54,11 @@ int rd_pack_convt2x2_weight(const float* w_iohw, float* wtf, float* wtd, int cin
 /* ---- 3x3 / stride 1 / pad 1 convolution, Cin % 4 == 0 (lib/UNet.py:4-5,44,65,85) - */
 /* z[N,H,W,Cout] = conv(x[N,H,W,Cin], w)          (replaces nn.Conv2d.forward, no bias) */
 int rd_conv3x3_fwd(const float* x, const float* wf, float* z, int n, int h, int w, int cin, int cout, rd_stream_t s);
+/* same, and the BatchNorm batch statistics of z come out of the GEMM epilogue: sums[2*Cout] doubles
+ * (sum, sum of squares per channel) -- the input of rd_bn_stats_finalize -- without re-reading z */
+size_t rd_conv3x3_fwd_stats_ws_bytes(int n, int h, int w, int cin, int cout);
+int rd_conv3x3_fwd_stats(const float* x, const float* wf, float* z, double* sums, int n, int h, int w, int cin, int cout,
+                         void* ws, size_t ws_bytes, rd_stream_t s);
 /* dx[N,H,W,Cin] = conv^T(dz)                     (autograd data gradient of the above) */
 int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int h, int w, int cin, int cout,
                         rd_stream_t s);
@@ -65,6 +70,9 @@ int rd_conv3x3_bwd_weight(const float* x, const float* dz, float* dw_oihw, int n
 /* ---- first encoder conv: NCHW input with 1..6 channels -> NHWC (lib/UNet.py:159) -- */
 int rd_conv3x3_first_fwd(const float* x_nchw, const float* w_oihw, float* z, int n, int h, int w, int cin, int cout,
                          rd_stream_t s);
+size_t rd_conv3x3_first_fwd_stats_ws_bytes(int n, int h, int w, int cin, int cout);
+int rd_conv3x3_first_fwd_stats(const float* x_nchw, const float* w_oihw, float* z, double* sums, int n, int h, int w,
+                               int cin, int cout, void* ws, size_t ws_bytes, rd_stream_t s);
 size_t rd_conv3x3_first_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout);
 int rd_conv3x3_first_bwd_weight(const float* x_nchw, const float* dz, float* dw_oihw, int n, int h, int w, int cin,
                                 int cout, void* ws, size_t ws_bytes, rd_stream_t s);

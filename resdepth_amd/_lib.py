@@ -32,10 +32,14 @@ SIGNATURES = {
     "rd_pack_conv3x3_weight": (I, [P, P, P, I, I, P]),
     "rd_pack_convt2x2_weight": (I, [P, P, P, I, I, P]),
     "rd_conv3x3_fwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "rd_conv3x3_fwd_stats_ws_bytes": (SZ, [I, I, I, I, I]),
+    "rd_conv3x3_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_conv3x3_bwd_data": (I, [P, P, P, I, I, I, I, I, P]),
     "rd_conv3x3_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_conv3x3_bwd_weight": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_conv3x3_first_fwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "rd_conv3x3_first_fwd_stats_ws_bytes": (SZ, [I, I, I, I, I]),
+    "rd_conv3x3_first_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_conv3x3_first_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_conv3x3_first_bwd_weight": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_conv3x3_last_fwd": (I, [P, P, P, P, I, P, I, I, I, I, P]),

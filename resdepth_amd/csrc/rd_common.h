@@ -26,6 +26,9 @@ struct ProfScope {
     }
 };
 
+// second stage of the per-channel reductions (rd_elementwise.hip): sums[c] = sum_b partial[b*qc + c], fixed order
+int reduce_partials_f32(const float* partial, double* sums, int nb, int qc, hipStream_t s);
+
 inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;

@@ -77,6 +77,20 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const double* __res
     if (threadIdx.x < 16 && col < QC) sums[col] = r;
 }
 
+__global__ __launch_bounds__(256) void partial_reduce_f32_kernel(const float* __restrict__ partial,
+                                                                 double* __restrict__ sums, int nb, int QC) {
+    __shared__ double red[256];
+    const double r = sliced_column_sum<float>(partial, nb, QC, QC, red);
+    const int col = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x < 16 && col < QC) sums[col] = r;
+}
+
+int reduce_partials_f32(const float* partial, double* sums, int nb, int qc, hipStream_t s) {
+    hipLaunchKernelGGL(partial_reduce_f32_kernel, dim3(cdiv(qc, 16)), dim3(256), 0, s, partial, sums, nb, qc);
+    RD_LAUNCH_CHECK("partial_reduce_f32");
+    return RD_OK;
+}
+
 struct RowPlan {
     int CQ, RP, nb;
     long rows_per_block;
@@ -348,6 +362,7 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sums, float* __r
 // ---- first encoder convolution (NCHW input, CIN <= 6) ----------------------------------------
 constexpr int FT_H = 8, FT_W = 32;
 
+// WGRAD=false: forward (optionally also per-block BN statistics partials [grid][2][Cout] in `partial`)
 template <int CIN, bool WGRAD>
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ z_or_null, const float* __restrict__ dz,
@@ -355,7 +370,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                                                          int CQ, int PS, int tiles_x, int tiles_y, int ntiles) {
     constexpr int TW2 = FT_W + 2, TH2 = FT_H + 2, NT = 9 * CIN;
     __shared__ float tile[TH2 * TW2 * CIN];
-    __shared__ float red[WGRAD ? 256 * 4 : 1];
+    __shared__ float red[256 * 4];
+    float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};   // forward: running BN sums of this thread
     const int t = threadIdx.x, cq = t % CQ, ps = t / CQ;
     const bool active = ps < PS;
     float wreg[NT][4];
@@ -394,6 +410,11 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                         for (int k = 0; k < 4; ++k) acc[k] = fmaf(xv, wreg[j][k], acc[k]);
                     }
                     *reinterpret_cast<float4*>(z_or_null + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        st_s[k] += acc[k];
+                        st_q[k] = fmaf(acc[k], acc[k], st_q[k]);
+                    }
                 } else {
                     const float4 d4 = *reinterpret_cast<const float4*>(dz + o);
                     const float d[4] = {d4.x, d4.y, d4.z, d4.w};
@@ -404,6 +425,25 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 #pragma unroll
                         for (int k = 0; k < 4; ++k) wreg[j][k] = fmaf(xv, d[k], wreg[j][k]);
                     }
+                }
+            }
+        }
+    }
+    if (!WGRAD && partial) {
+        // BN statistics of this block: fixed-order reduction over the pixel slots -> partial[block][2][Cout]
+        float* out = partial + (long)blockIdx.x * 2 * Cout;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[t * 4 + k] = active ? (q == 0 ? st_s[k] : st_q[k]) : 0.f;
+            __syncthreads();
+            if (t < CQ) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float sacc = 0.f;
+                    for (int r = 0; r < PS; ++r) sacc += red[(r * CQ + t) * 4 + k];
+                    out[(long)q * Cout + t * 4 + k] = sacc;
                 }
             }
         }
@@ -957,15 +997,34 @@ extern "C" {
 
 int rd_conv3x3_first_fwd(const float* x, const float* wt, float* z, int n, int h, int w, int cin, int cout,
                          rd_stream_t s) {
+    return rd_conv3x3_first_fwd_stats(x, wt, z, nullptr, n, h, w, cin, cout, nullptr, 0, s);
+}
+
+size_t rd_conv3x3_first_fwd_stats_ws_bytes(int n, int h, int w, int cin, int cout) {
+    int tx, ty, nt;
+    const int grid = first_grid(n, h, w, &tx, &ty, &nt);
+    return (size_t)grid * 2 * cout * sizeof(float);
+}
+
+int rd_conv3x3_first_fwd_stats(const float* x, const float* wt, float* z, double* sums, int n, int h, int w, int cin,
+                               int cout, void* ws, size_t ws_bytes, rd_stream_t s) {
     RD_REQUIRE(x && wt && z, "rd_conv3x3_first_fwd: null pointer");
     RD_REQUIRE(cout % 4 == 0 && cout / 4 <= 256 && cout > 0, "rd_conv3x3_first_fwd: Cout must be a multiple of 4, <= 1024");
     int tx, ty, nt;
     const int grid = first_grid(n, h, w, &tx, &ty, &nt);
-    ProfScope ps((hipStream_t)s, "conv_first_fwd", 2.0 * n * h * w * cout * 9.0 * cin,
-                 4.0 * n * h * w * (double)(cin + cout));
-    if (int e = launch_first<false>(x, wt, z, nullptr, nullptr, n, h, w, cin, cout, grid, tx, ty, nt, (hipStream_t)s))
-        return e;
-    RD_LAUNCH_CHECK("conv_first_fwd");
+    if (sums && (!ws || ws_bytes < (size_t)grid * 2 * cout * sizeof(float))) {
+        set_error("rd_conv3x3_first_fwd_stats: workspace too small");
+        return RD_ERR_WS;
+    }
+    {
+        ProfScope ps((hipStream_t)s, "conv_first_fwd", 2.0 * n * h * w * cout * 9.0 * cin,
+                     4.0 * n * h * w * (double)(cin + cout));
+        if (int e = launch_first<false>(x, wt, z, nullptr, sums ? (float*)ws : nullptr, n, h, w, cin, cout, grid, tx, ty,
+                                        nt, (hipStream_t)s))
+            return e;
+        RD_LAUNCH_CHECK("conv_first_fwd");
+    }
+    if (sums) return reduce_partials_f32((const float*)ws, sums, grid, 2 * cout, (hipStream_t)s);
     return RD_OK;
 }
 

@@ -42,6 +42,7 @@ struct NtParams {
     int vec;  // epilogue may use 16-byte accesses (N % 4 == 0 and, for the transposed conv, Cout % 4 == 0)
     int ablate;  // tuning only (RD_ABLATE): 1 = no global reloads, 2 = no LDS restores, 4 = no barriers (wrong results)
     unsigned a_bytes, b_bytes;  // extents of the A / B tensors for the buffer descriptors
+    float* stats;  // EPI_STORE only, nullable: per-(tile_m) column sums / sums of squares [tiles_m][2][N] (BN statistics)
 };
 
 
@@ -192,8 +193,10 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
     // are staged through LDS (one row-band of BM/WM rows per pass) so that HBM sees 16 B per lane and whole
     // contiguous rows per wave; bias / skip-add of the transposed convolution ride the same pass.
     constexpr int CS = BN + 4, ROWS = BM / WM, Q = BN / 4;
-    static_assert(ROWS * CS <= (BM + BN) * LS, "epilogue staging must fit the operand buffers");
+    static_assert(ROWS * CS + 512 <= (BM + BN) * LS, "epilogue staging (+ statistics scratch) must fit the operand buffers");
     float* Cs = smem;
+    float* red = smem + ROWS * CS;          // 2 x 256 floats for the fused BatchNorm statistics
+    float tot_s = 0.f, tot_q = 0.f;         // threads t < BN: column totals over the passes
     for (int pass = 0; pass < WM; ++pass) {
         __syncthreads();
         if (wm == pass) {
@@ -206,6 +209,29 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
                         Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CS + wn * TN * 32 + j * 32 + lrow] = acc[i][j][r];
         }
         __syncthreads();
+        if (EPI == EPI_STORE && p.stats) {
+            // fused BN statistics: column sums over this pass's rows (fixed order), combined over the row groups
+            constexpr int G = 256 / BN;      // row groups
+            const int col = t % BN, grp = t / BN;
+            float ss = 0.f, qq = 0.f;
+            for (int row = grp; row < ROWS; row += G) {
+                if (m0 + pass * ROWS + row < p.M) {
+                    const float v = Cs[row * CS + col];
+                    ss += v;
+                    qq = fmaf(v, v, qq);
+                }
+            }
+            red[t] = ss;
+            red[256 + t] = qq;
+            __syncthreads();
+            if (t < BN) {
+#pragma unroll
+                for (int g2 = 0; g2 < G; ++g2) {
+                    tot_s += red[g2 * BN + t];
+                    tot_q += red[256 + g2 * BN + t];
+                }
+            }
+        }
         if (p.vec) {
             for (int e = t; e < ROWS * Q; e += 256) {
                 const int row = e / Q, q4 = e - row * Q;
@@ -250,10 +276,15 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
             }
         }
     }
+    if (EPI == EPI_STORE && p.stats && t < BN && n0 + t < p.N) {
+        float* out = p.stats + (long)tile_m * 2 * p.N;
+        out[n0 + t] = tot_s;
+        out[p.N + n0 + t] = tot_q;
+    }
 }
 
 template <int AMODE, int EPI>
-static int launch_nt(NtParams p, hipStream_t s, const char* cls) {
+static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_out = nullptr) {
     const long flops = 2L * p.M * p.N * p.K;
     const double bytes = 4.0 * ((double)p.M * p.Cin * (AMODE == A_UP2 ? 4 : 1) + (double)p.N * p.K + (double)p.M * p.N);
     p.chunks = cdiv(p.Cin, 32);
@@ -285,6 +316,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls) {
     snprintf(pcls, sizeof(pcls), "%s|igemm_nt<%s,%d,%d>", cls, cfg == 0 ? "128,128" : cfg == 1 ? "128,64" : "64,64",
              AMODE, EPI);
     ProfScope ps(s, pcls, (double)flops, bytes);
+    if (tiles_m_out) *tiles_m_out = cdiv(p.M, cfg == 2 ? 64 : 128);
     if (cfg == 2) {
         p.tiles_n = cdiv(p.N, 64);
         const int grid = cdiv(p.M, 64) * p.tiles_n;
@@ -324,7 +356,7 @@ struct TnParams {
 };
 
 template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void wgrad_tn_kernel(TnParams p) {
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(TnParams p) {   // (256,3) fits 128 VGPRs but measured slower
     constexpr int BK = 32;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AQ = BM / 4, BQ = BN / 4;          // float4 per row
@@ -522,25 +554,41 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cl
     return RD_OK;
 }
 
-// slab[s][m][n] summed over s and scattered into the torch weight layout.
+// slab[s][m][n] summed over s (fixed order, fp64) and scattered into the torch weight layout.
 //  mode 0 (conv3x3): m = co, n = tap*Cin + ci  ->  dw[(co*Cin + ci)*9 + tap]
 //  mode 1 (convT)  : m = ab*Cout + co, n = ci  ->  dw[(ci*Cout + co)*4 + ab]
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M, int N, int splits,
-                                   int mode, int Cin, int Cout) {
-    const long total = (long)M * N;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        double acc = 0.0;
-        for (int s = 0; s < splits; ++s) acc += (double)slab[(long)s * total + e];
+// One thread owns four consecutive n (16-byte coalesced slab reads, four splits in flight).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M,
+                                                          int N, int splits, int mode, int Cin, int Cout) {
+    const long total = (long)M * N, quads = total >> 2;   // N % 4 == 0 (channels are multiples of 4)
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long)gridDim.x * blockDim.x) {
+        const float4* src = reinterpret_cast<const float4*>(slab) + q;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int s = 0;
+        for (; s + 3 < splits; s += 4) {
+            const float4 v0 = src[(long)s * quads], v1 = src[(long)(s + 1) * quads];
+            const float4 v2 = src[(long)(s + 2) * quads], v3 = src[(long)(s + 3) * quads];
+            a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+            a1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+            a2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+            a3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+        }
+        for (; s < splits; ++s) {
+            const float4 v = src[(long)s * quads];
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        }
+        const long e = q << 2;
         const int m = (int)(e / N), n = (int)(e - (long)m * N);
-        long o;
+        const float r[4] = {(float)a0, (float)a1, (float)a2, (float)a3};
         if (mode == 0) {
-            const int tap = n / Cin, ci = n - tap * Cin;
-            o = ((long)m * Cin + ci) * 9 + tap;
+            const int tap = n / Cin, ci = n - tap * Cin;     // the quad stays inside one tap (Cin % 4 == 0)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dw[((long)m * Cin + ci + k) * 9 + tap] = r[k];
         } else {
             const int ab = m / Cout, co = m - ab * Cout;
-            o = ((long)n * Cout + co) * 4 + ab;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dw[((long)(n + k) * Cout + co) * 4 + ab] = r[k];
         }
-        dw[o] = (float)acc;
     }
 }
 
@@ -612,14 +660,32 @@ int rd_pack_convt2x2_weight(const float* w, float* wtf, float* wtd, int cin, int
 }
 
 int rd_conv3x3_fwd(const float* x, const float* wf, float* z, int n, int h, int w, int cin, int cout, rd_stream_t s) {
+    return rd_conv3x3_fwd_stats(x, wf, z, nullptr, n, h, w, cin, cout, nullptr, 0, s);
+}
+
+size_t rd_conv3x3_fwd_stats_ws_bytes(int n, int h, int w, int cin, int cout) {
+    (void)cin;
+    return (size_t)cdiv((long)n * h * w, 64) * 2 * cout * sizeof(float);
+}
+
+int rd_conv3x3_fwd_stats(const float* x, const float* wf, float* z, double* sums, int n, int h, int w, int cin, int cout,
+                         void* ws, size_t ws_bytes, rd_stream_t s) {
     if (int e = check_conv_args(n, h, w, cin, cout)) return e;
     RD_REQUIRE(x && wf && z, "rd_conv3x3_fwd: null pointer");
     RD_REQUIRE(cin % 4 == 0, "rd_conv3x3_fwd: Cin must be a multiple of 4 (got %d); use rd_conv3x3_first_fwd", cin);
+    if (sums && (!ws || ws_bytes < rd_conv3x3_fwd_stats_ws_bytes(n, h, w, cin, cout))) {
+        set_error("rd_conv3x3_fwd_stats: workspace too small");
+        return RD_ERR_WS;
+    }
     NtParams p = {};
     p.A = x; p.B = wf; p.C = z;
     p.M = n * h * w; p.N = cout; p.K = 9 * cin; p.Cin = cin;
     p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
-    return launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_fwd");
+    p.stats = sums ? (float*)ws : nullptr;
+    int tiles_m = 0;
+    if (int e = launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_fwd", &tiles_m)) return e;
+    if (sums) return reduce_partials_f32((const float*)ws, sums, tiles_m, 2 * cout, (hipStream_t)s);
+    return RD_OK;
 }
 
 int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int h, int w, int cin, int cout,
@@ -658,7 +724,7 @@ int rd_conv3x3_bwd_weight(const float* x, const float* dz, float* dw, int n, int
     p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
     if (int e = launch_tn<WA_PLAIN, WB_CONV3>(p, pl, (hipStream_t)s, "conv3x3_wgrad")) return e;
     ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N)), dim3(256), 0, (hipStream_t)s,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N / 4)), dim3(256), 0, (hipStream_t)s,
                        (const float*)ws, dw, p.M, p.N, pl.splits, 0, cin, cout);
     RD_LAUNCH_CHECK("slab_reduce");
     return RD_OK;
@@ -712,7 +778,7 @@ int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw, int n, 
     p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
     if (int e = launch_tn<WA_UP2, WB_PLAIN>(p, pl, (hipStream_t)s, "convt2x2_wgrad")) return e;
     ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N)), dim3(256), 0, (hipStream_t)s,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N / 4)), dim3(256), 0, (hipStream_t)s,
                        (const float*)ws, dw, p.M, p.N, pl.splits, 1, cin, cout);
     RD_LAUNCH_CHECK("slab_reduce");
     return RD_OK;

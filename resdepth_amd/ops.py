@@ -46,6 +46,18 @@ def conv3x3_fwd(x, wf):
     return z
 
 
+def conv3x3_fwd_stats(x, wf):
+    """-> (z, sums[2*Cout] float64): the BN batch statistics come out of the GEMM epilogue."""
+    n, h, w, cin = x.shape
+    cout = wf.shape[0]
+    z = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
+    sums = torch.empty(2 * cout, device=x.device, dtype=torch.float64)
+    ws = workspace(load().rd_conv3x3_fwd_stats_ws_bytes(n, h, w, cin, cout), x.device)
+    check(load().rd_conv3x3_fwd_stats(ptr(_f32(x, "x")), ptr(wf), ptr(z), ptr(sums), n, h, w, cin, cout, ws.data_ptr(),
+                                      ws.numel(), stream_ptr()), "conv3x3_fwd_stats")
+    return z, sums
+
+
 def conv3x3_bwd_data(dz, wd):
     n, h, w, cout = dz.shape
     cin = wd.shape[0]
@@ -73,6 +85,17 @@ def conv3x3_first_fwd(x_nchw, w):
     check(load().rd_conv3x3_first_fwd(ptr(_f32(x_nchw, "x")), ptr(w.detach()), ptr(z), n, h, wd_, cin, cout,
                                       stream_ptr()), "conv3x3_first_fwd")
     return z
+
+
+def conv3x3_first_fwd_stats(x_nchw, w):
+    n, cin, h, wd_ = x_nchw.shape
+    cout = w.shape[0]
+    z = torch.empty(n, h, wd_, cout, device=x_nchw.device, dtype=torch.float32)
+    sums = torch.empty(2 * cout, device=x_nchw.device, dtype=torch.float64)
+    ws = workspace(load().rd_conv3x3_first_fwd_stats_ws_bytes(n, h, wd_, cin, cout), x_nchw.device)
+    check(load().rd_conv3x3_first_fwd_stats(ptr(_f32(x_nchw, "x")), ptr(w.detach()), ptr(z), ptr(sums), n, h, wd_, cin,
+                                            cout, ws.data_ptr(), ws.numel(), stream_ptr()), "conv3x3_first_fwd_stats")
+    return z, sums
 
 
 def conv3x3_first_bwd_weight(x_nchw, dz, out=None):

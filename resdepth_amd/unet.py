@@ -203,10 +203,11 @@ class UNet(nn.Module):
         return pk
 
     # ------------------------------------------------------------------------------------------
-    def _bn_forward(self, z, bn: nn.BatchNorm2d, slope, pool, training):
+    def _bn_forward(self, z, bn: nn.BatchNorm2d, slope, pool, training, sums=None):
         c = z.shape[-1]
         if training:
-            sums = ops.bn_stats_partial(z)
+            if sums is None:
+                sums = ops.bn_stats_partial(z)
             count = z.numel() // c
             if self.sync_bn and self.grad_sync is not None:
                 count = self.grad_sync.allreduce_stats(sums, count)
@@ -223,23 +224,29 @@ class UNet(nn.Module):
         pk = self._packed()
         se, sb, sd_ = _SLOPES[self.act_fn_encoder], _SLOPES[self.act_fn_bottleneck], _SLOPES[self.act_fn_decoder]
         S = {"x": x, "enc": [], "dec": [], "training": training} if save else None
+
+        def conv_stats(inp, wf):
+            return ops.conv3x3_fwd_stats(inp, wf) if training else (ops.conv3x3_fwd(inp, wf), None)
+
         skips = []
         cur = None
         for i in range(d):
             blk = self.encoder[i][0]
+            sums = None                      # training: BN statistics come out of the conv kernel's epilogue
             if i == 0:
-                z = ops.conv3x3_first_fwd(x, blk[0].weight)
+                z, sums = ops.conv3x3_first_fwd_stats(x, blk[0].weight) if training else \
+                    (ops.conv3x3_first_fwd(x, blk[0].weight), None)
             else:
-                z = ops.conv3x3_fwd(cur, pk["enc"][i - 1][0])
-            a, p, idx, mean, invstd, count = self._bn_forward(z, blk[1], se, True, training)
+                z, sums = conv_stats(cur, pk["enc"][i - 1][0])
+            a, p, idx, mean, invstd, count = self._bn_forward(z, blk[1], se, True, training, sums)
             skips.append(a)
             if save:
                 S["enc"].append({"z": z, "idx": idx, "mean": mean, "invstd": invstd, "count": count, "p": p})
                 if keep_skips:               # tests only: the backward never needs the skip activations
                     S["enc"][-1]["a"] = a
             cur = p
-        zb = ops.conv3x3_fwd(cur, pk["bott"][0])
-        ab, _, _, mean, invstd, count = self._bn_forward(zb, self.bottleneck[1], sb, False, training)
+        zb, sums = conv_stats(cur, pk["bott"][0])
+        ab, _, _, mean, invstd, count = self._bn_forward(zb, self.bottleneck[1], sb, False, training, sums)
         if save:
             S["bott"] = {"z": zb, "mean": mean, "invstd": invstd, "count": count, "a": ab}
         cur = ab
@@ -250,8 +257,8 @@ class UNet(nn.Module):
             rec = {"s": s}
             if i < d - 1:
                 blk = self.decoder[i][1]
-                zd = ops.conv3x3_fwd(s, pk["dec_c"][i][0])
-                ad, _, _, mean, invstd, count = self._bn_forward(zd, blk[1], sd_, False, training)
+                zd, sums = conv_stats(s, pk["dec_c"][i][0])
+                ad, _, _, mean, invstd, count = self._bn_forward(zd, blk[1], sd_, False, training, sums)
                 rec.update(z=zd, mean=mean, invstd=invstd, count=count, a=ad)
                 cur = ad
             else:

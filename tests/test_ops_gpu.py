@@ -303,3 +303,25 @@ def test_errors_are_reported():
         ops.conv3x3_fwd(torch.zeros(1, 4, 4, 3, device=dev()), torch.zeros(8, 9, 3, device=dev()))
     with pytest.raises(RuntimeError, match="powers of two"):
         ops.conv3x3_fwd(torch.zeros(1, 6, 4, 4, device=dev()), torch.zeros(8, 9, 4, device=dev()))
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 16, 8, 24), (8, 64, 64, 32, 128), (3, 32, 32, 20, 36), (2, 16, 16, 128, 256)])
+def test_conv_epilogue_statistics_match_separate_pass(n, h, w, cin, cout):
+    """BN batch statistics fused into the conv epilogues == the stand-alone statistics kernel == torch."""
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    wf, _ = ops.pack_conv3x3_weight(wt.to(dev()))
+    z, sums = ops.conv3x3_fwd_stats(nhwc(x), wf)
+    assert torch.equal(z, ops.conv3x3_fwd(nhwc(x), wf))
+    ref = ops.bn_stats_partial(z)
+    close(sums.cpu(), ref.cpu(), tol=1e-6, name="fused vs separate")
+    zc = nchw(z).double()
+    close(sums[:cout].cpu(), zc.sum((0, 2, 3)), tol=1e-6, name="sum")
+    close(sums[cout:].cpu(), (zc * zc).sum((0, 2, 3)), tol=1e-6, name="sumsq")
+    x3 = torch.randn(n, 3, h, w, generator=g)
+    w3 = torch.randn(cout, 3, 3, 3, generator=g) / 5
+    z3, s3 = ops.conv3x3_first_fwd_stats(x3.to(dev()), w3.to(dev()))
+    assert torch.equal(z3, ops.conv3x3_first_fwd(x3.to(dev()), w3.to(dev())))
+    close(s3.cpu(), ops.bn_stats_partial(z3).cpu(), tol=1e-6, name="first conv fused vs separate")
