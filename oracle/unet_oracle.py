@@ -34,6 +34,7 @@ class Spec:
     act_fn_encoder: str = "relu"
     act_fn_decoder: str = "relu"
     act_fn_bottleneck: str = "relu"
+    do_BN: bool = True
     bias_conv_layer: bool = False
     outer_skip: bool = True
     outer_skip_BN: bool = False
@@ -66,8 +67,12 @@ def param_layout(spec: Spec):
 
     def conv(prefix, cout, cin):
         out.append((prefix + ".weight", (cout, cin, 3, 3), "param"))
+        if not spec.do_BN:                 # conv_block without BN carries the bias (lib/UNet.py:48-52)
+            out.append((prefix + ".bias", (cout,), "param"))
 
     def bn(prefix, c):
+        if not spec.do_BN and not prefix.startswith("layer_outer_skip"):
+            return
         out.append((prefix + ".weight", (c,), "param"))
         out.append((prefix + ".bias", (c,), "param"))
         out.append((prefix + ".running_mean", (c,), "buffer"))
@@ -110,12 +115,15 @@ def init_state_dict(spec: Spec, seed: int) -> Dict[str, torch.Tensor]:
     fd = spec.filter_depths
 
     def conv(prefix, cin, cout, bias):
+        bias = bias or (not spec.do_BN and prefix != "last_layer")
         m = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=bias)
         sd[prefix + ".weight"] = m.weight.detach().clone()
         if bias:
             sd[prefix + ".bias"] = m.bias.detach().clone()
 
     def bn(prefix, c):
+        if not spec.do_BN and not prefix.startswith("layer_outer_skip"):
+            return
         sd[prefix + ".weight"] = torch.ones(c)
         sd[prefix + ".bias"] = torch.zeros(c)
         sd[prefix + ".running_mean"] = torch.zeros(c)
@@ -154,13 +162,16 @@ def _bn_act(z, sd, prefix, slope, training, update_running, mask=None):
     `mask` (bool, optional) imposes the activation's branch decision (True = positive branch) instead of
     deriving it from the sign of the BN output: used by the parity tests to compare gradients under
     IDENTICAL discrete decisions (one flipped ReLU in a 10^6-element layer moves rel-L2 by 1e-3)."""
-    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
-    if training and not update_running:
-        rm, rv = rm.clone(), rv.clone()
-    y = F.batch_norm(z, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"],
-                     training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
-    if training and update_running:
-        sd[prefix + ".num_batches_tracked"] += 1
+    if prefix + ".running_mean" in sd:
+        rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+        if training and not update_running:
+            rm, rv = rm.clone(), rv.clone()
+        y = F.batch_norm(z, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"],
+                         training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
+        if training and update_running:
+            sd[prefix + ".num_batches_tracked"] += 1
+    else:                                  # do_BN=False: the conv's own bias was already added by the caller
+        y = z
     if mask is not None:
         return torch.where(mask, y, y * slope)
     return F.leaky_relu(y, slope) if slope != 0.0 else F.relu(y)
@@ -185,7 +196,7 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, spec: Spec, training: 
     skips = []
     out = x
     for i in range(d):                                            # lib/UNet.py:201-207
-        z = F.conv2d(out, sd[f"encoder.{i}.0.0.weight"], None, 1, 1)
+        z = F.conv2d(out, sd[f"encoder.{i}.0.0.weight"], sd.get(f"encoder.{i}.0.0.bias"), 1, 1)
         a = _bn_act(z, sd, f"encoder.{i}.0.1", se, training, update_running, dec.get(f"mask_e{i}"))
         skips.append(a)
         if f"idx{i}" in dec:          # imposed arg-max (flat H*W indices, as torch returns them)
@@ -194,7 +205,7 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, spec: Spec, training: 
         else:
             out, idx = F.max_pool2d(a, 2, 2, return_indices=True)
         k[f"z{i}"], k[f"a{i}"], k[f"p{i}"], k[f"idx{i}"] = z, a, out, idx
-    z = F.conv2d(out, sd["bottleneck.0.weight"], None, 1, 1)       # lib/UNet.py:210
+    z = F.conv2d(out, sd["bottleneck.0.weight"], sd.get("bottleneck.0.bias"), 1, 1)       # lib/UNet.py:210
     out = _bn_act(z, sd, "bottleneck.1", sb, training, update_running, dec.get("mask_b"))
     k["zb"], k["ab"] = z, out
     for i in range(d):                                            # lib/UNet.py:213-224
@@ -203,7 +214,7 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, spec: Spec, training: 
         s = skips[-1 - i] + u                                     # SkipConnection: ADD, lib/UNet.py:100-101
         k[f"u{i}"], k[f"s{i}"] = u, s
         if i < d - 1:
-            z = F.conv2d(s, sd[f"decoder.{i}.1.0.weight"], None, 1, 1)
+            z = F.conv2d(s, sd[f"decoder.{i}.1.0.weight"], sd.get(f"decoder.{i}.1.0.bias"), 1, 1)
             out = _bn_act(z, sd, f"decoder.{i}.1.1", sdec, training, update_running, dec.get(f"mask_d{i}"))
             k[f"zd{i}"], k[f"ad{i}"] = z, out
         else:

@@ -122,15 +122,11 @@ class UNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _unsupported(self) -> Optional[str]:
-        if not self.do_BN:
-            return "do_BN=False"
         if self.up_mode != "transpose":
             return "up_mode='bilinear'"
         for a in (self.act_fn_encoder, self.act_fn_decoder, self.act_fn_bottleneck):
             if a == "prelu":
                 return "activation 'prelu'"
-        if self.do_outer_skip and self.do_outer_skip_BN:
-            return "outer_skip_BN=True"
         if self.start_kernel % 4 != 0:
             return "start_kernel not a multiple of 4"
         if not 1 <= self.n_input_channels <= 6:
@@ -203,8 +199,27 @@ class UNet(nn.Module):
         return pk
 
     # ------------------------------------------------------------------------------------------
-    def _bn_forward(self, z, bn: nn.BatchNorm2d, slope, pool, training, sums=None):
+    def _const(self, c, value, device):
+        key = (c, value, str(device))
+        cache = self.__dict__.setdefault("_const_cache", {})
+        if key not in cache:
+            cache[key] = torch.full((c,), float(value), device=device, dtype=torch.float32)
+        return cache[key]
+
+    def _norm_of(self, block):
+        """(BatchNorm2d module | None, conv bias | None) of a conv block (lib/UNet.py:36-52: with do_BN=False the block is
+        conv(bias=True) -> activation)."""
+        if self.do_BN:
+            return block[1], None
+        return None, block[0].bias
+
+    def _bn_forward(self, z, bn, slope, pool, training, sums=None, bias=None):
         c = z.shape[-1]
+        if bn is None:
+            # do_BN=False: activation(conv + bias) == the fused BN-apply kernel with mean 0, invstd 1, gamma 1, beta = bias
+            mean, invstd = self._const(c, 0.0, z.device), self._const(c, 1.0, z.device)
+            a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, invstd, bias, slope, pool)
+            return a, p, idx, mean, invstd, 1
         if training:
             if sums is None:
                 sums = ops.bn_stats_partial(z)
@@ -226,7 +241,9 @@ class UNet(nn.Module):
         S = {"x": x, "enc": [], "dec": [], "training": training} if save else None
 
         def conv_stats(inp, wf):
-            return ops.conv3x3_fwd_stats(inp, wf) if training else (ops.conv3x3_fwd(inp, wf), None)
+            if training and self.do_BN:
+                return ops.conv3x3_fwd_stats(inp, wf)
+            return ops.conv3x3_fwd(inp, wf), None
 
         skips = []
         cur = None
@@ -234,11 +251,12 @@ class UNet(nn.Module):
             blk = self.encoder[i][0]
             sums = None                      # training: BN statistics come out of the conv kernel's epilogue
             if i == 0:
-                z, sums = ops.conv3x3_first_fwd_stats(x, blk[0].weight) if training else \
+                z, sums = ops.conv3x3_first_fwd_stats(x, blk[0].weight) if (training and self.do_BN) else \
                     (ops.conv3x3_first_fwd(x, blk[0].weight), None)
             else:
                 z, sums = conv_stats(cur, pk["enc"][i - 1][0])
-            a, p, idx, mean, invstd, count = self._bn_forward(z, blk[1], se, True, training, sums)
+            bn, cbias = self._norm_of(blk)
+            a, p, idx, mean, invstd, count = self._bn_forward(z, bn, se, True, training, sums, cbias)
             skips.append(a)
             if save:
                 S["enc"].append({"z": z, "idx": idx, "mean": mean, "invstd": invstd, "count": count, "p": p})
@@ -246,7 +264,8 @@ class UNet(nn.Module):
                     S["enc"][-1]["a"] = a
             cur = p
         zb, sums = conv_stats(cur, pk["bott"][0])
-        ab, _, _, mean, invstd, count = self._bn_forward(zb, self.bottleneck[1], sb, False, training, sums)
+        bn, cbias = self._norm_of(self.bottleneck)
+        ab, _, _, mean, invstd, count = self._bn_forward(zb, bn, sb, False, training, sums, cbias)
         if save:
             S["bott"] = {"z": zb, "mean": mean, "invstd": invstd, "count": count, "a": ab}
         cur = ab
@@ -258,16 +277,46 @@ class UNet(nn.Module):
             if i < d - 1:
                 blk = self.decoder[i][1]
                 zd, sums = conv_stats(s, pk["dec_c"][i][0])
-                ad, _, _, mean, invstd, count = self._bn_forward(zd, blk[1], sd_, False, training, sums)
+                bn, cbias = self._norm_of(blk)
+                ad, _, _, mean, invstd, count = self._bn_forward(zd, bn, sd_, False, training, sums, cbias)
                 rec.update(z=zd, mean=mean, invstd=invstd, count=count, a=ad)
                 cur = ad
             else:
                 cur = s
             if save:
                 S["dec"].append(rec)
-        out = ops.conv3x3_last_fwd(cur, self.last_layer.weight, self.last_layer.bias,
-                                   x if self.do_outer_skip else None)
+        x_res = x if self.do_outer_skip else None
+        if self.do_outer_skip and self.do_outer_skip_BN:
+            x_res, obn = self._outer_bn_forward(x, training)          # BatchNorm2d(1) on channel 0 (lib/UNet.py:230-237)
+            if save:
+                S["outer_bn"] = obn
+        out = ops.conv3x3_last_fwd(cur, self.last_layer.weight, self.last_layer.bias, x_res)
         return out, S
+
+    def _outer_bn_forward(self, x, training):
+        """BatchNorm2d(1) on x[:, 0:1].  A one-channel tensor is viewed as [P/4, 4] ("four pseudo-channels") so the
+        NHWC float4 kernels apply; the four partial statistics are combined (tiny torch ops on 8 doubles)."""
+        bn = self.layer_outer_skip[0]
+        n, _, h, w = x.shape
+        x0 = x[:, 0:1].contiguous()
+        v = x0.view(1, 1, (n * h * w) // 4, 4)
+        g4, b4 = bn.weight.detach().expand(4).contiguous(), bn.bias.detach().expand(4).contiguous()
+        if training:
+            s8 = ops.bn_stats_partial(v).view(2, 4).sum(1, keepdim=True).expand(2, 4).contiguous().view(8)
+            count = n * h * w
+            if self.sync_bn and self.grad_sync is not None:
+                count = self.grad_sync.allreduce_stats(s8, count)
+            rm4, rv4 = bn.running_mean.expand(4).contiguous(), bn.running_var.expand(4).contiguous()
+            mean4, inv4 = ops.bn_stats_finalize(s8, count, rm4, rv4, bn.num_batches_tracked, eps=bn.eps,
+                                                momentum=bn.momentum)
+            bn.running_mean.copy_(rm4[0:1])
+            bn.running_var.copy_(rv4[0:1])
+        else:
+            count = n * h * w
+            mean4, inv4 = ops.bn_eval_stats(bn.running_mean.expand(4).contiguous(), bn.running_var.expand(4).contiguous(),
+                                            eps=bn.eps)
+        y, _, _ = ops.bn_act_pool_fwd(v, mean4, inv4, g4, b4, 1.0, False)       # slope 1 = identity activation
+        return y.view(n, 1, h, w), {"v": v, "mean": mean4, "invstd": inv4, "g4": g4, "b4": b4, "count": count}
 
     def _engine_backward(self, S, dout):
         """Writes every parameter gradient into a flat gradient buffer; returns the list of views
@@ -301,8 +350,19 @@ class UNet(nn.Module):
             if sync is not None:
                 sync.params_ready(self, [index[id(p)] for p in ps if p is not None])
 
-        def bn_backward(rec, bn, slope, g_full, g_pool, idx, extra_bias=None):
+        def bn_backward(rec, block, slope, g_full, g_pool, idx, extra_bias=None):
             c = rec["z"].shape[-1]
+            bn, cbias = self._norm_of(block)
+            if bn is None:
+                # do_BN=False: a = act(z + bias); d bias = sum g', dz = g' (the "eval" form of the fused kernels)
+                one = self._const(c, 1.0, rec["z"].device)
+                sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], one, cbias, slope, g_full, g_pool, idx)
+                if extra_bias is not None:
+                    gv(extra_bias).copy_(sums[2 * c:3 * c])
+                dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], one, cbias, slope, g_full, g_pool, idx,
+                                          sums, 1.0, False, dgamma=None, dbeta=gv(cbias))
+                done(cbias, extra_bias)
+                return dz
             sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
                                          g_pool, idx)
             if extra_bias is not None:
@@ -328,6 +388,15 @@ class UNet(nn.Module):
         ops.conv3x3_last_bwd_weight(S["dec"][d - 1]["s"], dout, gv(ll.weight),
                                     gv(ll.bias) if ll.bias is not None else None, want_bias=ll.bias is not None)
         done(ll.weight, ll.bias)
+        if "outer_bn" in S:
+            # BatchNorm2d(1) on the outer skip: only its affine parameters need gradients (x is an input)
+            ob = S["outer_bn"]
+            obn = self.layer_outer_skip[0]
+            s12 = ops.bn_act_bwd_reduce(ob["v"], ob["mean"], ob["invstd"], ob["g4"], ob["b4"], 1.0,
+                                        dout.view(ob["v"].shape), None, None)
+            gv(obn.bias).copy_(s12[0:4].sum().reshape(1))
+            gv(obn.weight).copy_(s12[4:8].sum().reshape(1))
+            done(obn.weight, obn.bias)
         g = ops.conv3x3_last_bwd_data(dout, ll.weight, c0)
         skipgrad = [None] * d
         gp = None
@@ -340,12 +409,12 @@ class UNet(nn.Module):
             skipgrad[d - 1 - i] = g       # gradient wrt the encoder skip a_{d-1-i} (SkipConnection is an ADD)
             if i > 0:
                 blk = self.decoder[i - 1][1]
-                dz = bn_backward(src, blk[1], sd_, dprev, None, None)
+                dz = bn_backward(src, blk, sd_, dprev, None, None)
                 ops.conv3x3_bwd_weight(S["dec"][i - 1]["s"], dz, gv(blk[0].weight))
                 done(blk[0].weight)
                 g = ops.conv3x3_bwd_data(dz, pk["dec_c"][i - 1][1])
             else:
-                dz = bn_backward(src, self.bottleneck[1], sb, dprev, None, None)
+                dz = bn_backward(src, self.bottleneck, sb, dprev, None, None)
                 ops.conv3x3_bwd_weight(S["enc"][d - 1]["p"], dz, gv(self.bottleneck[0].weight))
                 done(self.bottleneck[0].weight)
                 gp = ops.conv3x3_bwd_data(dz, pk["bott"][1])
@@ -356,7 +425,7 @@ class UNet(nn.Module):
             # ConvTranspose2d whose output was added to this skip (decoder level d-1-i)
             j = d - 1 - i
             up = self.decoder[j][0] if j < d - 1 else self.decoder[j]
-            dz = bn_backward(e, blk[1], se, skipgrad[i], gp, e["idx"], extra_bias=up.bias)
+            dz = bn_backward(e, blk, se, skipgrad[i], gp, e["idx"], extra_bias=up.bias)
             skipgrad[i] = None
             if i > 0:
                 ops.conv3x3_bwd_weight(S["enc"][i - 1]["p"], dz, gv(blk[0].weight))

@@ -293,6 +293,11 @@ if __name__ == "__main__":
               seed_w=5, seed_x=6)
     tiny_case("g2b_cap", dict(n_input_channels=2, start_kernel=16, depth=4, max_filter_depth=32,
                               bias_conv_layer=True, outer_skip=False), n=1, t=64, seed_w=7, seed_x=8)
+    tiny_case("g7_nobn", dict(n_input_channels=2, start_kernel=8, depth=2, do_BN=False, bias_conv_layer=True), n=2,
+              t=16, seed_w=11, seed_x=12)
+    tiny_case("g8_lrelu_oskipbn", dict(n_input_channels=3, start_kernel=8, depth=2, act_fn_encoder="lrelu",
+                                       act_fn_decoder="lrelu", act_fn_bottleneck="lrelu", outer_skip_BN=True,
+                                       bias_conv_layer=True), n=3, t=16, seed_w=13, seed_x=14)
     op_cases()
     init_digest()
     full_digest()
