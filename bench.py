@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="SyncBN (single-device-equivalent statistics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
+    ap.add_argument("--workload", choices=["S", "M"], default="S",
+                    help="S = cfg-S (BASELINE configs[1], the headline metric); M = cfg-M (configs[3]: 2-ch 512x512 depth-6)")
     ap.add_argument("--infer", action="store_true",
                     help="measure the tiled full-raster inference sweep instead (BASELINE configs[4], cfg-G: 3-ch tiles of "
                          "256x256 at stride 128 over a synthetic --raster x --raster DSM, eval-mode BN, linear blend)")
@@ -153,14 +155,16 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(0)
-    model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).train()
+    wl = {"S": dict(c=3, t=256, depth=5, flop=FLOP_PER_TILE, name="config_ResDepth-stereo (cfg-S): 3-ch 256x256 tiles, depth-5 U-Net"),
+          "M": dict(c=2, t=512, depth=6, flop=241.66e9, name="config_ResDepth-mono (cfg-M): 2-ch 512x512 tiles, depth-6 U-Net")}[args.workload]
+    model = UNet(n_input_channels=wl["c"], start_kernel=64, depth=wl["depth"], bias_conv_layer=True).to(dev).train()
     if use_dist:
         gs = dp.attach(model, sync_bn=args.sync_bn)
         dp.broadcast_parameters(model, 0)
     opt = FusedAdam(model.parameters(), lr=2e-4, weight_decay=1e-5)
 
     n = args.batch
-    b = O.synthetic_batch(n, 3, 256, seed=1234 + rank)
+    b = O.synthetic_batch(n, wl["c"], wl["t"], seed=1234 + rank)
     x = b["input"].to(dev)
     y = b["target"].to(dev)
     mask = b["loss_mask"].to(dev)
@@ -249,20 +253,21 @@ def main():
                     "alg_flop_per_launch": dom["flops"] / dom["launches"],
                     "launches_per_step": dom["launches"] / args.steps}
         out = {
-            "metric": "DSM tiles/sec fwd+bwd (256x256, 3-ch, depth-5 U-Net)", "value": round(tiles_s, 2),
+            "metric": "DSM tiles/sec fwd+bwd (256x256, 3-ch, depth-5 U-Net)" if args.workload == "S" else
+                      "DSM tiles/sec fwd+bwd (512x512, 2-ch, depth-6 U-Net)", "value": round(tiles_s, 2),
             "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (randn tiles resident in HBM, default-initialised weights)",
-            "config": {"workload": "config_ResDepth-stereo (cfg-S): 3-ch 256x256 tiles, depth-5 U-Net, fwd+loss+bwd+Adam",
+            "config": {"workload": wl["name"] + ", fwd+loss+bwd+Adam",
                        "tiles_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"dp{world}" + ("+syncbn" if args.sync_bn else "")},
-            "e2e": {"tflops": round(tiles_s / world * FLOP_PER_TILE / 1e12, 2),
-                    "frac_f32_peak": round(tiles_s / world * FLOP_PER_TILE / 1e12 / PEAK_F32_TFLOPS, 4)},
+            "e2e": {"tflops": round(tiles_s / world * wl["flop"] / 1e12, 2),
+                    "frac_f32_peak": round(tiles_s / world * wl["flop"] / 1e12 / PEAK_F32_TFLOPS, 4)},
             "roofline": roof,
             "kernels": kernels,
             "loss_first_last": [round(loss_vals[0], 6), round(loss_vals[-1], 6)] if loss_vals else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "S":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if use_dist:
