@@ -77,7 +77,7 @@ def infer_main(args, world, rank, dev):
         predict_linear_blend(loader, model)
     torch.cuda.synchronize()
     if not args.no_prof:
-        _lib.prof_reset(); _lib.prof_enable(True)
+        _lib.prof_reset(); _lib.prof_enable(2 if args.prof_all else 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = predict_linear_blend(loader, model)
@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="SyncBN (single-device-equivalent statistics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
+    ap.add_argument("--prof-all", action="store_true",
+                    help="bracket EVERY kernel launch with HIP events (complete breakdown; costs ~4%% of the step). Default: "
+                         "only the MFMA kernel classes the roofline needs (~1%%)")
     ap.add_argument("--workload", choices=["S", "M"], default="S",
                     help="S = cfg-S (BASELINE configs[1], the headline metric); M = cfg-M (configs[3]: 2-ch 512x512 depth-6)")
     ap.add_argument("--infer", action="store_true",
@@ -193,7 +196,7 @@ def main():
     prof = not args.no_prof
     if prof:
         _lib.prof_reset()
-        _lib.prof_enable(True)
+        _lib.prof_enable(2 if args.prof_all else 1)
     losses.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):

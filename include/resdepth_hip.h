@@ -181,7 +181,7 @@ typedef struct {
     double flops;   /* summed algorithmic FLOPs declared at launch */
     double bytes;   /* summed algorithmic HBM bytes declared at launch */
 } rd_prof_entry;
-int rd_prof_enable(int on);
+int rd_prof_enable(int level);   /* 0 off; 1 = the MFMA (roofline) kernel classes only; 2 = every kernel class */
 int rd_prof_reset(void);
 int rd_prof_collect(rd_prof_entry* out, int max_entries); /* returns number of classes, <0 on error */
 

@@ -146,8 +146,11 @@ def param_generation(flat_ptr: int) -> int:
 
 
 # ---- profiler -----------------------------------------------------------------------------------
-def prof_enable(on: bool):
-    check(load().rd_prof_enable(1 if on else 0))
+def prof_enable(level):
+    """0/False off; 1 = MFMA (roofline) kernel classes only; 2/True = every kernel class."""
+    if level is True:
+        level = 2
+    check(load().rd_prof_enable(int(level)))
 
 
 def prof_reset():

@@ -11,14 +11,15 @@ void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
 // ---- profiling (rd_prof_*) -----------------------------------------------------------
-bool prof_on();
+int prof_level();   // 0 off, 1 = MFMA (roofline) kernel classes only, 2 = every kernel class
 void prof_begin(hipStream_t s, const char* cls, double flops, double bytes);
 void prof_end(hipStream_t s);
 
 struct ProfScope {
     hipStream_t s;
     bool on;
-    ProfScope(hipStream_t s_, const char* cls, double flops, double bytes) : s(s_), on(prof_on()) {
+    ProfScope(hipStream_t s_, const char* cls, double flops, double bytes, bool mfma_class = false)
+        : s(s_), on(prof_level() >= (mfma_class ? 1 : 2)) {
         if (on) prof_begin(s, cls, flops, bytes);
     }
     ~ProfScope() {

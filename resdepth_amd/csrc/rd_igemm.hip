@@ -315,7 +315,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     char pcls[64];   // "<operation>|<kernel symbol>": the kernel symbol is what rocprofv3 reports
     snprintf(pcls, sizeof(pcls), "%s|igemm_nt<%s,%d,%d>", cls, cfg == 0 ? "128,128" : cfg == 1 ? "128,64" : "64,64",
              AMODE, EPI);
-    ProfScope ps(s, pcls, (double)flops, bytes);
+    ProfScope ps(s, pcls, (double)flops, bytes, true);
     if (tiles_m_out) *tiles_m_out = cdiv(p.M, cfg == 2 ? 64 : 128);
     if (cfg == 2) {
         p.tiles_n = cdiv(p.N, 64);
@@ -530,7 +530,7 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cl
     char pcls[64];
     snprintf(pcls, sizeof(pcls), "%s|wgrad_tn<%d,%d,%d,%d>", cls, pl.bm, pl.bn, AMODE, BMODE);
     ProfScope ps(s, pcls, 2.0 * p.M * p.N * (double)p.Kp,
-                 4.0 * ((double)p.Kp * p.lda * (AMODE == WA_UP2 ? 4 : 1) + (double)p.Kp * p.ldb + (double)p.M * p.N));
+                 4.0 * ((double)p.Kp * p.lda * (AMODE == WA_UP2 ? 4 : 1) + (double)p.Kp * p.ldb + (double)p.M * p.N), true);
     const double a_bytes = 4.0 * (double)p.Kp * p.lda * (AMODE == WA_UP2 ? 4 : 1), b_bytes = 4.0 * (double)p.Kp * p.ldb;
     if (a_bytes >= 4294967040.0 || b_bytes >= 4294967040.0) {
         set_error("%s: operand larger than the 4 GiB buffer-descriptor range", cls);

@@ -37,13 +37,13 @@ struct ProfClass {
     double ms = 0, flops = 0, bytes = 0;
 };
 static std::mutex g_mu;
-static volatile bool g_on = false;
+static volatile int g_level = 0;
 static std::vector<ProfRec> g_recs;
 static std::vector<ProfClass> g_cls;
 static std::vector<hipEvent_t> g_free_events;
 static thread_local int t_open = -1;
 
-bool prof_on() { return g_on; }
+int prof_level() { return g_level; }
 
 static hipEvent_t get_event() {
     if (!g_free_events.empty()) {
@@ -113,7 +113,7 @@ const char* rd_last_error_string(void) { return rd::g_err; }
 
 int rd_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(rd::g_mu);
-    rd::g_on = on != 0;
+    rd::g_level = on < 0 ? 0 : (on > 2 ? 2 : on);
     return RD_OK;
 }
 

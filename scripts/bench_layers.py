@@ -17,7 +17,7 @@ reps = 5
 
 def timed(fn):
     fn(); torch.cuda.synchronize()
-    _lib.prof_reset(); _lib.prof_enable(True)
+    _lib.prof_reset(); _lib.prof_enable(2)
     for _ in range(reps):
         fn()
     _lib.prof_enable(False)

@@ -6,7 +6,7 @@ REPO="$(pwd)"
 OUT="$REPO/gpurun_out/prof"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --prof-all"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 PMCBENCH="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA -d "$OUT/pmc_sq" -o bench --output-format csv -- $PMCBENCH > /dev/null 2> "$OUT/pmc_sq.err"
