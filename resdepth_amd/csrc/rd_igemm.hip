@@ -309,6 +309,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     const int tiles_128x64 = cdiv(p.M, 128) * cdiv(p.N, 64);
     int cfg;
     if (p.M < 128 || tiles_128x64 < 1024) cfg = 2;
+    else if (EPI == EPI_CONVT && p.K <= 256) cfg = 2;   // scatter epilogue dominates: small tiles keep more of it in flight
     else if (p.N >= 128 && p.K <= 640 && cdiv(p.M, 128) * cdiv(p.N, 128) >= 1536) cfg = 0;
     else cfg = 1;
     if (force >= 0 && force <= 2 && !(force == 0 && p.N <= 64)) cfg = force;
