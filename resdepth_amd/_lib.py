@@ -124,8 +124,9 @@ def ptr(t):
 _ws = {}
 
 
-def workspace(nbytes: int, device) -> torch.Tensor:
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
+    """`slot` separates scratch buffers that are in use on different streams at the same time."""
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), slot)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

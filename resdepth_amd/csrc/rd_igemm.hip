@@ -509,6 +509,11 @@ static TnPlan plan_tn(int M, int N, long Kp) {
     TnPlan pl;
     pl.bm = M > 64 ? 128 : 64;
     pl.bn = N > 64 ? 128 : 64;
+    static const int tforce = getenv("RD_TN_TILE") ? atoi(getenv("RD_TN_TILE")) : -1;   // tuning: bm*1000 + bn
+    if (tforce > 0) {
+        pl.bm = tforce / 1000;
+        pl.bn = tforce % 1000;
+    }
     pl.tiles_m = cdiv(M, pl.bm);
     pl.tiles_n = cdiv(N, pl.bn);
     const int tiles = pl.tiles_m * pl.tiles_n;

@@ -43,6 +43,7 @@ class GradSync:
         self._launched = []
         self._handles = []
         self._model_key = None
+        self.launch_stream = None   # set by the two-stream backward: the stream the wgrad kernels run on
 
     # ---- small collectives ---------------------------------------------------------------------
     def allreduce_loss_sums(self, sums: torch.Tensor, numel: int) -> int:
@@ -96,7 +97,16 @@ class GradSync:
     def _launch(self, model, bi):
         b = self._buckets[bi]
         view = model._flat_grad[b["lo"]:b["hi"]]
-        h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if self.launch_stream is not None and view.is_cuda:
+            # a bucket mixes gradients produced on the main stream (BN / bias) and on the wgrad stream: the collective
+            # is issued from the wgrad stream after it has caught up with the main stream (cheap: main runs ahead)
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(self.launch_stream):
+                if cur != self.launch_stream:
+                    self.launch_stream.wait_stream(cur)
+                h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        else:
+            h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._handles.append(h)
         self._launched[bi] = True
 

@@ -66,13 +66,13 @@ def conv3x3_bwd_data(dz, wd):
     return dx
 
 
-def conv3x3_bwd_weight(x, dz, out=None):
+def conv3x3_bwd_weight(x, dz, out=None, ws_slot=0):
     n, h, w, cin = x.shape
     cout = dz.shape[3]
     if out is None:
         out = torch.empty(cout, cin, 3, 3, device=x.device, dtype=torch.float32)
     nb = load().rd_conv3x3_bwd_weight_ws_bytes(n, h, w, cin, cout)
-    ws = workspace(nb, x.device)
+    ws = workspace(nb, x.device, ws_slot)
     check(load().rd_conv3x3_bwd_weight(ptr(x), ptr(dz), ptr(out), n, h, w, cin, cout, ws.data_ptr(), ws.numel(),
                                        stream_ptr()), "conv3x3_bwd_weight")
     return out
@@ -98,13 +98,13 @@ def conv3x3_first_fwd_stats(x_nchw, w):
     return z, sums
 
 
-def conv3x3_first_bwd_weight(x_nchw, dz, out=None):
+def conv3x3_first_bwd_weight(x_nchw, dz, out=None, ws_slot=0):
     n, cin, h, wd_ = x_nchw.shape
     cout = dz.shape[3]
     if out is None:
         out = torch.empty(cout, cin, 3, 3, device=dz.device, dtype=torch.float32)
     nb = load().rd_conv3x3_first_bwd_weight_ws_bytes(n, h, wd_, cin, cout)
-    ws = workspace(nb, dz.device)
+    ws = workspace(nb, dz.device, ws_slot)
     check(load().rd_conv3x3_first_bwd_weight(ptr(x_nchw), ptr(dz), ptr(out), n, h, wd_, cin, cout, ws.data_ptr(),
                                              ws.numel(), stream_ptr()), "conv3x3_first_bwd_weight")
     return out
@@ -127,14 +127,14 @@ def conv3x3_last_bwd_data(dout, w, c):
     return ds
 
 
-def conv3x3_last_bwd_weight(s, dout, dw=None, dbias=None, want_bias=True):
+def conv3x3_last_bwd_weight(s, dout, dw=None, dbias=None, want_bias=True, ws_slot=0):
     n, h, wd_, c = s.shape
     if dw is None:
         dw = torch.empty(1, c, 3, 3, device=s.device, dtype=torch.float32)
     if dbias is None and want_bias:
         dbias = torch.empty(1, device=s.device, dtype=torch.float32)
     nb = load().rd_conv3x3_last_bwd_weight_ws_bytes(n, h, wd_, c)
-    ws = workspace(nb, s.device)
+    ws = workspace(nb, s.device, ws_slot)
     check(load().rd_conv3x3_last_bwd_weight(ptr(s), ptr(dout), ptr(dw), ptr(dbias), n, h, wd_, c, ws.data_ptr(),
                                             ws.numel(), stream_ptr()), "conv3x3_last_bwd_weight")
     return dw, dbias
@@ -158,13 +158,13 @@ def convt2x2_bwd_data(dout, wtd):
     return dx
 
 
-def convt2x2_bwd_weight(x, dout, out=None):
+def convt2x2_bwd_weight(x, dout, out=None, ws_slot=0):
     n, h, w, cin = x.shape
     cout = dout.shape[3]
     if out is None:
         out = torch.empty(cin, cout, 2, 2, device=x.device, dtype=torch.float32)
     nb = load().rd_convt2x2_bwd_weight_ws_bytes(n, h, w, cin, cout)
-    ws = workspace(nb, x.device)
+    ws = workspace(nb, x.device, ws_slot)
     check(load().rd_convt2x2_bwd_weight(ptr(x), ptr(dout), ptr(out), n, h, w, cin, cout, ws.data_ptr(), ws.numel(),
                                         stream_ptr()), "convt2x2_bwd_weight")
     return out

@@ -119,6 +119,8 @@ class UNet(nn.Module):
         self._pack_key = None
         self.grad_sync = None        # optional resdepth_amd.dp.GradSync (data-parallel hooks)
         self.sync_bn = False
+        self.two_stream_backward = True   # weight gradients on a second HIP stream, overlapping the dgrad/BN chain
+        self._side_stream = None
 
     # ------------------------------------------------------------------------------------------
     def _unsupported(self) -> Optional[str]:
@@ -346,9 +348,39 @@ class UNet(nn.Module):
             grads[i] = g
             return g
 
+        # Two-stream backward: the weight gradients are off the critical path (dz -> dgrad -> BN-bwd -> dz' ...) and the
+        # HBM-bound elementwise kernels on that path complement the MFMA-bound wgrad GEMMs, so every wgrad is enqueued
+        # on a second HIP stream behind an event recorded after its dz.  Tensors produced on the main stream and read
+        # there are pinned with record_stream; the main stream joins the side stream before the backward returns.
+        main = torch.cuda.current_stream()
+        side = None
+        if self.two_stream_backward:
+            if self._side_stream is None or self._side_stream.device != dout.device:
+                self._side_stream = torch.cuda.Stream(device=dout.device)
+            side = self._side_stream
+            if sync is not None:
+                sync.launch_stream = side
+        elif sync is not None:
+            sync.launch_stream = None
+
         def done(*ps):
             if sync is not None:
                 sync.params_ready(self, [index[id(p)] for p in ps if p is not None])
+
+        def wgrad(fn, reads, *args, ready=()):
+            """run fn(*args) (a weight-gradient op writing into the flat gradient buffer) on the side stream"""
+            if side is None:
+                fn(*args)
+                done(*ready)
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                fn(*args, ws_slot=1)
+                for t_ in reads:
+                    t_.record_stream(side)
+                done(*ready)
 
         def bn_backward(rec, block, slope, g_full, g_pool, idx, extra_bias=None):
             c = rec["z"].shape[-1]
@@ -385,9 +417,9 @@ class UNet(nn.Module):
         c0 = self.filter_depths[0]
         # head (lib/UNet.py:227-244): the outer residual add passes dout straight through to x (not needed)
         ll = self.last_layer
-        ops.conv3x3_last_bwd_weight(S["dec"][d - 1]["s"], dout, gv(ll.weight),
-                                    gv(ll.bias) if ll.bias is not None else None, want_bias=ll.bias is not None)
-        done(ll.weight, ll.bias)
+        wgrad(lambda *a, **k: ops.conv3x3_last_bwd_weight(*a, want_bias=ll.bias is not None, **k), (dout,),
+              S["dec"][d - 1]["s"], dout, gv(ll.weight), gv(ll.bias) if ll.bias is not None else None,
+              ready=(ll.weight, ll.bias))
         if "outer_bn" in S:
             # BatchNorm2d(1) on the outer skip: only its affine parameters need gradients (x is an input)
             ob = S["outer_bn"]
@@ -403,20 +435,18 @@ class UNet(nn.Module):
         for i in reversed(range(d)):
             up = self.decoder[i][0] if i < d - 1 else self.decoder[i]
             src = S["dec"][i - 1] if i > 0 else S["bott"]
-            ops.convt2x2_bwd_weight(src["a"], g, gv(up.weight))
-            done(up.weight)
+            wgrad(ops.convt2x2_bwd_weight, (g,), src["a"], g, gv(up.weight), ready=(up.weight,))
             dprev = ops.convt2x2_bwd_data(g, pk["dec_t"][i][1])
             skipgrad[d - 1 - i] = g       # gradient wrt the encoder skip a_{d-1-i} (SkipConnection is an ADD)
             if i > 0:
                 blk = self.decoder[i - 1][1]
                 dz = bn_backward(src, blk, sd_, dprev, None, None)
-                ops.conv3x3_bwd_weight(S["dec"][i - 1]["s"], dz, gv(blk[0].weight))
-                done(blk[0].weight)
+                wgrad(ops.conv3x3_bwd_weight, (dz,), S["dec"][i - 1]["s"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
                 g = ops.conv3x3_bwd_data(dz, pk["dec_c"][i - 1][1])
             else:
                 dz = bn_backward(src, self.bottleneck, sb, dprev, None, None)
-                ops.conv3x3_bwd_weight(S["enc"][d - 1]["p"], dz, gv(self.bottleneck[0].weight))
-                done(self.bottleneck[0].weight)
+                wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][d - 1]["p"], dz, gv(self.bottleneck[0].weight),
+                      ready=(self.bottleneck[0].weight,))
                 gp = ops.conv3x3_bwd_data(dz, pk["bott"][1])
         for i in reversed(range(d)):
             e = S["enc"][i]
@@ -428,11 +458,12 @@ class UNet(nn.Module):
             dz = bn_backward(e, blk, se, skipgrad[i], gp, e["idx"], extra_bias=up.bias)
             skipgrad[i] = None
             if i > 0:
-                ops.conv3x3_bwd_weight(S["enc"][i - 1]["p"], dz, gv(blk[0].weight))
+                wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][i - 1]["p"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
                 gp = ops.conv3x3_bwd_data(dz, pk["enc"][i - 1][1])
             else:
-                ops.conv3x3_first_bwd_weight(S["x"], dz, gv(blk[0].weight))
-            done(blk[0].weight)
+                wgrad(ops.conv3x3_first_bwd_weight, (dz,), S["x"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
+        if side is not None:
+            main.wait_stream(side)           # every weight gradient (and bucket launch) is ordered before what follows
         if sync is not None:
             sync.finish(self)
         elif self.grad_sync is not None:
