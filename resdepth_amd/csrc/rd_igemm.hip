@@ -40,7 +40,6 @@ struct NtParams {
     int chunks, nk, taps;
     int tiles_n;
     int vec;  // epilogue may use 16-byte accesses (N % 4 == 0 and, for the transposed conv, Cout % 4 == 0)
-    int ablate;  // tuning only (RD_ABLATE): 1 = no global reloads, 2 = no LDS restores, 4 = no barriers (wrong results)
     unsigned a_bytes, b_bytes;  // extents of the A / B tensors for the buffer descriptors
     float* stats;  // EPI_STORE only, nullable: per-(tile_m) column sums / sums of squares [tiles_m][2][N] (BN statistics)
 };
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
     __syncthreads();
     for (int kt = 0; kt < p.nk; ++kt) {
         const bool more = kt + 1 < p.nk;
-        if (more && !(p.ablate & 1)) load_tile(kt + 1);
+        if (more) load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float4 af[TM], bf[TN];
@@ -182,10 +181,10 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
                 }
             }
         }
-        if (!(p.ablate & 4)) __syncthreads();
-        if (more && !(p.ablate & 2)) {
+        __syncthreads();
+        if (more) {
             store_tile();
-            if (!(p.ablate & 4)) __syncthreads();
+            __syncthreads();
         }
     }
 
@@ -289,8 +288,6 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     const double bytes = 4.0 * ((double)p.M * p.Cin * (AMODE == A_UP2 ? 4 : 1) + (double)p.N * p.K + (double)p.M * p.N);
     p.chunks = cdiv(p.Cin, 32);
     p.vec = (p.N % 4 == 0) && (EPI != EPI_CONVT || p.Cout % 4 == 0);
-    static const int ablate = getenv("RD_ABLATE") ? atoi(getenv("RD_ABLATE")) : 0;
-    p.ablate = ablate;
     const double a_bytes = 4.0 * p.M * p.Cin * (AMODE == A_UP2 ? 4 : 1), b_bytes = 4.0 * p.N * p.K;
     if (a_bytes >= 4294967040.0 || b_bytes >= 4294967040.0) {
         set_error("%s: operand larger than the 4 GiB buffer-descriptor range (A %.0f B, B %.0f B)", cls, a_bytes, b_bytes);
