@@ -166,6 +166,20 @@ int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, 
 int rd_blend_accumulate(const float* pred, const float* mean, const float* std, const int* pos, const int* reg, int n,
                         int tile_size, int stride, double* raster, int rows, int cols, rd_stream_t s);
 
+/* ---- training-sample assembly from rasters resident in HBM (lib/DsmOrthoDataset.py:161-291, lib/torch_transforms.py) */
+/* sums[i] = (sum, count) over the T x T patch at pos[i] = (y, x) of the planes plane_idx[i*P .. i*P+P-1] of a planar
+ * raster stack (plane stride in floats), skipping pixels equal to `nodata` when use_nodata (the masked patch mean the
+ * reference takes with np.ma.mean).  One block per patch, fixed-order reduction. */
+int rd_patch_sums(const float* planes, long long plane_stride, const int* plane_idx, int p_per_patch, const int* pos,
+                  int n, int tile, int width, float nodata, int use_nodata, double* sums, rd_stream_t s);
+/* input[i] = cat((dsm_in - dsm_mean[i]) / dsm_std, (ortho[pair] - ortho_mean[i]) / ortho_std), target[i] =
+ * (dsm_gt - dsm_mean[i]) / dsm_std, mask[i] = (dsm_gt != 0) & (dsm_gt != nodata), all augmented by
+ * rot90(k) -> flipud -> fliplr with aug[i] = k | flip_v << 2 | flip_h << 3 (dsm_gt / target / mask nullable together). */
+int rd_assemble_patches(const float* dsm_in, const float* dsm_gt, const float* ortho_planes, long long plane_stride,
+                        const int* pair_idx, int views, const int* pos, const int* aug, const float* dsm_mean,
+                        float dsm_std, const float* ortho_mean, float ortho_std, float nodata, int n, int tile, int width,
+                        float* input, float* target, uint8_t* mask, rd_stream_t s);
+
 /* ---- layout helpers ----------------------------------------------------------------- */
 int rd_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s);
 int rd_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s);

@@ -9,6 +9,8 @@ from .optim import FusedAdam  # noqa: F401
 from .trainer import Trainer, AverageMeter  # noqa: F401
 from .data import SyntheticDsmOrthoDataset  # noqa: F401
 from .inference import predict_linear_blend, SyntheticRasterTiles  # noqa: F401
+from .sampler import GpuPatchSampler  # noqa: F401
 
 __all__ = ["UNet", "SkipConnection", "MaskedL1Loss", "masked_l1_loss", "FusedAdam", "Trainer", "AverageMeter",
-           "SyntheticDsmOrthoDataset", "predict_linear_blend", "SyntheticRasterTiles"]
+           "SyntheticDsmOrthoDataset", "predict_linear_blend", "SyntheticRasterTiles",
+           "GpuPatchSampler"]

@@ -772,6 +772,74 @@ __global__ __launch_bounds__(256) void blend_tile_kernel(const float* __restrict
     raster[(long)y * cols + x] += (double)den * w;
 }
 
+// ---- training-sample assembly -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patch_sums_kernel(const float* __restrict__ planes, long plane_stride,
+                                                         const int* __restrict__ plane_idx, int P,
+                                                         const int* __restrict__ pos, int T, int W, float nodata,
+                                                         int use_nodata, double* __restrict__ sums) {
+    __shared__ double red[2 * 256];
+    const int i = blockIdx.x, y0 = pos[i * 2], x0 = pos[i * 2 + 1];
+    double s = 0.0, c = 0.0;
+    for (int p = 0; p < P; ++p) {
+        const float* pl = planes + (long)plane_idx[i * P + p] * plane_stride;
+        for (int e = threadIdx.x; e < T * T; e += 256) {
+            const float v = pl[(long)(y0 + e / T) * W + x0 + e % T];
+            if (!use_nodata || v != nodata) {
+                s += v;
+                c += 1.0;
+            }
+        }
+    }
+    red[threadIdx.x] = s;
+    red[256 + threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[threadIdx.x] += red[threadIdx.x + off];
+            red[256 + threadIdx.x] += red[256 + threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sums[i * 2] = red[0];
+        sums[i * 2 + 1] = red[256];
+    }
+}
+
+__global__ __launch_bounds__(256) void assemble_patches_kernel(
+    const float* __restrict__ dsm_in, const float* __restrict__ dsm_gt, const float* __restrict__ ortho, long plane_stride,
+    const int* __restrict__ pair_idx, int V, const int* __restrict__ pos, const int* __restrict__ aug,
+    const float* __restrict__ dsm_mean, float dsm_std, const float* __restrict__ ortho_mean, float ortho_std, float nodata,
+    int n, int T, int W, float* __restrict__ input, float* __restrict__ target, uint8_t* __restrict__ mask) {
+    const int C = 1 + V;
+    const long total = (long)n * (C + 1) * T * T;    // channel C = the target / mask plane
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % T), r = (int)((e / T) % T);
+        const int ch = (int)((e / ((long)T * T)) % (C + 1));
+        const int i = (int)(e / ((long)T * T * (C + 1)));
+        if (ch == C && !dsm_gt) continue;
+        // inverse of rot90(k) -> flipud -> fliplr
+        const int a = aug ? aug[i] : 0, k = a & 3;
+        const int c1 = (a & 8) ? T - 1 - c : c, r1 = (a & 4) ? T - 1 - r : r;
+        int sr, sc;
+        if (k == 0) { sr = r1; sc = c1; }
+        else if (k == 1) { sr = c1; sc = T - 1 - r1; }
+        else if (k == 2) { sr = T - 1 - r1; sc = T - 1 - c1; }
+        else { sr = T - 1 - c1; sc = r1; }
+        const long src = (long)(pos[i * 2] + sr) * W + pos[i * 2 + 1] + sc;
+        if (ch == 0) {
+            input[((long)i * C) * T * T + (long)r * T + c] = __fdiv_rn(__fsub_rn(dsm_in[src], dsm_mean[i]), dsm_std);
+        } else if (ch < C) {
+            const float v = ortho[(long)pair_idx[i * V + ch - 1] * plane_stride + src];
+            input[((long)i * C + ch) * T * T + (long)r * T + c] = __fdiv_rn(__fsub_rn(v, ortho_mean[i]), ortho_std);
+        } else {
+            const float g = dsm_gt[src];
+            target[(long)i * T * T + (long)r * T + c] = __fdiv_rn(__fsub_rn(g, dsm_mean[i]), dsm_std);
+            mask[(long)i * T * T + (long)r * T + c] = (g != 0.f && g != nodata) ? 1 : 0;
+        }
+    }
+}
+
 // ---- layout ---------------------------------------------------------------------------------------
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW) {
     const long total = (long)N * C * HW;
@@ -1163,6 +1231,34 @@ int rd_blend_accumulate(const float* pred, const float* mean, const float* stdv,
         hipLaunchKernelGGL(blend_tile_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, pred, mean, stdv, pos, reg, i,
                            tile_size, stride, raster, rows, cols);
     RD_LAUNCH_CHECK("blend_accumulate");
+    return RD_OK;
+}
+
+int rd_patch_sums(const float* planes, long long plane_stride, const int* plane_idx, int p_per_patch, const int* pos,
+                  int n, int tile, int width, float nodata, int use_nodata, double* sums, rd_stream_t s) {
+    RD_REQUIRE(planes && plane_idx && pos && sums && n > 0 && tile > 0 && width >= tile && p_per_patch > 0,
+               "rd_patch_sums: bad arguments");
+    ProfScope ps((hipStream_t)s, "patch_sums", 0, 4.0 * n * p_per_patch * tile * tile);
+    hipLaunchKernelGGL(patch_sums_kernel, dim3(n), dim3(256), 0, (hipStream_t)s, planes, (long)plane_stride, plane_idx,
+                       p_per_patch, pos, tile, width, nodata, use_nodata, sums);
+    RD_LAUNCH_CHECK("patch_sums");
+    return RD_OK;
+}
+
+int rd_assemble_patches(const float* dsm_in, const float* dsm_gt, const float* ortho_planes, long long plane_stride,
+                        const int* pair_idx, int views, const int* pos, const int* aug, const float* dsm_mean,
+                        float dsm_std, const float* ortho_mean, float ortho_std, float nodata, int n, int tile, int width,
+                        float* input, float* target, uint8_t* mask, rd_stream_t s) {
+    RD_REQUIRE(dsm_in && pos && dsm_mean && input && n > 0 && tile > 0 && width >= tile && views >= 0,
+               "rd_assemble_patches: bad arguments");
+    RD_REQUIRE(views == 0 || (ortho_planes && pair_idx && ortho_mean), "rd_assemble_patches: ortho inputs missing");
+    RD_REQUIRE(!dsm_gt || (target && mask), "rd_assemble_patches: target / mask outputs missing");
+    const long total = (long)n * (views + 2) * tile * tile;
+    ProfScope ps((hipStream_t)s, "assemble_patches", 0, 8.0 * total);
+    hipLaunchKernelGGL(assemble_patches_kernel, dim3(grid_cap((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s,
+                       dsm_in, dsm_gt, ortho_planes, (long)plane_stride, pair_idx, views, pos, aug, dsm_mean, dsm_std,
+                       ortho_mean, ortho_std, nodata, n, tile, width, input, target, mask);
+    RD_LAUNCH_CHECK("assemble_patches");
     return RD_OK;
 }
 

@@ -1,0 +1,90 @@
+"""Training-sample assembly on the GPU: the per-sample work of the reference's
+`DsmOrthoDataset.__getitem__` (lib/DsmOrthoDataset.py:161-291) -- patch extraction, masked per-patch mean centring and
+division by the global DSM std, ortho-image normalisation, loss mask, rot90 / flip augmentation
+(lib/torch_transforms.py) -- as two kernels over rasters that stay resident in HBM (288 GB holds any city raster),
+producing the collated batch dict directly on the device.  The reference does this per sample on the CPU with
+per-channel numpy loops and cannot feed more than a few hundred tiles/s.
+
+Raster I/O (GeoTIFF via GDAL) and the choice of valid patch positions stay with the caller (out of scope)."""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, load, ptr, stream_ptr
+
+
+class GpuPatchSampler:
+    def __init__(self, dsm_input, dsm_target=None, orthos=None, tile_size: int = 256, nodata: float = -9999.0,
+                 dsm_std: float = 1.0, ortho_mean=None, ortho_std: float = 1.0, device="cuda"):
+        """dsm_input / dsm_target: [H, W] float32; orthos: [V_total, H, W] float32 (planar).  ortho_mean=None => per-patch
+        mean over the views of the sample (lib/DsmOrthoDataset.py:231-233)."""
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("resdepth_amd.GpuPatchSampler needs a HIP device (no CPU fallback)")
+        f = lambda t: None if t is None else torch.as_tensor(t, dtype=torch.float32).to(dev).contiguous()
+        self.dsm_in, self.dsm_gt, self.orthos = f(dsm_input), f(dsm_target), f(orthos)
+        self.h, self.w = self.dsm_in.shape
+        self.tile, self.nodata = int(tile_size), float(nodata)
+        self.dsm_std, self.ortho_mean, self.ortho_std = float(dsm_std), ortho_mean, float(ortho_std)
+        self.device = dev
+
+    def sample(self, positions, pairs=None, aug=None):
+        """positions: int [n,2] (y, x); pairs: int [n,V] plane indices into `orthos`; aug: int [n,3] (k, flip_v, flip_h)
+        or None.  Returns the DataLoader-shaped batch dict with device tensors."""
+        dev, t = self.device, self.tile
+        pos = torch.as_tensor(positions, dtype=torch.int32).reshape(-1, 2).to(dev).contiguous()
+        n = pos.shape[0]
+        if int(pos[:, 0].max()) + t > self.h or int(pos[:, 1].max()) + t > self.w or int(pos.min()) < 0:
+            raise ValueError("patch position outside the raster")
+        v = 0
+        pair_t = omean = None
+        if self.orthos is not None and pairs is not None:
+            pair_t = torch.as_tensor(pairs, dtype=torch.int32).reshape(n, -1).to(dev).contiguous()
+            v = pair_t.shape[1]
+        zero = torch.zeros(n, dtype=torch.int32, device=dev)
+        sums = torch.empty(n, 2, dtype=torch.float64, device=dev)
+        check(load().rd_patch_sums(ptr(self.dsm_in), self.h * self.w, ptr(zero), 1, ptr(pos), n, t, self.w, self.nodata, 1,
+                                   ptr(sums), stream_ptr()), "patch_sums")
+        dsm_mean = (sums[:, 0] / sums[:, 1]).to(torch.float32)
+        if v:
+            if self.ortho_mean is None:
+                osum = torch.empty(n, 2, dtype=torch.float64, device=dev)
+                check(load().rd_patch_sums(ptr(self.orthos), self.h * self.w, ptr(pair_t), v, ptr(pos), n, t, self.w, 0.0, 0,
+                                           ptr(osum), stream_ptr()), "patch_sums")
+                omean = (osum[:, 0] / osum[:, 1]).to(torch.float32)
+            else:
+                omean = torch.full((n,), float(self.ortho_mean), dtype=torch.float32, device=dev)
+        aug_t = None
+        if aug is not None:
+            a = torch.as_tensor(aug, dtype=torch.int32).reshape(n, 3)
+            aug_t = (a[:, 0] | (a[:, 1] << 2) | (a[:, 2] << 3)).to(torch.int32).to(dev).contiguous()
+        inp = torch.empty(n, 1 + v, t, t, dtype=torch.float32, device=dev)
+        tgt = msk = None
+        if self.dsm_gt is not None:
+            tgt = torch.empty(n, 1, t, t, dtype=torch.float32, device=dev)
+            msk = torch.empty(n, 1, t, t, dtype=torch.uint8, device=dev)
+        check(load().rd_assemble_patches(ptr(self.dsm_in), ptr(self.dsm_gt), ptr(self.orthos) if v else None,
+                                         self.h * self.w, ptr(pair_t), v, ptr(pos), ptr(aug_t), ptr(dsm_mean), self.dsm_std,
+                                         ptr(omean), self.ortho_std, self.nodata, n, t, self.w, ptr(inp), ptr(tgt), ptr(msk),
+                                         stream_ptr()), "assemble_patches")
+        batch = {"input": inp, "dsm_mean": dsm_mean, "dsm_std": torch.full((n,), self.dsm_std, device=dev),
+                 "patch_offset_x": pos[:, 1], "patch_offset_y": pos[:, 0],
+                 "nodata": torch.full((n,), self.nodata, device=dev)}
+        if tgt is not None:
+            batch["target"], batch["loss_mask"] = tgt, msk.view(torch.bool)
+        return batch
+
+    def random_batch(self, n: int, pairs, generator=None, augment: bool = True):
+        """n random patch positions (uniform over the raster) + the reference's augmentation draws
+        (k in {0..3}, flips with probability 1/2)."""
+        g = generator
+        ys = torch.randint(0, self.h - self.tile + 1, (n,), generator=g)
+        xs = torch.randint(0, self.w - self.tile + 1, (n,), generator=g)
+        aug = None
+        if augment:
+            aug = torch.stack([torch.randint(0, 4, (n,), generator=g), torch.randint(0, 2, (n,), generator=g),
+                               torch.randint(0, 2, (n,), generator=g)], 1)
+        pair = torch.as_tensor(pairs, dtype=torch.int32)
+        if pair.dim() == 1:
+            pair = pair.unsqueeze(0).expand(n, -1)
+        return self.sample(torch.stack([ys, xs], 1), pair, aug)
