@@ -128,6 +128,9 @@ def main():
                          "only the MFMA kernel classes the roofline needs (~1%%)")
     ap.add_argument("--workload", choices=["S", "M"], default="S",
                     help="S = cfg-S (BASELINE configs[1], the headline metric); M = cfg-M (configs[3]: 2-ch 512x512 depth-6)")
+    ap.add_argument("--from-rasters", action="store_true",
+                    help="draw a fresh augmented batch from HBM-resident synthetic rasters with resdepth_amd.GpuPatchSampler "
+                         "inside every timed step (sample assembly + train step) instead of re-using one resident batch")
     ap.add_argument("--infer", action="store_true",
                     help="measure the tiled full-raster inference sweep instead (BASELINE configs[4], cfg-G: 3-ch tiles of "
                          "256x256 at stride 128 over a synthetic --raster x --raster DSM, eval-mode BN, linear blend)")
@@ -178,10 +181,24 @@ def main():
     mean, std = b["dsm_mean"].to(torch.float32).to(dev), b["dsm_std"].to(dev)
     params = list(model.parameters())
     losses = []
+    sampler = None
+    if args.from_rasters:
+        from resdepth_amd import GpuPatchSampler
+        gr = torch.Generator().manual_seed(99 + rank)
+        R = 4096
+        dsm_r = torch.randn(R, R, generator=gr) * 3.0 + 400.0
+        sampler = GpuPatchSampler(dsm_r, dsm_r + torch.randn(R, R, generator=gr), torch.rand(wl["c"] - 1, R, R, generator=gr) * 200,
+                                  tile_size=wl["t"], dsm_std=3.0, ortho_mean=100.0, ortho_std=50.0, device=dev)
+        pair = list(range(wl["c"] - 1))
 
     def step():
-        y_pred = model(x)
-        loss = masked_l1_loss(y_pred, y, mask, mean, std, grad_sync=gs)
+        if sampler is not None:
+            bb = sampler.random_batch(n, pair, generator=gr)
+            xx, yy, mm, me, sd_ = bb["input"], bb["target"], bb["loss_mask"], bb["dsm_mean"], bb["dsm_std"]
+        else:
+            xx, yy, mm, me, sd_ = x, y, mask, mean, std
+        y_pred = model(xx)
+        loss = masked_l1_loss(y_pred, yy, mm, me, sd_, grad_sync=gs)
         loss.backward()
         opt.step()
         for p in params:
@@ -276,7 +293,9 @@ def main():
                       "DSM tiles/sec fwd+bwd (512x512, 2-ch, depth-6 U-Net)", "value": round(tiles_s, 2),
             "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (randn tiles resident in HBM, default-initialised weights)",
+            "dtype": "f32", "data": ("synthetic rasters resident in HBM, a fresh augmented batch assembled on the GPU every step"
+                                     if args.from_rasters else
+                                     "synthetic (randn tiles resident in HBM, default-initialised weights)"),
             "config": {"workload": wl["name"] + ", fwd+loss+bwd+Adam",
                        "tiles_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"dp{world}" + ("+syncbn" if args.sync_bn else ""),

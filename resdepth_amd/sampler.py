@@ -32,10 +32,12 @@ class GpuPatchSampler:
         """positions: int [n,2] (y, x); pairs: int [n,V] plane indices into `orthos`; aug: int [n,3] (k, flip_v, flip_h)
         or None.  Returns the DataLoader-shaped batch dict with device tensors."""
         dev, t = self.device, self.tile
-        pos = torch.as_tensor(positions, dtype=torch.int32).reshape(-1, 2).to(dev).contiguous()
+        pos = torch.as_tensor(positions, dtype=torch.int32).reshape(-1, 2)
+        if not pos.is_cuda:          # validate on the host (no device->host sync in the training loop)
+            if int(pos[:, 0].max()) + t > self.h or int(pos[:, 1].max()) + t > self.w or int(pos.min()) < 0:
+                raise ValueError("patch position outside the raster")
+        pos = pos.to(dev).contiguous()
         n = pos.shape[0]
-        if int(pos[:, 0].max()) + t > self.h or int(pos[:, 1].max()) + t > self.w or int(pos.min()) < 0:
-            raise ValueError("patch position outside the raster")
         v = 0
         pair_t = omean = None
         if self.orthos is not None and pairs is not None:
