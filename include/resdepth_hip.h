@@ -180,6 +180,14 @@ int rd_assemble_patches(const float* dsm_in, const float* dsm_gt, const float* o
                         float dsm_std, const float* ortho_mean, float ortho_std, float nodata, int n, int tile, int width,
                         float* input, float* target, uint8_t* mask, rd_stream_t s);
 
+/* ---- masked residual statistics of a refined DSM (lib/evaluation.py:11-131) ------------------------ */
+/* residual r = raster - gt where raster != nodata, gt != nodata, mask (nullable) != 0 and, if threshold > 0,
+ * |r| <= threshold.  out[8] (doubles, device): count, max, min, MAE, RMSE, absolute median, median,
+ * NMAD = 1.4826 * median|r - absolute median| (exact medians; even counts average the two middle values). */
+size_t rd_residual_stats_ws_bytes(long long n);
+int rd_residual_stats(const double* raster, const float* gt, const uint8_t* mask, long long n, double nodata,
+                      double threshold, double* out, void* ws, size_t ws_bytes, rd_stream_t s);
+
 /* ---- layout helpers ----------------------------------------------------------------- */
 int rd_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s);
 int rd_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s);

@@ -67,6 +67,8 @@ SIGNATURES = {
     "rd_blend_accumulate": (I, [P, P, P, P, P, I, I, I, P, I, I, P]),
     "rd_patch_sums": (I, [P, LL, P, I, P, I, I, I, F, I, P, P]),
     "rd_assemble_patches": (I, [P, P, P, LL, P, I, P, P, P, F, P, F, F, I, I, I, P, P, P, P]),
+    "rd_residual_stats_ws_bytes": (SZ, [LL]),
+    "rd_residual_stats": (I, [P, P, P, LL, D, D, P, P, SZ, P]),
     "rd_nchw_to_nhwc": (I, [P, P, I, I, I, I, P]),
     "rd_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
     "rd_prof_enable": (I, [I]),

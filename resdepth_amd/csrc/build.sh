@@ -9,7 +9,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form"
 mkdir -p "$HERE/obj"
 pids=()
-for f in rd_runtime rd_igemm rd_elementwise; do
+for f in rd_runtime rd_igemm rd_elementwise rd_stats; do
   if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/rd_common.h" -nt "$HERE/obj/$f.o" ] \
      || [ "$HERE/../../include/resdepth_hip.h" -nt "$HERE/obj/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
@@ -17,5 +17,5 @@ for f in rd_runtime rd_igemm rd_elementwise; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj/rd_runtime.o "$HERE"/obj/rd_igemm.o "$HERE"/obj/rd_elementwise.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj/rd_runtime.o "$HERE"/obj/rd_igemm.o "$HERE"/obj/rd_elementwise.o "$HERE"/obj/rd_stats.o
 echo "built $OUT"
