@@ -341,3 +341,33 @@ def test_other_baseline_configs_against_oracle(name, kw, n, t):
     for k in sd1:
         if "running" in k:
             np.testing.assert_allclose(sd1[k].cpu().numpy(), work[k].float().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("n,t,kw", [
+    (1, 32, dict(n_input_channels=1, start_kernel=4, depth=3, bias_conv_layer=True)),     # batch 1, smallest legal tile 2^(depth+2)
+    (5, 8, dict(n_input_channels=4, start_kernel=12, depth=1, bias_conv_layer=False)),    # odd batch, non-power-of-two channels
+    (2, 64, dict(n_input_channels=6, start_kernel=8, depth=4, max_filter_depth=16, bias_conv_layer=True, outer_skip=False)),
+])
+def test_edge_shapes_against_oracle(n, t, kw):
+    """Ragged / extreme shapes: batch 1, tiny tiles, channel counts that are not powers of two, six input channels,
+    a filter-depth cap that makes every level equally wide."""
+    from resdepth_amd import UNet, masked_l1_loss
+    spec = O.Spec(**{"depth": 8, **kw})
+    torch.manual_seed(4)
+    model = UNet(**kw)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    b = O.synthetic_batch(n, kw["n_input_channels"], t, seed=31)
+    model = model.to(DEV).train()
+    yp = model(b["input"].to(DEV))
+    loss = masked_l1_loss(yp, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
+    loss.backward()
+    leaves = {k: sd0[k].clone().requires_grad_(True) for k in O.param_keys(spec)}
+    work = dict(sd0)
+    work.update(leaves)
+    yo = O.forward(work, b["input"], spec, training=True)
+    lo = O.masked_l1_loss(yo, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
+    go = torch.autograd.grad(lo, list(leaves.values()))
+    assert float((yp.detach().cpu() - yo.detach()).abs().max()) <= 1e-4
+    assert abs(float(loss) - float(lo)) <= 1e-5 * abs(float(lo))
+    for (k, p), gr in zip(model.named_parameters(), go):
+        assert rel_l2(p.grad, gr) <= 2e-3, (k, rel_l2(p.grad, gr))
