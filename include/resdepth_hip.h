@@ -122,22 +122,27 @@ int rd_bn_eval_stats(const float* running_mean, const float* running_var, float 
  * if pooled != NULL also the 2x2/2 max-pool of a (lib/UNet.py:161,167): pooled[N,H/2,W/2,C] and
  * idx (uint8, window position 0..3 = dy*2+dx; first maximum in row-major order, NaN wins). */
 int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                       float slope, float* a, float* pooled, uint8_t* idx, int n, int h, int w, int c, rd_stream_t s);
+                       float slope, const float* slope_dev, float* a, float* pooled, uint8_t* idx, int n, int h, int w,
+                       int c, rd_stream_t s);
 
 /* Backward of conv -> BN -> act [-> pool].  The gradient wrt `a` is g_full (same resolution,
  * nullable) + unpool(g_pool via idx) (nullable).
- * Phase 1 -> sums[3*C] doubles: sum g', sum g'*xhat (g' = gradient after the activation mask),
- *            and sum g_full (un-masked; the bias gradient of the ConvTranspose2d feeding a skip add).
+ * Phase 1 -> sums[4*C] doubles: sum g', sum g'*xhat (g' = gradient after the activation mask),
+ *            sum g_full (un-masked; the bias gradient of the ConvTranspose2d feeding a skip add), and
+ *            sum_{y<=0} g*y (per channel; its total is the gradient of nn.PReLU()'s single slope).
+ * slope_dev (nullable): device pointer to a learnable PReLU slope (lib/UNet.py:29); when non-NULL it
+ *            overrides the immediate `slope` (ReLU = 0, LeakyReLU = 0.01).
  * Phase 2 -> dz; dgamma/dbeta are sums[C..2C) / sums[0..C) (written by rd_bn_act_bwd_apply).
  * training=0 treats mean/invstd as constants (eval-mode BN). */
 size_t rd_bn_act_bwd_ws_bytes(int n, int h, int w, int c);
 int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                         float slope, const float* g_full, const float* g_pool, const uint8_t* idx, double* sums, int n,
-                         int h, int w, int c, void* ws, size_t ws_bytes, rd_stream_t s);
+                         float slope, const float* slope_dev, const float* g_full, const float* g_pool,
+                         const uint8_t* idx, double* sums, int n, int h, int w, int c, void* ws, size_t ws_bytes,
+                         rd_stream_t s);
 int rd_bn_act_bwd_apply(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                        float slope, const float* g_full, const float* g_pool, const uint8_t* idx, const double* sums,
-                        double count, int training, float* dz, float* dgamma, float* dbeta, int n, int h, int w, int c,
-                        rd_stream_t s);
+                        float slope, const float* slope_dev, const float* g_full, const float* g_pool,
+                        const uint8_t* idx, const double* sums, double count, int training, float* dz, float* dgamma,
+                        float* dbeta, int n, int h, int w, int c, rd_stream_t s);
 
 /* ---- masked, de-normalised L1 (lib/Trainer.py:87-100, lib/data_normalization.py:29-38) */
 /* sums[0] = sum over valid pixels |(yp*std_i+mean_i) - (y*std_i+mean_i)|, sums[1] = #valid.

@@ -45,13 +45,15 @@ class Spec:
         return [min(self.start_kernel * (2 ** i), self.max_filter_depth) for i in range(self.depth)]
 
 
-def _slope(name: str) -> float:
-    # lib/UNet.py:27-33 -- ReLU / LeakyReLU(default negative_slope 0.01)
+def _slope(name: str):
+    # lib/UNet.py:27-33 -- ReLU / LeakyReLU(default negative_slope 0.01) / PReLU (learnable, one parameter, init 0.25)
     if name == "relu":
         return 0.0
     if name == "lrelu":
         return 0.01
-    raise ValueError(f"oracle supports relu|lrelu, got {name!r}")
+    if name == "prelu":
+        return "prelu"
+    raise ValueError(f"oracle supports relu|lrelu|prelu, got {name!r}")
 
 
 def param_layout(spec: Spec):
@@ -79,19 +81,28 @@ def param_layout(spec: Spec):
         out.append((prefix + ".running_var", (c,), "buffer"))
         out.append((prefix + ".num_batches_tracked", (), "buffer"))
 
+    ai = 2 if spec.do_BN else 1          # index of the activation module inside a conv block
+
+    def act(prefix, name):
+        if name == "prelu":
+            out.append((f"{prefix}.{ai}.weight", (1,), "param"))
+
     cin = spec.n_input_channels
     for i, c in enumerate(fd):
         conv(f"encoder.{i}.0.0", c, cin)
         bn(f"encoder.{i}.0.1", c)
+        act(f"encoder.{i}.0", spec.act_fn_encoder)
         cin = c
     conv("bottleneck.0", fd[-1], fd[-1])
     bn("bottleneck.1", fd[-1])
+    act("bottleneck", spec.act_fn_bottleneck)
     up = list(reversed(fd))
     for i, (ci, co) in enumerate(zip(up[:-1], up[1:])):
         out.append((f"decoder.{i}.0.weight", (ci, ci, 2, 2), "param"))
         out.append((f"decoder.{i}.0.bias", (ci,), "param"))
         conv(f"decoder.{i}.1.0", co, ci)
         bn(f"decoder.{i}.1.1", co)
+        act(f"decoder.{i}.1", spec.act_fn_decoder)
     out.append((f"decoder.{spec.depth - 1}.weight", (up[-1], up[-1], 2, 2), "param"))
     out.append((f"decoder.{spec.depth - 1}.bias", (up[-1],), "param"))
     out.append(("last_layer.weight", (1, spec.start_kernel, 3, 3), "param"))
@@ -152,6 +163,9 @@ def init_state_dict(spec: Spec, seed: int) -> Dict[str, torch.Tensor]:
     conv("last_layer", spec.start_kernel, 1, spec.bias_conv_layer)
     if spec.outer_skip and spec.outer_skip_BN:
         bn("layer_outer_skip.0", 1)
+    for k, shape, _ in param_layout(spec):           # PReLU slopes: constant init 0.25, no RNG draw
+        if k not in sd:
+            sd[k] = torch.full(shape, 0.25)
     # return in state_dict order
     return {k: sd[k] for k, _, _ in param_layout(spec)}
 
@@ -172,6 +186,9 @@ def _bn_act(z, sd, prefix, slope, training, update_running, mask=None):
             sd[prefix + ".num_batches_tracked"] += 1
     else:                                  # do_BN=False: the conv's own bias was already added by the caller
         y = z
+    if slope == "prelu":
+        w = sd[prefix.rsplit(".", 1)[0] + (".2" if prefix + ".running_mean" in sd else ".1") + ".weight"]
+        return torch.where(mask, y, y * w) if mask is not None else F.prelu(y, w)
     if mask is not None:
         return torch.where(mask, y, y * slope)
     return F.leaky_relu(y, slope) if slope != 0.0 else F.relu(y)

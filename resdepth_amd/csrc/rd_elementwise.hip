@@ -188,11 +188,13 @@ template <bool POOL>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd,
                                                               const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float slope,
+                                                              const float* __restrict__ beta, float slope_val,
+                                                              const float* __restrict__ slope_dev,
                                                               float* __restrict__ a, float* __restrict__ pooled,
                                                               uint8_t* __restrict__ idx, long rows, int H, int W, int C,
                                                               int CQ) {
     // rows = pooled pixels (POOL) or pixels; one thread per (row, cq)
+    const float slope = slope_dev ? slope_dev[0] : slope_val;   // PReLU: learnable slope read on the device
     const long total = rows * CQ;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int cq = (int)(e % CQ);
@@ -252,18 +254,20 @@ template <bool POOL, bool APPLY>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float slope, const float* __restrict__ g_full,
+                                                         float slope_val, const float* __restrict__ slope_dev,
+                                                         const float* __restrict__ g_full,
                                                          const float* __restrict__ g_pool,
                                                          const uint8_t* __restrict__ idx, double* __restrict__ partial,
                                                          const double* __restrict__ sums, double count, int training,
                                                          float* __restrict__ dz, long rows, int H, int W, int C, int CQ,
                                                          int RP, long rows_per_block) {
-    __shared__ double red[APPLY ? 1 : 12 * 256];
+    __shared__ double red[APPLY ? 1 : 16 * 256];
     const int t = threadIdx.x, cq = t % CQ, pr = t / CQ;
     const bool active = pr < RP;
-    double acc[12];
+    const float slope = slope_dev ? slope_dev[0] : slope_val;
+    double acc[16];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0;
     float sc[4], sh[4], mu[4], is[4], k1[4] = {0, 0, 0, 0}, k2[4] = {0, 0, 0, 0};
     {
         const float4 m4 = *reinterpret_cast<const float4*>(mean + cq * 4);
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
                     pi[0] = i4.x; pi[1] = i4.y; pi[2] = i4.z; pi[3] = i4.w;
                 }
             }
-            float pacc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float pacc[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < (POOL ? 4 : 1); ++k) {
                 const long pix = POOL ? base + (k >> 1) * W + (k & 1) : base;
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
                         pacc[q] += gm;
                         pacc[4 + q] = fmaf(gm, xh, pacc[4 + q]);
                         pacc[8 + q] += gf[q];
+                        if (!(y > 0.f)) pacc[12 + q] = fmaf(g, y, pacc[12 + q]);   // d/d(slope) of PReLU
                     } else {
                         o[q] = training ? sc[q] * (gm - k1[q] - xh * k2[q]) : sc[q] * gm;
                     }
@@ -333,19 +338,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
             }
             if (!APPLY) {
 #pragma unroll
-                for (int q = 0; q < 12; ++q) acc[q] += (double)pacc[q];
+                for (int q = 0; q < 16; ++q) acc[q] += (double)pacc[q];
             }
         }
     }
     if (!APPLY) {
-        reduce_rows<12>(acc, red, t, CQ, RP, active);
+        reduce_rows<16>(acc, red, t, CQ, RP, active);
         if (t < CQ) {
-            double* out = partial + (long)blockIdx.x * 3 * C;
+            double* out = partial + (long)blockIdx.x * 4 * C;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 out[cq * 4 + q] = acc[q];
                 out[C + cq * 4 + q] = acc[4 + q];
                 out[2 * C + cq * 4 + q] = acc[8 + q];
+                out[3 * C + cq * 4 + q] = acc[12 + q];
             }
         }
     }
@@ -937,7 +943,8 @@ int rd_bn_eval_stats(const float* running_mean, const float* running_var, float 
 }
 
 int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                       float slope, float* a, float* pooled, uint8_t* idx, int n, int h, int w, int c, rd_stream_t s) {
+                       float slope, const float* slope_dev, float* a, float* pooled, uint8_t* idx, int n, int h, int w,
+                       int c, rd_stream_t s) {
     RD_REQUIRE(z && mean && invstd && gamma && beta && a, "rd_bn_act_pool_fwd: null pointer");
     RD_REQUIRE(c % 4 == 0 && c > 0, "rd_bn_act_pool_fwd: C must be a multiple of 4 (got %d)", c);
     const int CQ = c / 4;
@@ -947,11 +954,11 @@ int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, c
         const long rows = pixels / 4;
         ProfScope ps((hipStream_t)s, "bn_act_pool_fwd", 0, 4.0 * pixels * c * 2.25 + 0.25 * pixels * c);
         hipLaunchKernelGGL((bn_act_pool_fwd_kernel<true>), dim3(grid_cap((rows * CQ + 255) / 256, 8192)), dim3(256), 0,
-                           (hipStream_t)s, z, mean, invstd, gamma, beta, slope, a, pooled, idx, rows, h, w, c, CQ);
+                           (hipStream_t)s, z, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, idx, rows, h, w, c, CQ);
     } else {
         ProfScope ps((hipStream_t)s, "bn_act_fwd", 0, 8.0 * pixels * c);
         hipLaunchKernelGGL((bn_act_pool_fwd_kernel<false>), dim3(grid_cap((pixels * CQ + 255) / 256, 8192)), dim3(256),
-                           0, (hipStream_t)s, z, mean, invstd, gamma, beta, slope, a, (float*)nullptr,
+                           0, (hipStream_t)s, z, mean, invstd, gamma, beta, slope, slope_dev, a, (float*)nullptr,
                            (uint8_t*)nullptr, pixels, h, w, c, CQ);
     }
     RD_LAUNCH_CHECK("bn_act_pool_fwd");
@@ -961,12 +968,13 @@ int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, c
 size_t rd_bn_act_bwd_ws_bytes(int n, int h, int w, int c) {
     RowPlan pl;
     if (!plan_rows((long)n * h * w, c, &pl)) return 0;
-    return (size_t)pl.nb * 3 * c * sizeof(double);  // upper bound (pooled variant uses fewer rows)
+    return (size_t)pl.nb * 4 * c * sizeof(double);  // upper bound (pooled variant uses fewer rows)
 }
 
 int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                         float slope, const float* g_full, const float* g_pool, const uint8_t* idx, double* sums, int n,
-                         int h, int w, int c, void* ws, size_t ws_bytes, rd_stream_t s) {
+                         float slope, const float* slope_dev, const float* g_full, const float* g_pool,
+                         const uint8_t* idx, double* sums, int n, int h, int w, int c, void* ws, size_t ws_bytes,
+                         rd_stream_t s) {
     RD_REQUIRE(z && mean && invstd && gamma && beta && sums, "rd_bn_act_bwd_reduce: null pointer");
     RD_REQUIRE(g_full || g_pool, "rd_bn_act_bwd_reduce: no gradient source");
     RD_REQUIRE(!g_pool || idx, "rd_bn_act_bwd_reduce: g_pool needs idx");
@@ -975,7 +983,7 @@ int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd,
     const long rows = pool ? pixels / 4 : pixels;
     RowPlan pl;
     RD_REQUIRE(plan_rows(rows, c, &pl), "rd_bn_act_bwd_reduce: C must be a multiple of 4 and <= 1024 (got %d)", c);
-    const size_t need = (size_t)pl.nb * 3 * c * sizeof(double);
+    const size_t need = (size_t)pl.nb * 4 * c * sizeof(double);
     if (!ws || ws_bytes < need) {
         set_error("rd_bn_act_bwd_reduce: workspace too small (%zu < %zu)", ws_bytes, need);
         return RD_ERR_WS;
@@ -983,20 +991,21 @@ int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd,
     ProfScope ps((hipStream_t)s, "bn_act_bwd_reduce", 0, 4.0 * pixels * c * (1 + (g_full ? 1 : 0) + (pool ? 0.3 : 0)));
     if (pool)
         hipLaunchKernelGGL((bn_act_bwd_kernel<true, false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean, invstd,
-                           gamma, beta, slope, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
+                           gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
                            (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
     else
         hipLaunchKernelGGL((bn_act_bwd_kernel<false, false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
-                           invstd, gamma, beta, slope, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
+                           invstd, gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
                            (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(3 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
-                       sums, pl.nb, 3 * c);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(4 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
+                       sums, pl.nb, 4 * c);
     RD_LAUNCH_CHECK("bn_act_bwd_reduce");
     return RD_OK;
 }
 
 int rd_bn_act_bwd_apply(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                        float slope, const float* g_full, const float* g_pool, const uint8_t* idx, const double* sums,
+                        float slope, const float* slope_dev, const float* g_full, const float* g_pool,
+                        const uint8_t* idx, const double* sums,
                         double count, int training, float* dz, float* dgamma, float* dbeta, int n, int h, int w, int c,
                         rd_stream_t s) {
     RD_REQUIRE(z && mean && invstd && gamma && beta && sums && dz, "rd_bn_act_bwd_apply: null pointer");
@@ -1013,11 +1022,11 @@ int rd_bn_act_bwd_apply(const float* z, const float* mean, const float* invstd, 
                      4.0 * pixels * c * (2 + (g_full ? 1 : 0) + (pool ? 0.3 : 0)));
         if (pool)
             hipLaunchKernelGGL((bn_act_bwd_kernel<true, true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
-                               invstd, gamma, beta, slope, g_full, g_pool, idx, (double*)nullptr, sums, count, training,
-                               dz, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
+                               invstd, gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)nullptr, sums, count,
+                               training, dz, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
         else
             hipLaunchKernelGGL((bn_act_bwd_kernel<false, true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
-                               invstd, gamma, beta, slope, g_full, g_pool, idx, (double*)nullptr, sums, count, training,
+                               invstd, gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)nullptr, sums, count, training,
                                dz, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
     }
     if (dgamma || dbeta)

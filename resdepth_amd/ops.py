@@ -212,7 +212,8 @@ def bn_eval_stats(running_mean, running_var, eps=BN_EPS):
     return mean, invstd
 
 
-def bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, pool):
+def bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, pool, slope_dev=None):
+    """slope_dev: optional 1-element fp32 device tensor (nn.PReLU().weight) overriding `slope`."""
     n, h, w, c = z.shape
     a = torch.empty_like(z)
     pooled = idx = None
@@ -220,29 +221,31 @@ def bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, pool):
         pooled = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.float32)
         idx = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.uint8)
     check(load().rd_bn_act_pool_fwd(ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
-                                    float(slope), ptr(a), ptr(pooled), ptr(idx), n, h, w, c, stream_ptr()),
+                                    float(slope), ptr(slope_dev), ptr(a), ptr(pooled), ptr(idx), n, h, w, c,
+                                    stream_ptr()),
           "bn_act_pool_fwd")
     return a, pooled, idx
 
 
-def bn_act_bwd_reduce(z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx):
-    """-> sums [3*C] float64: sum g', sum g'*xhat, sum g_full."""
+def bn_act_bwd_reduce(z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx, slope_dev=None):
+    """-> sums [4*C] float64: sum g', sum g'*xhat, sum g_full, sum_{y<=0} g*y (PReLU slope gradient)."""
     n, h, w, c = z.shape
-    sums = torch.empty(3 * c, device=z.device, dtype=torch.float64)
+    sums = torch.empty(4 * c, device=z.device, dtype=torch.float64)
     nb = load().rd_bn_act_bwd_ws_bytes(n, h, w, c)
     ws = workspace(nb, z.device)
     check(load().rd_bn_act_bwd_reduce(ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
-                                      float(slope), ptr(g_full), ptr(g_pool), ptr(idx), ptr(sums), n, h, w, c,
-                                      ws.data_ptr(), ws.numel(), stream_ptr()), "bn_act_bwd_reduce")
+                                      float(slope), ptr(slope_dev), ptr(g_full), ptr(g_pool), ptr(idx), ptr(sums),
+                                      n, h, w, c, ws.data_ptr(), ws.numel(), stream_ptr()), "bn_act_bwd_reduce")
     return sums
 
 
 def bn_act_bwd_apply(z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx, sums, count, training=True,
-                     dgamma=None, dbeta=None):
+                     dgamma=None, dbeta=None, slope_dev=None):
     n, h, w, c = z.shape
     dz = torch.empty_like(z)
     check(load().rd_bn_act_bwd_apply(ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
-                                     float(slope), ptr(g_full), ptr(g_pool), ptr(idx), ptr(sums), float(count),
+                                     float(slope), ptr(slope_dev), ptr(g_full), ptr(g_pool), ptr(idx), ptr(sums),
+                                     float(count),
                                      1 if training else 0, ptr(dz), ptr(dgamma), ptr(dbeta), n, h, w, c, stream_ptr()),
           "bn_act_bwd_apply")
     return dz

@@ -126,9 +126,6 @@ class UNet(nn.Module):
     def _unsupported(self) -> Optional[str]:
         if self.up_mode != "transpose":
             return "up_mode='bilinear'"
-        for a in (self.act_fn_encoder, self.act_fn_decoder, self.act_fn_bottleneck):
-            if a == "prelu":
-                return "activation 'prelu'"
         if self.start_kernel % 4 != 0:
             return "start_kernel not a multiple of 4"
         if not 1 <= self.n_input_channels <= 6:
@@ -215,12 +212,26 @@ class UNet(nn.Module):
             return block[1], None
         return None, block[0].bias
 
+    def _act_of(self, block, name):
+        """Activation of a conv block as the fused kernels take it: a float negative slope (ReLU 0, LeakyReLU 0.01), or
+        the block's own nn.PReLU().weight Parameter (lib/UNet.py:27-33; index 2 with BN, 1 without)."""
+        if name == "prelu":
+            return block[2 if self.do_BN else 1].weight
+        return _SLOPES[name]
+
+    @staticmethod
+    def _split_slope(slope):
+        if isinstance(slope, torch.Tensor):
+            return 0.0, slope.detach()
+        return slope, None
+
     def _bn_forward(self, z, bn, slope, pool, training, sums=None, bias=None):
         c = z.shape[-1]
+        slope, sdev = self._split_slope(slope)
         if bn is None:
             # do_BN=False: activation(conv + bias) == the fused BN-apply kernel with mean 0, invstd 1, gamma 1, beta = bias
             mean, invstd = self._const(c, 0.0, z.device), self._const(c, 1.0, z.device)
-            a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, invstd, bias, slope, pool)
+            a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, invstd, bias, slope, pool, sdev)
             return a, p, idx, mean, invstd, 1
         if training:
             if sums is None:
@@ -233,13 +244,12 @@ class UNet(nn.Module):
         else:
             mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, eps=bn.eps)
             count = z.numel() // c
-        a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, bn.weight, bn.bias, slope, pool)
+        a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, bn.weight, bn.bias, slope, pool, sdev)
         return a, p, idx, mean, invstd, count
 
     def _engine_forward(self, x, training: bool, save: bool, keep_skips: bool = False):
         d = self.depth
         pk = self._packed()
-        se, sb, sd_ = _SLOPES[self.act_fn_encoder], _SLOPES[self.act_fn_bottleneck], _SLOPES[self.act_fn_decoder]
         S = {"x": x, "enc": [], "dec": [], "training": training} if save else None
 
         def conv_stats(inp, wf):
@@ -258,7 +268,8 @@ class UNet(nn.Module):
             else:
                 z, sums = conv_stats(cur, pk["enc"][i - 1][0])
             bn, cbias = self._norm_of(blk)
-            a, p, idx, mean, invstd, count = self._bn_forward(z, bn, se, True, training, sums, cbias)
+            a, p, idx, mean, invstd, count = self._bn_forward(z, bn, self._act_of(blk, self.act_fn_encoder), True, training,
+                                                              sums, cbias)
             skips.append(a)
             if save:
                 S["enc"].append({"z": z, "idx": idx, "mean": mean, "invstd": invstd, "count": count, "p": p})
@@ -267,7 +278,8 @@ class UNet(nn.Module):
             cur = p
         zb, sums = conv_stats(cur, pk["bott"][0])
         bn, cbias = self._norm_of(self.bottleneck)
-        ab, _, _, mean, invstd, count = self._bn_forward(zb, bn, sb, False, training, sums, cbias)
+        ab, _, _, mean, invstd, count = self._bn_forward(zb, bn, self._act_of(self.bottleneck, self.act_fn_bottleneck),
+                                                         False, training, sums, cbias)
         if save:
             S["bott"] = {"z": zb, "mean": mean, "invstd": invstd, "count": count, "a": ab}
         cur = ab
@@ -280,7 +292,8 @@ class UNet(nn.Module):
                 blk = self.decoder[i][1]
                 zd, sums = conv_stats(s, pk["dec_c"][i][0])
                 bn, cbias = self._norm_of(blk)
-                ad, _, _, mean, invstd, count = self._bn_forward(zd, bn, sd_, False, training, sums, cbias)
+                ad, _, _, mean, invstd, count = self._bn_forward(zd, bn, self._act_of(blk, self.act_fn_decoder), False,
+                                                                 training, sums, cbias)
                 rec.update(z=zd, mean=mean, invstd=invstd, count=count, a=ad)
                 cur = ad
             else:
@@ -327,7 +340,6 @@ class UNet(nn.Module):
         data-parallel bucketing in resdepth_amd.dp relies on for overlap."""
         d = self.depth
         pk = self._packed()
-        se, sb, sd_ = _SLOPES[self.act_fn_encoder], _SLOPES[self.act_fn_bottleneck], _SLOPES[self.act_fn_decoder]
         training = S["training"]
         params = self._param_list()
         index = {id(p): i for i, p in enumerate(params)}
@@ -382,35 +394,45 @@ class UNet(nn.Module):
                     t_.record_stream(side)
                 done(*ready)
 
-        def bn_backward(rec, block, slope, g_full, g_pool, idx, extra_bias=None):
+        def bn_backward(rec, block, act_name, g_full, g_pool, idx, extra_bias=None):
             c = rec["z"].shape[-1]
             bn, cbias = self._norm_of(block)
+            act = self._act_of(block, act_name)
+            slope, sdev = self._split_slope(act)
+            prelu_w = act if sdev is not None else None
+
+            def side_grads(sums):
+                # by-products of the same reduction: ConvTranspose2d bias (skip add) and the PReLU slope
+                if extra_bias is not None:
+                    gv(extra_bias).copy_(sums[2 * c:3 * c])
+                if prelu_w is not None:
+                    gv(prelu_w).copy_(sums[3 * c:4 * c].sum().reshape(1))
+
             if bn is None:
                 # do_BN=False: a = act(z + bias); d bias = sum g', dz = g' (the "eval" form of the fused kernels)
                 one = self._const(c, 1.0, rec["z"].device)
-                sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], one, cbias, slope, g_full, g_pool, idx)
-                if extra_bias is not None:
-                    gv(extra_bias).copy_(sums[2 * c:3 * c])
+                sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], one, cbias, slope, g_full, g_pool, idx,
+                                             slope_dev=sdev)
+                side_grads(sums)
                 dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], one, cbias, slope, g_full, g_pool, idx,
-                                          sums, 1.0, False, dgamma=None, dbeta=gv(cbias))
-                done(cbias, extra_bias)
+                                          sums, 1.0, False, dgamma=None, dbeta=gv(cbias), slope_dev=sdev)
+                done(cbias, prelu_w, extra_bias)
                 return dz
             sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
-                                         g_pool, idx)
-            if extra_bias is not None:
-                gv(extra_bias).copy_(sums[2 * c:3 * c])
+                                         g_pool, idx, slope_dev=sdev)
+            side_grads(sums)
             if sync_bn:
                 local = sums[:2 * c].clone()
                 self.grad_sync.allreduce_sums(sums)
                 gv(bn.weight).copy_(local[c:2 * c])
                 gv(bn.bias).copy_(local[:c])
                 dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
-                                          g_pool, idx, sums, rec["count"], training)
+                                          g_pool, idx, sums, rec["count"], training, slope_dev=sdev)
             else:
                 dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
                                           g_pool, idx, sums, rec["count"], training, dgamma=gv(bn.weight),
-                                          dbeta=gv(bn.bias))
-            done(bn.weight, bn.bias, extra_bias)
+                                          dbeta=gv(bn.bias), slope_dev=sdev)
+            done(bn.weight, bn.bias, prelu_w, extra_bias)
             return dz
 
         dout = dout.contiguous()
@@ -440,11 +462,11 @@ class UNet(nn.Module):
             skipgrad[d - 1 - i] = g       # gradient wrt the encoder skip a_{d-1-i} (SkipConnection is an ADD)
             if i > 0:
                 blk = self.decoder[i - 1][1]
-                dz = bn_backward(src, blk, sd_, dprev, None, None)
+                dz = bn_backward(src, blk, self.act_fn_decoder, dprev, None, None)
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["dec"][i - 1]["s"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
                 g = ops.conv3x3_bwd_data(dz, pk["dec_c"][i - 1][1])
             else:
-                dz = bn_backward(src, self.bottleneck, sb, dprev, None, None)
+                dz = bn_backward(src, self.bottleneck, self.act_fn_bottleneck, dprev, None, None)
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][d - 1]["p"], dz, gv(self.bottleneck[0].weight),
                       ready=(self.bottleneck[0].weight,))
                 gp = ops.conv3x3_bwd_data(dz, pk["bott"][1])
@@ -455,7 +477,7 @@ class UNet(nn.Module):
             # ConvTranspose2d whose output was added to this skip (decoder level d-1-i)
             j = d - 1 - i
             up = self.decoder[j][0] if j < d - 1 else self.decoder[j]
-            dz = bn_backward(e, blk, se, skipgrad[i], gp, e["idx"], extra_bias=up.bias)
+            dz = bn_backward(e, blk, self.act_fn_encoder, skipgrad[i], gp, e["idx"], extra_bias=up.bias)
             skipgrad[i] = None
             if i > 0:
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][i - 1]["p"], dz, gv(blk[0].weight), ready=(blk[0].weight,))

@@ -298,6 +298,9 @@ if __name__ == "__main__":
     tiny_case("g8_lrelu_oskipbn", dict(n_input_channels=3, start_kernel=8, depth=2, act_fn_encoder="lrelu",
                                        act_fn_decoder="lrelu", act_fn_bottleneck="lrelu", outer_skip_BN=True,
                                        bias_conv_layer=True), n=3, t=16, seed_w=13, seed_x=14)
+    tiny_case("g11_prelu", dict(n_input_channels=2, start_kernel=8, depth=2, act_fn_encoder="prelu",
+                                act_fn_decoder="prelu", act_fn_bottleneck="prelu", bias_conv_layer=True), n=2, t=16,
+              seed_w=15, seed_x=16, lr=5e-3)
     op_cases()
     init_digest()
     full_digest()

@@ -198,7 +198,7 @@ def test_bn_act_pool_forward_backward(n, h, w, c, slope, pool):
     close(nchw(dz), x.grad, tol=2e-5, name="bn dz")
     close(dgam.cpu(), gam.grad, tol=1e-5, name="dgamma")
     close(dbet.cpu(), bet.grad, tol=1e-5, name="dbeta")
-    close(bs[2 * c:].float().cpu(), g_full.sum((0, 2, 3)), tol=1e-5, name="sum g_full")
+    close(bs[2 * c:3 * c].float().cpu(), g_full.sum((0, 2, 3)), tol=1e-5, name="sum g_full")
     # eval mode: running statistics, constants in the backward
     emean, einv = ops.bn_eval_stats(drm, drv)
     ea, _, _ = ops.bn_act_pool_fwd(z, emean, einv, ga, be, slope, False)
@@ -234,6 +234,41 @@ def test_pool_ties_and_nan_known_answer(g4):
     sums = ops.bn_act_bwd_reduce(z2, zero, one, one, zero, 1.0, None, nhwc(gy), idx)
     dz = ops.bn_act_bwd_apply(z2, zero, one, one, zero, 1.0, None, nhwc(gy), idx, sums, 1.0, False)
     assert torch.equal(nchw(dz), gx)
+
+
+@pytest.mark.parametrize("pool", [False, True])
+def test_prelu_learnable_slope_on_device(pool):
+    """nn.PReLU() (lib/UNet.py:29): the slope is read from device memory and its gradient is the 4th reduced quantity."""
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(77)
+    n, h, w, c = 2, 16, 16, 8
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    gam = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
+    bet = (torch.randn(c, generator=g) * 0.3).requires_grad_(True)
+    sl = torch.tensor([0.25], requires_grad=True)
+    y = F.batch_norm(x, None, None, gam, bet, True, 0.1, 1e-5)
+    a = F.prelu(y, sl)
+    g_full = torch.randn(a.shape, generator=g)
+    obj = (a * g_full).sum()
+    g_pool = None
+    if pool:
+        p = F.max_pool2d(a, 2, 2)
+        g_pool = torch.randn(p.shape, generator=g)
+        obj = obj + (p * g_pool).sum()
+    obj.backward()
+    z = nhwc(x.detach())
+    mean, invstd = ops.bn_stats_finalize(ops.bn_stats_partial(z), n * h * w, torch.zeros(c, device=dev()),
+                                         torch.ones(c, device=dev()), torch.zeros((), dtype=torch.long, device=dev()))
+    ga, be, dsl = gam.detach().to(dev()), bet.detach().to(dev()), sl.detach().to(dev())
+    da, dp, didx = ops.bn_act_pool_fwd(z, mean, invstd, ga, be, 0.0, pool, slope_dev=dsl)
+    close(nchw(da), a.detach(), tol=2e-6, name="prelu act")
+    gf, gp = nhwc(g_full), (nhwc(g_pool) if pool else None)
+    bs = ops.bn_act_bwd_reduce(z, mean, invstd, ga, be, 0.0, gf, gp, didx, slope_dev=dsl)
+    dgam, dbet = torch.empty(c, device=dev()), torch.empty(c, device=dev())
+    dz = ops.bn_act_bwd_apply(z, mean, invstd, ga, be, 0.0, gf, gp, didx, bs, n * h * w, True, dgam, dbet, slope_dev=dsl)
+    close(nchw(dz), x.grad, tol=2e-5, name="prelu dz")
+    close(dgam.cpu(), gam.grad, tol=1e-5, name="prelu dgamma")
+    close(bs[3 * c:].sum().float().cpu().reshape(1), sl.grad, tol=1e-5, name="d slope")
 
 
 def test_masked_l1_known_answers(g4):
