@@ -100,6 +100,22 @@ size_t rd_convt2x2_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout);
 int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw_iohw, int n, int h, int w, int cin, int cout,
                            void* ws, size_t ws_bytes, rd_stream_t s);
 
+/* ---- bilinear up-mode: nn.Upsample(scale_factor=2, 'bilinear') -> conv1x1 (lib/UNet.py:8-9,17-24) -----
+ * The 1x1 convolution is applied on the coarse grid (it commutes with the interpolation), then
+ * rd_upsample2x_add_fwd interpolates, adds the conv bias and the skip tensor (SkipConnection, lib/UNet.py:96-101).
+ * w: torch layout [Cout][Cin][1][1]; wt = its transpose [Cin][Cout] for the data gradient. */
+int rd_pack_conv1x1_weight(const float* w, float* wt, int cout, int cin, rd_stream_t s);
+int rd_conv1x1_fwd(const float* x, const float* w, float* out, long long pixels, int cin, int cout, rd_stream_t s);
+int rd_conv1x1_bwd_data(const float* dy, const float* wt, float* dx, long long pixels, int cin, int cout, rd_stream_t s);
+size_t rd_conv1x1_bwd_weight_ws_bytes(long long pixels, int cin, int cout);
+int rd_conv1x1_bwd_weight(const float* x, const float* dy, float* dw, long long pixels, int cin, int cout, void* ws,
+                          size_t ws_bytes, rd_stream_t s);
+/* out[N,2H,2W,C] = skip (nullable) + bias (nullable) + bilinear2x(t[N,H,W,C]), align_corners=False */
+int rd_upsample2x_add_fwd(const float* t, const float* bias, const float* skip, float* out, int n, int h, int w, int c,
+                          rd_stream_t s);
+/* adjoint of the interpolation: dt[N,H,W,C] = bilinear2x^T(g[N,2H,2W,C]) (gather form, deterministic) */
+int rd_upsample2x_bwd(const float* g, float* dt, int n, int h, int w, int c, rd_stream_t s);
+
 /* per-channel sum over pixels: out[c] = sum_p g[p][c]   (bias gradients) */
 size_t rd_channel_sum_ws_bytes(long long pixels, int c);
 int rd_channel_sum(const float* g, float* out, long long pixels, int c, void* ws, size_t ws_bytes, rd_stream_t s);

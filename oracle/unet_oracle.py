@@ -38,6 +38,7 @@ class Spec:
     bias_conv_layer: bool = False
     outer_skip: bool = True
     outer_skip_BN: bool = False
+    up_mode: str = "transpose"      # 'transpose' | 'bilinear' (lib/UNet.py:17-24)
 
     @property
     def filter_depths(self) -> List[int]:
@@ -97,14 +98,21 @@ def param_layout(spec: Spec):
     bn("bottleneck.1", fd[-1])
     act("bottleneck", spec.act_fn_bottleneck)
     up = list(reversed(fd))
+
+    def upconv(prefix, c):
+        if spec.up_mode == "bilinear":     # Sequential(Upsample, conv1x1): the conv is module 1 (lib/UNet.py:20)
+            out.append((prefix + ".1.weight", (c, c, 1, 1), "param"))
+            out.append((prefix + ".1.bias", (c,), "param"))
+        else:
+            out.append((prefix + ".weight", (c, c, 2, 2), "param"))
+            out.append((prefix + ".bias", (c,), "param"))
+
     for i, (ci, co) in enumerate(zip(up[:-1], up[1:])):
-        out.append((f"decoder.{i}.0.weight", (ci, ci, 2, 2), "param"))
-        out.append((f"decoder.{i}.0.bias", (ci,), "param"))
+        upconv(f"decoder.{i}.0", ci)
         conv(f"decoder.{i}.1.0", co, ci)
         bn(f"decoder.{i}.1.1", co)
         act(f"decoder.{i}.1", spec.act_fn_decoder)
-    out.append((f"decoder.{spec.depth - 1}.weight", (up[-1], up[-1], 2, 2), "param"))
-    out.append((f"decoder.{spec.depth - 1}.bias", (up[-1],), "param"))
+    upconv(f"decoder.{spec.depth - 1}", up[-1])
     out.append(("last_layer.weight", (1, spec.start_kernel, 3, 3), "param"))
     if spec.bias_conv_layer:
         out.append(("last_layer.bias", (1,), "param"))
@@ -142,8 +150,10 @@ def init_state_dict(spec: Spec, seed: int) -> Dict[str, torch.Tensor]:
         sd[prefix + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
 
     def upconv(prefix, c):
-        torch.nn.Conv2d(c, c, 1, 1)                       # discarded conv1x1 draw
-        m = torch.nn.ConvTranspose2d(c, c, 2, 2)
+        c1 = torch.nn.Conv2d(c, c, 1, 1)                  # conv1x1 of the bilinear branch: drawn first, always
+        m = torch.nn.ConvTranspose2d(c, c, 2, 2)          # ... then the transposed conv; one of the two is discarded
+        if spec.up_mode == "bilinear":
+            prefix, m = prefix + ".1", c1
         sd[prefix + ".weight"] = m.weight.detach().clone()
         sd[prefix + ".bias"] = m.bias.detach().clone()
 
@@ -227,7 +237,10 @@ def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, spec: Spec, training: 
     k["zb"], k["ab"] = z, out
     for i in range(d):                                            # lib/UNet.py:213-224
         pre = f"decoder.{i}.0" if i < d - 1 else f"decoder.{i}"
-        u = F.conv_transpose2d(out, sd[pre + ".weight"], sd[pre + ".bias"], stride=2)
+        if spec.up_mode == "bilinear":    # nn.Upsample(mode='bilinear', scale_factor=2) -> conv1x1  (lib/UNet.py:20)
+            u = F.conv2d(F.interpolate(out, scale_factor=2, mode="bilinear"), sd[pre + ".1.weight"], sd[pre + ".1.bias"])
+        else:
+            u = F.conv_transpose2d(out, sd[pre + ".weight"], sd[pre + ".bias"], stride=2)
         s = skips[-1 - i] + u                                     # SkipConnection: ADD, lib/UNet.py:100-101
         k[f"u{i}"], k[f"s{i}"] = u, s
         if i < d - 1:

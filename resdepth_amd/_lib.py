@@ -50,6 +50,13 @@ SIGNATURES = {
     "rd_convt2x2_bwd_data": (I, [P, P, P, I, I, I, I, I, P]),
     "rd_convt2x2_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_convt2x2_bwd_weight": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),
+    "rd_pack_conv1x1_weight": (I, [P, P, I, I, P]),
+    "rd_conv1x1_fwd": (I, [P, P, P, LL, I, I, P]),
+    "rd_conv1x1_bwd_data": (I, [P, P, P, LL, I, I, P]),
+    "rd_conv1x1_bwd_weight_ws_bytes": (SZ, [LL, I, I]),
+    "rd_conv1x1_bwd_weight": (I, [P, P, P, LL, I, I, P, SZ, P]),
+    "rd_upsample2x_add_fwd": (I, [P, P, P, P, I, I, I, I, P]),
+    "rd_upsample2x_bwd": (I, [P, P, I, I, I, I, P]),
     "rd_channel_sum_ws_bytes": (SZ, [LL, I]),
     "rd_channel_sum": (I, [P, P, LL, I, P, SZ, P]),
     "rd_bn_stats_ws_bytes": (SZ, [LL, I]),

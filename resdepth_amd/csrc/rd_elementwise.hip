@@ -778,6 +778,104 @@ __global__ __launch_bounds__(256) void blend_tile_kernel(const float* __restrict
     raster[(long)y * cols + x] += (double)den * w;
 }
 
+// ---- bilinear 2x upsampling (up_mode='bilinear', lib/UNet.py:20) ---------------------------------------------
+// nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False): src = max(0.5*(dst+0.5)-0.5, 0), i0 = floor(src),
+// i1 = i0 + (i0 < size-1), l1 = src - i0, l0 = 1 - l1   (same arithmetic as ATen's upsample_bilinear2d).
+__device__ __forceinline__ void up2_src(int dst, int size, int& i0, int& i1, float& l0, float& l1) {
+    const float src = fmaxf(0.5f * ((float)dst + 0.5f) - 0.5f, 0.f);
+    i0 = (int)src;
+    i1 = i0 + (i0 < size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+// out[n,2h,2w,c] = skip + bias + up2(t[n,h,w,c]); one thread per (fine pixel, 4 channels)
+__global__ __launch_bounds__(256) void upsample2x_add_kernel(const float* __restrict__ t, const float* __restrict__ bias,
+                                                             const float* __restrict__ skip, float* __restrict__ out,
+                                                             long total, int h, int w, int CQ) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(e % CQ);
+        const long pix = e / CQ;
+        const int x = (int)(pix % (2 * w)), y = (int)((pix / (2 * w)) % (2 * h));
+        const long img = pix / ((long)4 * w * h);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        up2_src(y, h, y0, y1, ly0, ly1);
+        up2_src(x, w, x0, x1, lx0, lx1);
+        const long C = (long)CQ * 4;
+        const float* base = t + img * h * w * C + cq * 4;
+        const float4 v00 = *reinterpret_cast<const float4*>(base + ((long)y0 * w + x0) * C);
+        const float4 v01 = *reinterpret_cast<const float4*>(base + ((long)y0 * w + x1) * C);
+        const float4 v10 = *reinterpret_cast<const float4*>(base + ((long)y1 * w + x0) * C);
+        const float4 v11 = *reinterpret_cast<const float4*>(base + ((long)y1 * w + x1) * C);
+        float4 r;
+        r.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+        r.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+        r.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+        r.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+        if (bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + cq * 4);
+            r.x += b4.x; r.y += b4.y; r.z += b4.z; r.w += b4.w;
+        }
+        if (skip) {
+            const float4 s4 = *reinterpret_cast<const float4*>(skip + e * 4);
+            r.x = s4.x + r.x; r.y = s4.y + r.y; r.z = s4.z + r.z; r.w = s4.w + r.w;
+        }
+        *reinterpret_cast<float4*>(out + e * 4) = r;
+    }
+}
+
+// adjoint: dt[n,h,w,c] = up2^T(g[n,2h,2w,c]).  Gather form (no atomics, fixed summation order): coarse pixel i receives
+// from the fine rows 2i-1 .. 2i+2 whichever interpolation weights name it (clamped borders fold two weights into one).
+__device__ __forceinline__ void up2_adj_weights(int i, int size, int r0, float wgt[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + k;
+        float wk = 0.f;
+        if (r >= 0 && r < 2 * size) {
+            int i0, i1;
+            float l0, l1;
+            up2_src(r, size, i0, i1, l0, l1);
+            if (i0 == i) wk += l0;
+            if (i1 == i) wk += l1;
+        }
+        wgt[k] = wk;
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample2x_adj_kernel(const float* __restrict__ g, float* __restrict__ dt,
+                                                             long total, int h, int w, int CQ) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(e % CQ);
+        const long pix = e / CQ;
+        const int j = (int)(pix % w), i = (int)((pix / w) % h);
+        const long img = pix / ((long)w * h);
+        float wy[4], wx[4];
+        up2_adj_weights(i, h, 2 * i - 1, wy);
+        up2_adj_weights(j, w, 2 * j - 1, wx);
+        const long C = (long)CQ * 4;
+        const float* base = g + img * 4 * h * w * C + cq * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int r = 2 * i - 1 + a;
+            if (wy[a] == 0.f) continue;
+            float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int cc = 2 * j - 1 + b;
+                if (wx[b] == 0.f) continue;
+                const float4 v = *reinterpret_cast<const float4*>(base + ((long)r * 2 * w + cc) * C);
+                row.x = fmaf(wx[b], v.x, row.x); row.y = fmaf(wx[b], v.y, row.y);
+                row.z = fmaf(wx[b], v.z, row.z); row.w = fmaf(wx[b], v.w, row.w);
+            }
+            acc.x = fmaf(wy[a], row.x, acc.x); acc.y = fmaf(wy[a], row.y, acc.y);
+            acc.z = fmaf(wy[a], row.z, acc.z); acc.w = fmaf(wy[a], row.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(dt + e * 4) = acc;
+    }
+}
+
 // ---- training-sample assembly -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void patch_sums_kernel(const float* __restrict__ planes, long plane_stride,
                                                          const int* __restrict__ plane_idx, int P,
@@ -871,6 +969,29 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
 using namespace rd;
 
 extern "C" {
+
+int rd_upsample2x_add_fwd(const float* t, const float* bias, const float* skip, float* out, int n, int h, int w, int c,
+                          rd_stream_t s) {
+    RD_REQUIRE(t && out && n > 0 && h > 0 && w > 0, "rd_upsample2x_add_fwd: bad arguments");
+    RD_REQUIRE(c > 0 && c % 4 == 0, "rd_upsample2x_add_fwd: C must be a multiple of 4 (got %d)", c);
+    const long total = (long)n * 4 * h * w * (c / 4);
+    ProfScope ps((hipStream_t)s, "upsample2x_add", 0, 4.0 * ((double)n * h * w * c * (1 + 4 + (skip ? 4 : 0))));
+    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_cap((total + 255) / 256, 16384)), dim3(256), 0, (hipStream_t)s, t, bias, skip, out,
+                       total, h, w, c / 4);
+    RD_LAUNCH_CHECK("upsample2x_add");
+    return RD_OK;
+}
+
+int rd_upsample2x_bwd(const float* g, float* dt, int n, int h, int w, int c, rd_stream_t s) {
+    RD_REQUIRE(g && dt && n > 0 && h > 0 && w > 0, "rd_upsample2x_bwd: bad arguments");
+    RD_REQUIRE(c > 0 && c % 4 == 0, "rd_upsample2x_bwd: C must be a multiple of 4 (got %d)", c);
+    const long total = (long)n * h * w * (c / 4);
+    ProfScope ps((hipStream_t)s, "upsample2x_bwd", 0, 4.0 * ((double)n * h * w * c * 5));
+    hipLaunchKernelGGL(upsample2x_adj_kernel, dim3(grid_cap((total + 255) / 256, 16384)), dim3(256), 0, (hipStream_t)s, g, dt, total, h, w,
+                       c / 4);
+    RD_LAUNCH_CHECK("upsample2x_bwd");
+    return RD_OK;
+}
 
 size_t rd_channel_sum_ws_bytes(long long pixels, int c) {
     RowPlan pl;

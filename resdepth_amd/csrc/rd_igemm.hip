@@ -560,6 +560,7 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cl
 // slab[s][m][n] summed over s (fixed order, fp64) and scattered into the torch weight layout.
 //  mode 0 (conv3x3): m = co, n = tap*Cin + ci  ->  dw[(co*Cin + ci)*9 + tap]
 //  mode 1 (convT)  : m = ab*Cout + co, n = ci  ->  dw[(ci*Cout + co)*4 + ab]
+//  mode 2 (conv1x1): m = co, n = ci             ->  dw[co*Cin + ci]
 // One thread owns four consecutive n (16-byte coalesced slab reads, four splits in flight).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M,
                                                           int N, int splits, int mode, int Cin, int Cout) {
@@ -583,7 +584,9 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         const long e = q << 2;
         const int m = (int)(e / N), n = (int)(e - (long)m * N);
         const float r[4] = {(float)a0, (float)a1, (float)a2, (float)a3};
-        if (mode == 0) {
+        if (mode == 2) {                                      // plain [M][N] (conv1x1: dw[co][ci])
+            *reinterpret_cast<float4*>(dw + e) = make_float4(r[0], r[1], r[2], r[3]);
+        } else if (mode == 0) {
             const int tap = n / Cin, ci = n - tap * Cin;     // the quad stays inside one tap (Cin % 4 == 0)
 #pragma unroll
             for (int k = 0; k < 4; ++k) dw[((long)m * Cin + ci + k) * 9 + tap] = r[k];
@@ -606,6 +609,14 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
         const float v = w[((long)co * cin + ci) * 9 + tap];
         wf[e] = v;
         if (wd) wd[((long)ci * 9 + (8 - tap)) * cout + co] = v;
+    }
+}
+
+__global__ void transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int rows, int cols) {
+    const long total = (long)rows * cols;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % cols), r = (int)(e / cols);
+        wt[(long)c * rows + r] = w[e];
     }
 }
 
@@ -783,6 +794,68 @@ int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw, int n, 
     ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N / 4)), dim3(256), 0, (hipStream_t)s,
                        (const float*)ws, dw, p.M, p.N, pl.splits, 1, cin, cout);
+    RD_LAUNCH_CHECK("slab_reduce");
+    return RD_OK;
+}
+
+// ---- conv1x1 of the bilinear up-mode (lib/UNet.py:8-9,20).  A 1x1 convolution commutes with the bilinear
+// interpolation (both linear; the interpolation weights sum to 1 so the bias commutes too), so the engine applies it on
+// the COARSE grid -- a plain [pixels x Cin] x [Cin x Cout] GEMM with a quarter of the reference's work.
+int rd_pack_conv1x1_weight(const float* w, float* wt, int cout, int cin, rd_stream_t s) {
+    RD_REQUIRE(w && wt && cout > 0 && cin > 0, "rd_pack_conv1x1_weight: bad arguments");
+    ProfScope ps((hipStream_t)s, "pack_weights", 0, 8.0 * cout * cin);
+    hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long)cout * cin)), dim3(256), 0, (hipStream_t)s, w, wt, cout, cin);
+    RD_LAUNCH_CHECK("pack_conv1x1");
+    return RD_OK;
+}
+
+int rd_conv1x1_fwd(const float* x, const float* w, float* out, long long pixels, int cin, int cout, rd_stream_t s) {
+    RD_REQUIRE(x && w && out && pixels > 0 && cin > 0 && cout > 0, "rd_conv1x1_fwd: bad arguments");
+    RD_REQUIRE(cin % 4 == 0, "rd_conv1x1_fwd: Cin must be a multiple of 4 (got %d)", cin);
+    RD_REQUIRE(pixels * 4LL < (1LL << 31), "rd_conv1x1_fwd: pixel count too large for 32-bit tile indices");
+    NtParams p = {};
+    p.A = x; p.B = w; p.C = out;
+    p.M = (int)pixels; p.N = cout; p.K = cin; p.Cin = cin;
+    p.H = 1; p.W = 1; p.logH = 0; p.logW = 0;
+    return launch_nt<A_PLAIN, EPI_STORE>(p, (hipStream_t)s, "conv1x1_fwd");
+}
+
+int rd_conv1x1_bwd_data(const float* dy, const float* wt, float* dx, long long pixels, int cin, int cout, rd_stream_t s) {
+    RD_REQUIRE(dy && wt && dx && pixels > 0 && cin > 0 && cout > 0, "rd_conv1x1_bwd_data: bad arguments");
+    RD_REQUIRE(cout % 4 == 0, "rd_conv1x1_bwd_data: Cout must be a multiple of 4 (got %d)", cout);
+    RD_REQUIRE(pixels * 4LL < (1LL << 31), "rd_conv1x1_bwd_data: pixel count too large for 32-bit tile indices");
+    NtParams p = {};
+    p.A = dy; p.B = wt; p.C = dx;
+    p.M = (int)pixels; p.N = cin; p.K = cout; p.Cin = cout;
+    p.H = 1; p.W = 1; p.logH = 0; p.logW = 0;
+    return launch_nt<A_PLAIN, EPI_STORE>(p, (hipStream_t)s, "conv1x1_dgrad");
+}
+
+size_t rd_conv1x1_bwd_weight_ws_bytes(long long pixels, int cin, int cout) {
+    TnPlan pl = plan_tn(cout, cin, (long)pixels);
+    return (size_t)pl.splits * cout * cin * sizeof(float);
+}
+
+int rd_conv1x1_bwd_weight(const float* x, const float* dy, float* dw, long long pixels, int cin, int cout, void* ws,
+                          size_t ws_bytes, rd_stream_t s) {
+    RD_REQUIRE(x && dy && dw && pixels > 0, "rd_conv1x1_bwd_weight: bad arguments");
+    RD_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "rd_conv1x1_bwd_weight: channels must be multiples of 4 (%d, %d)", cin,
+               cout);
+    const size_t need = rd_conv1x1_bwd_weight_ws_bytes(pixels, cin, cout);
+    if (ws_bytes < need || !ws) {
+        set_error("rd_conv1x1_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
+        return RD_ERR_WS;
+    }
+    TnPlan pl = plan_tn(cout, cin, (long)pixels);
+    TnParams p = {};
+    p.A = dy; p.B = x; p.slab = (float*)ws;
+    p.M = cout; p.N = cin; p.Kp = (long)pixels;
+    p.lda = cout; p.ldb = cin; p.Cin = cin; p.Cout = cout;
+    p.H = 1; p.W = 1; p.logH = 0; p.logW = 0;
+    if (int e = launch_tn<WA_PLAIN, WB_PLAIN>(p, pl, (hipStream_t)s, "conv1x1_wgrad")) return e;
+    ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N / 4)), dim3(256), 0, (hipStream_t)s,
+                       (const float*)ws, dw, p.M, p.N, pl.splits, 2, cin, cout);
     RD_LAUNCH_CHECK("slab_reduce");
     return RD_OK;
 }

@@ -170,6 +170,58 @@ def convt2x2_bwd_weight(x, dout, out=None, ws_slot=0):
     return out
 
 
+# ---- bilinear up-mode (lib/UNet.py:17-24): conv1x1 on the coarse grid, then interpolate + bias + skip ---------
+def pack_conv1x1_weight(w):
+    """w: [Cout, Cin, 1, 1] (torch) -> (w itself viewed [Cout, Cin], its transpose [Cin, Cout] for the data gradient)."""
+    cout, cin = w.shape[0], w.shape[1]
+    wt = torch.empty(cin, cout, device=w.device, dtype=torch.float32)
+    check(load().rd_pack_conv1x1_weight(ptr(w.detach()), ptr(wt), cout, cin, stream_ptr()), "pack_conv1x1")
+    return w.detach().view(cout, cin), wt
+
+
+def conv1x1_fwd(x, w2d):
+    n, h, w, cin = x.shape
+    cout = w2d.shape[0]
+    out = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
+    check(load().rd_conv1x1_fwd(ptr(_f32(x, "x")), ptr(w2d), ptr(out), n * h * w, cin, cout, stream_ptr()), "conv1x1_fwd")
+    return out
+
+
+def conv1x1_bwd_data(dy, wt):
+    n, h, w, cout = dy.shape
+    cin = wt.shape[0]
+    dx = torch.empty(n, h, w, cin, device=dy.device, dtype=torch.float32)
+    check(load().rd_conv1x1_bwd_data(ptr(dy), ptr(wt), ptr(dx), n * h * w, cin, cout, stream_ptr()), "conv1x1_bwd_data")
+    return dx
+
+
+def conv1x1_bwd_weight(x, dy, out=None, ws_slot=0):
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    if out is None:
+        out = torch.empty(cout, cin, 1, 1, device=x.device, dtype=torch.float32)
+    nb = load().rd_conv1x1_bwd_weight_ws_bytes(n * h * w, cin, cout)
+    ws = workspace(nb, x.device, ws_slot)
+    check(load().rd_conv1x1_bwd_weight(ptr(x), ptr(dy), ptr(out), n * h * w, cin, cout, ws.data_ptr(), ws.numel(),
+                                       stream_ptr()), "conv1x1_bwd_weight")
+    return out
+
+
+def upsample2x_add_fwd(t, bias=None, skip=None):
+    n, h, w, c = t.shape
+    out = torch.empty(n, 2 * h, 2 * w, c, device=t.device, dtype=torch.float32)
+    check(load().rd_upsample2x_add_fwd(ptr(t), ptr(bias.detach() if bias is not None else None), ptr(skip), ptr(out),
+                                       n, h, w, c, stream_ptr()), "upsample2x_add_fwd")
+    return out
+
+
+def upsample2x_bwd(g):
+    n, h2, w2, c = g.shape
+    dt = torch.empty(n, h2 // 2, w2 // 2, c, device=g.device, dtype=torch.float32)
+    check(load().rd_upsample2x_bwd(ptr(g), ptr(dt), n, h2 // 2, w2 // 2, c, stream_ptr()), "upsample2x_bwd")
+    return dt
+
+
 def channel_sum(g, out=None):
     c = g.shape[-1]
     pixels = g.numel() // c

@@ -124,8 +124,6 @@ class UNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _unsupported(self) -> Optional[str]:
-        if self.up_mode != "transpose":
-            return "up_mode='bilinear'"
         if self.start_kernel % 4 != 0:
             return "start_kernel not a multiple of 4"
         if not 1 <= self.n_input_channels <= 6:
@@ -190,12 +188,24 @@ class UNet(nn.Module):
             pk["enc"].append(ops.pack_conv3x3_weight(self.encoder[i][0][0].weight))
         pk["bott"] = ops.pack_conv3x3_weight(self.bottleneck[0].weight)
         for i in range(d):
-            up = self.decoder[i][0] if i < d - 1 else self.decoder[i]
-            pk["dec_t"].append(ops.pack_convt2x2_weight(up.weight))
+            up = self._up_of(i)
+            pk["dec_t"].append(ops.pack_conv1x1_weight(up.weight) if self.up_mode == "bilinear"
+                               else ops.pack_convt2x2_weight(up.weight))
             if i < d - 1:
                 pk["dec_c"].append(ops.pack_conv3x3_weight(self.decoder[i][1][0].weight))
         self._pack_cache, self._pack_key = pk, key
         return pk
+
+    def _up_of(self, i):
+        """The parameterised module of decoder level i's up-convolution: the ConvTranspose2d, or the conv1x1 behind the
+        nn.Upsample of the bilinear variant (lib/UNet.py:17-24)."""
+        up = self.decoder[i][0] if i < self.depth - 1 else self.decoder[i]
+        return up[1] if self.up_mode == "bilinear" else up
+
+    def _up_forward(self, cur, packed, up, skip):
+        if self.up_mode == "bilinear":
+            return ops.upsample2x_add_fwd(ops.conv1x1_fwd(cur, packed[0]), up.bias, skip)
+        return ops.convt2x2_fwd(cur, packed[0], up.bias, skip)
 
     # ------------------------------------------------------------------------------------------
     def _const(self, c, value, device):
@@ -284,8 +294,7 @@ class UNet(nn.Module):
             S["bott"] = {"z": zb, "mean": mean, "invstd": invstd, "count": count, "a": ab}
         cur = ab
         for i in range(d):
-            up = self.decoder[i][0] if i < d - 1 else self.decoder[i]
-            s = ops.convt2x2_fwd(cur, pk["dec_t"][i][0], up.bias, skips[d - 1 - i])
+            s = self._up_forward(cur, pk["dec_t"][i], self._up_of(i), skips[d - 1 - i])
             skips[d - 1 - i] = None          # the skip tensor is not needed by the backward pass
             rec = {"s": s}
             if i < d - 1:
@@ -455,10 +464,15 @@ class UNet(nn.Module):
         skipgrad = [None] * d
         gp = None
         for i in reversed(range(d)):
-            up = self.decoder[i][0] if i < d - 1 else self.decoder[i]
+            up = self._up_of(i)
             src = S["dec"][i - 1] if i > 0 else S["bott"]
-            wgrad(ops.convt2x2_bwd_weight, (g,), src["a"], g, gv(up.weight), ready=(up.weight,))
-            dprev = ops.convt2x2_bwd_data(g, pk["dec_t"][i][1])
+            if self.up_mode == "bilinear":
+                dt = ops.upsample2x_bwd(g)            # adjoint of the interpolation; then the coarse-grid conv1x1
+                wgrad(ops.conv1x1_bwd_weight, (dt,), src["a"], dt, gv(up.weight), ready=(up.weight,))
+                dprev = ops.conv1x1_bwd_data(dt, pk["dec_t"][i][1])
+            else:
+                wgrad(ops.convt2x2_bwd_weight, (g,), src["a"], g, gv(up.weight), ready=(up.weight,))
+                dprev = ops.convt2x2_bwd_data(g, pk["dec_t"][i][1])
             skipgrad[d - 1 - i] = g       # gradient wrt the encoder skip a_{d-1-i} (SkipConnection is an ADD)
             if i > 0:
                 blk = self.decoder[i - 1][1]
@@ -476,7 +490,7 @@ class UNet(nn.Module):
             # third reduction output = per-channel sum of the skip gradient = bias gradient of the
             # ConvTranspose2d whose output was added to this skip (decoder level d-1-i)
             j = d - 1 - i
-            up = self.decoder[j][0] if j < d - 1 else self.decoder[j]
+            up = self._up_of(j)
             dz = bn_backward(e, blk, self.act_fn_encoder, skipgrad[i], gp, e["idx"], extra_bias=up.bias)
             skipgrad[i] = None
             if i > 0:

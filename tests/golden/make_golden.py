@@ -301,6 +301,8 @@ if __name__ == "__main__":
     tiny_case("g11_prelu", dict(n_input_channels=2, start_kernel=8, depth=2, act_fn_encoder="prelu",
                                 act_fn_decoder="prelu", act_fn_bottleneck="prelu", bias_conv_layer=True), n=2, t=16,
               seed_w=15, seed_x=16, lr=5e-3)
+    tiny_case("g12_bilinear", dict(n_input_channels=3, start_kernel=8, depth=3, up_mode="bilinear",
+                                   bias_conv_layer=True), n=2, t=32, seed_w=17, seed_x=18, lr=2e-3)
     op_cases()
     init_digest()
     full_digest()

@@ -271,6 +271,46 @@ def test_prelu_learnable_slope_on_device(pool):
     close(bs[3 * c:].sum().float().cpu().reshape(1), sl.grad, tol=1e-5, name="d slope")
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8), (1, 1, 1, 4), (3, 4, 16, 12), (1, 2, 1, 8)])
+def test_bilinear_upsample_matches_torch_and_adjoint(shape):
+    """nn.Upsample(scale_factor=2, mode='bilinear') (lib/UNet.py:20) + bias + skip, and its adjoint."""
+    from resdepth_amd import ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(5)
+    t = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    bias = torch.randn(c, generator=g)
+    skip = torch.randn(n, c, 2 * h, 2 * w, generator=g)
+    ref = F.interpolate(t, scale_factor=2, mode="bilinear") + bias.view(1, -1, 1, 1) + skip
+    gy = torch.randn(ref.shape, generator=g)
+    (ref * gy).sum().backward()
+    out = ops.upsample2x_add_fwd(nhwc(t.detach()), bias.to(dev()), nhwc(skip))
+    close(nchw(out), ref.detach(), tol=1e-6, name="upsample fwd")
+    dt = ops.upsample2x_bwd(nhwc(gy))
+    close(nchw(dt), t.grad, tol=1e-6, name="upsample adjoint")
+
+
+def test_conv1x1_coarse_grid_equals_reference_order():
+    """conv1x1(upsample(x)) (reference order) == upsample(conv1x1(x)) (engine order) to fp32 rounding."""
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(6)
+    n, c, h, w = 2, 24, 16, 16
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    conv = torch.nn.Conv2d(c, c, 1)
+    skip = torch.randn(n, c, 2 * h, 2 * w, generator=g)
+    ref = conv(F.interpolate(x, scale_factor=2, mode="bilinear")) + skip
+    gy = torch.randn(ref.shape, generator=g)
+    (ref * gy).sum().backward()
+    wd = conv.weight.detach().to(dev())
+    w2d, wt = ops.pack_conv1x1_weight(wd)
+    xd = nhwc(x.detach())
+    out = ops.upsample2x_add_fwd(ops.conv1x1_fwd(xd, w2d), conv.bias.detach().to(dev()), nhwc(skip))
+    close(nchw(out), ref.detach(), tol=2e-6, name="bilinear up-conv fwd")
+    dt = ops.upsample2x_bwd(nhwc(gy))
+    close(nchw(ops.conv1x1_bwd_data(dt, wt)), x.grad, tol=2e-6, name="bilinear up-conv dgrad")
+    close(ops.conv1x1_bwd_weight(xd, dt).cpu(), conv.weight.grad, tol=2e-6, name="conv1x1 wgrad")
+    close(ops.channel_sum(nhwc(gy)).cpu(), conv.bias.grad, tol=2e-6, name="conv1x1 bias grad = sum of fine gradient")
+
+
 def test_masked_l1_known_answers(g4):
     from resdepth_amd import masked_l1_loss
     t = lambda k: torch.from_numpy(g4["l1/" + k].copy())

@@ -10,7 +10,7 @@ import torch
 from conftest import load_json, load_npz
 from oracle import unet_oracle as O
 
-TINY = ["g1_tiny3.npz", "g2a_tiny1.npz", "g2b_cap.npz", "g7_nobn.npz", "g8_lrelu_oskipbn.npz", "g11_prelu.npz"]
+TINY = ["g1_tiny3.npz", "g2a_tiny1.npz", "g2b_cap.npz", "g7_nobn.npz", "g8_lrelu_oskipbn.npz", "g11_prelu.npz", "g12_bilinear.npz"]
 
 
 def _spec(kwargs):

@@ -40,7 +40,7 @@ def _train_iter(model, opt, batch):
 
 
 @pytest.mark.parametrize("name", ["g1_tiny3.npz", "g2a_tiny1.npz", "g2b_cap.npz", "g7_nobn.npz", "g8_lrelu_oskipbn.npz",
-                                  "g11_prelu.npz"])
+                                  "g11_prelu.npz", "g12_bilinear.npz"])
 def test_tiny_net_against_reference_fixture(name):
     from resdepth_amd import UNet, FusedAdam
     g = load_npz(name)
