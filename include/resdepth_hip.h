@@ -42,6 +42,15 @@ int rd_version(void);
 const char* rd_last_error_string(void);
 
 /* ---- weight (re)packing: torch layouts -> GEMM operand layouts ------------------- */
+/* Every packed operand B[rows][K = taps*Cin] is ONE opaque caller-owned buffer of
+ * rd_packed_weight_bytes(rows, taps, Cin) bytes: the fp32 GEMM layout (rows*K floats, described
+ * below) followed by the same matrix pre-split into three bf16 terms per element in the LDS row
+ * layout of the split-bf16 MFMA kernels.  The conv entry points take the buffer's
+ * base pointer.  (rows, taps, Cin) per operand:
+ *   conv3x3  wf: (Cout, 9, Cin)   wd: (Cin, 9, Cout)
+ *   convT2x2 wtf: (4*Cout, 1, Cin)  wtd: (Cin, 4, Cout)
+ *   conv1x1  wf: (Cout, 1, Cin)   wt: (Cin, 1, Cout) */
+size_t rd_packed_weight_bytes(int rows, int taps, int cin);
 /* nn.Conv2d weight [Cout][Cin][3][3] (lib/UNet.py:4-5) ->
  *   wf[co][tap][ci]              B operand of the forward implicit GEMM
  *   wd[ci][tap][co] = w[co][ci][8-tap]   B operand of the data-gradient GEMM (nullable) */
@@ -103,9 +112,9 @@ int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw_iohw, in
 /* ---- bilinear up-mode: nn.Upsample(scale_factor=2, 'bilinear') -> conv1x1 (lib/UNet.py:8-9,17-24) -----
  * The 1x1 convolution is applied on the coarse grid (it commutes with the interpolation), then
  * rd_upsample2x_add_fwd interpolates, adds the conv bias and the skip tensor (SkipConnection, lib/UNet.py:96-101).
- * w: torch layout [Cout][Cin][1][1]; wt = its transpose [Cin][Cout] for the data gradient. */
-int rd_pack_conv1x1_weight(const float* w, float* wt, int cout, int cin, rd_stream_t s);
-int rd_conv1x1_fwd(const float* x, const float* w, float* out, long long pixels, int cin, int cout, rd_stream_t s);
+ * w: torch layout [Cout][Cin][1][1] -> packed wf ([Cout][Cin]) and wt (its transpose [Cin][Cout], nullable). */
+int rd_pack_conv1x1_weight(const float* w, float* wf, float* wt, int cout, int cin, rd_stream_t s);
+int rd_conv1x1_fwd(const float* x, const float* wf, float* out, long long pixels, int cin, int cout, rd_stream_t s);
 int rd_conv1x1_bwd_data(const float* dy, const float* wt, float* dx, long long pixels, int cin, int cout, rd_stream_t s);
 size_t rd_conv1x1_bwd_weight_ws_bytes(long long pixels, int cin, int cout);
 int rd_conv1x1_bwd_weight(const float* x, const float* dy, float* dw, long long pixels, int cin, int cout, void* ws,

@@ -13,7 +13,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libresdepth_hip.so")
+# RESDEPTH_HIP_LIB: alternative build of the same library (kernel diagnosis builds, scripts/ablate.sh)
+LIB_PATH = os.environ.get("RESDEPTH_HIP_LIB") or os.path.join(_HERE, "libresdepth_hip.so")
 
 _lib = None
 _lock = threading.Lock()
@@ -50,7 +51,8 @@ SIGNATURES = {
     "rd_convt2x2_bwd_data": (I, [P, P, P, I, I, I, I, I, P]),
     "rd_convt2x2_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_convt2x2_bwd_weight": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),
-    "rd_pack_conv1x1_weight": (I, [P, P, I, I, P]),
+    "rd_pack_conv1x1_weight": (I, [P, P, P, I, I, P]),
+    "rd_packed_weight_bytes": (SZ, [I, I, I]),
     "rd_conv1x1_fwd": (I, [P, P, P, LL, I, I, P]),
     "rd_conv1x1_bwd_data": (I, [P, P, P, LL, I, I, P]),
     "rd_conv1x1_bwd_weight_ws_bytes": (SZ, [LL, I, I]),

@@ -19,6 +19,7 @@
 // fragment reads are bank-conflict free (MI355X guide, LDS table); the MFMA k-pairing is
 // permuted so that one b128 read feeds four consecutive MFMA k-steps.
 #include <stdlib.h>
+#include <string.h>
 
 #include "rd_common.h"
 
@@ -29,7 +30,8 @@ enum { EPI_STORE = 0, EPI_CONVT = 1 };
 
 struct NtParams {
     const float* A;
-    const float* B;
+    const float* B;        // fp32 GEMM layout [N][K]            (exact-f32 MFMA kernel)
+    const void* Bsplit;    // split-bf16 layout [N][nk][3][16]   (split kernel; follows B in the packed buffer)
     float* C;
     const float* bias;
     const float* skip;
@@ -61,6 +63,114 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
     // logical tiles so neighbouring tiles (which share A rows / B panels) share one L2.
     const int q = nb >> 3, r = nb & 7, x = b & 7, within = b >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + within;
+}
+
+// ---- epilogue shared by the NT kernels.  D[i][j]: lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5) (the C/D
+// map is the same for the f32 and the bf16 MFMA shapes).
+template <int BM, int BN, int WM, int WN, int EPI, int SMEM_WORDS, int EB = BM / WM / 32>
+__device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem, const NtParams& p,
+                                            int m0, int n0, int tile_m) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, half = lane >> 5;
+    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+    // ---- epilogue.  D[i][j]: lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5).  The accumulators
+    // are staged through LDS (EB 32-row blocks of one wave row-band per pass) so that HBM sees 16 B per lane and whole
+    // contiguous rows per wave; bias / skip-add of the transposed convolution ride the same pass.
+    constexpr int CS = BN + 4, ROWS = EB * 32, Q = BN / 4, PPB = TM / EB;   // PPB passes per wave row-band
+    static_assert(TM % EB == 0, "EB must divide TM");
+    static_assert(ROWS * CS + 512 <= SMEM_WORDS, "epilogue staging (+ statistics scratch) must fit the operand buffers");
+    float* Cs = smem;
+    float* red = smem + ROWS * CS;          // 2 x 256 floats for the fused BatchNorm statistics
+    float tot_s = 0.f, tot_q = 0.f;         // threads t < BN: column totals over the passes
+#pragma unroll
+    for (int pass = 0; pass < WM * PPB; ++pass) {
+        const int rowbase = (pass / PPB) * (TM * 32) + (pass % PPB) * ROWS;   // first tile row of this pass
+        __syncthreads();
+        if (wm == pass / PPB) {
+#pragma unroll
+            for (int ii = 0; ii < EB; ++ii)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Cs[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CS + wn * TN * 32 + j * 32 + lrow] =
+                            acc[(pass % PPB) * EB + ii][j][r];
+        }
+        __syncthreads();
+        if (EPI == EPI_STORE && p.stats) {
+            // fused BN statistics: column sums over this pass's rows (fixed order), combined over the row groups
+            constexpr int G = 256 / BN;      // row groups
+            const int col = t % BN, grp = t / BN;
+            float ss = 0.f, qq = 0.f;
+            for (int row = grp; row < ROWS; row += G) {
+                if (m0 + rowbase + row < p.M) {
+                    const float v = Cs[row * CS + col];
+                    ss += v;
+                    qq = fmaf(v, v, qq);
+                }
+            }
+            red[t] = ss;
+            red[256 + t] = qq;
+            __syncthreads();
+            if (t < BN) {
+#pragma unroll
+                for (int g2 = 0; g2 < G; ++g2) {
+                    tot_s += red[g2 * BN + t];
+                    tot_q += red[256 + g2 * BN + t];
+                }
+            }
+        }
+        if (p.vec) {
+            for (int e = t; e < ROWS * Q; e += 256) {
+                const int row = e / Q, q4 = e - row * Q;
+                const int m = m0 + rowbase + row, n = n0 + q4 * 4;
+                if (m >= p.M || n >= p.N) continue;
+                float4 v = *reinterpret_cast<const float4*>(&Cs[row * CS + q4 * 4]);
+                if (EPI == EPI_STORE) {
+                    *reinterpret_cast<float4*>(p.C + (long)m * p.N + n) = v;
+                } else {
+                    const int ab = n / p.Cout, co = n - ab * p.Cout;
+                    const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+                    const long opix = ((long)img * (2 * H) + 2 * ii + (ab >> 1)) * (2 * W) + 2 * jj + (ab & 1);
+                    const long o = opix * p.Cout + co;
+                    if (p.bias) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co);
+                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                    }
+                    if (p.skip) {
+                        const float4 s4 = *reinterpret_cast<const float4*>(p.skip + o);
+                        v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w;
+                    }
+                    *reinterpret_cast<float4*>(p.C + o) = v;
+                }
+            }
+        } else {
+            for (int e = t; e < ROWS * BN; e += 256) {
+                const int row = e / BN, c = e - row * BN;
+                const int m = m0 + rowbase + row, n = n0 + c;
+                if (m >= p.M || n >= p.N) continue;
+                float v = Cs[row * CS + c];
+                if (EPI == EPI_STORE) {
+                    p.C[(long)m * p.N + n] = v;
+                } else {
+                    const int ab = n / p.Cout, co = n - ab * p.Cout;
+                    const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+                    const long opix = ((long)img * (2 * H) + 2 * ii + (ab >> 1)) * (2 * W) + 2 * jj + (ab & 1);
+                    const long o = opix * p.Cout + co;
+                    if (p.bias) v += p.bias[co];
+                    if (p.skip) v = p.skip[o] + v;
+                    p.C[o] = v;
+                }
+            }
+        }
+    }
+    if (EPI == EPI_STORE && p.stats && t < BN && n0 + t < p.N) {
+        float* out = p.stats + (long)tile_m * 2 * p.N;
+        out[n0 + t] = tot_s;
+        out[p.N + n0 + t] = tot_q;
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
@@ -188,145 +298,342 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
         }
     }
 
-    // ---- epilogue.  D[i][j]: lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5).  The accumulators
-    // are staged through LDS (one row-band of BM/WM rows per pass) so that HBM sees 16 B per lane and whole
-    // contiguous rows per wave; bias / skip-add of the transposed convolution ride the same pass.
-    constexpr int CS = BN + 4, ROWS = BM / WM, Q = BN / 4;
-    static_assert(ROWS * CS + 512 <= (BM + BN) * LS, "epilogue staging (+ statistics scratch) must fit the operand buffers");
-    float* Cs = smem;
-    float* red = smem + ROWS * CS;          // 2 x 256 floats for the fused BatchNorm statistics
-    float tot_s = 0.f, tot_q = 0.f;         // threads t < BN: column totals over the passes
-    for (int pass = 0; pass < WM; ++pass) {
-        __syncthreads();
-        if (wm == pass) {
+    nt_epilogue<BM, BN, WM, WN, EPI, (BM + BN) * LS>(acc, smem, p, m0, n0, tile_m);
+}
+
+// ------------------------------------------------------------------------------------------
+//  Split-bf16 NT kernel: the same implicit GEMM on v_mfma_f32_32x32x16_bf16
+// ------------------------------------------------------------------------------------------
+// Every fp32 operand is split EXACTLY into three bf16 terms x = x1 + x2 + x3 (8 significant bits each, by truncation)
+// and a*b is evaluated as the six bf16 products of weight >= 2^-16 (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1) with fp32
+// accumulation.  Each bf16 product is exact in fp32; the dropped terms (a2b3, a3b2, a3b3) are <= 2^-23 |ab|, below the
+// rounding error of one fp32 multiply -- results agree with the exact-f32 MFMA kernel to fp32 rounding (same parity
+// tolerances in tests/).  Six MFMAs at 16x the f32-MFMA rate = 2.67x the fp32 matrix roofline (419 TFLOP/s).
+//   A (activations / gradients): split while staged into LDS (4 VALU per element + 3 v_perm per pair).
+//   B (weights): split ONCE by the pack kernels into the LDS row layout, staged by plain 16-byte copies.
+//   K-step = 16 k-values (one MFMA K), LDS double-buffered (one barrier per K-step), two K-steps of global loads
+//   in flight.  LDS row = 3 terms x 16 bf16 (96 B) + 16 B pad = 112 B: the 16 rows of a ds_read_b128 lane group start
+//   on 16 distinct bank quads.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SK = 16;      // k-values per K-step
+constexpr int SROWB = 96;   // bytes of one (row, K-step) in the packed split-B tensor
+
+// x = h + m + l exactly; h, m, l have <= 8 significant bits (bf16-representable), returned as fp32 bit patterns
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xffff0000u;
+    const float r = x - __uint_as_float(h);
+    m = __float_as_uint(r) & 0xffff0000u;
+    l = __float_as_uint(r - __uint_as_float(m));
+}
+// float4 (4 consecutive k) -> three 8-byte groups of 4 bf16 (one per term); v_perm_b32 -> {hi16(odd), hi16(even)}
+__device__ __forceinline__ void split_pack4(const float4 v, uint2& ph, uint2& pm, uint2& pl) {
+#if defined(RD_ABLATE) && (RD_ABLATE & 1)   // diagnosis builds only (scripts/ablate.sh): no split arithmetic
+    ph = pm = pl = make_uint2(__builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u),
+                              __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u));
+    return;
+#endif
+    unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+    split3(v.x, h0, m0, l0);
+    split3(v.y, h1, m1, l1);
+    split3(v.z, h2, m2, l2);
+    split3(v.w, h3, m3, l3);
+    ph = make_uint2(__builtin_amdgcn_perm(h1, h0, 0x07060302u), __builtin_amdgcn_perm(h3, h2, 0x07060302u));
+    pm = make_uint2(__builtin_amdgcn_perm(m1, m0, 0x07060302u), __builtin_amdgcn_perm(m3, m2, 0x07060302u));
+    pl = make_uint2(__builtin_amdgcn_perm(l1, l0, 0x07060302u), __builtin_amdgcn_perm(l3, l2, 0x07060302u));
+}
+__device__ __forceinline__ uint4 buf_load4u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
+}
+
+// LDS image of the A tile: one 128-byte row per pixel and stage = 8 chunks of 16 B, chunk c = 2*term + khalf (6 used).
+// Chunks are XOR-swizzled by swz(row) so that (a) the 16 rows of a ds_read_b128 lane group hit 16 distinct bank quads
+// and (b) the 4 rows of a ds_write_b64 lane group (rows r, r+2, r+4, r+6 by the thread->row map below) hit 4 distinct
+// 32-byte spans: no LDS bank conflicts on either side.
+__device__ __forceinline__ int swz(int r) { return (r ^ (r >> 3)) & 7; }
+
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TN == 1, "each wave owns one 32-column block: its B fragments come straight from global memory");
+    constexpr int AI = BM / 64;                       // A: 4 float4 per 16-k row, 64 rows per pass
+    constexpr int STAGE = BM * 32;                    // words per LDS stage (A only)
+    constexpr int EPI_WORDS = 32 * (BN + 4) + 512;    // epilogue staging: one 32-row block per pass
+    constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    // staging map: 4 lanes per row (c4 = 16-byte quarter of the 64-byte k-row); within 16 lanes the rows are r, r+2, r+4, r+6
+    const int c4 = t & 3;
+    const int r0 = wave * 16 + ((lane >> 5) << 3) + (((lane >> 2) & 3) << 1) + ((lane >> 4) & 1);
+
+    f32x16 acc[TM][1];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.Bsplit, p.b_bytes);
+    unsigned a_off[AI], a_val[AI];
+    int a_wr[AI];       // LDS word address of this thread's 8 bytes of term 0 (terms 1, 2: chunk +2, +4 before the swizzle)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * CS + wn * TN * 32 + j * 32 + lrow] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (EPI == EPI_STORE && p.stats) {
-            // fused BN statistics: column sums over this pass's rows (fixed order), combined over the row groups
-            constexpr int G = 256 / BN;      // row groups
-            const int col = t % BN, grp = t / BN;
-            float ss = 0.f, qq = 0.f;
-            for (int row = grp; row < ROWS; row += G) {
-                if (m0 + pass * ROWS + row < p.M) {
-                    const float v = Cs[row * CS + col];
-                    ss += v;
-                    qq = fmaf(v, v, qq);
-                }
+    for (int i = 0; i < AI; ++i) {
+        const int row = r0 + 64 * i;
+        const int m = m0 + row;
+        const bool inm = m < p.M;
+        unsigned val = 0;
+        long pix = m;
+        if (AMODE == A_CONV3) {
+            const int y = (m >> logW) & (H - 1), x = m & (W - 1);
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+                if (((unsigned)(y + dy) < (unsigned)H) && ((unsigned)(x + dx) < (unsigned)W)) val |= 1u << t9;
             }
-            red[t] = ss;
-            red[256 + t] = qq;
-            __syncthreads();
-            if (t < BN) {
-#pragma unroll
-                for (int g2 = 0; g2 < G; ++g2) {
-                    tot_s += red[g2 * BN + t];
-                    tot_q += red[256 + g2 * BN + t];
-                }
-            }
-        }
-        if (p.vec) {
-            for (int e = t; e < ROWS * Q; e += 256) {
-                const int row = e / Q, q4 = e - row * Q;
-                const int m = m0 + pass * ROWS + row, n = n0 + q4 * 4;
-                if (m >= p.M || n >= p.N) continue;
-                float4 v = *reinterpret_cast<const float4*>(&Cs[row * CS + q4 * 4]);
-                if (EPI == EPI_STORE) {
-                    *reinterpret_cast<float4*>(p.C + (long)m * p.N + n) = v;
-                } else {
-                    const int ab = n / p.Cout, co = n - ab * p.Cout;
-                    const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
-                    const long opix = ((long)img * (2 * H) + 2 * ii + (ab >> 1)) * (2 * W) + 2 * jj + (ab & 1);
-                    const long o = opix * p.Cout + co;
-                    if (p.bias) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co);
-                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-                    }
-                    if (p.skip) {
-                        const float4 s4 = *reinterpret_cast<const float4*>(p.skip + o);
-                        v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w;
-                    }
-                    *reinterpret_cast<float4*>(p.C + o) = v;
-                }
-            }
+        } else if (AMODE == A_PLAIN) {
+            val = 1u;
         } else {
-            for (int e = t; e < ROWS * BN; e += 256) {
-                const int row = e / BN, c = e - row * BN;
-                const int m = m0 + pass * ROWS + row, n = n0 + c;
-                if (m >= p.M || n >= p.N) continue;
-                float v = Cs[row * CS + c];
-                if (EPI == EPI_STORE) {
-                    p.C[(long)m * p.N + n] = v;
-                } else {
-                    const int ab = n / p.Cout, co = n - ab * p.Cout;
-                    const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
-                    const long opix = ((long)img * (2 * H) + 2 * ii + (ab >> 1)) * (2 * W) + 2 * jj + (ab & 1);
-                    const long o = opix * p.Cout + co;
-                    if (p.bias) v += p.bias[co];
-                    if (p.skip) v = p.skip[o] + v;
-                    p.C[o] = v;
-                }
-            }
+            const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+            pix = ((long)img * (2 * H) + 2 * ii) * (2 * W) + 2 * jj;
+            val = 0xFu;
         }
+        a_val[i] = inm ? val : 0u;
+        a_off[i] = (unsigned)((pix * p.Cin + c4 * 4) * 4);
+        a_wr[i] = row * 32 + (c4 & 1) * 2;
     }
-    if (EPI == EPI_STORE && p.stats && t < BN && n0 + t < p.N) {
-        float* out = p.stats + (long)tile_m * 2 * p.N;
-        out[n0 + t] = tot_s;
-        out[p.N + n0 + t] = tot_q;
+    // B fragments: packed layout [row-block of 32][kt][term][lane][16 B] (split_pack_kernel): one fully coalesced
+    // 1 KB load per (wave, term, K-step)
+    const int nb = (n0 >> 5) + wn;
+    const unsigned b_off = (nb * 32 < p.N) ? (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16) : kOOB;
+
+    auto load_a = [&](int kt, float4 (&ra)[AI]) {
+#if defined(RD_ABLATE) && (RD_ABLATE & 4)   // diagnosis: no A global loads after the prologue
+        if (kt > 3) return;
+#endif
+        // K order = channel-chunk outer, tap inner (see the f32 kernel).  kt >= nk (prefetch running past the end):
+        // every lane carries the out-of-range offset -- keeps the number of outstanding loads static for s_waitcnt
+        const int chunk = kt / p.taps;
+        const int tap = kt - chunk * p.taps;
+        int shift;
+        if (AMODE == A_CONV3) shift = (tap / 3 - 1) * W + (tap - (tap / 3) * 3 - 1);
+        else if (AMODE == A_PLAIN) shift = 0;
+        else shift = (tap >> 1) * (2 * W) + (tap & 1);
+        const unsigned toff = (unsigned)((shift * p.Cin + chunk * SK) * 4);
+        const bool cok = kt < p.nk && chunk * SK + c4 * 4 < p.Cin;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const bool ok = cok && ((a_val[i] >> tap) & 1u);
+            ra[i] = buf_load4(rsA, ok ? a_off[i] + toff : kOOB, 0);
+        }
+    };
+    auto load_b = [&](int kt, uint4 (&rb)[3]) {
+#if defined(RD_ABLATE) && (RD_ABLATE & 16)  // diagnosis: no B global loads after the prologue
+        if (kt > 2) return;
+#endif
+        const unsigned voff = kt < p.nk ? b_off : kOOB;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((kt * 3 + q) * 1024));
+    };
+    auto store_a = [&](float* stage, const float4 (&ra)[AI]) {
+#if defined(RD_ABLATE) && (RD_ABLATE & 2)   // diagnosis: no LDS stores (a never-true store keeps the loads alive)
+        if (p.nk < 0) stage[t] = ra[0].x + ra[AI - 1].w;
+        return;
+#endif
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int sw = swz(r0 + 64 * i), hi = c4 >> 1;
+            uint2 ph, pm, pl;
+            split_pack4(ra[i], ph, pm, pl);
+            *reinterpret_cast<uint2*>(stage + a_wr[i] + ((0 + hi) ^ sw) * 4) = ph;
+            *reinterpret_cast<uint2*>(stage + a_wr[i] + ((2 + hi) ^ sw) * 4) = pm;
+            *reinterpret_cast<uint2*>(stage + a_wr[i] + ((4 + hi) ^ sw) * 4) = pl;
+        }
+    };
+
+    const int lrow = lane & 31, half = lane >> 5;
+    int a_rd[TM][3];    // LDS word address of this lane's fragment of (row block i, term q) within a stage
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + lrow;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_rd[i][q] = row * 32 + ((2 * q + half) ^ swz(row)) * 4;
     }
+    bf16x8 af[TM][3];
+    auto read_a = [&](const float* stage, int i) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(stage + a_rd[i][q]);
+    };
+    // six products per (a, b) pair, smallest terms first; lane half g owns k = 8g .. 8g+7 (the same 8 k for A and B)
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#if defined(RD_ABLATE) && (RD_ABLATE & 8)
+    constexpr int NT6 = 1;
+#else
+    constexpr int NT6 = 6;
+#endif
+    // One K-step.  Software pipeline per tile j:  global load (step j-4) -> split + LDS write (step j-2) -> fragment
+    // read (step j-1, right after the MFMAs that last used the registers) -> MFMA (step j).  B: global load straight
+    // into fragment registers at step j-3.  One barrier per step; LDS stage of tile j = j & 1.
+    auto step = [&](int kt, float4 (&ra)[AI], uint4 (&bcur)[3], uint4 (&bnew)[3], float* wstage, const float* rstage) {
+        store_a(wstage, ra);          // tile kt+2
+        load_a(kt + 4, ra);
+        load_b(kt + 3, bnew);
+        bf16x8 bf[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bf[q] = __builtin_bit_cast(bf16x8, bcur[q]);
+        constexpr int GP = TM >= 2 ? 2 : 1;       // row blocks interleaved per group (independent accumulators)
+#pragma unroll
+        for (int g = 0; g < TM; g += GP) {
+#pragma unroll
+            for (int t6 = 0; t6 < NT6; ++t6)
+#pragma unroll
+                for (int i = g; i < g + GP; ++i)
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t6]], bf[PB[t6]], acc[i][0], 0, 0, 0);
+#if !(defined(RD_ABLATE) && (RD_ABLATE & 32))   // diagnosis: no fragment reads
+#pragma unroll
+            for (int i = g; i < g + GP; ++i) read_a(rstage, i);      // tile kt+1, consumed one step later
+#endif
+        }
+        __syncthreads();
+    };
+
+    float* st0 = smem;
+    float* st1 = smem + STAGE;
+    float4 ra0[AI], ra1[AI];
+    uint4 b0[3], b1[3], b2[3], b3[3];
+    load_a(0, ra0);
+    load_a(1, ra1);
+    load_b(0, b0);
+    load_b(1, b1);
+    load_b(2, b2);
+    store_a(st0, ra0);
+    load_a(2, ra0);
+    store_a(st1, ra1);
+    load_a(3, ra1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) read_a(st0, i);
+    __syncthreads();
+    for (int kt = 0; kt < p.nk; kt += 4) {      // nk is rounded up to a multiple of 4 with all-zero K-steps
+        step(kt, ra0, b0, b3, st0, st1);
+        step(kt + 1, ra1, b1, b0, st1, st0);
+        step(kt + 2, ra0, b2, b1, st0, st1);
+        step(kt + 3, ra1, b3, b2, st1, st0);
+    }
+    nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m);
+}
+
+// fp32 GEMM-layout B[N][K] (K = taps*Cin, tap-major) -> split-bf16 fragment layout
+//   [row block nb = n/32][kt][term q][lane = 32*(j/8) + n%32][8 bf16: k = 8*(j/8) .. +7]      (16 bytes per lane)
+// kt = chunk*taps + tap, j = channel within the 16-channel chunk; rows beyond N and channels beyond Cin are zero.
+__global__ void split_pack_kernel(const float* __restrict__ B, unsigned short* __restrict__ out, int N, int K, int Cin,
+                                  int taps, int nk) {
+    const long rows32 = (long)((N + 31) / 32) * 32;
+    const long total = rows32 * nk * SK;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(e % SK);
+        const int kt = (int)((e / SK) % nk);
+        const long n = e / ((long)SK * nk);
+        const int chunk = kt / taps, tap = kt - chunk * taps, ci = chunk * SK + j;
+        const float v = (n < N && ci < Cin) ? B[n * K + (long)tap * Cin + ci] : 0.f;
+        unsigned h, m, l;
+        split3(v, h, m, l);
+        const long blk = ((n >> 5) * nk + kt) * 3;
+        const int lane = (j >> 3) * 32 + (int)(n & 31);
+        unsigned short* o = out + ((blk * 64 + lane) << 3) + (j & 7);
+        o[0] = (unsigned short)(h >> 16);
+        o[64 * 8] = (unsigned short)(m >> 16);
+        o[2 * 64 * 8] = (unsigned short)(l >> 16);
+    }
+}
+
+// ---- packed weight buffers -------------------------------------------------------------------------------
+// One opaque buffer per GEMM operand B[rows][K = taps*Cin]:  [rows*K floats, fp32 GEMM layout] [pad to 16 B]
+// [rows * nk16 * 96 bytes, split-bf16 layout], nk16 = taps * ceil(Cin/16).  rd_packed_weight_bytes() sizes it.
+static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+static inline int nk16_of(int taps, int cin) { return taps * cdiv(cin, SK); }
+static inline size_t packed_f32_bytes(long rows, int taps, int cin) { return align16((size_t)rows * taps * cin * 4); }
+static inline long rows32_of(long rows) { return (rows + 31) / 32 * 32; }
+static inline size_t packed_bytes(long rows, int taps, int cin) {
+    return packed_f32_bytes(rows, taps, cin) + (size_t)rows32_of(rows) * nk16_of(taps, cin) * SROWB;
+}
+
+// RD_MFMA=f32 forces the exact-f32 MFMA kernels; default: split-bf16 (see igemm_nt_split_kernel)
+static int mfma_split() {
+    static const int v = (getenv("RD_MFMA") && !strcmp(getenv("RD_MFMA"), "f32")) ? 0 : 1;
+    return v;
+}
+
+static int split_pack(const float* b_f32, long rows, int taps, int cin, hipStream_t s) {
+    unsigned short* out = (unsigned short*)((char*)b_f32 + packed_f32_bytes(rows, taps, cin));
+    const int nk = nk16_of(taps, cin);
+    const long total = rows32_of(rows) * nk * SK;
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(split_pack_kernel, dim3((int)g), dim3(256), 0, s, b_f32, out, (int)rows, taps * cin, cin, taps, nk);
+    RD_LAUNCH_CHECK("split_pack");
+    return RD_OK;
 }
 
 template <int AMODE, int EPI>
 static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_out = nullptr) {
     const long flops = 2L * p.M * p.N * p.K;
     const double bytes = 4.0 * ((double)p.M * p.Cin * (AMODE == A_UP2 ? 4 : 1) + (double)p.N * p.K + (double)p.M * p.N);
-    p.chunks = cdiv(p.Cin, 32);
+    const int split = mfma_split();
+    const int taps = p.K / p.Cin;
+    p.taps = taps;
+    p.chunks = cdiv(p.Cin, split ? SK : 32);
+    p.nk = taps * p.chunks;
     p.vec = (p.N % 4 == 0) && (EPI != EPI_CONVT || p.Cout % 4 == 0);
-    const double a_bytes = 4.0 * p.M * p.Cin * (AMODE == A_UP2 ? 4 : 1), b_bytes = 4.0 * p.N * p.K;
+    const double a_bytes = 4.0 * p.M * p.Cin * (AMODE == A_UP2 ? 4 : 1);
+    const double b_bytes = split ? (double)rows32_of(p.N) * p.nk * SROWB : 4.0 * p.N * p.K;
     if (a_bytes >= 4294967040.0 || b_bytes >= 4294967040.0) {
         set_error("%s: operand larger than the 4 GiB buffer-descriptor range (A %.0f B, B %.0f B)", cls, a_bytes, b_bytes);
         return RD_ERR_ARG;
     }
     p.a_bytes = (unsigned)a_bytes;
     p.b_bytes = (unsigned)b_bytes;
-    const int taps = p.K / p.Cin;
-    p.taps = taps;
-    p.nk = taps * p.chunks;
-    // Tile choice (measured per layer on MI355X, scripts/bench_layers.py): with the lean buffer-load loader the
-    // launch BALANCE matters more than per-block efficiency -- 1024 tiles of 128x128 at 3 resident blocks/CU run
-    // 1.33 rounds (~105 TF) where 2048 tiles of 128x64 run 130+ TF.  128x128 only pays for short-K problems
-    // (few K-steps per tile -> amortise the epilogue over a bigger tile); tiny grids take 64x64.
+    p.Bsplit = (const char*)p.B + packed_f32_bytes(p.N, taps, p.Cin);
     static const int force = getenv("RD_NT_TILE") ? atoi(getenv("RD_NT_TILE")) : -1;   // tuning override
     const int tiles_128x64 = cdiv(p.M, 128) * cdiv(p.N, 64);
     int cfg;
-    if (p.M < 128 || tiles_128x64 < 1024) cfg = 2;
-    else if (EPI == EPI_CONVT && p.K <= 256) cfg = 2;   // scatter epilogue dominates: small tiles keep more of it in flight
-    else if (p.N >= 128 && p.K <= 640 && cdiv(p.M, 128) * cdiv(p.N, 128) >= 1536) cfg = 0;
-    else cfg = 1;
+    if (split) {
+        // split kernel: two 128x128 blocks (57 KB LDS each) per CU; measured per layer with scripts/bench_layers.py
+        if (p.M < 128 || tiles_128x64 < 1024) cfg = 2;
+        else if (EPI == EPI_CONVT && p.K <= 256) cfg = 2;   // scatter epilogue dominates: small tiles keep more in flight
+        else if (p.N >= 128) cfg = 0;
+        else cfg = 1;
+    } else {
+        // Tile choice (measured per layer on MI355X, scripts/bench_layers.py): with the lean buffer-load loader the
+        // launch BALANCE matters more than per-block efficiency -- 1024 tiles of 128x128 at 3 resident blocks/CU run
+        // 1.33 rounds (~105 TF) where 2048 tiles of 128x64 run 130+ TF.  128x128 only pays for short-K problems
+        // (few K-steps per tile -> amortise the epilogue over a bigger tile); tiny grids take 64x64.
+        if (p.M < 128 || tiles_128x64 < 1024) cfg = 2;
+        else if (EPI == EPI_CONVT && p.K <= 256) cfg = 2;   // scatter epilogue dominates: small tiles keep more in flight
+        else if (p.N >= 128 && p.K <= 640 && cdiv(p.M, 128) * cdiv(p.N, 128) >= 1536) cfg = 0;
+        else cfg = 1;
+    }
     if (force >= 0 && force <= 2 && !(force == 0 && p.N <= 64)) cfg = force;
     char pcls[64];   // "<operation>|<kernel symbol>": the kernel symbol is what rocprofv3 reports
-    snprintf(pcls, sizeof(pcls), "%s|igemm_nt<%s,%d,%d>", cls, cfg == 0 ? "128,128" : cfg == 1 ? "128,64" : "64,64",
-             AMODE, EPI);
+    snprintf(pcls, sizeof(pcls), "%s|igemm_nt%s<%s,%d,%d>", cls, split ? "_split" : "",
+             cfg == 0 ? "128,128" : cfg == 1 ? "128,64" : "64,64", AMODE, EPI);
     ProfScope ps(s, pcls, (double)flops, bytes, true);
     if (tiles_m_out) *tiles_m_out = cdiv(p.M, cfg == 2 ? 64 : 128);
-    if (cfg == 2) {
-        p.tiles_n = cdiv(p.N, 64);
-        const int grid = cdiv(p.M, 64) * p.tiles_n;
-        hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
-    } else if (cfg == 0) {
-        p.tiles_n = cdiv(p.N, 128);
-        const int grid = cdiv(p.M, 128) * p.tiles_n;
-        hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+    const int bm = cfg == 2 ? 64 : 128, bn = cfg == 0 ? 128 : 64;
+    p.tiles_n = cdiv(p.N, bn);
+    const int grid = cdiv(p.M, bm) * p.tiles_n;
+    if (split) {
+        if (cfg == 2) hipLaunchKernelGGL((igemm_nt_split_kernel<64, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+        else if (cfg == 0) hipLaunchKernelGGL((igemm_nt_split_kernel<128, 128, 1, 4, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((igemm_nt_split_kernel<128, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
     } else {
-        p.tiles_n = cdiv(p.N, 64);
-        const int grid = cdiv(p.M, 128) * p.tiles_n;
-        hipLaunchKernelGGL((igemm_nt_kernel<128, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+        if (cfg == 2) hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+        else if (cfg == 0) hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((igemm_nt_kernel<128, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
     }
     RD_LAUNCH_CHECK(cls);
     return RD_OK;
@@ -655,12 +962,19 @@ using namespace rd;
 
 extern "C" {
 
+size_t rd_packed_weight_bytes(int rows, int taps, int cin) {
+    if (rows <= 0 || taps <= 0 || cin <= 0) return 0;
+    return packed_bytes(rows, taps, cin);
+}
+
 int rd_pack_conv3x3_weight(const float* w, float* wf, float* wd, int cout, int cin, rd_stream_t s) {
     RD_REQUIRE(w && wf && cout > 0 && cin > 0, "rd_pack_conv3x3_weight: bad arguments");
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 12.0 * cout * cin * 9);
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for((long)cout * cin * 9)), dim3(256), 0, (hipStream_t)s, w, wf,
                        wd, cout, cin);
     RD_LAUNCH_CHECK("pack_conv3x3");
+    if (int e = split_pack(wf, cout, 9, cin, (hipStream_t)s)) return e;
+    if (wd) return split_pack(wd, cin, 9, cout, (hipStream_t)s);
     return RD_OK;
 }
 
@@ -670,6 +984,8 @@ int rd_pack_convt2x2_weight(const float* w, float* wtf, float* wtd, int cin, int
     hipLaunchKernelGGL(pack_convt_kernel, dim3(grid_for((long)cout * cin * 4)), dim3(256), 0, (hipStream_t)s, w, wtf,
                        wtd, cin, cout);
     RD_LAUNCH_CHECK("pack_convt");
+    if (int e = split_pack(wtf, 4L * cout, 1, cin, (hipStream_t)s)) return e;
+    if (wtd) return split_pack(wtd, cin, 4, cout, (hipStream_t)s);
     return RD_OK;
 }
 
@@ -801,12 +1117,17 @@ int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw, int n, 
 // ---- conv1x1 of the bilinear up-mode (lib/UNet.py:8-9,20).  A 1x1 convolution commutes with the bilinear
 // interpolation (both linear; the interpolation weights sum to 1 so the bias commutes too), so the engine applies it on
 // the COARSE grid -- a plain [pixels x Cin] x [Cin x Cout] GEMM with a quarter of the reference's work.
-int rd_pack_conv1x1_weight(const float* w, float* wt, int cout, int cin, rd_stream_t s) {
-    RD_REQUIRE(w && wt && cout > 0 && cin > 0, "rd_pack_conv1x1_weight: bad arguments");
-    ProfScope ps((hipStream_t)s, "pack_weights", 0, 8.0 * cout * cin);
+int rd_pack_conv1x1_weight(const float* w, float* wf, float* wt, int cout, int cin, rd_stream_t s) {
+    RD_REQUIRE(w && wf && cout > 0 && cin > 0, "rd_pack_conv1x1_weight: bad arguments");
+    ProfScope ps((hipStream_t)s, "pack_weights", 0, 16.0 * cout * cin);
+    if (int e = check_hip(hipMemcpyAsync(wf, w, (size_t)cout * cin * 4, hipMemcpyDeviceToDevice, (hipStream_t)s),
+                          "pack_conv1x1 copy"))
+        return e;
+    if (int e = split_pack(wf, cout, 1, cin, (hipStream_t)s)) return e;
+    if (!wt) return RD_OK;
     hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long)cout * cin)), dim3(256), 0, (hipStream_t)s, w, wt, cout, cin);
     RD_LAUNCH_CHECK("pack_conv1x1");
-    return RD_OK;
+    return split_pack(wt, cin, 1, cout, (hipStream_t)s);
 }
 
 int rd_conv1x1_fwd(const float* x, const float* w, float* out, long long pixels, int cin, int cout, rd_stream_t s) {

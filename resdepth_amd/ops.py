@@ -22,18 +22,25 @@ def _f32(t, name):
     return t
 
 
+def _packed_buffer(rows, taps, cin, device):
+    """Opaque packed GEMM operand (fp32 layout + split-bf16 layout, include/resdepth_hip.h); shape[0] == rows."""
+    nbytes = load().rd_packed_weight_bytes(rows, taps, cin)
+    cols = (nbytes + 4 * rows - 1) // (4 * rows)
+    return torch.empty(rows, cols, device=device, dtype=torch.float32)
+
+
 def pack_conv3x3_weight(w, need_dgrad=True):
     cout, cin = w.shape[0], w.shape[1]
-    wf = torch.empty(cout, 9, cin, device=w.device, dtype=torch.float32)
-    wd = torch.empty(cin, 9, cout, device=w.device, dtype=torch.float32) if need_dgrad else None
+    wf = _packed_buffer(cout, 9, cin, w.device)
+    wd = _packed_buffer(cin, 9, cout, w.device) if need_dgrad else None
     check(load().rd_pack_conv3x3_weight(ptr(w.detach()), ptr(wf), ptr(wd), cout, cin, stream_ptr()), "pack_conv3x3")
     return wf, wd
 
 
 def pack_convt2x2_weight(w, need_dgrad=True):
     cin, cout = w.shape[0], w.shape[1]
-    wtf = torch.empty(4 * cout, cin, device=w.device, dtype=torch.float32)
-    wtd = torch.empty(cin, 4 * cout, device=w.device, dtype=torch.float32) if need_dgrad else None
+    wtf = _packed_buffer(4 * cout, 1, cin, w.device)
+    wtd = _packed_buffer(cin, 4, cout, w.device) if need_dgrad else None
     check(load().rd_pack_convt2x2_weight(ptr(w.detach()), ptr(wtf), ptr(wtd), cin, cout, stream_ptr()), "pack_convt")
     return wtf, wtd
 
@@ -172,11 +179,12 @@ def convt2x2_bwd_weight(x, dout, out=None, ws_slot=0):
 
 # ---- bilinear up-mode (lib/UNet.py:17-24): conv1x1 on the coarse grid, then interpolate + bias + skip ---------
 def pack_conv1x1_weight(w):
-    """w: [Cout, Cin, 1, 1] (torch) -> (w itself viewed [Cout, Cin], its transpose [Cin, Cout] for the data gradient)."""
+    """w: [Cout, Cin, 1, 1] (torch) -> packed (forward operand [Cout, Cin], data-gradient operand [Cin, Cout])."""
     cout, cin = w.shape[0], w.shape[1]
-    wt = torch.empty(cin, cout, device=w.device, dtype=torch.float32)
-    check(load().rd_pack_conv1x1_weight(ptr(w.detach()), ptr(wt), cout, cin, stream_ptr()), "pack_conv1x1")
-    return w.detach().view(cout, cin), wt
+    wf = _packed_buffer(cout, 1, cin, w.device)
+    wt = _packed_buffer(cin, 1, cout, w.device)
+    check(load().rd_pack_conv1x1_weight(ptr(w.detach()), ptr(wf), ptr(wt), cout, cin, stream_ptr()), "pack_conv1x1")
+    return wf, wt
 
 
 def conv1x1_fwd(x, w2d):
