@@ -30,6 +30,15 @@ struct ProfScope {
 // second stage of the per-channel reductions (rd_elementwise.hip): sums[c] = sum_b partial[b*qc + c], fixed order
 int reduce_partials_f32(const float* partial, double* sums, int nb, int qc, hipStream_t s);
 
+// split-bf16 MFMA arithmetic enabled (default) or RD_MFMA=f32 (rd_igemm.hip)
+int mfma_split();
+// conv3x3 weight-gradient strip kernel (rd_wgrad_strip.hip): number of split-K slabs it will write for this shape
+// (0 = shape not handled, use the TN kernel), and its launcher (*splits_out = 0 when it did not run; *swapped_out = 1
+// when the slab is the mirrored transpose [Cin][(8 - tap) * Cout + co], see plan_strip)
+int wgrad_strip_splits(int n, int h, int w, int cin, int cout);
+int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int h, int w, int cin, int cout, hipStream_t s,
+                       int* splits_out, int* swapped_out);
+
 inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;

@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include "rd_common.h"
+#include "rd_mfma_dev.h"
 
 namespace rd {
 
@@ -46,24 +47,6 @@ struct NtParams {
     float* stats;  // EPI_STORE only, nullable: per-(tile_m) column sums / sums of squares [tiles_m][2][N] (BN statistics)
 };
 
-
-typedef int v4i32 __attribute__((ext_vector_type(4)));
-constexpr unsigned kOOB = 0xFFFFFF00u;  // voffset beyond any descriptor extent: the hardware returns zeros
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
-}
-
-__device__ __forceinline__ int xcd_remap(int b, int nb) {
-    // blocks are dispatched round-robin over the 8 XCDs; give every XCD a contiguous range of
-    // logical tiles so neighbouring tiles (which share A rows / B panels) share one L2.
-    const int q = nb >> 3, r = nb & 7, x = b & 7, within = b >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + within;
-}
 
 // ---- epilogue shared by the NT kernels.  D[i][j]: lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5) (the C/D
 // map is the same for the f32 and the bf16 MFMA shapes).
@@ -314,38 +297,6 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
 //   K-step = 16 k-values (one MFMA K), LDS double-buffered (one barrier per K-step), two K-steps of global loads
 //   in flight.  LDS row = 3 terms x 16 bf16 (96 B) + 16 B pad = 112 B: the 16 rows of a ds_read_b128 lane group start
 //   on 16 distinct bank quads.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int SK = 16;      // k-values per K-step
-constexpr int SROWB = 96;   // bytes of one (row, K-step) in the packed split-B tensor
-
-// x = h + m + l exactly; h, m, l have <= 8 significant bits (bf16-representable), returned as fp32 bit patterns
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-    h = __float_as_uint(x) & 0xffff0000u;
-    const float r = x - __uint_as_float(h);
-    m = __float_as_uint(r) & 0xffff0000u;
-    l = __float_as_uint(r - __uint_as_float(m));
-}
-// float4 (4 consecutive k) -> three 8-byte groups of 4 bf16 (one per term); v_perm_b32 -> {hi16(odd), hi16(even)}
-__device__ __forceinline__ void split_pack4(const float4 v, uint2& ph, uint2& pm, uint2& pl) {
-#if defined(RD_ABLATE) && (RD_ABLATE & 1)   // diagnosis builds only (scripts/ablate.sh): no split arithmetic
-    ph = pm = pl = make_uint2(__builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u),
-                              __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u));
-    return;
-#endif
-    unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-    split3(v.x, h0, m0, l0);
-    split3(v.y, h1, m1, l1);
-    split3(v.z, h2, m2, l2);
-    split3(v.w, h3, m3, l3);
-    ph = make_uint2(__builtin_amdgcn_perm(h1, h0, 0x07060302u), __builtin_amdgcn_perm(h3, h2, 0x07060302u));
-    pm = make_uint2(__builtin_amdgcn_perm(m1, m0, 0x07060302u), __builtin_amdgcn_perm(m3, m2, 0x07060302u));
-    pl = make_uint2(__builtin_amdgcn_perm(l1, l0, 0x07060302u), __builtin_amdgcn_perm(l3, l2, 0x07060302u));
-}
-__device__ __forceinline__ uint4 buf_load4u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
-}
-
 // LDS image of the A tile: one 128-byte row per pixel and stage = 8 chunks of 16 B, chunk c = 2*term + khalf (6 used).
 // Chunks are XOR-swizzled by swz(row) so that (a) the 16 rows of a ds_read_b128 lane group hit 16 distinct bank quads
 // and (b) the 4 rows of a ds_write_b64 lane group (rows r, r+2, r+4, r+6 by the thread->row map below) hit 4 distinct
@@ -530,24 +481,37 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 // fp32 GEMM-layout B[N][K] (K = taps*Cin, tap-major) -> split-bf16 fragment layout
 //   [row block nb = n/32][kt][term q][lane = 32*(j/8) + n%32][8 bf16: k = 8*(j/8) .. +7]      (16 bytes per lane)
 // kt = chunk*taps + tap, j = channel within the 16-channel chunk; rows beyond N and channels beyond Cin are zero.
-__global__ void split_pack_kernel(const float* __restrict__ B, unsigned short* __restrict__ out, int N, int K, int Cin,
+__global__ void split_pack_kernel(const float* __restrict__ B, uint4* __restrict__ out, int N, int K, int Cin,
                                   int taps, int nk) {
+    // one thread per (row n, K-step kt, k-half g): 8 consecutive channels -> one 16-byte fragment piece per term
     const long rows32 = (long)((N + 31) / 32) * 32;
-    const long total = rows32 * nk * SK;
+    const long total = rows32 * nk * 2;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(e % SK);
-        const int kt = (int)((e / SK) % nk);
-        const long n = e / ((long)SK * nk);
-        const int chunk = kt / taps, tap = kt - chunk * taps, ci = chunk * SK + j;
-        const float v = (n < N && ci < Cin) ? B[n * K + (long)tap * Cin + ci] : 0.f;
-        unsigned h, m, l;
-        split3(v, h, m, l);
+        const int g = (int)(e & 1);
+        const int kt = (int)((e >> 1) % nk);
+        const long n = (e >> 1) / nk;
+        const int chunk = kt / taps, tap = kt - chunk * taps, ci0 = chunk * SK + g * 8;
+        float v[8];
+        const float* src = B + n * K + (long)tap * Cin + ci0;
+        if (n < N && ci0 + 8 <= Cin && (((size_t)src & 15) == 0)) {
+            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (n < N && ci0 + j < Cin) ? src[j] : 0.f;
+        }
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
         const long blk = ((n >> 5) * nk + kt) * 3;
-        const int lane = (j >> 3) * 32 + (int)(n & 31);
-        unsigned short* o = out + ((blk * 64 + lane) << 3) + (j & 7);
-        o[0] = (unsigned short)(h >> 16);
-        o[64 * 8] = (unsigned short)(m >> 16);
-        o[2 * 64 * 8] = (unsigned short)(l >> 16);
+        const int lane = g * 32 + (int)(n & 31);
+        const unsigned sel = 0x07060302u;
+        out[blk * 64 + lane] = make_uint4(__builtin_amdgcn_perm(h[1], h[0], sel), __builtin_amdgcn_perm(h[3], h[2], sel),
+                                          __builtin_amdgcn_perm(h[5], h[4], sel), __builtin_amdgcn_perm(h[7], h[6], sel));
+        out[(blk + 1) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(m[1], m[0], sel), __builtin_amdgcn_perm(m[3], m[2], sel),
+                                                __builtin_amdgcn_perm(m[5], m[4], sel), __builtin_amdgcn_perm(m[7], m[6], sel));
+        out[(blk + 2) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(l[1], l[0], sel), __builtin_amdgcn_perm(l[3], l[2], sel),
+                                                __builtin_amdgcn_perm(l[5], l[4], sel), __builtin_amdgcn_perm(l[7], l[6], sel));
     }
 }
 
@@ -563,17 +527,17 @@ static inline size_t packed_bytes(long rows, int taps, int cin) {
 }
 
 // RD_MFMA=f32 forces the exact-f32 MFMA kernels; default: split-bf16 (see igemm_nt_split_kernel)
-static int mfma_split() {
+int mfma_split() {
     static const int v = (getenv("RD_MFMA") && !strcmp(getenv("RD_MFMA"), "f32")) ? 0 : 1;
     return v;
 }
 
 static int split_pack(const float* b_f32, long rows, int taps, int cin, hipStream_t s) {
-    unsigned short* out = (unsigned short*)((char*)b_f32 + packed_f32_bytes(rows, taps, cin));
+    uint4* out = (uint4*)((char*)b_f32 + packed_f32_bytes(rows, taps, cin));
     const int nk = nk16_of(taps, cin);
-    const long total = rows32_of(rows) * nk * SK;
+    const long total = rows32_of(rows) * nk * 2;
     long g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
+    if (g > 8192) g = 8192;
     hipLaunchKernelGGL(split_pack_kernel, dim3((int)g), dim3(256), 0, s, b_f32, out, (int)rows, taps * cin, cin, taps, nk);
     RD_LAUNCH_CHECK("split_pack");
     return RD_OK;
@@ -583,8 +547,9 @@ template <int AMODE, int EPI>
 static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_out = nullptr) {
     const long flops = 2L * p.M * p.N * p.K;
     const double bytes = 4.0 * ((double)p.M * p.Cin * (AMODE == A_UP2 ? 4 : 1) + (double)p.N * p.K + (double)p.M * p.N);
-    const int split = mfma_split();
     const int taps = p.K / p.Cin;
+    // short-K transposed convolutions are bound by their scatter epilogue, not by the contraction: exact-f32 MFMA kernel
+    const int split = mfma_split() && !(EPI == EPI_CONVT && p.K <= 128);
     p.taps = taps;
     p.chunks = cdiv(p.Cin, split ? SK : 32);
     p.nk = taps * p.chunks;
@@ -805,6 +770,186 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnParams p) {   // (256,3
         }
 }
 
+// ---- split-bf16 version of the weight-gradient kernel (see igemm_nt_split_kernel for the arithmetic) -----------------
+// Both operands are k-major in memory (pixels x channels) while the bf16 MFMA wants 8 consecutive k per lane, so the
+// transpose happens in registers on the way into LDS: a staging task = 4 pixels x 4 channels (four 16-byte loads);
+// for each channel the 4 pixel values of one term are packed into 8 bytes and written to that channel's LDS row
+// (128-byte rows: chunk = 2*term + khalf, XOR-swizzled by (row >> 1) & 7 -- conflict-free b64 writes and b128 reads).
+// Threads [0, BM) stage A, [BM, BM+BN) stage B (wave-uniform roles).  K-step = 16 pixels, LDS double-buffered, two
+// K-steps of global loads in flight.
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int STAGE = (BM + BN) * 32;            // words
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int nb_mn = p.tiles_mn;
+    const int gb = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = gb / nb_mn;
+    const int lb = gb - split * nb_mn;
+    const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+
+    // staging role of this thread
+    const bool isA = t < BM, active = t < BM + BN;
+    const int idx = isA ? t : t - BM;
+    const int kq = idx & 3, quad = idx >> 2;          // pixel quarter of the 16-pixel K-step, channel quad
+    const int col0 = (isA ? m0 : n0) + quad * 4;
+    const bool col_ok = active && col0 < (isA ? p.M : p.N);
+    int a_col = col0, a_qa = 0, a_qb = 0;
+    if (AMODE == WA_UP2 && isA) {
+        const int ab = col0 / p.Cout;
+        a_col = col0 - ab * p.Cout;
+        a_qa = ab >> 1;
+        a_qb = ab & 1;
+    }
+    int b_col = col0, b_dy = 0, b_dx = 0;
+    if (BMODE == WB_CONV3 && !isA) {
+        const int tap = col0 / p.Cin;
+        b_col = col0 - tap * p.Cin;
+        b_dy = tap / 3 - 1;
+        b_dx = tap - (tap / 3) * 3 - 1;
+    }
+    const int b_shift = b_dy * W + b_dx;
+    const int lds_row0 = (isA ? 0 : BM) + quad * 4;   // LDS rows of this task's 4 channels
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const long k_begin = (long)split * p.kchunk;
+    long k_end = k_begin + p.kchunk;
+    if (k_end > p.Kp) k_end = p.Kp;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
+
+    auto load_task = [&](long kbase, float4 (&x)[4]) {
+        const int rem = (int)(k_end - kbase);   // pixels of this K-step that exist (may be <= 0 past the end)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = kq * 4 + j;
+            const bool ok = col_ok && row < rem;
+            if (isA) {
+                if (AMODE == WA_UP2) {
+                    const int m = (int)kbase + row;
+                    const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+                    const long src = ((long)img * (2 * H) + 2 * ii + a_qa) * (2 * W) + 2 * jj + a_qb;
+                    x[j] = buf_load4(rsA, ok ? (unsigned)((src * p.lda + a_col) * 4) : kOOB, 0);
+                } else {
+                    x[j] = buf_load4(rsA, ok ? (unsigned)((row * p.lda + a_col) * 4) : kOOB, (unsigned)(kbase * p.lda * 4));
+                }
+            } else {
+                if (BMODE == WB_CONV3) {
+                    const int m = (int)kbase + row;
+                    const int y = (m >> logW) & (H - 1), xx = m & (W - 1);
+                    const bool in = ok && ((unsigned)(y + b_dy) < (unsigned)H) && ((unsigned)(xx + b_dx) < (unsigned)W);
+                    x[j] = buf_load4(rsB, in ? (unsigned)((((long)m + b_shift) * p.ldb + b_col) * 4) : kOOB, 0);
+                } else {
+                    x[j] = buf_load4(rsB, ok ? (unsigned)((row * p.ldb + b_col) * 4) : kOOB, (unsigned)(kbase * p.ldb * 4));
+                }
+            }
+        }
+    };
+    auto store_task = [&](float* stage, const float4 (&x)[4]) {
+        if (!active) return;
+        unsigned h[4][4], m[4][4], l[4][4];     // [pixel j][channel c]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            split3(x[j].x, h[j][0], m[j][0], l[j][0]);
+            split3(x[j].y, h[j][1], m[j][1], l[j][1]);
+            split3(x[j].z, h[j][2], m[j][2], l[j][2]);
+            split3(x[j].w, h[j][3], m[j][3], l[j][3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = lds_row0 + c;
+            const int sw = (row >> 1) & 7;
+            float* base = stage + row * 32 + (kq & 1) * 2;
+            const int hi = kq >> 1;
+            *reinterpret_cast<uint2*>(base + ((0 + hi) ^ sw) * 4) =
+                make_uint2(__builtin_amdgcn_perm(h[1][c], h[0][c], 0x07060302u), __builtin_amdgcn_perm(h[3][c], h[2][c], 0x07060302u));
+            *reinterpret_cast<uint2*>(base + ((2 + hi) ^ sw) * 4) =
+                make_uint2(__builtin_amdgcn_perm(m[1][c], m[0][c], 0x07060302u), __builtin_amdgcn_perm(m[3][c], m[2][c], 0x07060302u));
+            *reinterpret_cast<uint2*>(base + ((4 + hi) ^ sw) * 4) =
+                make_uint2(__builtin_amdgcn_perm(l[1][c], l[0][c], 0x07060302u), __builtin_amdgcn_perm(l[3][c], l[2][c], 0x07060302u));
+        }
+    };
+
+    const int lrow = lane & 31, half = lane >> 5;
+    int a_rd[TM][3], b_rd[TN][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + lrow;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_rd[i][q] = row * 32 + ((2 * q + half) ^ ((row >> 1) & 7)) * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = BM + (wn * TN + j) * 32 + lrow;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b_rd[j][q] = row * 32 + ((2 * q + half) ^ ((row >> 1) & 7)) * 4;
+    }
+    auto mma_tile = [&](const float* stage) {
+        bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(stage + a_rd[i][q]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bf[j][q] = *reinterpret_cast<const bf16x8*>(stage + b_rd[j][q]);
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t6]], bf[j][PB[t6]], acc[i][j], 0, 0, 0);
+    };
+
+    if (k_begin < k_end) {
+        float* st0 = smem;
+        float* st1 = smem + STAGE;
+        float4 x0[4], x1[4];
+        load_task(k_begin, x0);
+        load_task(k_begin + SK, x1);
+        store_task(st0, x0);
+        __syncthreads();
+        for (long kb = k_begin; kb < k_end; kb += 2 * SK) {     // kchunk is a multiple of 32
+            load_task(kb + 2 * SK, x0);
+            mma_tile(st0);
+            store_task(st1, x1);
+            __syncthreads();
+            load_task(kb + 3 * SK, x1);
+            mma_tile(st1);
+            store_task(st0, x0);
+            __syncthreads();
+        }
+    }
+
+    float* out = p.slab + (long)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * TN * 32 + j * 32 + lrow;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.M) out[(long)m * p.N + n] = acc[i][j][r];
+            }
+        }
+}
+
 struct TnPlan {
     int bm, bn, tiles_m, tiles_n, splits, kchunk;
 };
@@ -838,7 +983,10 @@ static TnPlan plan_tn(int M, int N, long Kp) {
 template <int AMODE, int BMODE>
 static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cls) {
     char pcls[64];
-    snprintf(pcls, sizeof(pcls), "%s|wgrad_tn<%d,%d,%d,%d>", cls, pl.bm, pl.bn, AMODE, BMODE);
+    // the split kernel stages both operands through registers + LDS (two transposes): it only pays on full 128x128 tiles
+    static const int tn_force = getenv("RD_TN_SPLIT") ? atoi(getenv("RD_TN_SPLIT")) : -1;   // tuning override
+    const int split = tn_force >= 0 ? tn_force : (mfma_split() && pl.bm == 128 && pl.bn == 128);
+    snprintf(pcls, sizeof(pcls), "%s|wgrad_tn%s<%d,%d,%d,%d>", cls, split ? "_split" : "", pl.bm, pl.bn, AMODE, BMODE);
     ProfScope ps(s, pcls, 2.0 * p.M * p.N * (double)p.Kp,
                  4.0 * ((double)p.Kp * p.lda * (AMODE == WA_UP2 ? 4 : 1) + (double)p.Kp * p.ldb + (double)p.M * p.N), true);
     const double a_bytes = 4.0 * (double)p.Kp * p.lda * (AMODE == WA_UP2 ? 4 : 1), b_bytes = 4.0 * (double)p.Kp * p.ldb;
@@ -852,6 +1000,18 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cl
     p.tiles_n = pl.tiles_n;
     p.tiles_mn = pl.tiles_m * pl.tiles_n;
     const int grid = p.tiles_mn * pl.splits;
+    if (split) {
+        if (pl.bm == 128 && pl.bn == 128)
+            hipLaunchKernelGGL((wgrad_tn_split_kernel<128, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+        else if (pl.bm == 128)
+            hipLaunchKernelGGL((wgrad_tn_split_kernel<128, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+        else if (pl.bn == 128)
+            hipLaunchKernelGGL((wgrad_tn_split_kernel<64, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((wgrad_tn_split_kernel<64, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+        RD_LAUNCH_CHECK(cls);
+        return RD_OK;
+    }
     if (pl.bm == 128 && pl.bn == 128)
         hipLaunchKernelGGL((wgrad_tn_kernel<128, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
     else if (pl.bm == 128)
@@ -868,6 +1028,7 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cl
 //  mode 0 (conv3x3): m = co, n = tap*Cin + ci  ->  dw[(co*Cin + ci)*9 + tap]
 //  mode 1 (convT)  : m = ab*Cout + co, n = ci  ->  dw[(ci*Cout + co)*4 + ab]
 //  mode 2 (conv1x1): m = co, n = ci             ->  dw[co*Cin + ci]
+//  mode 3 (conv3x3, swapped strip kernel): m = ci, n = (8-tap)*Cout + co  ->  dw[(co*Cin + ci)*9 + tap]
 // One thread owns four consecutive n (16-byte coalesced slab reads, four splits in flight).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M,
                                                           int N, int splits, int mode, int Cin, int Cout) {
@@ -891,7 +1052,11 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         const long e = q << 2;
         const int m = (int)(e / N), n = (int)(e - (long)m * N);
         const float r[4] = {(float)a0, (float)a1, (float)a2, (float)a3};
-        if (mode == 2) {                                      // plain [M][N] (conv1x1: dw[co][ci])
+        if (mode == 3) {                                      // mirrored transpose of the strip kernel: m = ci, n = (8-tap)*Cout + co
+            const int tq = n / Cout, co = n - tq * Cout;     // the quad stays inside one tap (Cout % 4 == 0)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dw[((long)(co + k) * Cin + m) * 9 + (8 - tq)] = r[k];
+        } else if (mode == 2) {                               // plain [M][N] (conv1x1: dw[co][ci])
             *reinterpret_cast<float4*>(dw + e) = make_float4(r[0], r[1], r[2], r[3]);
         } else if (mode == 0) {
             const int tap = n / Cin, ci = n - tap * Cin;     // the quad stays inside one tap (Cin % 4 == 0)
@@ -1031,6 +1196,7 @@ int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int 
 }
 
 size_t rd_conv3x3_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout) {
+    if (const int ss = wgrad_strip_splits(n, h, w, cin, cout)) return (size_t)ss * cout * 9 * cin * sizeof(float);
     TnPlan pl = plan_tn(cout, 9 * cin, (long)n * h * w);
     return (size_t)pl.splits * cout * 9 * cin * sizeof(float);
 }
@@ -1045,6 +1211,19 @@ int rd_conv3x3_bwd_weight(const float* x, const float* dz, float* dw, int n, int
     if (ws_bytes < need || !ws) {
         set_error("rd_conv3x3_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
         return RD_ERR_WS;
+    }
+    int strip_splits = 0, strip_swapped = 0;
+    if (int e = wgrad_strip_launch(x, dz, (float*)ws, n, h, w, cin, cout, (hipStream_t)s, &strip_splits, &strip_swapped)) return e;
+    if (strip_splits > 0) {
+        ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (strip_splits + 1) * (double)cout * 9 * cin);
+        if (strip_swapped)
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)cout * 9 * cin / 4)), dim3(256), 0, (hipStream_t)s,
+                               (const float*)ws, dw, cin, 9 * cout, strip_splits, 3, cin, cout);
+        else
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)cout * 9 * cin / 4)), dim3(256), 0, (hipStream_t)s,
+                               (const float*)ws, dw, cout, 9 * cin, strip_splits, 0, cin, cout);
+        RD_LAUNCH_CHECK("slab_reduce");
+        return RD_OK;
     }
     TnPlan pl = plan_tn(cout, 9 * cin, (long)n * h * w);
     TnParams p = {};

@@ -1,0 +1,266 @@
+// conv3x3 weight gradient, strip kernel (split-bf16 MFMA).  Own translation unit: it is built WITHOUT
+// -amdgpu-mfma-vgpr-form -- its 9 accumulators (144 registers) live in AGPRs, the MFMA's native C/D file, while the
+// other kernels (<= 64 accumulator registers) are faster with everything in arch VGPRs (see build.sh).
+#include <stdlib.h>
+
+#include "rd_common.h"
+#include "rd_mfma_dev.h"
+
+namespace rd {
+
+// dW[co][tap][ci] = sum_{img,y,x} dz[img,y,x,co] * X[img,y+dy,x+dx,ci].  The TN kernel above stages the x tile once
+// per tap and the dz tile once per 128 output columns; here one block owns (128 co) x (all 9 taps) x (32 ci) and walks
+// down a 16-pixel-wide column strip of one image, one image row (= one K-step of 16 pixels) at a time:
+//   * dz row y            -> LDS once (double-buffered), shared by the 9 taps;
+//   * x halo row y+1      -> LDS once per dx in {-1,0,+1} (the bf16 fragments need 16-byte aligned k, so the three
+//                            horizontal shifts are three staged images; the vertical shifts are ring slots), kept in a
+//                            4-row ring and used by the three rows y-1, y, y+1 that need it;
+//   * wave w owns output-channel block w (32 co): 9 accumulators (one per tap), 54 MFMAs per K-step.
+// Staging traffic per MFMA is ~2.5x lower than in the TN kernel.  Same register-transpose staging tasks (4 px x 4 ch)
+// and swizzled 128-byte LDS rows as wgrad_tn_split_kernel.
+struct WsParams {
+    const float* dz;
+    const float* x;
+    float* slab;        // [splits][M][N]
+    int Cin, Cout, M, N;
+    int H, W, logH, logW;
+    int strips_x, chunks_y, rows_per_chunk;
+    int tiles_ci, tiles_mn;
+    unsigned a_bytes, b_bytes;
+};
+
+__global__ __launch_bounds__(256) void wgrad_strip_kernel(WsParams p) {
+    constexpr int A_ROWS = 128, B_ROWS = 96;                   // LDS rows per A stage / per ring slot
+    constexpr int RING0 = 2 * A_ROWS * 32;                     // word offset of the halo ring
+    __shared__ __attribute__((aligned(16))) float smem[(2 * A_ROWS + 4 * B_ROWS) * 32];
+
+    const int gb = xcd_remap(blockIdx.x, gridDim.x);           // blocks of one strip share an XCD's L2
+    const int split = gb / p.tiles_mn;
+    const int lb = gb - split * p.tiles_mn;
+    const int tile_ci = lb % p.tiles_ci, tile_m = lb / p.tiles_ci;
+    const int m0 = tile_m * 128, ci0 = tile_ci * 32;
+    const int sx = split % p.strips_x;
+    const int cy = (split / p.strips_x) % p.chunks_y;
+    const int img = split / (p.strips_x * p.chunks_y);
+    const int x0 = sx * 16, ya = cy * p.rows_per_chunk, yb = ya + p.rows_per_chunk;
+    const int H = p.H, W = p.W;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    // staging role: threads [0,128) dz row (32 channel quads x 4 pixel quarters), [128,224) x halo row (3 dx x 8 x 4)
+    const bool isA = __builtin_amdgcn_readfirstlane(t) < 128;   // wave-uniform role: waves 0,1 stage dz, waves 2,3 stage x
+    const bool active = t < 224;
+    const int idx = isA ? t : t - 128;
+    const int kq = idx & 3;
+    const int quad = isA ? (idx >> 2) : ((idx >> 2) & 7);
+    const int dxi = isA ? 0 : (idx >> 5);
+    const int ch = isA ? m0 + quad * 4 : ci0 + quad * 4;
+    const bool ch_ok = active && ch < (isA ? p.Cout : p.Cin);
+    const int px0 = x0 + kq * 4 + (isA ? 0 : dxi - 1);         // first of this task's 4 pixels
+    const int lds_row0 = isA ? quad * 4 : dxi * 32 + quad * 4;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.dz, p.a_bytes), rsB = make_rsrc(p.x, p.b_bytes);
+
+    // virtual step yy stages T(yy) = { dz row yy+1, x halo row yy+2 } and multiplies row yy.
+    // Addressing is split into a per-thread part (fixed for the whole strip: pixel column, channel, validity) and a
+    // per-row scalar part, so a K-step costs a handful of SALU/VALU instructions besides the split arithmetic.
+    const int C = isA ? p.Cout : p.Cin;
+    unsigned voff[4];                       // byte offset of pixel j's 16 bytes within an image row; kOOB when masked
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool in = ch_ok && (unsigned)(px0 + j) < (unsigned)W;
+        voff[j] = in ? (unsigned)(((px0 + j) * C + ch) * 4) : kOOB;
+    }
+    const unsigned row_bytes = (unsigned)W * C * 4;
+    const unsigned img_base = (unsigned)img * H * row_bytes;      // operands are < 4 GiB (checked by the launcher)
+    auto load_task = [&](int yy, float4 (&v)[4]) {
+        const int r = isA ? yy + 1 : yy + 2;
+        const bool ok = isA ? (r >= ya && r < yb) : (r >= 0 && r < H && r <= yb);
+        const unsigned soff = ok ? img_base + (unsigned)r * row_bytes : 0u;
+        if (isA) {      // (a descriptor chosen per lane would make the compiler emit waterfall loops)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = buf_load4(rsA, ok ? voff[j] : kOOB, soff);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = buf_load4(rsB, ok ? voff[j] : kOOB, soff);
+        }
+    };
+    // LDS word offsets of this task's channel rows: rows lds_row0 + c, swizzle (row >> 1) & 7 -> c in {0,1} share one
+    // swizzle value, c in {2,3} the next one (lds_row0 is a multiple of 4)
+    int wr_e[3];
+    {
+        const int sw = (lds_row0 >> 1) & 7, hi = kq >> 1;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wr_e[q] = lds_row0 * 32 + (kq & 1) * 2 + ((2 * q + hi) ^ sw) * 4;
+    }
+    auto store_task = [&](int yy, const float4 (&v)[4]) {
+        if (!active) return;
+        float* region = isA ? smem + ((yy + 1) & 1) * (A_ROWS * 32) : smem + RING0 + ((yy + 3) & 3) * (B_ROWS * 32);
+        const unsigned sel = 0x07060302u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned h[4], m[4], l[4];      // the 4 pixels of channel c
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xv = c == 0 ? v[j].x : c == 1 ? v[j].y : c == 2 ? v[j].z : v[j].w;
+                split3(xv, h[j], m[j], l[j]);
+            }
+            const int flip = (c >> 1) * 4;  // next swizzle value = chunk index ^ 1 = word offset ^ 4
+            float* rowp = region + c * 32;
+            *reinterpret_cast<uint2*>(rowp + (wr_e[0] ^ flip)) =
+                make_uint2(__builtin_amdgcn_perm(h[1], h[0], sel), __builtin_amdgcn_perm(h[3], h[2], sel));
+            *reinterpret_cast<uint2*>(rowp + (wr_e[1] ^ flip)) =
+                make_uint2(__builtin_amdgcn_perm(m[1], m[0], sel), __builtin_amdgcn_perm(m[3], m[2], sel));
+            *reinterpret_cast<uint2*>(rowp + (wr_e[2] ^ flip)) =
+                make_uint2(__builtin_amdgcn_perm(l[1], l[0], sel), __builtin_amdgcn_perm(l[3], l[2], sel));
+        }
+    };
+
+    const int lrow = lane & 31, half = lane >> 5;
+    int a_rd[3], b_rd[3][3];
+    {
+        const int row = wave * 32 + lrow;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_rd[q] = row * 32 + ((2 * q + half) ^ ((row >> 1) & 7)) * 4;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int rb = d * 32 + lrow;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b_rd[d][q] = rb * 32 + ((2 * q + half) ^ ((rb >> 1) & 7)) * 4;
+        }
+    }
+    f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    auto mma_row = [&](int y) {
+        // one block per CU (80 KB LDS): latency is hidden inside the wave -- the B fragments of the next vertical tap
+        // are fetched while the 18 MFMAs of the current one run (two fragment register sets)
+        const float* a_stage = smem + (y & 1) * (A_ROWS * 32);
+        bf16x8 af[3], bf[2][3][3];
+        auto read_b = [&](int dy, bf16x8 (&dst)[3][3]) {
+            const float* slot = smem + RING0 + ((y + dy) & 3) * (B_ROWS * 32);      // image row y+dy-1 lives in slot (row+1)&3
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dst[d][q] = *reinterpret_cast<const bf16x8*>(slot + b_rd[d][q]);
+        };
+#pragma unroll
+        for (int q = 0; q < 3; ++q) af[q] = *reinterpret_cast<const bf16x8*>(a_stage + a_rd[q]);
+        read_b(0, bf[0]);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            if (dy < 2) read_b(dy + 1, bf[(dy + 1) & 1]);
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    acc[dy * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t6]], bf[dy & 1][d][PB[t6]], acc[dy * 3 + d], 0, 0, 0);
+        }
+    };
+
+    float4 v0[4], v1[4];
+    const int ys = ya - 3;                       // three warm-up steps fill the halo ring and the first dz row
+    load_task(ys, v0);
+    load_task(ys + 1, v1);
+    store_task(ys, v0);
+    load_task(ys + 2, v0);
+    __syncthreads();
+    store_task(ys + 1, v1);
+    load_task(ys + 3, v1);
+    __syncthreads();
+    store_task(ys + 2, v0);
+    load_task(ys + 4, v0);
+    __syncthreads();
+    for (int yy = ya; yy < yb; yy += 2) {        // rows_per_chunk is even; no branches around the MFMAs (accumulators stay
+        store_task(yy, v1);                      // in AGPRs across the loop)
+        load_task(yy + 2, v1);
+        mma_row(yy);
+        __syncthreads();
+        store_task(yy + 1, v0);
+        load_task(yy + 3, v0);
+        mma_row(yy + 1);
+        __syncthreads();
+    }
+
+    float* out = p.slab + (long)split * p.M * p.N;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        const int n = tp * p.Cin + ci0 + lrow;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < p.M) out[(long)m * p.N + n] = acc[tp][r];
+        }
+    }
+}
+
+struct WsPlan {
+    int ok, swapped, rows_per_chunk, chunks_y, strips_x, tiles_m, tiles_ci, splits;
+};
+
+// The strip kernel needs W >= 16, the shifted operand's channels % 32 == 0 and a full 128-channel block on the other
+// side.  When Cout < 128 <= Cin the roles are swapped (pl.swapped): dW[co][tap][ci] = sum_p x[p][ci] * dz[p - tap][co],
+// i.e. the same kernel with x as the un-shifted operand, dz as the shifted one and the taps mirrored; the slab is then
+// [Cin][(8 - tap) * Cout + co] and the reduction kernel un-mirrors it.
+static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
+    WsPlan pl = {};
+    static const int force = getenv("RD_WG_STRIP") ? atoi(getenv("RD_WG_STRIP")) : -1;   // tuning override (0 = never)
+    if (!mfma_split() || force == 0 || w < 16 || h < 4) return pl;
+    if (cout >= 128 && cout % 4 == 0 && cin % 32 == 0) {
+        pl.swapped = 0;
+    } else if (cin >= 128 && cin % 4 == 0 && cout % 32 == 0) {
+        pl.swapped = 1;
+        const int tmp = cin; cin = cout; cout = tmp;
+    } else {
+        return pl;
+    }
+    pl.ok = 1;
+    pl.strips_x = w / 16;
+    pl.tiles_m = cdiv(cout, 128);
+    pl.tiles_ci = cin / 32;
+    const long base = (long)pl.tiles_m * pl.tiles_ci * n * pl.strips_x;
+    int rows = h;
+    while (base * (h / rows) < 768 && rows > 32) rows >>= 1;
+    pl.rows_per_chunk = rows;
+    pl.chunks_y = h / rows;
+    pl.splits = n * pl.strips_x * pl.chunks_y;
+    return pl;
+}
+
+
+int wgrad_strip_splits(int n, int h, int w, int cin, int cout) {
+    const WsPlan pl = plan_strip(n, h, w, cin, cout);
+    return pl.ok ? pl.splits : 0;
+}
+
+int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int h, int w, int cin, int cout, hipStream_t s,
+                       int* splits_out, int* swapped_out) {
+    const WsPlan wp = plan_strip(n, h, w, cin, cout);
+    *splits_out = 0;
+    *swapped_out = 0;
+    if (!wp.ok) return RD_OK;
+    if (wp.swapped) {
+        const float* tp = x; x = dz; dz = tp;
+        const int tc = cin; cin = cout; cout = tc;
+    }
+    WsParams q = {};
+    q.dz = dz; q.x = x; q.slab = slab;
+    q.Cin = cin; q.Cout = cout; q.M = cout; q.N = 9 * cin;
+    q.H = h; q.W = w; q.logH = ilog2_exact(h); q.logW = ilog2_exact(w);
+    q.strips_x = wp.strips_x; q.chunks_y = wp.chunks_y; q.rows_per_chunk = wp.rows_per_chunk;
+    q.tiles_ci = wp.tiles_ci; q.tiles_mn = wp.tiles_m * wp.tiles_ci;
+    const double ab = 4.0 * n * h * w * (double)cout, bb = 4.0 * n * h * w * (double)cin;
+    RD_REQUIRE(ab < 4294967040.0 && bb < 4294967040.0, "rd_conv3x3_bwd_weight: operand beyond the 4 GiB descriptor range");
+    q.a_bytes = (unsigned)ab; q.b_bytes = (unsigned)bb;
+    ProfScope ps(s, "conv3x3_wgrad|wgrad_strip", 2.0 * cout * 9.0 * cin * (double)n * h * w, ab + bb + 4.0 * cout * 9.0 * cin,
+                 true);
+    hipLaunchKernelGGL(wgrad_strip_kernel, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
+    RD_LAUNCH_CHECK("wgrad_strip");
+    *splits_out = wp.splits;
+    *swapped_out = wp.swapped;
+    return RD_OK;
+}
+
+}  // namespace rd
