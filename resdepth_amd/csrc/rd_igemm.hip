@@ -21,6 +21,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "rd_common.h"
 #include "rd_mfma_dev.h"
 
@@ -42,6 +44,7 @@ struct NtParams {
     int Cout;  // EPI_CONVT: channels per (a,b) quadrant
     int chunks, nk, taps;
     int tiles_n;
+    int patch;  // halo kernel: tile rows are an 8x16-pixel patch (row r -> pixel m0 + (r >> 4) * W + (r & 15))
     int vec;  // epilogue may use 16-byte accesses (N % 4 == 0 and, for the transposed conv, Cout % 4 == 0)
     unsigned a_bytes, b_bytes;  // extents of the A / B tensors for the buffer descriptors
     float* stats;  // EPI_STORE only, nullable: per-(tile_m) column sums / sums of squares [tiles_m][2][N] (BN statistics)
@@ -61,6 +64,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
     // ---- epilogue.  D[i][j]: lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5).  The accumulators
     // are staged through LDS (EB 32-row blocks of one wave row-band per pass) so that HBM sees 16 B per lane and whole
     // contiguous rows per wave; bias / skip-add of the transposed convolution ride the same pass.
+    auto row_to_m = [&](int r) { return p.patch ? m0 + (r >> 4) * W + (r & 15) : m0 + r; };
     constexpr int CS = BN + 4, ROWS = EB * 32, Q = BN / 4, PPB = TM / EB;   // PPB passes per wave row-band
     static_assert(TM % EB == 0, "EB must divide TM");
     static_assert(ROWS * CS + 512 <= SMEM_WORDS, "epilogue staging (+ statistics scratch) must fit the operand buffers");
@@ -88,7 +92,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
             const int col = t % BN, grp = t / BN;
             float ss = 0.f, qq = 0.f;
             for (int row = grp; row < ROWS; row += G) {
-                if (m0 + rowbase + row < p.M) {
+                if (row_to_m(rowbase + row) < p.M) {
                     const float v = Cs[row * CS + col];
                     ss += v;
                     qq = fmaf(v, v, qq);
@@ -108,7 +112,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
         if (p.vec) {
             for (int e = t; e < ROWS * Q; e += 256) {
                 const int row = e / Q, q4 = e - row * Q;
-                const int m = m0 + rowbase + row, n = n0 + q4 * 4;
+                const int m = row_to_m(rowbase + row), n = n0 + q4 * 4;
                 if (m >= p.M || n >= p.N) continue;
                 float4 v = *reinterpret_cast<const float4*>(&Cs[row * CS + q4 * 4]);
                 if (EPI == EPI_STORE) {
@@ -132,7 +136,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
         } else {
             for (int e = t; e < ROWS * BN; e += 256) {
                 const int row = e / BN, c = e - row * BN;
-                const int m = m0 + rowbase + row, n = n0 + c;
+                const int m = row_to_m(rowbase + row), n = n0 + c;
                 if (m >= p.M || n >= p.N) continue;
                 float v = Cs[row * CS + c];
                 if (EPI == EPI_STORE) {
@@ -478,6 +482,151 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
     nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m);
 }
 
+// ---- conv3x3 forward / data gradient with halo reuse (split-bf16) ----------------------------------------------------
+// The general split kernel above stages the activation tile once per (tap, 16-channel chunk).  For the 3x3 convolution
+// this kernel makes the block tile an 8x16-pixel PATCH and stages the patch with its one-pixel halo (10x18 pixels) once
+// per 16-channel chunk; the nine taps are nine fragment reads at constant row offsets (LDS row = halo pixel, 112-byte
+// stride -> the tap shift is an instruction immediate).  Activation staging (global loads, split arithmetic, LDS
+// writes) drops ~6x and there is one barrier per chunk instead of per K-step.  Weights: unchanged (pre-split fragment
+// layout straight from global memory, kt = chunk*9 + tap, three register sets).
+template <int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
+    constexpr int BM = 128, PH = 8, PW = 16, HW_ = PW + 2, HROWS = (PH + 2) * HW_;   // 180 halo pixels
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TN == 1, "one 32-column block per wave");
+    constexpr int RS = 28;                            // LDS row stride in words (3 terms x 16 bf16 + 16 B pad)
+    constexpr int STAGE = HROWS * RS;
+    constexpr int NLD = (HROWS * 4 + 255) / 256;      // staging float4 per thread and chunk
+    constexpr int EPI_WORDS = 32 * (BN + 4) + 512;
+    constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
+    const int n0 = tile_n * BN;
+    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+    const int pxs = W >> 4, pys = H >> 3;             // patches per image row / column
+    const int pbx = tile_m % pxs, pby = (tile_m / pxs) % pys, img = tile_m / (pxs * pys);
+    const int x0 = pbx * PW, y0 = pby * PH;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    (void)logW; (void)logH;
+
+    f32x16 acc[TM][1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.Bsplit, p.b_bytes);
+    // staging tasks: element e = t + 256 k -> halo pixel e >> 2, 16-byte quarter e & 3 of its 64-byte channel chunk
+    unsigned s_off[NLD];
+    int s_lds[NLD];
+    const int c4 = t & 3;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = t + 256 * k, hr = e >> 2;
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool ok = hr < HROWS && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        s_off[k] = ok ? (unsigned)(((((long)img * H + y) * W + x) * p.Cin + c4 * 4) * 4) : kOOB;
+        s_lds[k] = hr < HROWS ? hr * RS + c4 * 2 : -1;
+    }
+    const int nb = (n0 >> 5) + wn;
+    const unsigned b_off = (nb * 32 < p.N) ? (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16) : kOOB;
+
+    auto load_halo = [&](int chunk, float4 (&rh)[NLD]) {
+        const bool cok = chunk < p.chunks && chunk * SK + c4 * 4 < p.Cin;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) rh[k] = buf_load4(rsA, cok ? s_off[k] : kOOB, (unsigned)(chunk * SK * 4));
+    };
+    auto store_halo = [&](float* stage, const float4 (&rh)[NLD]) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            if (s_lds[k] < 0) continue;
+            uint2 ph, pm, pl;
+            split_pack4(rh[k], ph, pm, pl);
+            float* row = stage + s_lds[k];
+            *reinterpret_cast<uint2*>(row) = ph;
+            *reinterpret_cast<uint2*>(row + 8) = pm;
+            *reinterpret_cast<uint2*>(row + 16) = pl;
+        }
+    };
+    auto load_b = [&](int kt, uint4 (&rb)[3]) {
+        const unsigned voff = kt < p.nk ? b_off : kOOB;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((kt * 3 + q) * 1024));
+    };
+
+    const int lrow = lane & 31, half = lane >> 5;
+    int a_rd[TM];       // word address of (top-left tap, term 0) of this lane's pixel in a stage
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + lrow;            // tile row -> patch pixel (row >> 4, row & 15)
+        a_rd[i] = ((row >> 4) * HW_ + (row & 15)) * RS + half * 4;
+    }
+    bf16x8 af[TM][3];
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    constexpr int GP = TM >= 2 ? 2 : 1;
+
+    float* stage_cur = smem;
+    float* stage_nxt = smem + STAGE;
+    float4 rh[NLD];
+    uint4 b0[3], b1[3], b2[3];
+    load_halo(0, rh);
+    load_b(0, b0);
+    load_b(1, b1);
+    store_halo(stage_cur, rh);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(stage_cur + a_rd[i] + q * 8);
+
+    // tap step: MFMAs of (chunk, TAP) with the fragments in af / bcur; prefetch the weights two steps ahead; reload af
+    // for the next step right after its last use (next tap of this chunk, or tap 0 of the next chunk's stage)
+    auto tap_step = [&](int kt, auto tap_c, uint4 (&bcur)[3], uint4 (&bnew)[3]) {
+        constexpr int TAP = decltype(tap_c)::value;
+        constexpr int NEXT = TAP == 8 ? 0 : ((TAP + 1) / 3 * HW_ + (TAP + 1) % 3) * RS;
+        load_b(kt + 2, bnew);
+        bf16x8 bf[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bf[q] = __builtin_bit_cast(bf16x8, bcur[q]);
+        const float* nstage = TAP == 8 ? stage_nxt : stage_cur;
+#pragma unroll
+        for (int g = 0; g < TM; g += GP) {
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int i = g; i < g + GP; ++i)
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t6]], bf[PB[t6]], acc[i][0], 0, 0, 0);
+#pragma unroll
+            for (int i = g; i < g + GP; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(nstage + a_rd[i] + NEXT + q * 8);
+        }
+    };
+    for (int chunk = 0; chunk < p.chunks; ++chunk) {
+        const int kt = chunk * 9;
+        load_halo(chunk + 1, rh);                             // next chunk's patch: in flight during taps 0..4
+        tap_step(kt + 0, std::integral_constant<int, 0>(), b0, b2);
+        tap_step(kt + 1, std::integral_constant<int, 1>(), b1, b0);
+        tap_step(kt + 2, std::integral_constant<int, 2>(), b2, b1);
+        tap_step(kt + 3, std::integral_constant<int, 3>(), b0, b2);
+        tap_step(kt + 4, std::integral_constant<int, 4>(), b1, b0);
+        store_halo(stage_nxt, rh);                            // the other stage was last read before the previous barrier
+        tap_step(kt + 5, std::integral_constant<int, 5>(), b2, b1);
+        tap_step(kt + 6, std::integral_constant<int, 6>(), b0, b2);
+        tap_step(kt + 7, std::integral_constant<int, 7>(), b1, b0);
+        __syncthreads();                                      // next stage complete before tap 8 prefetches from it
+        tap_step(kt + 8, std::integral_constant<int, 8>(), b2, b1);
+        float* tmp = stage_cur; stage_cur = stage_nxt; stage_nxt = tmp;
+    }
+    __syncthreads();
+    const int m0 = ((img * H + y0) * W) + x0;
+    nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m);
+}
+
 // fp32 GEMM-layout B[N][K] (K = taps*Cin, tap-major) -> split-bf16 fragment layout
 //   [row block nb = n/32][kt][term q][lane = 32*(j/8) + n%32][8 bf16: k = 8*(j/8) .. +7]      (16 bytes per lane)
 // kt = chunk*taps + tap, j = channel within the 16-channel chunk; rows beyond N and channels beyond Cin are zero.
@@ -583,14 +732,34 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
         else cfg = 1;
     }
     if (force >= 0 && force <= 2 && !(force == 0 && p.N <= 64)) cfg = force;
+    static const int halo_force = getenv("RD_NT_HALO") ? atoi(getenv("RD_NT_HALO")) : -1;   // tuning override (0 = never)
+    const bool halo = split && AMODE == A_CONV3 && EPI == EPI_STORE && p.W >= 16 && p.H >= 8 && cfg != 2 && halo_force != 0;
     char pcls[64];   // "<operation>|<kernel symbol>": the kernel symbol is what rocprofv3 reports
-    snprintf(pcls, sizeof(pcls), "%s|igemm_nt%s<%s,%d,%d>", cls, split ? "_split" : "",
-             cfg == 0 ? "128,128" : cfg == 1 ? "128,64" : "64,64", AMODE, EPI);
+    if (halo)
+        snprintf(pcls, sizeof(pcls), "%s|conv3_halo_split<%d>", cls, cfg == 0 ? 128 : 64);
+    else
+        snprintf(pcls, sizeof(pcls), "%s|igemm_nt%s<%s,%d,%d>", cls, split ? "_split" : "",
+                 cfg == 0 ? "128,128" : cfg == 1 ? "128,64" : "64,64", AMODE, EPI);
     ProfScope ps(s, pcls, (double)flops, bytes, true);
     if (tiles_m_out) *tiles_m_out = cdiv(p.M, cfg == 2 ? 64 : 128);
     const int bm = cfg == 2 ? 64 : 128, bn = cfg == 0 ? 128 : 64;
     p.tiles_n = cdiv(p.N, bn);
     const int grid = cdiv(p.M, bm) * p.tiles_n;
+    if (halo) {
+        // 3x3 convolution on 8x16-pixel patches with halo reuse
+        p.patch = 1;
+        const int tiles_m = (p.M >> 7);       // (H/8) * (W/16) patches per image, 128 pixels each
+        if (tiles_m_out) *tiles_m_out = tiles_m;
+        if (cfg == 0) {
+            p.tiles_n = cdiv(p.N, 128);
+            hipLaunchKernelGGL((conv3_halo_split_kernel<128, 1, 4, EPI_STORE>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        } else {
+            p.tiles_n = cdiv(p.N, 64);
+            hipLaunchKernelGGL((conv3_halo_split_kernel<64, 2, 2, EPI_STORE>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        }
+        RD_LAUNCH_CHECK(cls);
+        return RD_OK;
+    }
     if (split) {
         if (cfg == 2) hipLaunchKernelGGL((igemm_nt_split_kernel<64, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
         else if (cfg == 0) hipLaunchKernelGGL((igemm_nt_split_kernel<128, 128, 1, 4, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
