@@ -664,6 +664,48 @@ __global__ void split_pack_kernel(const float* __restrict__ B, uint4* __restrict
     }
 }
 
+// conv3x3 weights straight from the torch layout w[co][ci][3][3] into BOTH split-bf16 fragment tensors in one launch
+// (split mode never reads the fp32 GEMM layouts of a 3x3 convolution):
+//   pieces [0, Tf)      forward operand   rows n = co, k = (tap, ci):        w[co][ci0+j][tap]
+//   pieces [Tf, Tf+Td)  data-gradient operand rows n = ci, k = (tap', co):   w[co0+j][ci][8-tap']
+// one thread per 16-byte fragment piece (row n, K-step kt = chunk*9 + tap, k-half g); gathered, cached loads.
+__global__ void split_pack_conv3x3_kernel(const float* __restrict__ w, uint4* __restrict__ outf, uint4* __restrict__ outd,
+                                          int cout, int cin) {
+    const int nkf = 9 * ((cin + SK - 1) / SK), nkd = 9 * ((cout + SK - 1) / SK);
+    const long rf = (long)((cout + 31) / 32) * 32, rd_ = (long)((cin + 31) / 32) * 32;
+    const long Tf = rf * nkf * 2, Td = outd ? rd_ * nkd * 2 : 0;
+    for (long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x; e0 < Tf + Td; e0 += (long)gridDim.x * blockDim.x) {
+        const bool fwd = e0 < Tf;
+        const long e = fwd ? e0 : e0 - Tf;
+        const int nk = fwd ? nkf : nkd, N = fwd ? cout : cin, Kc = fwd ? cin : cout;
+        const int g = (int)(e & 1);
+        const int kt = (int)((e >> 1) % nk);
+        const long n = (e >> 1) / nk;
+        const int chunk = kt / 9, tap = kt - chunk * 9, c0 = chunk * SK + g * 8;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            float x = 0.f;
+            if (n < N && c < Kc) x = fwd ? w[((long)n * cin + c) * 9 + tap] : w[((long)c * cin + n) * 9 + (8 - tap)];
+            v[j] = x;
+        }
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
+        const long blk = ((n >> 5) * nk + kt) * 3;
+        const int lane = g * 32 + (int)(n & 31);
+        const unsigned sel = 0x07060302u;
+        uint4* out = fwd ? outf : outd;
+        out[blk * 64 + lane] = make_uint4(__builtin_amdgcn_perm(h[1], h[0], sel), __builtin_amdgcn_perm(h[3], h[2], sel),
+                                          __builtin_amdgcn_perm(h[5], h[4], sel), __builtin_amdgcn_perm(h[7], h[6], sel));
+        out[(blk + 1) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(m[1], m[0], sel), __builtin_amdgcn_perm(m[3], m[2], sel),
+                                                __builtin_amdgcn_perm(m[5], m[4], sel), __builtin_amdgcn_perm(m[7], m[6], sel));
+        out[(blk + 2) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(l[1], l[0], sel), __builtin_amdgcn_perm(l[3], l[2], sel),
+                                                __builtin_amdgcn_perm(l[5], l[4], sel), __builtin_amdgcn_perm(l[7], l[6], sel));
+    }
+}
+
 // ---- packed weight buffers -------------------------------------------------------------------------------
 // One opaque buffer per GEMM operand B[rows][K = taps*Cin]:  [rows*K floats, fp32 GEMM layout] [pad to 16 B]
 // [rows * nk16 * 96 bytes, split-bf16 layout], nk16 = taps * ceil(Cin/16).  rd_packed_weight_bytes() sizes it.
@@ -1247,19 +1289,43 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restri
         const int ci = (int)(e % cin);
         const int tap = (int)((e / cin) % 9);
         const int co = (int)(e / ((long)cin * 9));
-        const float v = w[((long)co * cin + ci) * 9 + tap];
-        wf[e] = v;
-        if (wd) wd[((long)ci * 9 + (8 - tap)) * cout + co] = v;
+        wf[e] = w[((long)co * cin + ci) * 9 + tap];
+        if (wd) {
+            // the same e read as an index into wd[ci'][tap'][co']: coalesced stores, gathered (cached) loads
+            const int co2 = (int)(e % cout);
+            const int tap2 = (int)((e / cout) % 9);
+            const int ci2 = (int)(e / ((long)cout * 9));
+            wd[e] = w[((long)co2 * cin + ci2) * 9 + (8 - tap2)];
+        }
     }
 }
 
-__global__ void transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int rows, int cols) {
-    const long total = (long)rows * cols;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(e % cols), r = (int)(e / cols);
-        wt[(long)c * rows + r] = w[e];
+// out[c][g'][r] = in[r][g][c] for a matrix in[rows][groups][cols] (g' = groups-1-g when flip, else g): 32x32 LDS tiles,
+// coalesced on both sides.  conv3x3: wd[ci][8-tap][co] = wf[co][tap][ci]; plain transposes use groups = 1.
+__global__ __launch_bounds__(256) void tiled_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                              int groups, int cols, int flip) {
+    __shared__ float tile[32][33];
+    const int tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (long b = blockIdx.x; b < (long)groups * tiles_r * tiles_c; b += gridDim.x) {
+        const int tc = (int)(b % tiles_c), tr = (int)((b / tiles_c) % tiles_r), g = (int)(b / ((long)tiles_c * tiles_r));
+        const int r0 = tr * 32, c0 = tc * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            tile[ty + 8 * k][tx] = (r < rows && c < cols) ? in[((long)r * groups + g) * cols + c] : 0.f;
+        }
+        __syncthreads();
+        const int go = flip ? groups - 1 - g : g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;
+            if (r < rows && c < cols) out[((long)c * groups + go) * rows + r] = tile[tx][ty + 8 * k];
+        }
+        __syncthreads();
     }
 }
+
 
 __global__ void pack_convt_kernel(const float* __restrict__ w, float* __restrict__ wtf, float* __restrict__ wtd,
                                   int cin, int cout) {
@@ -1269,9 +1335,14 @@ __global__ void pack_convt_kernel(const float* __restrict__ w, float* __restrict
         const int ci = (int)(e % cin);
         const int co = (int)((e / cin) % cout);
         const int ab = (int)(e / ((long)cin * cout));
-        const float v = w[((long)ci * cout + co) * 4 + ab];
-        wtf[e] = v;
-        if (wtd) wtd[(long)ci * 4 * cout + (long)ab * cout + co] = v;
+        wtf[e] = w[((long)ci * cout + co) * 4 + ab];
+        if (wtd) {
+            // e as an index into wtd[ci'][(ab', co')]: coalesced stores
+            const int co2 = (int)(e % cout);
+            const int ab2 = (int)((e / cout) % 4);
+            const int ci2 = (int)(e / ((long)cout * 4));
+            wtd[e] = w[((long)ci2 * cout + co2) * 4 + ab2];
+        }
     }
 }
 
@@ -1304,8 +1375,23 @@ size_t rd_packed_weight_bytes(int rows, int taps, int cin) {
 int rd_pack_conv3x3_weight(const float* w, float* wf, float* wd, int cout, int cin, rd_stream_t s) {
     RD_REQUIRE(w && wf && cout > 0 && cin > 0, "rd_pack_conv3x3_weight: bad arguments");
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 12.0 * cout * cin * 9);
+    if (mfma_split()) {     // split kernels only: both fragment tensors in one launch, fp32 GEMM layouts left unwritten
+        uint4* of = (uint4*)((char*)wf + packed_f32_bytes(cout, 9, cin));
+        uint4* od = wd ? (uint4*)((char*)wd + packed_f32_bytes(cin, 9, cout)) : nullptr;
+        const long pieces = rows32_of(cout) * nk16_of(9, cin) * 2 + (wd ? rows32_of(cin) * nk16_of(9, cout) * 2 : 0);
+        long g = (pieces + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, od, cout, cin);
+        RD_LAUNCH_CHECK("pack_conv3x3");
+        return RD_OK;
+    }
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for((long)cout * cin * 9)), dim3(256), 0, (hipStream_t)s, w, wf,
-                       wd, cout, cin);
+                       (float*)nullptr, cout, cin);
+    if (wd) {
+        const long tiles = 9L * cdiv(cout, 32) * cdiv(cin, 32);
+        hipLaunchKernelGGL(tiled_transpose_kernel, dim3((int)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)s,
+                           (const float*)wf, wd, cout, 9, cin, 1);
+    }
     RD_LAUNCH_CHECK("pack_conv3x3");
     if (int e = split_pack(wf, cout, 9, cin, (hipStream_t)s)) return e;
     if (wd) return split_pack(wd, cin, 9, cout, (hipStream_t)s);
@@ -1316,7 +1402,12 @@ int rd_pack_convt2x2_weight(const float* w, float* wtf, float* wtd, int cin, int
     RD_REQUIRE(w && wtf && cout > 0 && cin > 0, "rd_pack_convt2x2_weight: bad arguments");
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 12.0 * cout * cin * 4);
     hipLaunchKernelGGL(pack_convt_kernel, dim3(grid_for((long)cout * cin * 4)), dim3(256), 0, (hipStream_t)s, w, wtf,
-                       wtd, cin, cout);
+                       (float*)nullptr, cin, cout);
+    if (wtd) {
+        const long tiles = (long)cdiv(4 * cout, 32) * cdiv(cin, 32);
+        hipLaunchKernelGGL(tiled_transpose_kernel, dim3((int)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)s,
+                           (const float*)wtf, wtd, 4 * cout, 1, cin, 0);
+    }
     RD_LAUNCH_CHECK("pack_convt");
     if (int e = split_pack(wtf, 4L * cout, 1, cin, (hipStream_t)s)) return e;
     if (wtd) return split_pack(wtd, cin, 4, cout, (hipStream_t)s);
@@ -1473,7 +1564,11 @@ int rd_pack_conv1x1_weight(const float* w, float* wf, float* wt, int cout, int c
         return e;
     if (int e = split_pack(wf, cout, 1, cin, (hipStream_t)s)) return e;
     if (!wt) return RD_OK;
-    hipLaunchKernelGGL(transpose_kernel, dim3(grid_for((long)cout * cin)), dim3(256), 0, (hipStream_t)s, w, wt, cout, cin);
+    {
+        const long tiles = (long)cdiv(cout, 32) * cdiv(cin, 32);
+        hipLaunchKernelGGL(tiled_transpose_kernel, dim3((int)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)s, w, wt,
+                           cout, 1, cin, 0);
+    }
     RD_LAUNCH_CHECK("pack_conv1x1");
     return split_pack(wt, cin, 1, cout, (hipStream_t)s);
 }

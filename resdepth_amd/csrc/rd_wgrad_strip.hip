@@ -24,7 +24,7 @@ struct WsParams {
     float* slab;        // [splits][M][N]
     int Cin, Cout, M, N;
     int H, W, logH, logW;
-    int strips_x, chunks_y, rows_per_chunk;
+    int strips_x, chunks_y, rows_per_chunk, reps;
     int tiles_ci, tiles_mn;
     unsigned a_bytes, b_bytes;
 };
@@ -39,10 +39,8 @@ __global__ __launch_bounds__(256) void wgrad_strip_kernel(WsParams p) {
     const int lb = gb - split * p.tiles_mn;
     const int tile_ci = lb % p.tiles_ci, tile_m = lb / p.tiles_ci;
     const int m0 = tile_m * 128, ci0 = tile_ci * 32;
-    const int sx = split % p.strips_x;
-    const int cy = (split / p.strips_x) % p.chunks_y;
-    const int img = split / (p.strips_x * p.chunks_y);
-    const int x0 = sx * 16, ya = cy * p.rows_per_chunk, yb = ya + p.rows_per_chunk;
+    // this block accumulates p.reps consecutive strips (strip id -> x strip, row chunk, image); set per strip below
+    int img = 0, x0 = 0, ya = 0, yb = 0;
     const int H = p.H, W = p.W;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
@@ -55,7 +53,7 @@ __global__ __launch_bounds__(256) void wgrad_strip_kernel(WsParams p) {
     const int dxi = isA ? 0 : (idx >> 5);
     const int ch = isA ? m0 + quad * 4 : ci0 + quad * 4;
     const bool ch_ok = active && ch < (isA ? p.Cout : p.Cin);
-    const int px0 = x0 + kq * 4 + (isA ? 0 : dxi - 1);         // first of this task's 4 pixels
+    const int pxr = kq * 4 + (isA ? 0 : dxi - 1);              // first of this task's 4 pixels, relative to the strip's x0
     const int lds_row0 = isA ? quad * 4 : dxi * 32 + quad * 4;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.dz, p.a_bytes), rsB = make_rsrc(p.x, p.b_bytes);
 
@@ -64,13 +62,22 @@ __global__ __launch_bounds__(256) void wgrad_strip_kernel(WsParams p) {
     // per-row scalar part, so a K-step costs a handful of SALU/VALU instructions besides the split arithmetic.
     const int C = isA ? p.Cout : p.Cin;
     unsigned voff[4];                       // byte offset of pixel j's 16 bytes within an image row; kOOB when masked
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool in = ch_ok && (unsigned)(px0 + j) < (unsigned)W;
-        voff[j] = in ? (unsigned)(((px0 + j) * C + ch) * 4) : kOOB;
-    }
     const unsigned row_bytes = (unsigned)W * C * 4;
-    const unsigned img_base = (unsigned)img * H * row_bytes;      // operands are < 4 GiB (checked by the launcher)
+    unsigned img_base = 0;                  // operands are < 4 GiB (checked by the launcher)
+    auto set_strip = [&](int sid) {
+        const int sx = sid % p.strips_x;
+        const int cy = (sid / p.strips_x) % p.chunks_y;
+        img = sid / (p.strips_x * p.chunks_y);
+        x0 = sx * 16;
+        ya = cy * p.rows_per_chunk;
+        yb = ya + p.rows_per_chunk;
+        img_base = (unsigned)img * H * row_bytes;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int px = x0 + pxr + j;
+            voff[j] = (ch_ok && (unsigned)px < (unsigned)W) ? (unsigned)((px * C + ch) * 4) : kOOB;
+        }
+    };
     auto load_task = [&](int yy, float4 (&v)[4]) {
         const int r = isA ? yy + 1 : yy + 2;
         const bool ok = isA ? (r >= ya && r < yb) : (r >= 0 && r < H && r <= yb);
@@ -161,27 +168,30 @@ __global__ __launch_bounds__(256) void wgrad_strip_kernel(WsParams p) {
     };
 
     float4 v0[4], v1[4];
-    const int ys = ya - 3;                       // three warm-up steps fill the halo ring and the first dz row
-    load_task(ys, v0);
-    load_task(ys + 1, v1);
-    store_task(ys, v0);
-    load_task(ys + 2, v0);
-    __syncthreads();
-    store_task(ys + 1, v1);
-    load_task(ys + 3, v1);
-    __syncthreads();
-    store_task(ys + 2, v0);
-    load_task(ys + 4, v0);
-    __syncthreads();
-    for (int yy = ya; yy < yb; yy += 2) {        // rows_per_chunk is even; no branches around the MFMAs (accumulators stay
-        store_task(yy, v1);                      // in AGPRs across the loop)
-        load_task(yy + 2, v1);
-        mma_row(yy);
+    for (int rep = 0; rep < p.reps; ++rep) {
+        set_strip(split * p.reps + rep);
+        const int ys = ya - 3;                   // three warm-up steps fill the halo ring and the first dz row
+        load_task(ys, v0);
+        load_task(ys + 1, v1);
+        store_task(ys, v0);
+        load_task(ys + 2, v0);
         __syncthreads();
-        store_task(yy + 1, v0);
-        load_task(yy + 3, v0);
-        mma_row(yy + 1);
+        store_task(ys + 1, v1);
+        load_task(ys + 3, v1);
         __syncthreads();
+        store_task(ys + 2, v0);
+        load_task(ys + 4, v0);
+        __syncthreads();
+        for (int yy = ya; yy < yb; yy += 2) {    // rows_per_chunk is even; no branches around the MFMAs (accumulators
+            store_task(yy, v1);                  // stay in AGPRs across the loops)
+            load_task(yy + 2, v1);
+            mma_row(yy);
+            __syncthreads();
+            store_task(yy + 1, v0);
+            load_task(yy + 3, v0);
+            mma_row(yy + 1);
+            __syncthreads();
+        }
     }
 
     float* out = p.slab + (long)split * p.M * p.N;
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256) void wgrad_strip_kernel(WsParams p) {
 }
 
 struct WsPlan {
-    int ok, swapped, rows_per_chunk, chunks_y, strips_x, tiles_m, tiles_ci, splits;
+    int ok, swapped, rows_per_chunk, chunks_y, strips_x, tiles_m, tiles_ci, reps, splits;
 };
 
 // The strip kernel needs W >= 16, the shifted operand's channels % 32 == 0 and a full 128-channel block on the other
@@ -225,7 +235,13 @@ static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
     while (base * (h / rows) < 768 && rows > 32) rows >>= 1;
     pl.rows_per_chunk = rows;
     pl.chunks_y = h / rows;
-    pl.splits = n * pl.strips_x * pl.chunks_y;
+    // every split costs one [Cout][9*Cin] slab of HBM traffic (written here, read by the reduction): with more than
+    // ~2048 blocks, give each block several strips instead
+    const long strips = (long)n * pl.strips_x * pl.chunks_y;
+    int reps = 1;
+    while (base * pl.chunks_y / (2 * reps) >= 1024 && strips % (2 * reps) == 0) reps *= 2;
+    pl.reps = reps;
+    pl.splits = (int)(strips / reps);
     return pl;
 }
 
@@ -249,7 +265,7 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     q.dz = dz; q.x = x; q.slab = slab;
     q.Cin = cin; q.Cout = cout; q.M = cout; q.N = 9 * cin;
     q.H = h; q.W = w; q.logH = ilog2_exact(h); q.logW = ilog2_exact(w);
-    q.strips_x = wp.strips_x; q.chunks_y = wp.chunks_y; q.rows_per_chunk = wp.rows_per_chunk;
+    q.strips_x = wp.strips_x; q.chunks_y = wp.chunks_y; q.rows_per_chunk = wp.rows_per_chunk; q.reps = wp.reps;
     q.tiles_ci = wp.tiles_ci; q.tiles_mn = wp.tiles_m * wp.tiles_ci;
     const double ab = 4.0 * n * h * w * (double)cout, bb = 4.0 * n * h * w * (double)cin;
     RD_REQUIRE(ab < 4294967040.0 && bb < 4294967040.0, "rd_conv3x3_bwd_weight: operand beyond the 4 GiB descriptor range");
