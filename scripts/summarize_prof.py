@@ -15,14 +15,19 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 def sym(name):
     """rocprof kernel name -> the short symbol used by rd_prof / bench.py."""
-    m = re.match(r"void rd::igemm_nt_kernel<(\d+), (\d+), \d+, \d+, (\d+), (\d+)>", name)
+    m = re.match(r"void rd::igemm_nt(_split)?_kernel<(\d+), (\d+), \d+, \d+, (\d+), (\d+)>", name)
     if m:
-        return "igemm_nt<%s,%s,%s,%s>" % m.groups()
-    m = re.match(r"void rd::wgrad_tn_kernel<(\d+), (\d+), \d+, \d+, (\d+), (\d+)>", name)
+        return "igemm_nt%s<%s,%s,%s,%s>" % (m.group(1) or "", m.group(2), m.group(3), m.group(4), m.group(5))
+    m = re.match(r"void rd::wgrad_tn(_split)?_kernel<(\d+), (\d+), \d+, \d+, (\d+), (\d+)>", name)
     if m:
-        return "wgrad_tn<%s,%s,%s,%s>" % m.groups()
+        return "wgrad_tn%s<%s,%s,%s,%s>" % (m.group(1) or "", m.group(2), m.group(3), m.group(4), m.group(5))
+    m = re.match(r"void rd::conv3_halo_split_kernel<(\d+),", name)
+    if m:
+        return "conv3_halo_split<%s>" % m.group(1)
     m = re.match(r"(?:void )?rd::(\w+)", name)
-    return m.group(1) if m else name[:40]
+    if m:
+        return m.group(1)[:-7] if m.group(1) == "wgrad_strip_kernel" else m.group(1)
+    return name[:40]
 
 
 def per_dispatch(path):
@@ -55,11 +60,11 @@ write = mean_by_sym(per_dispatch(os.path.join(SRC, "pmc_write", "bench_counter_c
 l2 = per_dispatch(os.path.join(SRC, "pmc_l2", "bench_counter_collection.csv"))
 hit, miss = mean_by_sym(l2, "TCC_HIT_sum"), mean_by_sym(l2, "TCC_MISS_sum")
 sq = per_dispatch(os.path.join(SRC, "pmc_sq", "bench_counter_collection.csv"))
-gui, dur, mf = mean_by_sym(sq, "GRBM_GUI_ACTIVE"), mean_by_sym(sq, "dur"), mean_by_sym(sq, "SQ_INSTS_MFMA")
+gui, dur, mf = mean_by_sym(sq, "GRBM_GUI_ACTIVE"), mean_by_sym(sq, "dur"), mean_by_sym(sq, "SQ_VALU_MFMA_BUSY_CYCLES")
 out = {"note": "FETCH_SIZE/WRITE_SIZE are KiB counters; fetch is doubled (gfx950 rocprofv3 tallies 128-B requests at 64 B "
                "for 16-B/lane coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE is uncalibrated. "
                "GRBM_GUI_ACTIVE is summed over the 8 XCDs (clock = GUI/8/duration). MFMA pipe utilisation = "
-               "SQ_INSTS_MFMA*64 cycles / (GUI/8 * 1024 SIMDs).",
+               "SQ_VALU_MFMA_BUSY_CYCLES / (GUI/8 * 1024 SIMDs).",
        "kernels": {}}
 for k, st in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"]):
     e = dict(st)
@@ -72,7 +77,7 @@ for k, st in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"]):
     if k in gui and dur.get(k):
         e["clock_ghz_under_pmc"] = gui[k] / 8 / dur[k]
         if mf.get(k):
-            e["mfma_pipe_util"] = mf[k] * 64 / (gui[k] / 8 * 1024)
+            e["mfma_pipe_util"] = mf[k] / (gui[k] / 8 * 1024)
     out["kernels"][k] = e
 json.dump(out, open(os.path.join(DST, f"{TAG}_summary.json"), "w"), indent=1)
 print("wrote", DST, "top kernels:")
