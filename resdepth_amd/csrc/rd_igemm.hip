@@ -759,7 +759,9 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     int cfg;
     if (split) {
         // split kernel: two 128x128 blocks (57 KB LDS each) per CU; measured per layer with scripts/bench_layers.py
-        if (p.M < 128 || tiles_128x64 < 1024) cfg = 2;
+        const bool halo_shape = AMODE == A_CONV3 && EPI == EPI_STORE && p.W >= 16 && p.H >= 8;
+        if (halo_shape && tiles_128x64 >= 512) cfg = (p.N >= 128 && tiles_128x64 >= 1024) ? 0 : 1;   // 16x16 levels: 128x64 patches
+        else if (p.M < 128 || tiles_128x64 < 1024) cfg = 2;
         else if (EPI == EPI_CONVT && p.K <= 256) cfg = 2;   // scatter epilogue dominates: small tiles keep more in flight
         else if (p.N >= 128) cfg = 0;
         else cfg = 1;

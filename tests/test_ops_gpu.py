@@ -45,6 +45,12 @@ CONV_SHAPES = [  # n, h, w, cin, cout
     (8, 64, 64, 64, 64),      # 128x64 tiles
     (2, 16, 16, 128, 256),    # multi K-chunk per tap, 64x64 path
     (3, 32, 32, 20, 36),      # non-power-of-two channels
+    (16, 64, 64, 20, 36),     # halo-reuse kernel <64>: ragged output channels, 16-channel chunk tail
+    (16, 64, 64, 24, 132),    # halo-reuse kernel <128>: ragged N tile (132 of 256 columns), chunk tail
+    (2, 32, 32, 32, 132),     # strip weight gradient with a masked output-channel block (132 = 128 + 4)
+    (2, 16, 32, 160, 32),     # strip weight gradient, swapped roles (Cout < 128 <= Cin), non-square image
+    (1, 8, 16, 64, 128),      # smallest image the strip kernel takes (one 16-pixel strip, 8 rows)
+    (4, 16, 16, 128, 128),    # 16x16 level: several strips per block
 ]
 
 
