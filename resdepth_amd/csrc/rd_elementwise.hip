@@ -10,6 +10,8 @@
 // CQ = C/4) of one pixel row (pr = t / CQ); consecutive lanes read consecutive 16-byte chunks, so a
 // wave touches 1 KiB of contiguous HBM per load instruction.  Per-channel reductions accumulate in
 // fp64 and go through fixed-order block partials (deterministic, no float atomics).
+#include <stdlib.h>
+
 #include "rd_common.h"
 
 namespace rd {
@@ -96,11 +98,13 @@ struct RowPlan {
     long rows_per_block;
 };
 
-static bool plan_rows(long rows, int C, RowPlan* pl) {
+static bool plan_rows(long rows, int C, RowPlan* pl, int maxblocks = 0) {
+    static const int dflt = getenv("RD_ROWS_BLOCKS") ? atoi(getenv("RD_ROWS_BLOCKS")) : 512;   // tuning override
+    if (maxblocks <= 0) maxblocks = dflt;
     if (C % 4 != 0 || C / 4 > 256 || C <= 0) return false;
     pl->CQ = C / 4;
     pl->RP = 256 / pl->CQ;
-    long rpb = (rows + 511) / 512;          // <= 512 first-stage blocks; the row loops are unrolled for MLP
+    long rpb = (rows + maxblocks - 1) / maxblocks;   // <= 512 first-stage blocks by default; the row loops are unrolled for MLP
     const long minr = (long)pl->RP * 8;
     if (rpb < minr) rpb = minr;
     rpb = (rpb + pl->RP - 1) / pl->RP * pl->RP;
@@ -551,19 +555,28 @@ __global__ __launch_bounds__(256) void conv_last_dgrad_kernel(const float* __res
     const long r0 = (long)blockIdx.x * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > P) r1 = P;
-    for (long p = r0 + pr; p < r1; p += RP) {
-        const int xx = (int)(p % W), yy = (int)((p / W) % H);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // 32-bit pixel arithmetic (P < 2^31, checked by the launcher); four pixels per iteration keep four independent
+    // gather/FMA chains and four 16-byte stores in flight per thread
+    const unsigned uW = (unsigned)W, uH = (unsigned)H;
+    for (long pb = r0 + pr; pb < r1; pb += 4L * RP) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const int sy = yy - dy, sx = xx - dx;
-            float d = 0.f;
-            if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) d = dout[p - dy * W - dx];
+        for (int u = 0; u < 4; ++u) {
+            const long p = pb + (long)u * RP;
+            if (p >= r1) break;
+            const unsigned pu = (unsigned)p;
+            const int xx = (int)(pu % uW), yy = (int)((pu / uW) % uH);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = fmaf(d, wr[tap][k], acc[k]);
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const int sy = yy - dy, sx = xx - dx;
+                float d = 0.f;
+                if ((unsigned)sy < uH && (unsigned)sx < uW) d = dout[p - dy * W - dx];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = fmaf(d, wr[tap][k], acc[k]);
+            }
+            *reinterpret_cast<float4*>(ds + p * C + cq * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
-        *reinterpret_cast<float4*>(ds + p * C + cq * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
@@ -585,19 +598,33 @@ __global__ __launch_bounds__(256) void conv_last_wgrad_kernel(const float* __res
     long r1 = r0 + rows_per_block;
     if (r1 > P) r1 = P;
     if (active) {
-        for (long p = r0 + pr; p < r1; p += RP) {
-            const int xx = (int)(p % W), yy = (int)((p / W) % H);
-            const float4 s4 = *reinterpret_cast<const float4*>(s_in + p * C + cq * 4);
-            const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+        // four pixels per iteration: four 16-byte loads of s in flight per thread (the kernel streams 4*P*C bytes once;
+        // with one load per iteration it was latency-bound at ~2 TB/s); 32-bit pixel arithmetic
+        const unsigned uW = (unsigned)W, uH = (unsigned)H;
+        for (long pb = r0 + pr; pb < r1; pb += 4L * RP) {
+            float4 s4[4];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                const int sy = yy - dy, sx = xx - dx;
-                float d = 0.f;
-                if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) d = dout[p - dy * W - dx];
+            for (int u = 0; u < 4; ++u) {
+                const long p = pb + (long)u * RP;
+                s4[u] = p < r1 ? *reinterpret_cast<const float4*>(s_in + p * C + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[tap][k] = fmaf(sv[k], d, acc[tap][k]);
-                if (tap == 4 && cq == 0) accb += d;
+            for (int u = 0; u < 4; ++u) {
+                const long p = pb + (long)u * RP;
+                if (p >= r1) break;
+                const unsigned pu = (unsigned)p;
+                const int xx = (int)(pu % uW), yy = (int)((pu / uW) % uH);
+                const float sv[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w};
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                    const int sy = yy - dy, sx = xx - dx;
+                    float d = 0.f;
+                    if ((unsigned)sy < uH && (unsigned)sx < uW) d = dout[p - dy * W - dx];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[tap][k] = fmaf(sv[k], d, acc[tap][k]);
+                    if (tap == 4 && cq == 0) accb += d;
+                }
             }
         }
     }
@@ -1256,6 +1283,11 @@ int rd_conv3x3_first_bwd_weight(const float* x, const float* dz, float* dw, int 
 }
 
 // ---- last conv -------------------------------------------------------------------------------------
+static int last_blocks() {      // first-stage blocks of the last-conv streaming kernels (tuning override)
+    static const int v = getenv("RD_LAST_BLOCKS") ? atoi(getenv("RD_LAST_BLOCKS")) : 2048;
+    return v;
+}
+
 int rd_conv3x3_last_fwd(const float* s_in, const float* wt, const float* bias, const float* x_nchw, int x_channels,
                         float* out, int n, int h, int w, int c, rd_stream_t s) {
     RD_REQUIRE(s_in && wt && out, "rd_conv3x3_last_fwd: null pointer");
@@ -1271,7 +1303,8 @@ int rd_conv3x3_last_fwd(const float* s_in, const float* wt, const float* bias, c
 int rd_conv3x3_last_bwd_data(const float* dout, const float* wt, float* ds, int n, int h, int w, int c, rd_stream_t s) {
     RD_REQUIRE(dout && wt && ds, "rd_conv3x3_last_bwd_data: null pointer");
     RowPlan pl;
-    RD_REQUIRE(plan_rows((long)n * h * w, c, &pl), "rd_conv3x3_last_bwd_data: C must be a multiple of 4, <= 1024");
+    RD_REQUIRE(plan_rows((long)n * h * w, c, &pl, last_blocks()), "rd_conv3x3_last_bwd_data: C must be a multiple of 4, <= 1024");
+    RD_REQUIRE((long)n * h * w < (1L << 31), "rd_conv3x3_last_bwd_data: pixel count must be < 2^31");
     ProfScope ps((hipStream_t)s, "conv_last_dgrad", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(c + 1));
     hipLaunchKernelGGL(conv_last_dgrad_kernel, dim3(pl.nb), dim3(256), 0, (hipStream_t)s, dout, wt, ds, (long)n * h * w,
                        h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
@@ -1281,7 +1314,7 @@ int rd_conv3x3_last_bwd_data(const float* dout, const float* wt, float* ds, int 
 
 size_t rd_conv3x3_last_bwd_weight_ws_bytes(int n, int h, int w, int c) {
     RowPlan pl;
-    if (!plan_rows((long)n * h * w, c, &pl)) return 0;
+    if (!plan_rows((long)n * h * w, c, &pl, last_blocks())) return 0;
     return (size_t)pl.nb * (9 * c + 1) * sizeof(double);
 }
 
@@ -1289,7 +1322,8 @@ int rd_conv3x3_last_bwd_weight(const float* s_in, const float* dout, float* dw, 
                                int c, void* ws, size_t ws_bytes, rd_stream_t s) {
     RD_REQUIRE(s_in && dout && dw, "rd_conv3x3_last_bwd_weight: null pointer");
     RowPlan pl;
-    RD_REQUIRE(plan_rows((long)n * h * w, c, &pl), "rd_conv3x3_last_bwd_weight: C must be a multiple of 4, <= 1024");
+    RD_REQUIRE(plan_rows((long)n * h * w, c, &pl, last_blocks()), "rd_conv3x3_last_bwd_weight: C must be a multiple of 4, <= 1024");
+    RD_REQUIRE((long)n * h * w < (1L << 31), "rd_conv3x3_last_bwd_weight: pixel count must be < 2^31");
     const size_t need = (size_t)pl.nb * (9 * c + 1) * sizeof(double);
     if (!ws || ws_bytes < need) {
         set_error("rd_conv3x3_last_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
