@@ -232,14 +232,16 @@ static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
     pl.tiles_ci = cin / 32;
     const long base = (long)pl.tiles_m * pl.tiles_ci * n * pl.strips_x;
     int rows = h;
-    while (base * (h / rows) < 768 && rows > 32) rows >>= 1;
+    static const int minb = getenv("RD_WG_MINBLOCKS") ? atoi(getenv("RD_WG_MINBLOCKS")) : 768;   // tuning override
+    while (base * (h / rows) < minb && rows > 32) rows >>= 1;
     pl.rows_per_chunk = rows;
     pl.chunks_y = h / rows;
     // every split costs one [Cout][9*Cin] slab of HBM traffic (written here, read by the reduction): with more than
     // ~2048 blocks, give each block several strips instead
     const long strips = (long)n * pl.strips_x * pl.chunks_y;
+    static const int target = getenv("RD_WG_BLOCKS") ? atoi(getenv("RD_WG_BLOCKS")) : 512;   // tuning override; measured: 512 (2 resident blocks/CU, one round) beats 1024/2048
     int reps = 1;
-    while (base * pl.chunks_y / (2 * reps) >= 1024 && strips % (2 * reps) == 0) reps *= 2;
+    while (base * pl.chunks_y / (2 * reps) >= target && strips % (2 * reps) == 0) reps *= 2;
     pl.reps = reps;
     pl.splits = (int)(strips / reps);
     return pl;

@@ -37,6 +37,15 @@ class _MaskedL1(torch.autograd.Function):
         return dyp, None, None, None, None, None
 
 
+def _to_device_f32(v, dev):
+    """Host values go through a pinned staging buffer and an ASYNCHRONOUS copy: a pageable `.to(device)` would block the
+    host until everything already enqueued on the stream (the whole forward) has finished."""
+    t = torch.as_tensor(v).flatten().to(torch.float32)
+    if not t.is_cuda:
+        t = t.pin_memory().to(dev, non_blocking=True)
+    return t.contiguous()
+
+
 def _prep(y_pred, y, loss_mask, mean, std):
     dev = y_pred.device
     if not y_pred.is_cuda:
@@ -48,8 +57,7 @@ def _prep(y_pred, y, loss_mask, mean, std):
         m = (m != 0).to(torch.uint8) if m.dtype != torch.bool else m.view(torch.uint8)
     # mean/std arrive as CPU tensors in the reference (batch['dsm_mean'|'dsm_std'], lib/Trainer.py:174-175) and
     # are converted with .tolist() -> python floats -> fp32 scalars
-    mean32 = torch.as_tensor(mean).flatten().to(torch.float32).to(dev).contiguous()
-    std32 = torch.as_tensor(std).flatten().to(torch.float32).to(dev).contiguous()
+    mean32, std32 = _to_device_f32(mean, dev), _to_device_f32(std, dev)
     if mean32.numel() != n or std32.numel() != n:
         raise ValueError("dsm_mean / dsm_std must hold one value per sample")
     return y_pred.contiguous(), y, m.contiguous(), mean32, std32
