@@ -57,6 +57,19 @@ def _block(cin, cout, act, do_bn):
     return nn.Sequential(_conv3x3(cin, cout, True), _make_activation(act))
 
 
+class _Packed:
+    """Packed weight operands per layer + the event that marks each one ready (see UNet._packed)."""
+
+    def __init__(self):
+        self.items, self.events = {}, {}
+
+    def get(self, key):
+        ev = self.events.pop(key, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        return self.items[key]
+
+
 class SkipConnection(nn.Module):
     """Parameter-free marker kept for module-tree parity (lib/UNet.py:96-101); the ADD itself is fused
     into the transposed-convolution epilogue."""
@@ -176,23 +189,42 @@ class UNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _packed(self):
-        """GEMM-layout copies of the conv / convT weights, rebuilt whenever a parameter changed."""
+        """GEMM-layout copies of the conv / convT weights, rebuilt whenever a parameter changed.  The re-packing is a
+        string of small HBM/latency-bound kernels, so it runs on the second HIP stream in the order the forward uses
+        the layers and every layer carries an event the first consumer waits on: the first convolutions (MFMA-bound)
+        overlap with the packing of the later layers."""
         params = self._param_list()
         key = (self._flat_param.data_ptr(), _lib.param_generation(self._flat_param.data_ptr()),
                tuple(p._version for p in params))
         if self._pack_key == key and self._pack_cache is not None:
             return self._pack_cache
         d = self.depth
-        pk = {"enc": [], "dec_t": [], "dec_c": []}
-        for i in range(1, d):
-            pk["enc"].append(ops.pack_conv3x3_weight(self.encoder[i][0][0].weight))
-        pk["bott"] = ops.pack_conv3x3_weight(self.bottleneck[0].weight)
-        for i in range(d):
-            up = self._up_of(i)
-            pk["dec_t"].append(ops.pack_conv1x1_weight(up.weight) if self.up_mode == "bilinear"
-                               else ops.pack_convt2x2_weight(up.weight))
-            if i < d - 1:
-                pk["dec_c"].append(ops.pack_conv3x3_weight(self.decoder[i][1][0].weight))
+        pk = _Packed()
+        main = torch.cuda.current_stream()
+        dev = self._flat_param.device
+        if self._side_stream is None or self._side_stream.device != dev:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        side = self._side_stream
+        side.wait_stream(main)                   # the parameters' last writer (optimizer step) ran on the main stream
+
+        def put(k, tensors):
+            for t_ in tensors:
+                if t_ is not None:
+                    t_.record_stream(main)       # allocated under the side stream, consumed on the main stream
+            ev = torch.cuda.Event()
+            ev.record(side)
+            pk.items[k], pk.events[k] = tensors, ev
+
+        with torch.cuda.stream(side):
+            for i in range(1, d):
+                put(("enc", i - 1), ops.pack_conv3x3_weight(self.encoder[i][0][0].weight))
+            put("bott", ops.pack_conv3x3_weight(self.bottleneck[0].weight))
+            for i in range(d):
+                up = self._up_of(i)
+                put(("dec_t", i), ops.pack_conv1x1_weight(up.weight) if self.up_mode == "bilinear"
+                    else ops.pack_convt2x2_weight(up.weight))
+                if i < d - 1:
+                    put(("dec_c", i), ops.pack_conv3x3_weight(self.decoder[i][1][0].weight))
         self._pack_cache, self._pack_key = pk, key
         return pk
 
@@ -276,7 +308,7 @@ class UNet(nn.Module):
                 z, sums = ops.conv3x3_first_fwd_stats(x, blk[0].weight) if (training and self.do_BN) else \
                     (ops.conv3x3_first_fwd(x, blk[0].weight), None)
             else:
-                z, sums = conv_stats(cur, pk["enc"][i - 1][0])
+                z, sums = conv_stats(cur, pk.get(("enc", i - 1))[0])
             bn, cbias = self._norm_of(blk)
             a, p, idx, mean, invstd, count = self._bn_forward(z, bn, self._act_of(blk, self.act_fn_encoder), True, training,
                                                               sums, cbias)
@@ -286,7 +318,7 @@ class UNet(nn.Module):
                 if keep_skips:               # tests only: the backward never needs the skip activations
                     S["enc"][-1]["a"] = a
             cur = p
-        zb, sums = conv_stats(cur, pk["bott"][0])
+        zb, sums = conv_stats(cur, pk.get("bott")[0])
         bn, cbias = self._norm_of(self.bottleneck)
         ab, _, _, mean, invstd, count = self._bn_forward(zb, bn, self._act_of(self.bottleneck, self.act_fn_bottleneck),
                                                          False, training, sums, cbias)
@@ -294,12 +326,12 @@ class UNet(nn.Module):
             S["bott"] = {"z": zb, "mean": mean, "invstd": invstd, "count": count, "a": ab}
         cur = ab
         for i in range(d):
-            s = self._up_forward(cur, pk["dec_t"][i], self._up_of(i), skips[d - 1 - i])
+            s = self._up_forward(cur, pk.get(("dec_t", i)), self._up_of(i), skips[d - 1 - i])
             skips[d - 1 - i] = None          # the skip tensor is not needed by the backward pass
             rec = {"s": s}
             if i < d - 1:
                 blk = self.decoder[i][1]
-                zd, sums = conv_stats(s, pk["dec_c"][i][0])
+                zd, sums = conv_stats(s, pk.get(("dec_c", i))[0])
                 bn, cbias = self._norm_of(blk)
                 ad, _, _, mean, invstd, count = self._bn_forward(zd, bn, self._act_of(blk, self.act_fn_decoder), False,
                                                                  training, sums, cbias)
@@ -469,21 +501,21 @@ class UNet(nn.Module):
             if self.up_mode == "bilinear":
                 dt = ops.upsample2x_bwd(g)            # adjoint of the interpolation; then the coarse-grid conv1x1
                 wgrad(ops.conv1x1_bwd_weight, (dt,), src["a"], dt, gv(up.weight), ready=(up.weight,))
-                dprev = ops.conv1x1_bwd_data(dt, pk["dec_t"][i][1])
+                dprev = ops.conv1x1_bwd_data(dt, pk.get(("dec_t", i))[1])
             else:
                 wgrad(ops.convt2x2_bwd_weight, (g,), src["a"], g, gv(up.weight), ready=(up.weight,))
-                dprev = ops.convt2x2_bwd_data(g, pk["dec_t"][i][1])
+                dprev = ops.convt2x2_bwd_data(g, pk.get(("dec_t", i))[1])
             skipgrad[d - 1 - i] = g       # gradient wrt the encoder skip a_{d-1-i} (SkipConnection is an ADD)
             if i > 0:
                 blk = self.decoder[i - 1][1]
                 dz = bn_backward(src, blk, self.act_fn_decoder, dprev, None, None)
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["dec"][i - 1]["s"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
-                g = ops.conv3x3_bwd_data(dz, pk["dec_c"][i - 1][1])
+                g = ops.conv3x3_bwd_data(dz, pk.get(("dec_c", i - 1))[1])
             else:
                 dz = bn_backward(src, self.bottleneck, self.act_fn_bottleneck, dprev, None, None)
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][d - 1]["p"], dz, gv(self.bottleneck[0].weight),
                       ready=(self.bottleneck[0].weight,))
-                gp = ops.conv3x3_bwd_data(dz, pk["bott"][1])
+                gp = ops.conv3x3_bwd_data(dz, pk.get("bott")[1])
         for i in reversed(range(d)):
             e = S["enc"][i]
             blk = self.encoder[i][0]
@@ -495,7 +527,7 @@ class UNet(nn.Module):
             skipgrad[i] = None
             if i > 0:
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][i - 1]["p"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
-                gp = ops.conv3x3_bwd_data(dz, pk["enc"][i - 1][1])
+                gp = ops.conv3x3_bwd_data(dz, pk.get(("enc", i - 1))[1])
             else:
                 wgrad(ops.conv3x3_first_bwd_weight, (dz,), S["x"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
         if side is not None:
