@@ -101,6 +101,13 @@ int rd_conv3x3_last_bwd_weight(const float* s_in, const float* dout, float* dw_o
  * out[N,2H,2W,Cout] = convT(x[N,H,W,Cin]) + bias + skip   (skip nullable)               */
 int rd_convt2x2_fwd(const float* x, const float* wtf, const float* bias, const float* skip, float* out, int n, int h,
                     int w, int cin, int cout, rd_stream_t s);
+/* Same, but the skip operand is given as the encoder level's PRE-BatchNorm conv output z_skip[N,2H,2W,Cout] plus that
+ * level's BN/activation parameters; the epilogue recomputes skip = act(gamma*(z-mean)*invstd + beta) (identical
+ * arithmetic to rd_bn_act_pool_fwd), so the encoder never has to write its full-resolution activation
+ * (rd_bn_act_pool_fwd with a == NULL).  slope / slope_dev as in rd_bn_act_pool_fwd. */
+int rd_convt2x2_fwd_bnskip(const float* x, const float* wtf, const float* bias, const float* z_skip, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, float slope, const float* slope_dev,
+                           float* out, int n, int h, int w, int cin, int cout, rd_stream_t s);
 /* dx[N,H,W,Cin] from dout[N,2H,2W,Cout] */
 int rd_convt2x2_bwd_data(const float* dout, const float* wtd, float* dx, int n, int h, int w, int cin, int cout,
                          rd_stream_t s);
@@ -143,7 +150,8 @@ int rd_bn_stats_finalize(const double* sums, double count, float eps, float mome
 int rd_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* invstd, int c,
                      rd_stream_t s);
 
-/* a = act(gamma*(z-mean)*invstd + beta), act = LeakyReLU(slope) (slope 0 = ReLU, lib/UNet.py:27-33);
+/* a = act(gamma*(z-mean)*invstd + beta), act = LeakyReLU(slope) (slope 0 = ReLU, lib/UNet.py:27-33); with pooling
+ * `a` may be NULL (the full-resolution activation is then not written, see rd_convt2x2_fwd_bnskip);
  * if pooled != NULL also the 2x2/2 max-pool of a (lib/UNet.py:161,167): pooled[N,H/2,W/2,C] and
  * idx (uint8, window position 0..3 = dy*2+dx; first maximum in row-major order, NaN wins). */
 int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "rd_conv3x3_last_bwd_weight_ws_bytes": (SZ, [I, I, I, I]),
     "rd_conv3x3_last_bwd_weight": (I, [P, P, P, P, I, I, I, I, P, SZ, P]),
     "rd_convt2x2_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "rd_convt2x2_fwd_bnskip": (I, [P, P, P, P, P, P, P, P, F, P, P, I, I, I, I, I, P]),
     "rd_convt2x2_bwd_data": (I, [P, P, P, I, I, I, I, I, P]),
     "rd_convt2x2_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_convt2x2_bwd_weight": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
                 y[1] = act_fn(fmaf(x.y, sc[1], sh[1]), slope);
                 y[2] = act_fn(fmaf(x.z, sc[2], sh[2]), slope);
                 y[3] = act_fn(fmaf(x.w, sc[3], sh[3]), slope);
-                *reinterpret_cast<float4*>(a + pix * C + cq * 4) = make_float4(y[0], y[1], y[2], y[3]);
+                if (a) *reinterpret_cast<float4*>(a + pix * C + cq * 4) = make_float4(y[0], y[1], y[2], y[3]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     // torch max_pool2d: (val > maxval) || isnan(val) replaces -> first max wins, NaN wins
@@ -1093,14 +1093,14 @@ int rd_bn_eval_stats(const float* running_mean, const float* running_var, float 
 int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                        float slope, const float* slope_dev, float* a, float* pooled, uint8_t* idx, int n, int h, int w,
                        int c, rd_stream_t s) {
-    RD_REQUIRE(z && mean && invstd && gamma && beta && a, "rd_bn_act_pool_fwd: null pointer");
+    RD_REQUIRE(z && mean && invstd && gamma && beta && (a || pooled), "rd_bn_act_pool_fwd: null pointer");
     RD_REQUIRE(c % 4 == 0 && c > 0, "rd_bn_act_pool_fwd: C must be a multiple of 4 (got %d)", c);
     const int CQ = c / 4;
     const long pixels = (long)n * h * w;
     if (pooled) {
         RD_REQUIRE(idx && h % 2 == 0 && w % 2 == 0, "rd_bn_act_pool_fwd: pooling needs idx and even H, W");
         const long rows = pixels / 4;
-        ProfScope ps((hipStream_t)s, "bn_act_pool_fwd", 0, 4.0 * pixels * c * 2.25 + 0.25 * pixels * c);
+        ProfScope ps((hipStream_t)s, "bn_act_pool_fwd", 0, 4.0 * pixels * c * (a ? 2.25 : 1.25) + 0.25 * pixels * c);
         hipLaunchKernelGGL((bn_act_pool_fwd_kernel<true>), dim3(grid_cap((rows * CQ + 255) / 256, 8192)), dim3(256), 0,
                            (hipStream_t)s, z, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, idx, rows, h, w, c, CQ);
     } else {

@@ -38,6 +38,15 @@ struct NtParams {
     float* C;
     const float* bias;
     const float* skip;
+    // EPI_CONVT, optional: `skip` holds the PRE-BatchNorm conv output z of the encoder level and the skip value is
+    // recomputed here as act(gamma*(z-mean)*invstd + beta) -- the encoder then never writes its full-resolution
+    // activation (same arithmetic as bn_act_pool_fwd_kernel, bit-identical values)
+    const float* sk_mean;
+    const float* sk_invstd;
+    const float* sk_gamma;
+    const float* sk_beta;
+    const float* sk_slope_dev;
+    float sk_slope;
     int M, N, K;
     int Cin;  // channels per tap (A row length)
     int H, W, logH, logW;
@@ -50,6 +59,8 @@ struct NtParams {
     float* stats;  // EPI_STORE only, nullable: per-(tile_m) column sums / sums of squares [tiles_m][2][N] (BN statistics)
 };
 
+
+__device__ __forceinline__ float skip_act(float y, float slope) { return y > 0.f ? y : y * slope; }
 
 // ---- epilogue shared by the NT kernels.  D[i][j]: lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5) (the C/D
 // map is the same for the f32 and the bf16 MFMA shapes).
@@ -127,7 +138,19 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
                     }
                     if (p.skip) {
-                        const float4 s4 = *reinterpret_cast<const float4*>(p.skip + o);
+                        float4 s4 = *reinterpret_cast<const float4*>(p.skip + o);
+                        if (p.sk_mean) {
+                            const float4 mu = *reinterpret_cast<const float4*>(p.sk_mean + co);
+                            const float4 is = *reinterpret_cast<const float4*>(p.sk_invstd + co);
+                            const float4 ga = *reinterpret_cast<const float4*>(p.sk_gamma + co);
+                            const float4 be = *reinterpret_cast<const float4*>(p.sk_beta + co);
+                            const float sl = p.sk_slope_dev ? p.sk_slope_dev[0] : p.sk_slope;
+                            const float sc0 = is.x * ga.x, sc1 = is.y * ga.y, sc2 = is.z * ga.z, sc3 = is.w * ga.w;
+                            s4.x = skip_act(fmaf(s4.x, sc0, be.x - mu.x * sc0), sl);
+                            s4.y = skip_act(fmaf(s4.y, sc1, be.y - mu.y * sc1), sl);
+                            s4.z = skip_act(fmaf(s4.z, sc2, be.z - mu.z * sc2), sl);
+                            s4.w = skip_act(fmaf(s4.w, sc3, be.w - mu.w * sc3), sl);
+                        }
                         v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w;
                     }
                     *reinterpret_cast<float4*>(p.C + o) = v;
@@ -147,7 +170,15 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                     const long opix = ((long)img * (2 * H) + 2 * ii + (ab >> 1)) * (2 * W) + 2 * jj + (ab & 1);
                     const long o = opix * p.Cout + co;
                     if (p.bias) v += p.bias[co];
-                    if (p.skip) v = p.skip[o] + v;
+                    if (p.skip) {
+                        float sv = p.skip[o];
+                        if (p.sk_mean) {
+                            const float sc0 = p.sk_invstd[co] * p.sk_gamma[co];
+                            sv = skip_act(fmaf(sv, sc0, p.sk_beta[co] - p.sk_mean[co] * sc0),
+                                          p.sk_slope_dev ? p.sk_slope_dev[0] : p.sk_slope);
+                        }
+                        v = sv + v;
+                    }
                     p.C[o] = v;
                 }
             }
@@ -1508,6 +1539,20 @@ int rd_convt2x2_fwd(const float* x, const float* wtf, const float* bias, const f
     RD_REQUIRE(cin % 4 == 0, "rd_convt2x2_fwd: Cin must be a multiple of 4 (got %d)", cin);
     NtParams p = {};
     p.A = x; p.B = wtf; p.C = out; p.bias = bias; p.skip = skip;
+    p.M = n * h * w; p.N = 4 * cout; p.K = cin; p.Cin = cin; p.Cout = cout;
+    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    return launch_nt<A_PLAIN, EPI_CONVT>(p, (hipStream_t)s, "convt2x2_fwd");
+}
+
+int rd_convt2x2_fwd_bnskip(const float* x, const float* wtf, const float* bias, const float* z_skip, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, float slope, const float* slope_dev,
+                           float* out, int n, int h, int w, int cin, int cout, rd_stream_t s) {
+    if (int e = check_conv_args(n, h, w, cin, cout)) return e;
+    RD_REQUIRE(x && wtf && out && z_skip && mean && invstd && gamma && beta, "rd_convt2x2_fwd_bnskip: null pointer");
+    RD_REQUIRE(cin % 4 == 0, "rd_convt2x2_fwd_bnskip: Cin must be a multiple of 4 (got %d)", cin);
+    NtParams p = {};
+    p.A = x; p.B = wtf; p.C = out; p.bias = bias; p.skip = z_skip;
+    p.sk_mean = mean; p.sk_invstd = invstd; p.sk_gamma = gamma; p.sk_beta = beta; p.sk_slope = slope; p.sk_slope_dev = slope_dev;
     p.M = n * h * w; p.N = 4 * cout; p.K = cin; p.Cin = cin; p.Cout = cout;
     p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
     return launch_nt<A_PLAIN, EPI_CONVT>(p, (hipStream_t)s, "convt2x2_fwd");

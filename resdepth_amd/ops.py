@@ -156,6 +156,18 @@ def convt2x2_fwd(x, wtf, bias, skip):
     return out
 
 
+def convt2x2_fwd_bnskip(x, wtf, bias, z_skip, mean, invstd, gamma, beta, slope, slope_dev=None):
+    """convT + bias + skip where skip = act(BN(z_skip)) is recomputed in the epilogue (the encoder level's activation is
+    never materialised at full resolution)."""
+    n, h, w, cin = x.shape
+    cout = wtf.shape[0] // 4
+    out = torch.empty(n, 2 * h, 2 * w, cout, device=x.device, dtype=torch.float32)
+    check(load().rd_convt2x2_fwd_bnskip(ptr(x), ptr(wtf), ptr(bias.detach() if bias is not None else None), ptr(z_skip),
+                                        ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()), float(slope),
+                                        ptr(slope_dev), ptr(out), n, h, w, cin, cout, stream_ptr()), "convt2x2_fwd_bnskip")
+    return out
+
+
 def convt2x2_bwd_data(dout, wtd):
     n, h2, w2, cout = dout.shape
     cin = wtd.shape[0]
@@ -272,10 +284,11 @@ def bn_eval_stats(running_mean, running_var, eps=BN_EPS):
     return mean, invstd
 
 
-def bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, pool, slope_dev=None):
-    """slope_dev: optional 1-element fp32 device tensor (nn.PReLU().weight) overriding `slope`."""
+def bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, pool, slope_dev=None, want_a=True):
+    """slope_dev: optional 1-element fp32 device tensor (nn.PReLU().weight) overriding `slope`.
+    want_a=False (pooling only): the full-resolution activation is not written (returned as None)."""
     n, h, w, c = z.shape
-    a = torch.empty_like(z)
+    a = torch.empty_like(z) if (want_a or not pool) else None
     pooled = idx = None
     if pool:
         pooled = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.float32)

@@ -237,6 +237,9 @@ class UNet(nn.Module):
     def _up_forward(self, cur, packed, up, skip):
         if self.up_mode == "bilinear":
             return ops.upsample2x_add_fwd(ops.conv1x1_fwd(cur, packed[0]), up.bias, skip)
+        if isinstance(skip, dict):           # skip = act(BN(z)) recomputed inside the transposed-conv epilogue
+            return ops.convt2x2_fwd_bnskip(cur, packed[0], up.bias, skip["z"], skip["mean"], skip["invstd"], skip["gamma"],
+                                           skip["beta"], skip["slope"], skip["slope_dev"])
         return ops.convt2x2_fwd(cur, packed[0], up.bias, skip)
 
     # ------------------------------------------------------------------------------------------
@@ -267,13 +270,18 @@ class UNet(nn.Module):
             return 0.0, slope.detach()
         return slope, None
 
-    def _bn_forward(self, z, bn, slope, pool, training, sums=None, bias=None):
+    def _bn_forward(self, z, bn, slope, pool, training, sums=None, bias=None, want_a=True):
+        """-> (a | skip descriptor, pooled, idx, mean, invstd, count).  want_a=False (pooled levels): the full-resolution
+        activation is not written; the first return value is then the descriptor the transposed convolution needs to
+        recompute it from z in its epilogue."""
         c = z.shape[-1]
         slope, sdev = self._split_slope(slope)
         if bn is None:
             # do_BN=False: activation(conv + bias) == the fused BN-apply kernel with mean 0, invstd 1, gamma 1, beta = bias
             mean, invstd = self._const(c, 0.0, z.device), self._const(c, 1.0, z.device)
-            a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, invstd, bias, slope, pool, sdev)
+            a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, invstd, bias, slope, pool, sdev, want_a=want_a)
+            if a is None:
+                a = {"z": z, "mean": mean, "invstd": invstd, "gamma": invstd, "beta": bias, "slope": slope, "slope_dev": sdev}
             return a, p, idx, mean, invstd, 1
         if training:
             if sums is None:
@@ -286,7 +294,9 @@ class UNet(nn.Module):
         else:
             mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, eps=bn.eps)
             count = z.numel() // c
-        a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, bn.weight, bn.bias, slope, pool, sdev)
+        a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, bn.weight, bn.bias, slope, pool, sdev, want_a=want_a)
+        if a is None:
+            a = {"z": z, "mean": mean, "invstd": invstd, "gamma": bn.weight, "beta": bn.bias, "slope": slope, "slope_dev": sdev}
         return a, p, idx, mean, invstd, count
 
     def _engine_forward(self, x, training: bool, save: bool, keep_skips: bool = False):
@@ -310,8 +320,10 @@ class UNet(nn.Module):
             else:
                 z, sums = conv_stats(cur, pk.get(("enc", i - 1))[0])
             bn, cbias = self._norm_of(blk)
+            # transposed up-mode: the skip activation is recomputed from z in the decoder's convT epilogue, not stored
+            lazy_skip = self.up_mode == "transpose" and not keep_skips
             a, p, idx, mean, invstd, count = self._bn_forward(z, bn, self._act_of(blk, self.act_fn_encoder), True, training,
-                                                              sums, cbias)
+                                                              sums, cbias, want_a=not lazy_skip)
             skips.append(a)
             if save:
                 S["enc"].append({"z": z, "idx": idx, "mean": mean, "invstd": invstd, "count": count, "p": p})
