@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __
 }
 
 // ---- last convolution C -> 1 (+bias, + x0) ----------------------------------------------------
-constexpr int LT_H = 8, LT_W = 32, LT_CH = 16, LT_STRIDE = LT_CH + 4;
+constexpr int LT_H = 8, LT_W = 32, LT_CH = 16, LT_STRIDE = LT_CH + 4;   // (32-channel chunks measured slower: 0.27 vs 0.21 ms)
 
 __global__ __launch_bounds__(256) void conv_last_fwd_kernel(const float* __restrict__ s_in, const float* __restrict__ w,
                                                             const float* __restrict__ bias,
