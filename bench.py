@@ -64,7 +64,10 @@ def infer_main(args, world, rank, dev):
     from resdepth_amd import UNet, SyntheticRasterTiles, predict_linear_blend, _lib
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # no device_id=: with the eager communicator initialisation it triggers, every step of this process ran 1.5-2 ms
+        # slower on the MI355X boxes (with or without collectives in flight); torch.cuda.set_device above already pins
+        # the rank to its GPU for the lazily created communicator
+        dist.init_process_group("nccl")
     torch.manual_seed(0)
     model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).eval()
     ds = SyntheticRasterTiles(args.raster, args.raster, 3, tile_size=256, seed=1, shard=(rank, world))
@@ -166,7 +169,10 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:          # --force-dist without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        # no device_id=: with the eager communicator initialisation it triggers, every step of this process ran 1.5-2 ms
+        # slower on the MI355X boxes (with or without collectives in flight); torch.cuda.set_device above already pins
+        # the rank to its GPU for the lazily created communicator
+        dist.init_process_group("nccl")
     torch.manual_seed(0)
     wl = {"S": dict(c=3, t=256, depth=5, flop=FLOP_PER_TILE, name="config_ResDepth-stereo (cfg-S): 3-ch 256x256 tiles, depth-5 U-Net"),
           "M": dict(c=2, t=512, depth=6, flop=241.66e9, name="config_ResDepth-mono (cfg-M): 2-ch 512x512 tiles, depth-6 U-Net")}[args.workload]
