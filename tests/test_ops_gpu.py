@@ -72,6 +72,57 @@ def test_conv3x3_fwd_dgrad_wgrad(n, h, w, cin, cout):
     close(dw.cpu(), wt.grad, name="wgrad")
 
 
+FULL_LAYERS = [  # cfg-S layers at the BASELINE batch (N=32): name, h, cin, cout -- no CPU reference at this size
+    ("enc1", 128, 64, 128), ("enc3", 32, 256, 512), ("dec2", 64, 256, 128), ("dec3", 128, 128, 64), ("enc4", 16, 512, 512)]
+
+
+@pytest.mark.parametrize("name,h,cin,cout", FULL_LAYERS)
+def test_conv3x3_adjoint_identities_and_linearity_at_full_size(name, h, cin, cout):
+    """Size-independent properties at BASELINE.json's full layer sizes (halo / strip kernels, several strips per block):
+    <conv(x), g> = <x, dgrad(g)> = <w, wgrad(x, g)>  (forward, data gradient and weight gradient are mutually adjoint)
+    and conv(a*x1 + b*x2) = a*conv(x1) + b*conv(x2).  Dot products in fp64 on the device."""
+    from resdepth_amd import ops
+    n = 32
+    gen = torch.Generator(device=dev()).manual_seed(h * 7 + cin)
+    x = torch.randn(n, h, h, cin, device=dev(), generator=gen)
+    x2 = torch.randn(n, h, h, cin, device=dev(), generator=gen)
+    g = torch.randn(n, h, h, cout, device=dev(), generator=gen)
+    w = torch.randn(cout, cin, 3, 3, device=dev(), generator=gen) / (3 * cin ** 0.5)
+    wf, wd = ops.pack_conv3x3_weight(w)
+    z = ops.conv3x3_fwd(x, wf)
+    dx = ops.conv3x3_bwd_data(g, wd)
+    dw = ops.conv3x3_bwd_weight(x, g)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    ref = dot(z, g)
+    scale = float(z.double().norm() * g.double().norm())
+    assert abs(dot(x, dx) - ref) <= 1e-5 * scale, (name, ref, dot(x, dx))
+    assert abs(dot(w, dw) - ref) <= 1e-5 * scale, (name, ref, dot(w, dw))
+    z12 = ops.conv3x3_fwd(0.75 * x - 1.5 * x2, wf)
+    z2 = ops.conv3x3_fwd(x2, wf)
+    lin = 0.75 * z - 1.5 * z2
+    assert rel_l2(z12, lin) <= 2e-6, (name, rel_l2(z12, lin))
+
+
+@pytest.mark.parametrize("h,c", [(128, 64), (64, 128), (32, 256), (16, 512)])
+def test_convt2x2_adjoint_identities_at_full_size(h, c):
+    """<convT(x) , g> = <x, dgrad(g)> = <w, wgrad(x, g)> at the cfg-S decoder sizes, batch 32 (bias and skip off)."""
+    from resdepth_amd import ops
+    n = 32
+    gen = torch.Generator(device=dev()).manual_seed(h + c)
+    x = torch.randn(n, h, h, c, device=dev(), generator=gen)
+    g = torch.randn(n, 2 * h, 2 * h, c, device=dev(), generator=gen)
+    w = torch.randn(c, c, 2, 2, device=dev(), generator=gen) / (2 * c ** 0.5)
+    wtf, wtd = ops.pack_convt2x2_weight(w)
+    out = ops.convt2x2_fwd(x, wtf, None, None)
+    dx = ops.convt2x2_bwd_data(g, wtd)
+    dw = ops.convt2x2_bwd_weight(x, g)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    ref = dot(out, g)
+    scale = float(out.double().norm() * g.double().norm())
+    assert abs(dot(x, dx) - ref) <= 1e-5 * scale, (ref, dot(x, dx))
+    assert abs(dot(w, dw) - ref) <= 1e-5 * scale, (ref, dot(w, dw))
+
+
 CONVT_SHAPES = [(2, 4, 8, 8, 12), (1, 2, 2, 4, 4), (4, 16, 16, 128, 128), (8, 32, 32, 64, 64), (2, 8, 8, 256, 256)]
 
 
