@@ -1,23 +1,27 @@
-// Implicit-GEMM convolution kernels on the exact-f32 matrix cores of gfx950
-// (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak).
+// Implicit-GEMM convolution kernels on the gfx950 matrix cores.
 //
-//  NT kernel  C[M][N] = A[M][K] * B[N][K]^T      M = pixels, K = taps*Cin (im2col on the fly)
+//  NT form  C[M][N] = A[M][K] * B[N][K]^T      M = pixels, K = taps*Cin (im2col on the fly)
 //      conv3x3 forward        A = x   (3x3 taps, zero padding),   B = wf[co][tap][ci]
 //      conv3x3 data-gradient  A = dz  (3x3 taps),                 B = wd[ci][tap][co] (flipped)
 //      convT2x2 forward       A = x   (1 tap),                    B = wtf[(ab,co)][ci], scatter epilogue
 //      convT2x2 data-gradient A = dout(4 taps on the fine grid),  B = wtd[ci][(ab,co)]
-//  TN kernel  C[M][N] = sum_p A[p][M] * B[p][N]   reduction over pixels, split-K slabs
+//      conv1x1 (bilinear up-mode)  A = x (1 tap), plain epilogue
+//  TN form  C[M][N] = sum_p A[p][M] * B[p][N]   reduction over pixels, split-K slabs
 //      conv3x3 weight-gradient   A = dz[p][co],         B = x[p+tap][ci]   -> [co][(tap,ci)]
 //      convT2x2 weight-gradient  A = dout[fine(p,ab)][co], B = x[p][ci]    -> [(ab,co)][ci]
 //
 // Replaces the ATen/cuDNN kernels behind nn.Conv2d / nn.ConvTranspose2d forward and autograd
 // (reference call sites lib/UNet.py:4-5, 21, 44, 63-65, 85, 181).
 //
-// Tiling: 256 threads = 4 waves (one per SIMD), block tile BMxBN, K-step 32, each wave a
-// (BM/WM)x(BN/WN) sub-tile of 32x32 MFMA accumulators.  Operands are staged global -> VGPR
-// (prefetched one K-step ahead) -> LDS.  NT LDS rows are padded to 36 floats so the b128
-// fragment reads are bank-conflict free (MI355X guide, LDS table); the MFMA k-pairing is
-// permuted so that one b128 read feeds four consecutive MFMA k-steps.
+// Two arithmetic modes, same fp32 results to rounding:
+//   * split-bf16 (default): operands split exactly into three bf16 terms, six products per multiply on
+//     v_mfma_f32_32x32x16_bf16 -- igemm_nt_split_kernel (generic NT), conv3_halo_split_kernel (3x3 forward / data
+//     gradient with halo reuse), wgrad_tn_split_kernel (generic TN); the 3x3 weight gradient lives in
+//     rd_wgrad_strip.hip.  Weights are pre-split by the pack kernels into MFMA-fragment order.
+//   * exact f32 (RD_MFMA=f32, and always for short-K transposed convolutions): v_mfma_f32_32x32x2_f32 --
+//     igemm_nt_kernel, wgrad_tn_kernel.  256 threads = 4 waves, block tile BMxBN, K-step 32, operands staged
+//     global -> VGPR (one K-step ahead) -> LDS rows padded to 36 floats (conflict-free b128 fragment reads, k-pairing
+//     permuted so that one read feeds four MFMA k-steps).
 #include <stdlib.h>
 #include <string.h>
 
