@@ -51,7 +51,36 @@ CONV_SHAPES = [  # n, h, w, cin, cout
     (2, 16, 32, 160, 32),     # strip weight gradient, swapped roles (Cout < 128 <= Cin), non-square image
     (1, 8, 16, 64, 128),      # smallest image the strip kernel takes (one 16-pixel strip, 8 rows)
     (4, 16, 16, 128, 128),    # 16x16 level: several strips per block
+    (1, 256, 16, 32, 128),    # one 16-pixel strip, 8 row chunks per image (strip kernel split along y)
+    (1, 64, 64, 64, 256),     # 4 strips x 2 row chunks, two output-channel tiles
+    (2, 128, 128, 32, 128),   # halo kernel on a small batch (N = 128: one column tile), strip kernel with chunks
 ]
+
+
+def _random_conv_shapes():
+    import random
+    rnd = random.Random(20260928)
+    out = []
+    for _ in range(14):
+        h = rnd.choice([8, 16, 32, 64]); w = rnd.choice([8, 16, 32, 64, 128])
+        n = rnd.choice([1, 2, 3, 5, 8])
+        cin = 4 * rnd.randint(1, 48); cout = 4 * rnd.randint(1, 48)
+        if rnd.random() < 0.4:
+            cin = rnd.choice([32, 64, 96, 128, 160])
+        if rnd.random() < 0.4:
+            cout = rnd.choice([128, 132, 192, 256])
+        if n * h * w * (cin + cout) > 6e6:      # keep the torch-CPU reference quick
+            n = 1
+        out.append((n, h, w, cin, cout))
+    return out
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", _random_conv_shapes())
+def test_conv3x3_random_shapes(n, h, w, cin, cout):
+    """Seeded random shapes across the tile / kernel selection rules (generic split kernel, halo kernel, strip and TN
+    weight-gradient kernels, swapped roles, ragged channel counts)."""
+    test_conv3x3_fwd_dgrad_wgrad(n, h, w, cin, cout)
+
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", CONV_SHAPES)
