@@ -241,6 +241,11 @@ typedef struct {
     double flops;   /* summed algorithmic FLOPs declared at launch */
     double bytes;   /* summed algorithmic HBM bytes declared at launch */
 } rd_prof_entry;
+/* Diagnosis knobs (tile-shape / kernel-selection overrides used by scripts/; never needed in production).  Names:
+ * mfma_f32 nt_tile nt_halo tn_tile tn_blocks tn_split wg_strip wg_minblocks wg_blocks rows_blocks last_blocks
+ * (resdepth_amd/csrc/rd_common.h: TuneKey).  Also settable at load time: RD_TUNE="name=value,..." */
+int rd_tune_set(const char* name, int value);
+int rd_tune_get(const char* name, int* value);
 int rd_prof_enable(int level);   /* 0 off; 1 = the MFMA (roofline) kernel classes only; 2 = every kernel class */
 int rd_prof_reset(void);
 int rd_prof_collect(rd_prof_entry* out, int max_entries); /* returns number of classes, <0 on error */

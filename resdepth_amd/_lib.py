@@ -6,6 +6,7 @@ on a HIP device, the call raises.  Build with `resdepth_amd/csrc/build.sh` (or
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import threading
@@ -13,7 +14,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RESDEPTH_HIP_LIB: alternative build of the same library (kernel diagnosis builds, scripts/ablate.sh)
+# RESDEPTH_HIP_LIB: alternative build of the same library (kernel diagnosis builds)
 LIB_PATH = os.environ.get("RESDEPTH_HIP_LIB") or os.path.join(_HERE, "libresdepth_hip.so")
 
 _lib = None
@@ -81,6 +82,8 @@ SIGNATURES = {
     "rd_residual_stats": (I, [P, P, P, LL, D, D, P, P, SZ, P]),
     "rd_nchw_to_nhwc": (I, [P, P, I, I, I, I, P]),
     "rd_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
+    "rd_tune_set": (I, [C.c_char_p, I]),
+    "rd_tune_get": (I, [C.c_char_p, P]),
     "rd_prof_enable": (I, [I]),
     "rd_prof_reset": (I, []),
     "rd_prof_collect": (I, [P, I]),
@@ -120,7 +123,17 @@ def check(rc: int, what: str = ""):
 
 
 def stream_ptr() -> int:
+    """HIP stream the next kernel is enqueued on: torch's current stream of the CURRENT device.  The engine entry points
+    (UNet.forward / backward, the loss, FusedAdam.step, predict_linear_blend) run under `device_of(tensor)` so that the
+    current device is the one the tensors live on."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def device_of(t):
+    """Context manager making `t`'s device current (torch ops guard the device themselves; raw launches do not)."""
+    if not t.is_cuda:
+        return contextlib.nullcontext()        # the call underneath raises "no CPU fallback"
+    return torch.cuda.device(t.device)
 
 
 def ptr(t):
@@ -134,30 +147,56 @@ def ptr(t):
     return t.data_ptr()
 
 
-# ---- workspace: one growing scratch buffer per device (stream-ordered use on the current stream)
+# ---- workspace: one growing scratch buffer per (device, HIP stream).  Every use is stream-ordered on the stream the
+# buffer is keyed by, so two models, or the forward and the autograd thread, can only share a buffer when they are
+# serialised by that stream anyway; concurrent streams (the weight-gradient side stream) get their own buffer.
 _ws = {}
+_ws_lock = threading.Lock()
 
 
 def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
-    """`slot` separates scratch buffers that are in use on different streams at the same time."""
-    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), slot)
-    buf = _ws.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _ws[key] = buf
+    dev = torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(index).cuda_stream, slot)
+    with _ws_lock:
+        buf = _ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            # the replaced buffer goes back to torch's caching allocator, which re-uses a block only in the order of the
+            # stream it was allocated under -- the same stream that is current here
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=torch.device("cuda", index))
+            _ws[key] = buf
     return buf
 
 
 # ---- parameter generation counter (bumped by in-place updates done through raw pointers) -------
 _param_gen = {}
+_global_gen = 0
 
 
-def bump_param_generation(flat_ptr: int):
-    _param_gen[flat_ptr] = _param_gen.get(flat_ptr, 0) + 1
+def bump_param_generation(flat_ptr=None):
+    """Tell every packed-weight cache that parameters were rewritten through raw pointers / `.data` (which does not bump
+    `Parameter._version`).  flat_ptr = the flat buffer that changed; None = "some parameter somewhere" (per-tensor
+    optimizer fallback, broadcast): invalidates every model's cache."""
+    global _global_gen
+    if flat_ptr is None:
+        _global_gen += 1
+    else:
+        _param_gen[flat_ptr] = _param_gen.get(flat_ptr, 0) + 1
 
 
-def param_generation(flat_ptr: int) -> int:
-    return _param_gen.get(flat_ptr, 0)
+def param_generation(flat_ptr: int):
+    return (_param_gen.get(flat_ptr, 0), _global_gen)
+
+
+# ---- diagnosis knobs ----------------------------------------------------------------------------
+def tune_set(name: str, value: int):
+    check(load().rd_tune_set(name.encode(), int(value)), "tune_set")
+
+
+def tune_get(name: str) -> int:
+    v = C.c_int(0)
+    check(load().rd_tune_get(name.encode(), C.cast(C.byref(v), C.c_void_p)), "tune_get")
+    return v.value
 
 
 # ---- profiler -----------------------------------------------------------------------------------

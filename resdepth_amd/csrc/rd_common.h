@@ -30,8 +30,25 @@ struct ProfScope {
 // second stage of the per-channel reductions (rd_elementwise.hip): sums[c] = sum_b partial[b*qc + c], fixed order
 int reduce_partials_f32(const float* partial, double* sums, int nb, int qc, hipStream_t s);
 
-// split-bf16 MFMA arithmetic enabled (default) or RD_MFMA=f32 (rd_igemm.hip)
-int mfma_split();
+// ---- tuning / diagnosis knobs (registry lives in rd_runtime.hip; set through rd_tune_set() or the RD_TUNE
+// environment variable "name=value,name=value" read once at load time).  The kernel translation units only read them.
+enum TuneKey {
+    TUNE_MFMA_F32 = 0,     // 1: exact-f32 MFMA kernels instead of split-bf16 (also RD_MFMA=f32)
+    TUNE_NT_TILE,          // -1 auto | 0: 128x128, 1: 128x64, 2: 64x64 tiles of the NT kernels
+    TUNE_NT_HALO,          // -1 auto | 0: never use the halo-reuse conv3x3 kernel
+    TUNE_TN_TILE,          // -1 auto | bm*1000 + bn
+    TUNE_TN_BLOCKS,        // target block count of the split-K TN kernels
+    TUNE_TN_SPLIT,         // -1 auto | 0/1 force the split-bf16 TN kernel off/on
+    TUNE_WG_STRIP,         // -1 auto | 0: never use the strip weight-gradient kernel
+    TUNE_WG_MINBLOCKS,     // strip kernel: minimum blocks before image rows are chunked
+    TUNE_WG_BLOCKS,        // strip kernel: target block count
+    TUNE_ROWS_BLOCKS,      // first-stage blocks of the per-channel reductions
+    TUNE_LAST_BLOCKS,      // first-stage blocks of the last-conv gradient kernels
+    TUNE_COUNT
+};
+int tune(int key);
+// split-bf16 MFMA arithmetic enabled (default) or exact f32 (TUNE_MFMA_F32)
+inline int mfma_split() { return !tune(TUNE_MFMA_F32); }
 // conv3x3 weight-gradient strip kernel (rd_wgrad_strip.hip): number of split-K slabs it will write for this shape
 // (0 = shape not handled, use the TN kernel), and its launcher (*splits_out = 0 when it did not run; *swapped_out = 1
 // when the slab is the mirrored transpose [Cin][(8 - tap) * Cout + co], see plan_strip)

@@ -99,8 +99,7 @@ struct RowPlan {
 };
 
 static bool plan_rows(long rows, int C, RowPlan* pl, int maxblocks = 0) {
-    static const int dflt = getenv("RD_ROWS_BLOCKS") ? atoi(getenv("RD_ROWS_BLOCKS")) : 512;   // tuning override
-    if (maxblocks <= 0) maxblocks = dflt;
+    if (maxblocks <= 0) maxblocks = tune(TUNE_ROWS_BLOCKS);
     if (C % 4 != 0 || C / 4 > 256 || C <= 0) return false;
     pl->CQ = C / 4;
     pl->RP = 256 / pl->CQ;
@@ -1283,10 +1282,7 @@ int rd_conv3x3_first_bwd_weight(const float* x, const float* dz, float* dw, int 
 }
 
 // ---- last conv -------------------------------------------------------------------------------------
-static int last_blocks() {      // first-stage blocks of the last-conv streaming kernels (tuning override)
-    static const int v = getenv("RD_LAST_BLOCKS") ? atoi(getenv("RD_LAST_BLOCKS")) : 2048;
-    return v;
-}
+static int last_blocks() { return tune(TUNE_LAST_BLOCKS); }   // first-stage blocks of the last-conv streaming kernels
 
 int rd_conv3x3_last_fwd(const float* s_in, const float* wt, const float* bias, const float* x_nchw, int x_channels,
                         float* out, int n, int h, int w, int c, rd_stream_t s) {

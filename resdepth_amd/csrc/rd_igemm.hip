@@ -402,9 +402,6 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
     const unsigned b_off = (nb * 32 < p.N) ? (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16) : kOOB;
 
     auto load_a = [&](int kt, float4 (&ra)[AI]) {
-#if defined(RD_ABLATE) && (RD_ABLATE & 4)   // diagnosis: no A global loads after the prologue
-        if (kt > 3) return;
-#endif
         // K order = channel-chunk outer, tap inner (see the f32 kernel).  kt >= nk (prefetch running past the end):
         // every lane carries the out-of-range offset -- keeps the number of outstanding loads static for s_waitcnt
         const int chunk = kt / p.taps;
@@ -422,18 +419,11 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
         }
     };
     auto load_b = [&](int kt, uint4 (&rb)[3]) {
-#if defined(RD_ABLATE) && (RD_ABLATE & 16)  // diagnosis: no B global loads after the prologue
-        if (kt > 2) return;
-#endif
         const unsigned voff = kt < p.nk ? b_off : kOOB;
 #pragma unroll
         for (int q = 0; q < 3; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((kt * 3 + q) * 1024));
     };
     auto store_a = [&](float* stage, const float4 (&ra)[AI]) {
-#if defined(RD_ABLATE) && (RD_ABLATE & 2)   // diagnosis: no LDS stores (a never-true store keeps the loads alive)
-        if (p.nk < 0) stage[t] = ra[0].x + ra[AI - 1].w;
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int sw = swz(r0 + 64 * i), hi = c4 >> 1;
@@ -460,11 +450,7 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
     };
     // six products per (a, b) pair, smallest terms first; lane half g owns k = 8g .. 8g+7 (the same 8 k for A and B)
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#if defined(RD_ABLATE) && (RD_ABLATE & 8)
-    constexpr int NT6 = 1;
-#else
     constexpr int NT6 = 6;
-#endif
     // One K-step.  Software pipeline per tile j:  global load (step j-4) -> split + LDS write (step j-2) -> fragment
     // read (step j-1, right after the MFMAs that last used the registers) -> MFMA (step j).  B: global load straight
     // into fragment registers at step j-3.  One barrier per step; LDS stage of tile j = j & 1.
@@ -483,10 +469,8 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 #pragma unroll
                 for (int i = g; i < g + GP; ++i)
                     acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t6]], bf[PB[t6]], acc[i][0], 0, 0, 0);
-#if !(defined(RD_ABLATE) && (RD_ABLATE & 32))   // diagnosis: no fragment reads
 #pragma unroll
             for (int i = g; i < g + GP; ++i) read_a(rstage, i);      // tile kt+1, consumed one step later
-#endif
         }
         __syncthreads();
     };
@@ -752,12 +736,6 @@ static inline size_t packed_bytes(long rows, int taps, int cin) {
     return packed_f32_bytes(rows, taps, cin) + (size_t)rows32_of(rows) * nk16_of(taps, cin) * SROWB;
 }
 
-// RD_MFMA=f32 forces the exact-f32 MFMA kernels; default: split-bf16 (see igemm_nt_split_kernel)
-int mfma_split() {
-    static const int v = (getenv("RD_MFMA") && !strcmp(getenv("RD_MFMA"), "f32")) ? 0 : 1;
-    return v;
-}
-
 static int split_pack(const float* b_f32, long rows, int taps, int cin, hipStream_t s) {
     uint4* out = (uint4*)((char*)b_f32 + packed_f32_bytes(rows, taps, cin));
     const int nk = nk16_of(taps, cin);
@@ -789,7 +767,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     p.a_bytes = (unsigned)a_bytes;
     p.b_bytes = (unsigned)b_bytes;
     p.Bsplit = (const char*)p.B + packed_f32_bytes(p.N, taps, p.Cin);
-    static const int force = getenv("RD_NT_TILE") ? atoi(getenv("RD_NT_TILE")) : -1;   // tuning override
+    const int force = tune(TUNE_NT_TILE);
     const int tiles_128x64 = cdiv(p.M, 128) * cdiv(p.N, 64);
     int cfg;
     if (split) {
@@ -811,7 +789,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
         else cfg = 1;
     }
     if (force >= 0 && force <= 2 && !(force == 0 && p.N <= 64)) cfg = force;
-    static const int halo_force = getenv("RD_NT_HALO") ? atoi(getenv("RD_NT_HALO")) : -1;   // tuning override (0 = never)
+    const int halo_force = tune(TUNE_NT_HALO);
     const bool halo = split && AMODE == A_CONV3 && EPI == EPI_STORE && p.W >= 16 && p.H >= 8 && cfg != 2 && halo_force != 0;
     char pcls[64];   // "<operation>|<kernel symbol>": the kernel symbol is what rocprofv3 reports
     if (halo)
@@ -1206,7 +1184,7 @@ static TnPlan plan_tn(int M, int N, long Kp) {
     TnPlan pl;
     pl.bm = M > 64 ? 128 : 64;
     pl.bn = N > 64 ? 128 : 64;
-    static const int tforce = getenv("RD_TN_TILE") ? atoi(getenv("RD_TN_TILE")) : -1;   // tuning: bm*1000 + bn
+    const int tforce = tune(TUNE_TN_TILE);
     if (tforce > 0) {
         pl.bm = tforce / 1000;
         pl.bn = tforce % 1000;
@@ -1215,7 +1193,7 @@ static TnPlan plan_tn(int M, int N, long Kp) {
     pl.tiles_n = cdiv(N, pl.bn);
     const int tiles = pl.tiles_m * pl.tiles_n;
     long ktiles = (Kp + 31) / 32;
-    static const int target = getenv("RD_TN_BLOCKS") ? atoi(getenv("RD_TN_BLOCKS")) : 1024;   // tuning override
+    const int target = tune(TUNE_TN_BLOCKS);
     long want = target / tiles;                   // whole rounds of resident blocks
     if (want < 1) want = 1;
     long maxs = ktiles / 8 > 0 ? ktiles / 8 : 1;  // at least 8 K-steps per split
@@ -1232,7 +1210,7 @@ template <int AMODE, int BMODE>
 static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cls) {
     char pcls[64];
     // the split kernel stages both operands through registers + LDS (two transposes): it only pays on full 128x128 tiles
-    static const int tn_force = getenv("RD_TN_SPLIT") ? atoi(getenv("RD_TN_SPLIT")) : -1;   // tuning override
+    const int tn_force = tune(TUNE_TN_SPLIT);
     const int split = tn_force >= 0 ? tn_force : (mfma_split() && pl.bm == 128 && pl.bn == 128);
     snprintf(pcls, sizeof(pcls), "%s|wgrad_tn%s<%d,%d,%d,%d>", cls, split ? "_split" : "", pl.bm, pl.bn, AMODE, BMODE);
     ProfScope ps(s, pcls, 2.0 * p.M * p.N * (double)p.Kp,

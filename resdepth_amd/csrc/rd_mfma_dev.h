@@ -35,11 +35,6 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
 }
 // float4 (4 consecutive k) -> three 8-byte groups of 4 bf16 (one per term); v_perm_b32 -> {hi16(odd), hi16(even)}
 __device__ __forceinline__ void split_pack4(const float4 v, uint2& ph, uint2& pm, uint2& pl) {
-#if defined(RD_ABLATE) && (RD_ABLATE & 1)   // diagnosis builds only (scripts/ablate.sh): no split arithmetic
-    ph = pm = pl = make_uint2(__builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u),
-                              __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u));
-    return;
-#endif
     unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
     split3(v.x, h0, m0, l0);
     split3(v.y, h1, m1, l1);

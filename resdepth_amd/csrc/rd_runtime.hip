@@ -1,5 +1,6 @@
 // Error reporting, version and the event-based kernel profiler of libresdepth_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -24,6 +25,36 @@ int check_hip(hipError_t e, const char* what) {
     set_error("%s: %s", what, hipGetErrorString(e));
     return RD_ERR_HIP;
 }
+
+// ---- tuning / diagnosis knobs -----------------------------------------------------------
+struct TuneEntry {
+    const char* name;
+    int value;
+};
+static TuneEntry g_tune[TUNE_COUNT] = {
+    {"mfma_f32", 0},   {"nt_tile", -1},      {"nt_halo", -1},    {"tn_tile", -1},     {"tn_blocks", 1024}, {"tn_split", -1},
+    {"wg_strip", -1},  {"wg_minblocks", 768}, {"wg_blocks", 512}, {"rows_blocks", 512}, {"last_blocks", 2048},
+};
+static int tune_index(const char* name, size_t len) {
+    for (int i = 0; i < TUNE_COUNT; ++i)
+        if (strlen(g_tune[i].name) == len && !strncmp(g_tune[i].name, name, len)) return i;
+    return -1;
+}
+static const int g_tune_env = [] {      // RD_TUNE="name=value,..." and the RD_MFMA=f32 mode switch, read once at load time
+    if (const char* m = getenv("RD_MFMA"))
+        if (!strcmp(m, "f32")) g_tune[TUNE_MFMA_F32].value = 1;
+    const char* e = getenv("RD_TUNE");
+    while (e && *e) {
+        const char* eq = strchr(e, '=');
+        if (!eq) break;
+        const int i = tune_index(e, (size_t)(eq - e));
+        if (i >= 0) g_tune[i].value = atoi(eq + 1);
+        e = strchr(eq, ',');
+        if (e) ++e;
+    }
+    return 0;
+}();
+int tune(int key) { return g_tune[key].value; }
 
 // ---- profiler ---------------------------------------------------------------------------
 struct ProfRec {
@@ -110,6 +141,26 @@ extern "C" {
 int rd_version(void) { return 100; }
 
 const char* rd_last_error_string(void) { return rd::g_err; }
+
+int rd_tune_set(const char* name, int value) {
+    const int i = name ? rd::tune_index(name, strlen(name)) : -1;
+    if (i < 0) {
+        rd::set_error("rd_tune_set: unknown knob '%s'", name ? name : "(null)");
+        return RD_ERR_ARG;
+    }
+    rd::g_tune[i].value = value;
+    return RD_OK;
+}
+
+int rd_tune_get(const char* name, int* value) {
+    const int i = name ? rd::tune_index(name, strlen(name)) : -1;
+    if (i < 0 || !value) {
+        rd::set_error("rd_tune_get: unknown knob '%s'", name ? name : "(null)");
+        return RD_ERR_ARG;
+    }
+    *value = rd::g_tune[i].value;
+    return RD_OK;
+}
 
 int rd_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(rd::g_mu);

@@ -216,7 +216,7 @@ struct WsPlan {
 // [Cin][(8 - tap) * Cout + co] and the reduction kernel un-mirrors it.
 static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
     WsPlan pl = {};
-    static const int force = getenv("RD_WG_STRIP") ? atoi(getenv("RD_WG_STRIP")) : -1;   // tuning override (0 = never)
+    const int force = tune(TUNE_WG_STRIP);
     if (!mfma_split() || force == 0 || w < 16 || h < 4) return pl;
     if (cout >= 128 && cout % 4 == 0 && cin % 32 == 0) {
         pl.swapped = 0;
@@ -232,14 +232,14 @@ static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
     pl.tiles_ci = cin / 32;
     const long base = (long)pl.tiles_m * pl.tiles_ci * n * pl.strips_x;
     int rows = h;
-    static const int minb = getenv("RD_WG_MINBLOCKS") ? atoi(getenv("RD_WG_MINBLOCKS")) : 768;   // tuning override
+    const int minb = tune(TUNE_WG_MINBLOCKS);
     while (base * (h / rows) < minb && rows > 32) rows >>= 1;
     pl.rows_per_chunk = rows;
     pl.chunks_y = h / rows;
     // every split costs one [Cout][9*Cin] slab of HBM traffic (written here, read by the reduction): with more than
     // ~2048 blocks, give each block several strips instead
     const long strips = (long)n * pl.strips_x * pl.chunks_y;
-    static const int target = getenv("RD_WG_BLOCKS") ? atoi(getenv("RD_WG_BLOCKS")) : 512;   // tuning override; measured: 512 (2 resident blocks/CU, one round) beats 1024/2048
+    const int target = tune(TUNE_WG_BLOCKS);   // measured: 512 (2 resident blocks/CU, one round) beats 1024/2048
     int reps = 1;
     while (base * pl.chunks_y / (2 * reps) >= target && strips % (2 * reps) == 0) reps *= 2;
     pl.reps = reps;

@@ -34,3 +34,15 @@ class SyntheticDsmOrthoDataset(Dataset):
             "patch_valid_pixels_uly": torch.tensor(0), "patch_valid_pixels_ulx": torch.tensor(0),
             "patch_valid_pixels_lry": torch.tensor(self.t), "patch_valid_pixels_lrx": torch.tensor(self.t),
         }
+
+
+def synthetic_batch(n: int, c: int, t: int, seed: int = 1234, nodata_frac: float = 0.05):
+    """One DataLoader-shaped synthetic batch: randn tiles, target = DSM channel + noise, ~5 % nodata in
+    the loss mask, per-sample dsm_mean / dsm_std -- the keys DsmOrthoDataset.__getitem__ + default collate produce
+    (lib/DsmOrthoDataset.py:281-291).  Used by bench.py's GPU leg (the oracle keeps its own generator for the tests)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, t, t, generator=g)
+    y = x[:, 0:1] + 0.3 * torch.randn(n, 1, t, t, generator=g)
+    mask = torch.rand(n, 1, t, t, generator=g) > nodata_frac
+    return {"input": x, "target": y, "loss_mask": mask,
+            "dsm_mean": torch.randn(n, generator=g, dtype=torch.float64) * 50.0, "dsm_std": torch.full((n,), 3.0)}

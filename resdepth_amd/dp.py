@@ -52,10 +52,24 @@ class GradSync:
         return numel * self.world
 
     def allreduce_stats(self, sums: torch.Tensor, count: int) -> int:
-        """SyncBN forward: (sum x, sum x^2) per channel -> global; returns the global pixel count
-        (every rank holds the same per-rank batch, as the sharding guarantees)."""
+        """SyncBN forward: (sum x, sum x^2) per channel -> global; returns the global pixel count.  Every rank must
+        hold the same per-rank batch: `shard_batch` guarantees it, `check_equal_across_ranks` (called by the Trainer
+        for its loaders) verifies it for user-built shards -- a smaller batch on one rank would silently bias the
+        statistics, since the count is not part of the exchange (it stays a host value; no device read-back)."""
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
         return count * self.world
+
+    def check_equal_across_ranks(self, value: int, what: str) -> None:
+        """Raise on every rank if `value` differs between ranks (loader lengths, batch sizes): unequal shards would
+        deadlock the per-step collectives or bias the SyncBN statistics."""
+        dev = "cuda" if dist.get_backend(self.pg) == "nccl" else "cpu"
+        mine = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(every, mine, group=self.pg)
+        vals = [int(v) for v in every]
+        if any(v != vals[0] for v in vals):
+            raise RuntimeError(f"resdepth_amd.dp: {what} differs across ranks ({vals}); every rank needs the same number of "
+                               "equally sized batches (use drop_last=True / equal shards)")
 
     def allreduce_sums(self, sums: torch.Tensor) -> None:
         """SyncBN backward: (sum g', sum g'*xhat, ...) -> global, in place."""
@@ -146,9 +160,22 @@ def attach(model, process_group=None, sync_bn: bool = False, bucket_bytes: int =
 
 
 def broadcast_parameters(model, src: int = 0, process_group=None) -> None:
-    """Rank `src`'s parameters and BN buffers to everyone (start of training / after loading a checkpoint)."""
-    for t in list(model.parameters()) + list(model.buffers()):
+    """Rank `src`'s parameters and BN buffers to everyone (start of training / after loading a checkpoint).  The
+    parameters go as ONE message when the model keeps them in its flat buffer; the packed GEMM-layout weight copies of
+    every rank are invalidated (the broadcast writes through `.data`, which autograd's version counters do not see)."""
+    from . import _lib
+    flat = getattr(model, "_flat_param", None)
+    params = list(model.parameters())
+    if flat is not None and params and params[0].data_ptr() == flat.data_ptr():
+        dist.broadcast(flat, src=src, group=process_group)
+    else:
+        for t in params:
+            dist.broadcast(t.data, src=src, group=process_group)
+    for t in model.buffers():
         dist.broadcast(t.data, src=src, group=process_group)
+    _lib.bump_param_generation(None)
+    if hasattr(model, "invalidate_packed"):
+        model.invalidate_packed()
 
 
 def shard_batch(batch: dict, rank: int, world: int) -> dict:

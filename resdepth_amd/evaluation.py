@@ -32,8 +32,9 @@ def get_statistics(raster, raster_gt, nodata, mask_gt=None, residual_threshold=N
     m = None
     if mask_gt is not None:
         m = torch.as_tensor(np.asarray(mask_gt) if not torch.is_tensor(mask_gt) else mask_gt).to(dev).to(torch.uint8).contiguous()
-    full = _stats(r, g, m, nodata, None, dev)
-    trunc = _stats(r, g, m, nodata, residual_threshold, dev) if residual_threshold else None
+    with torch.cuda.device(r.device):              # raw launches go to the current device's stream
+        full = _stats(r, g, m, nodata, None, r.device)
+        trunc = _stats(r, g, m, nodata, residual_threshold, r.device) if residual_threshold else None
     vals = full.cpu().tolist()
     stats = {"truncation": bool(residual_threshold)}
     stats.update(dict(zip(_KEYS, vals)))

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
-from . import ops
+from . import _lib, ops
 from .tiling import regular_grid
 
 
@@ -30,7 +30,9 @@ def predict_linear_blend(dataloader, model, reduce_to_rank0: bool = True):
     if not torch.cuda.is_available():
         raise RuntimeError("resdepth_amd.predict_linear_blend runs on a HIP device only (no CPU fallback)")
     is_dist = torch.distributed.is_available() and torch.distributed.is_initialized()
-    device = torch.device("cuda", torch.cuda.current_device())
+    first = next(model.parameters(), None)
+    # the model's own HIP device if it already lives on one, else the current device (the reference moves it to cuda:0)
+    device = first.device if first is not None and first.is_cuda else torch.device("cuda", torch.cuda.current_device())
     model.eval()
     model.to(device)
     ds = dataloader.dataset
@@ -51,8 +53,9 @@ def predict_linear_blend(dataloader, model, reduce_to_rank0: bool = True):
                                 "patch_valid_pixels_lrx")], 1).to(torch.int32).to(device)
             if mean.numel() != n or pos.shape[0] != n:
                 raise ValueError("batch dict fields must hold one value per tile")
-            ops.blend_accumulate(y_pred.contiguous(), mean.contiguous(), std.contiguous(), pos.contiguous(),
-                                 reg.contiguous(), tile_size, stride, raster)
+            with _lib.device_of(raster):
+                ops.blend_accumulate(y_pred.contiguous(), mean.contiguous(), std.contiguous(), pos.contiguous(),
+                                     reg.contiguous(), tile_size, stride, raster)
     if is_dist and reduce_to_rank0:
         torch.distributed.reduce(raster, dst=0, op=torch.distributed.ReduceOp.SUM)
     return raster.cpu().numpy()

@@ -12,17 +12,18 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 
 class _MaskedL1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y_pred, y, mask_u8, mean, std, grad_sync):
-        sums = ops.masked_l1_partial(y_pred, y, mask_u8, mean, std)
-        numel = y_pred.numel()
-        if grad_sync is not None:
-            numel = grad_sync.allreduce_loss_sums(sums, numel)
-        loss, _ = ops.masked_l1_finish(y_pred, y, mask_u8, mean, std, sums, numel, want_loss=True, want_grad=False)
+        with _lib.device_of(y_pred):
+            sums = ops.masked_l1_partial(y_pred, y, mask_u8, mean, std)
+            numel = y_pred.numel()
+            if grad_sync is not None:
+                numel = grad_sync.allreduce_loss_sums(sums, numel)
+            loss, _ = ops.masked_l1_finish(y_pred, y, mask_u8, mean, std, sums, numel, want_loss=True, want_grad=False)
         ctx.save_for_backward(y_pred, y, mask_u8, mean, std, sums)
         ctx.numel = numel
         return loss.reshape(())
@@ -32,8 +33,9 @@ class _MaskedL1(torch.autograd.Function):
         y_pred, y, mask_u8, mean, std, sums = ctx.saved_tensors
         # gout stays on the device: the kernel reads it through a pointer (no host sync)
         g = gout.detach().to(torch.float32).contiguous()
-        _, dyp = ops.masked_l1_finish(y_pred, y, mask_u8, mean, std, sums, ctx.numel, gout=g, want_loss=False,
-                                      want_grad=True)
+        with _lib.device_of(y_pred):
+            _, dyp = ops.masked_l1_finish(y_pred, y, mask_u8, mean, std, sums, ctx.numel, gout=g, want_loss=False,
+                                          want_grad=True)
         return dyp, None, None, None, None, None
 
 

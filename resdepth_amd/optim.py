@@ -26,6 +26,17 @@ class FusedAdam(torch.optim.Optimizer):
         self._flat_state = {}      # group index -> (flat_ptr, m, v)
         self.grad_scale = 1.0
 
+    def load_state_dict(self, state_dict):
+        """torch.optim.Optimizer.load_state_dict replaces state[p]['exp_avg'|'exp_avg_sq'] by the loaded tensors; the flat
+        moment buffers of a previous step would silently keep being used (and the loaded moments ignored), so drop
+        them: the next step() copies the loaded moments into fresh flat buffers and re-points the state views."""
+        super().load_state_dict(state_dict)
+        self._flat_state = {}
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._flat_state = {}
+
     @staticmethod
     def _flat_range(tensors):
         """(base_ptr, numel) if the tensors tile one contiguous fp32 range in order, else None."""
@@ -78,49 +89,54 @@ class FusedAdam(torch.optim.Optimizer):
             params = [p for p in group["params"]]
             if not params:
                 continue
-            if any(not p.is_cuda for p in params):
-                raise RuntimeError("resdepth_amd.FusedAdam: parameters must live on a HIP device (no CPU fallback)")
-            if group.get("amsgrad") or group.get("maximize"):
-                raise NotImplementedError("FusedAdam: amsgrad / maximize are not implemented")
-            if any(p.grad is None for p in params):
-                # torch.optim.Adam skips parameters without gradient; the flat kernel cannot
-                active = [p for p in params if p.grad is not None]
-                flat = None
-            else:
-                active = params
-                flat = self._ensure_state(group, gi)
-            b1, b2 = group["betas"]
-            lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
-            if flat is not None:
-                gr = self._flat_range([p.grad for p in params])
-            else:
-                gr = None
-                self._ensure_state_per_tensor(active)
-            # step counter (python float tensors like torch.optim.Adam's default path)
-            for p in active:
-                self.state[p]["step"] += 1
-            if not active:
-                continue
-            t = float(self.state[active[0]]["step"])
-            bc1 = 1.0 - b1 ** t
-            bc2 = 1.0 - b2 ** t
-            step_size = lr / bc1
-            bc2_sqrt = math.sqrt(bc2)
-            if flat is not None and gr is not None and gr[1] == flat[1].numel():
-                total = gr[1]
-                pflat = _as_flat(params[0].data, total)
-                gflat = _as_flat(params[0].grad, total)
-                ops.adam_step(pflat, gflat, flat[1], flat[2], b1, b2, eps, wd, step_size, bc2_sqrt, self.grad_scale)
-                _lib.bump_param_generation(flat[0])
-            else:
-                for p in active:
-                    st = self.state[p]
-                    g = p.grad.contiguous()
-                    ops.adam_step(p.data.view(-1) if p.data.is_contiguous() else p.data, g.view(-1),
-                                  st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1), b1, b2, eps, wd, step_size,
-                                  bc2_sqrt, self.grad_scale)
-                    p.data.add_(0)  # bump the version counter so packed-weight caches notice
+            with _lib.device_of(params[0]):
+                self._step_group(gi, group, params)
         return loss
+
+    def _step_group(self, gi, group, params):
+        if any(not p.is_cuda for p in params):
+            raise RuntimeError("resdepth_amd.FusedAdam: parameters must live on a HIP device (no CPU fallback)")
+        if group.get("amsgrad") or group.get("maximize"):
+            raise NotImplementedError("FusedAdam: amsgrad / maximize are not implemented")
+        if any(p.grad is None for p in params):
+            # torch.optim.Adam skips parameters without gradient; the flat kernel cannot
+            active = [p for p in params if p.grad is not None]
+            flat = None
+        else:
+            active = params
+            flat = self._ensure_state(group, gi)
+        b1, b2 = group["betas"]
+        lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
+        if flat is not None:
+            gr = self._flat_range([p.grad for p in params])
+        else:
+            gr = None
+            self._ensure_state_per_tensor(active)
+        # step counter (python float tensors like torch.optim.Adam's default path)
+        for p in active:
+            self.state[p]["step"] += 1
+        if not active:
+            return
+        t = float(self.state[active[0]]["step"])
+        bc1 = 1.0 - b1 ** t
+        bc2 = 1.0 - b2 ** t
+        step_size = lr / bc1
+        bc2_sqrt = math.sqrt(bc2)
+        if flat is not None and gr is not None and gr[1] == flat[1].numel():
+            total = gr[1]
+            pflat = _as_flat(params[0].data, total)
+            gflat = _as_flat(params[0].grad, total)
+            ops.adam_step(pflat, gflat, flat[1], flat[2], b1, b2, eps, wd, step_size, bc2_sqrt, self.grad_scale)
+            _lib.bump_param_generation(flat[0])
+        else:
+            for p in active:
+                st = self.state[p]
+                g = p.grad.contiguous()
+                ops.adam_step(p.data.view(-1) if p.data.is_contiguous() else p.data, g.view(-1),
+                              st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1), b1, b2, eps, wd, step_size,
+                              bc2_sqrt, self.grad_scale)
+            # `.data` writes do not bump Parameter._version: tell every packed-weight cache explicitly
+            _lib.bump_param_generation(None)
 
     def _ensure_state_per_tensor(self, params):
         for p in params:

@@ -31,6 +31,10 @@ class GpuPatchSampler:
     def sample(self, positions, pairs=None, aug=None):
         """positions: int [n,2] (y, x); pairs: int [n,V] plane indices into `orthos`; aug: int [n,3] (k, flip_v, flip_h)
         or None.  Returns the DataLoader-shaped batch dict with device tensors."""
+        with torch.cuda.device(self.device):       # raw launches go to the current device's stream
+            return self._sample(positions, pairs, aug)
+
+    def _sample(self, positions, pairs, aug):
         dev, t = self.device, self.tile
         pos = torch.as_tensor(positions, dtype=torch.int32).reshape(-1, 2)
         if not pos.is_cuda:          # validate on the host (no device->host sync in the training loop)

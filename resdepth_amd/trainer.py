@@ -113,6 +113,7 @@ class Trainer:
         if torch.cuda.is_available():
             local = int(os.environ.get("LOCAL_RANK", "0")) if self.is_dist else 0
             self.device = torch.device("cuda", local)
+            torch.cuda.set_device(self.device)     # raw kernel launches and RCCL use the current device
         else:
             self.device = torch.device("cpu")
         self.model = _get(args, "model")
@@ -138,6 +139,16 @@ class Trainer:
 
         first = next(iter(self.loader["train"]))          # the reference also draws one batch here (lib/Trainer.py:61-64)
         self.batch_size = first["input"].shape[0]
+        if self.is_dist and self.grad_sync is not None:
+            # every step issues collectives (loss normaliser, gradients, SyncBN): ranks with a different number of
+            # batches would deadlock, a different batch size would bias the SyncBN statistics
+            for phase in ("train", "val"):
+                if self.loader[phase] is not None:
+                    self.grad_sync.check_equal_across_ranks(len(self.loader[phase]), f"len({phase} loader)")
+            self.grad_sync.check_equal_across_ranks(self.batch_size, "batch size")
+            ds = getattr(self.loader["train"], "dataset", None)
+            if ds is not None and hasattr(ds, "__len__"):
+                self.grad_sync.check_equal_across_ranks(len(ds), "len(train dataset shard)")
         self.hparams = {"batch_size": self.batch_size, "lr_initial": self._get_lr(),
                         "optimizer": type(self.optimizer).__name__, "scheduler": "None", "patience": -1, "step_size": -1}
         if self.scheduler is not None:

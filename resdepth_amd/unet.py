@@ -564,13 +564,22 @@ class UNet(nn.Module):
         if x.shape[3] != t or (t & (t - 1)) != 0 or t < 2 ** self.depth:
             raise ValueError(f"tile size must be a power of two >= 2^depth = {2 ** self.depth} (got {tuple(x.shape[2:])})")
         x = x.contiguous().float()
-        self._ensure_flat()
-        params = self._param_list()
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        if not need_grad:
-            out, _ = self._engine_forward(x, self.training, save=False)
-            return out
-        return _UNetFunction.apply(x, self, *params)
+        with _lib.device_of(x):          # raw kernel launches go to the CURRENT device's stream: make it x's device
+            self._ensure_flat()
+            params = self._param_list()
+            if params[0].device != x.device:
+                raise RuntimeError(f"resdepth_amd.UNet: input on {x.device} but parameters on {params[0].device}")
+            need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+            if not need_grad:
+                out, _ = self._engine_forward(x, self.training, save=False)
+                return out
+            return _UNetFunction.apply(x, self, *params)
+
+    def invalidate_packed(self):
+        """Drop the packed (GEMM-layout) weight copies; the next forward re-packs.  Needed only after writing parameters
+        through `.data` / raw pointers without going through FusedAdam or resdepth_amd.dp (both invalidate themselves)."""
+        self._pack_key = None
+        self._pack_cache = None
 
 
 class _UNetFunction(torch.autograd.Function):
@@ -586,6 +595,7 @@ class _UNetFunction(torch.autograd.Function):
         model, S = ctx.model, ctx.saved
         if S is None:
             raise RuntimeError("resdepth_amd.UNet: backward called twice (activations were released)")
-        grads = model._engine_backward(S, dout)
+        with _lib.device_of(dout):
+            grads = model._engine_backward(S, dout)
         ctx.saved = None
         return (None, None, *grads)

@@ -1,5 +1,5 @@
-"""Per-layer timing of the MFMA kernels at the cfg-S shapes (N=32). Tuning aid; env RD_NT_TILE / RD_TN_BLOCKS
-override the tile / split heuristics (read once per process)."""
+"""Per-layer timing of the MFMA kernels at the cfg-S shapes (N=32).  Tuning aid; RD_TUNE="nt_tile=0,tn_blocks=512,..."
+overrides the tile / split heuristics (include/resdepth_hip.h: rd_tune_set)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,7 +28,7 @@ def timed(fn):
 
 
 tot = {}
-print(f"cfg RD_NT_TILE={os.environ.get('RD_NT_TILE')} RD_TN_BLOCKS={os.environ.get('RD_TN_BLOCKS')} N={N}")
+print(f"cfg RD_TUNE={os.environ.get('RD_TUNE')} N={N}")
 for name, h, cin, cout in layers:
     x = torch.randn(N, h, h, cin, device=dev)
     dz = torch.randn(N, h, h, cout, device=dev)
