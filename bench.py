@@ -34,27 +34,59 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA (2495 meas
 # pipe bounds them at 2500/6 fp32-equivalent TFLOP/s
 PEAK_SPLIT_TFLOPS = PEAK_BF16_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0
+# measured bounds: scripts/split_numerics.py / tests/test_split_numerics_gpu.py
+ARITHMETIC = ("fp32 storage and accumulation; MFMA-class kernels multiply exactly-split operands (x = x1+x2+x3, bf16 terms) on "
+              "v_mfma_f32_32x32x16_bf16, 6 of the 9 term products per multiply -- the three dropped products are below 2^-21 |ab| "
+              "(worst case); RD_MFMA=f32 selects the exact-f32 MFMA kernels")
 MFMA_CLASSES = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "convt2x2_fwd", "convt2x2_dgrad", "convt2x2_wgrad")
 
 
-def cpu_baseline(batch=4, timed=2):
-    """The oracle's train step (same module graph / loss / Adam as the reference) on the host CPU."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(warm=2, timed=5):
+    """the oracle's train step (same module graph / loss / Adam as the reference; the oracle is
+    the CPU restatement pinned on the reference, oracle/unet_oracle.py) on this box's host cores -- cfg-0 (1-ch, batch 4)
+    and cfg-S (3-ch) at batch 8, 2 warm-up + 5 timed steps each, median.  A bounded sample (~15 s of CPU work)."""
     from oracle import unet_oracle as O
+    host = os.cpu_count() or 1
     # thread count: best of a measured sweep on the 2 x 64-core EPYC 9575F host of the MI355X box
-    # (8: 0.59, 16: 0.54, 32: 0.62, 64: 1.10 s/step at batch 4; all 256 hardware threads: 62 s/step)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    spec = O.Spec(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True)
-    sd = O.init_state_dict(spec, 0)
-    b = O.synthetic_batch(batch, 3, 256, seed=1234)
-    state = {}
-    O.train_step(sd, b, spec, state)                      # warm-up
-    t0 = time.perf_counter()
-    for _ in range(timed):
-        O.train_step(sd, b, spec, state)
-    dt = (time.perf_counter() - t0) / timed
-    return {"value": round(batch / dt, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{timed} timed + 1 warm-up train steps (fwd+bwd+Adam) of batch {batch}, 3-ch 256x256 depth-5, "
-                      f"torch-CPU oracle, {dt * 1e3:.0f} ms/step"}
+    # (8: 0.59, 16: 0.54, 32: 0.62, 64: 1.10 s/step at batch 4; all 256 hardware threads: 62 s/step -- oneDNN's
+    # per-thread work gets too small and the two sockets thrash; BASELINE.md's "all cores" is therefore NOT the fast setting)
+    threads = min(16, host)
+    torch.set_num_threads(threads)
+
+    def run(c, batch):
+        spec = O.Spec(n_input_channels=c, start_kernel=64, depth=5, bias_conv_layer=True)
+        sd = O.init_state_dict(spec, 0)
+        b = O.synthetic_batch(batch, c, 256, seed=1234)
+        state, ts = {}, []
+        for i in range(warm + timed):
+            t0 = time.perf_counter()
+            O.train_step(sd, b, spec, state)
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        med = ts[len(ts) // 2]
+        return {"tiles_per_s": round(batch / med, 3), "batch": batch, "step_s_median": round(med, 4),
+                "step_s_min_max": [round(ts[0], 4), round(ts[-1], 4)]}
+
+    s8 = run(3, 8)
+    c0 = run(1, 4)
+    return {"value": s8["tiles_per_s"], "unit": "tiles/s", "cores": threads, "kind": "port",
+            "host_cores": host, "threads": threads, "cpu_model": _cpu_model(),
+            "cfg_S": s8, "cfg_0": c0,
+            "sample": f"{warm} warm-up + {timed} timed train steps (fwd+loss+bwd+Adam), median: cfg-S 3-ch 256x256 depth-5 at batch "
+                      f"{s8['batch']} ({s8['step_s_median'] * 1e3:.0f} ms/step) and cfg-0 1-ch at batch {c0['batch']} "
+                      f"({c0['step_s_median'] * 1e3:.0f} ms/step); torch-CPU oracle, {threads} threads of {host} hardware threads"}
 
 
 def infer_main(args, world, rank, dev):
@@ -84,7 +116,7 @@ def infer_main(args, world, rank, dev):
         predict_linear_blend(loader, model)
     torch.cuda.synchronize()
     if not args.no_prof:
-        _lib.prof_reset(); _lib.prof_enable(2 if args.prof_all else 1)
+        _lib.prof_reset(); _lib.prof_enable(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = predict_linear_blend(loader, model)
@@ -118,6 +150,142 @@ def infer_main(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+WORKLOADS = {
+    "S": dict(c=3, t=256, depth=5, flop=FLOP_PER_TILE, bytes_a=1.123e9,
+              name="config_ResDepth-stereo (cfg-S): 3-ch 256x256 tiles, depth-5 U-Net"),
+    "M": dict(c=2, t=512, depth=6, flop=241.66e9, bytes_a=4.470e9,
+              name="config_ResDepth-mono (cfg-M): 2-ch 512x512 tiles, depth-6 U-Net"),
+}
+
+
+class TrainBench:
+    """Model + optimizer + one resident synthetic batch of a workload; step() = the reference's training iteration."""
+
+    def __init__(self, wl, n, dev, rank=0, gs=None, from_rasters=False):
+        from resdepth_amd import UNet, FusedAdam, synthetic_batch
+        self.wl, self.n, self.gs = wl, n, gs
+        torch.manual_seed(0)
+        self.model = UNet(n_input_channels=wl["c"], start_kernel=64, depth=wl["depth"], bias_conv_layer=True).to(dev).train()
+        b = synthetic_batch(n, wl["c"], wl["t"], seed=1234 + rank)
+        self.x, self.y, self.mask = b["input"].to(dev), b["target"].to(dev), b["loss_mask"].to(dev)
+        self.mean, self.std = b["dsm_mean"].to(torch.float32).to(dev), b["dsm_std"].to(dev)
+        self.losses = []
+        self.sampler = None
+        if from_rasters:
+            from resdepth_amd import GpuPatchSampler
+            self.gr = torch.Generator().manual_seed(99 + rank)
+            R = 4096
+            dsm_r = torch.randn(R, R, generator=self.gr) * 3.0 + 400.0
+            self.sampler = GpuPatchSampler(dsm_r, dsm_r + torch.randn(R, R, generator=self.gr),
+                                           torch.rand(wl["c"] - 1, R, R, generator=self.gr) * 200, tile_size=wl["t"], dsm_std=3.0,
+                                           ortho_mean=100.0, ortho_std=50.0, device=dev)
+            self.pair = list(range(wl["c"] - 1))
+
+    def attach_optimizer(self):
+        from resdepth_amd import FusedAdam
+        self.opt = FusedAdam(self.model.parameters(), lr=2e-4, weight_decay=1e-5)
+        self.params = list(self.model.parameters())
+
+    def step(self):
+        from resdepth_amd import masked_l1_loss
+        if self.sampler is not None:
+            bb = self.sampler.random_batch(self.n, self.pair, generator=self.gr)
+            xx, yy, mm, me, sd_ = bb["input"], bb["target"], bb["loss_mask"], bb["dsm_mean"], bb["dsm_std"]
+        else:
+            xx, yy, mm, me, sd_ = self.x, self.y, self.mask, self.mean, self.std
+        y_pred = self.model(xx)
+        loss = masked_l1_loss(y_pred, yy, mm, me, sd_, grad_sync=self.gs)
+        loss.backward()
+        self.opt.step()
+        for p in self.params:
+            p.grad = None                     # lib/Trainer.py:221-222
+        self.losses.append(loss.detach())
+
+    def timed(self, steps, warmup, barrier=None):
+        """-> (wall seconds for `steps` steps between barriers, per-step HIP-event durations in ms).  The events are
+        recorded on torch's current stream, which every step joins with the weight-gradient stream before Adam, so one
+        event pair brackets the whole step."""
+        barrier = barrier or torch.cuda.synchronize
+        for _ in range(warmup):
+            self.step()
+        barrier()
+        self.losses.clear()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(steps):
+            self.step()
+            ev[i + 1].record()
+        barrier()
+        dt = time.perf_counter() - t0
+        return dt, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+
+
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if v else None
+
+
+def infer_sweep(dev, raster, batch, sweeps, warm=1):
+    """cfg-G on one GPU: `sweeps` full sweeps of a raster x raster synthetic DSM (tiles resident in HBM) -> (tiles/s, n_tiles)."""
+    from torch.utils.data import DataLoader
+    from resdepth_amd import UNet, SyntheticRasterTiles, predict_linear_blend
+    torch.manual_seed(0)
+    model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).eval()
+    ds = SyntheticRasterTiles(raster, raster, 3, tile_size=256, seed=1)
+    batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in DataLoader(ds, batch_size=batch, shuffle=False)]
+
+    class Loader(list):
+        dataset = ds
+    loader = Loader(batches)
+    for _ in range(warm):
+        predict_linear_blend(loader, model)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(sweeps):
+        predict_linear_blend(loader, model)
+    torch.cuda.synchronize()
+    return len(ds) * sweeps / (time.perf_counter() - t0), len(ds)
+
+
+def secondary_measurements(args, dev, tb):
+    """Numbers DESIGN.md quotes beside the headline, measured in the same invocation (few steps each; never `value`)."""
+    from resdepth_amd import _lib
+    out = {}
+    try:        # the exact-f32 MFMA kernels on the same workload (arithmetic A/B of the split-bf16 default)
+        _lib.tune_set("mfma_f32", 1)
+        tb.model.invalidate_packed()
+        dt, ev = tb.timed(5, 2)
+        out["exact_f32"] = {"tiles_per_s": round(tb.n * 5 / dt, 1), "step_ms_median": round(_median(ev), 3),
+                            "note": "same step on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32), 5 timed steps"}
+    except Exception as e:      # noqa: BLE001 -- a secondary number must never take the headline down
+        out["exact_f32"] = {"error": repr(e)[:200]}
+    finally:
+        _lib.tune_set("mfma_f32", 0)
+        tb.model.invalidate_packed()
+    try:
+        wl = WORKLOADS["M"]
+        tm = TrainBench(wl, 32, dev)
+        tm.attach_optimizer()
+        dt, ev = tm.timed(3, 2)
+        ts = 32 * 3 / dt
+        out["cfg_M"] = {"tiles_per_s": round(ts, 1), "step_ms_median": round(_median(ev), 3), "tflops": round(ts * wl["flop"] / 1e12, 1),
+                        "frac_f32_peak": round(ts * wl["flop"] / 1e12 / PEAK_F32_TFLOPS, 4),
+                        "workload": wl["name"] + ", batch 32, fwd+loss+bwd+Adam, 3 timed steps"}
+        del tm
+    except Exception as e:      # noqa: BLE001
+        out["cfg_M"] = {"error": repr(e)[:200]}
+    try:
+        ts, nt = infer_sweep(dev, 4096, 32, 2)
+        out["cfg_G"] = {"tiles_per_s": round(ts, 1), "tiles": nt, "tflops": round(ts * 19.80e9 / 1e12, 1),
+                        "workload": "cfg-G on one GPU: 4096x4096 raster, 256x256 tiles at stride 128, eval-mode BN, batch 32, "
+                                    "forward + linear blend, 2 timed sweeps"}
+    except Exception as e:      # noqa: BLE001
+        out["cfg_G"] = {"error": repr(e)[:200]}
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,13 +294,13 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBN (single-device-equivalent statistics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the exact-f32 / cfg-M / cfg-G secondary measurements")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
     ap.add_argument("--serial-backward", action="store_true",
                     help="disable the two-stream backward (weight gradients overlapping the dgrad/BN chain) in the timed region")
     ap.add_argument("--prof-steps", type=int, default=5, help="steps of the serialized, instrumented roofline pass")
-    ap.add_argument("--prof-all", action="store_true",
-                    help="bracket EVERY kernel launch with HIP events (complete breakdown; costs ~4%% of the step). Default: "
-                         "only the MFMA kernel classes the roofline needs (~1%%)")
+    ap.add_argument("--prof-mfma-only", action="store_true",
+                    help="roofline pass: bracket only the MFMA kernel classes with HIP events (default: every kernel class)")
     ap.add_argument("--workload", choices=["S", "M"], default="S",
                     help="S = cfg-S (BASELINE configs[1], the headline metric); M = cfg-M (configs[3]: 2-ch 512x512 depth-6)")
     ap.add_argument("--from-rasters", action="store_true",
@@ -142,6 +310,7 @@ def main():
                     help="measure the tiled full-raster inference sweep instead (BASELINE configs[4], cfg-G: 3-ch tiles of "
                          "256x256 at stride 128 over a synthetic --raster x --raster DSM, eval-mode BN, linear blend)")
     ap.add_argument("--raster", type=int, default=4096)
+    ap.add_argument("--prof-all", action="store_true", help="(kept for scripts) same as the default full breakdown")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the data-parallel code path (RCCL process group, bucketed all-reduce) even at world size 1")
     args = ap.parse_args()
@@ -157,14 +326,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from resdepth_amd import UNet, FusedAdam, masked_l1_loss, _lib, dp
-    from oracle import unet_oracle as O   # synthetic batch generator + cpu_baseline only (never the measured path)
+    from resdepth_amd import _lib, dp
     _lib.load()
 
     if args.infer:
         return infer_main(args, world, rank, dev)
     gs = None
     use_dist = world > 1 or args.force_dist
+    dist_info = None
     if use_dist:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:          # --force-dist without a launcher
@@ -173,47 +342,15 @@ def main():
         # slower on the MI355X boxes (with or without collectives in flight); torch.cuda.set_device above already pins
         # the rank to its GPU for the lazily created communicator
         dist.init_process_group("nccl")
-    torch.manual_seed(0)
-    wl = {"S": dict(c=3, t=256, depth=5, flop=FLOP_PER_TILE, name="config_ResDepth-stereo (cfg-S): 3-ch 256x256 tiles, depth-5 U-Net"),
-          "M": dict(c=2, t=512, depth=6, flop=241.66e9, name="config_ResDepth-mono (cfg-M): 2-ch 512x512 tiles, depth-6 U-Net")}[args.workload]
-    model = UNet(n_input_channels=wl["c"], start_kernel=64, depth=wl["depth"], bias_conv_layer=True).to(dev).train()
-    if use_dist:
-        gs = dp.attach(model, sync_bn=args.sync_bn)
-        dp.broadcast_parameters(model, 0)
-    opt = FusedAdam(model.parameters(), lr=2e-4, weight_decay=1e-5)
-    model.two_stream_backward = not args.serial_backward
-
+    wl = WORKLOADS[args.workload]
     n = args.batch
-    b = O.synthetic_batch(n, wl["c"], wl["t"], seed=1234 + rank)
-    x = b["input"].to(dev)
-    y = b["target"].to(dev)
-    mask = b["loss_mask"].to(dev)
-    mean, std = b["dsm_mean"].to(torch.float32).to(dev), b["dsm_std"].to(dev)
-    params = list(model.parameters())
-    losses = []
-    sampler = None
-    if args.from_rasters:
-        from resdepth_amd import GpuPatchSampler
-        gr = torch.Generator().manual_seed(99 + rank)
-        R = 4096
-        dsm_r = torch.randn(R, R, generator=gr) * 3.0 + 400.0
-        sampler = GpuPatchSampler(dsm_r, dsm_r + torch.randn(R, R, generator=gr), torch.rand(wl["c"] - 1, R, R, generator=gr) * 200,
-                                  tile_size=wl["t"], dsm_std=3.0, ortho_mean=100.0, ortho_std=50.0, device=dev)
-        pair = list(range(wl["c"] - 1))
-
-    def step():
-        if sampler is not None:
-            bb = sampler.random_batch(n, pair, generator=gr)
-            xx, yy, mm, me, sd_ = bb["input"], bb["target"], bb["loss_mask"], bb["dsm_mean"], bb["dsm_std"]
-        else:
-            xx, yy, mm, me, sd_ = x, y, mask, mean, std
-        y_pred = model(xx)
-        loss = masked_l1_loss(y_pred, yy, mm, me, sd_, grad_sync=gs)
-        loss.backward()
-        opt.step()
-        for p in params:
-            p.grad = None                     # lib/Trainer.py:221-222
-        losses.append(loss.detach())
+    tb = TrainBench(wl, n, dev, rank=rank, from_rasters=args.from_rasters)
+    if use_dist:
+        gs = dp.attach(tb.model, sync_bn=args.sync_bn)
+        tb.gs = gs
+        dp.broadcast_parameters(tb.model, 0)
+    tb.attach_optimizer()
+    tb.model.two_stream_backward = not args.serial_backward
 
     def barrier():
         if use_dist:
@@ -221,40 +358,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    losses.clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    timed_losses = list(losses)
+    dt, step_ms = tb.timed(args.steps, args.warmup, barrier)
+    timed_losses = list(tb.losses)
     # ---- per-kernel roofline pass.  In the timed region the weight-gradient kernels run concurrently with the
     # dgrad/BN chain on a second stream, so a kernel's event-to-event duration there includes time shared with another
     # kernel; the roofline numbers therefore come from a SERIALIZED pass of the same step, in this process, right after
     # the timed region (HIP events on the launch stream, rd_prof_*).  `value` is never taken from this pass.
     kern, prof_steps = [], 0
     if not args.no_prof:
-        model.two_stream_backward = False
-        step()
+        tb.model.two_stream_backward = False
+        tb.step()
         torch.cuda.synchronize()
         _lib.prof_reset()
-        _lib.prof_enable(2 if args.prof_all else 1)
+        _lib.prof_enable(1 if args.prof_mfma_only else 2)
         prof_steps = max(1, args.prof_steps)
         for _ in range(prof_steps):
-            step()
+            tb.step()
         torch.cuda.synchronize()
         _lib.prof_enable(0)
         kern = _lib.prof_collect()
-    losses[:] = timed_losses
-    loss_vals = [float(v) for v in losses]
+        tb.model.two_stream_backward = not args.serial_backward
+    loss_vals = [float(v) for v in timed_losses]
+    per_rank_ms = [dt / args.steps * 1e3]
     if use_dist:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(v) / args.steps * 1e3 for v in every]
+        dt = max(float(v) for v in every)               # MAX over ranks
+        dist_info = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size(),
+                     "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms]}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -272,6 +406,8 @@ def main():
                 e["tflops"] = round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2)
             if k["bytes"] > 0:
                 e["alg_gbs"] = round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1)
+                if op not in MFMA_CLASSES:              # HBM-class kernel: fraction of the 8 TB/s spec on ALGORITHMIC bytes
+                    e["hbm_frac"] = round(e["alg_gbs"] / PEAK_HBM_GBS, 3)
             kernels.append(e)
         # roofline of the dominant KERNEL (= one kernel symbol as rocprofv3 reports it; e.g. the conv3x3 forward
         # and data-gradient launches are the same igemm_nt instantiation)
@@ -285,46 +421,60 @@ def main():
         if by_sym:
             sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            traffic = None
-            try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (scripts/summarize_prof.py)
-                with open(os.path.join(ROOT, "profiles", "r01_summary.json")) as f:
-                    traffic = json.load(f)["kernels"][sym]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
-            is_split = any(tag in sym for tag in ("split", "strip"))
+            traffic, traffic_src = None, None
+            for name in ("r02_summary.json", "r01_summary.json"):
+                # HBM bytes per launch are NOT measured by this process: they come from the committed rocprofv3 PMC passes
+                # of this same command (scripts/profile.sh + scripts/summarize_prof.py; FETCH_SIZE doubled per the guide)
+                try:
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        traffic = json.load(f)["kernels"][sym]["hbm_bytes_per_launch"]
+                    traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, not this run)"
+                    break
+                except Exception:       # noqa: BLE001
+                    continue
+            is_split = any(tag in sym for tag in ("split", "strip", "convt_q"))
             peak = PEAK_SPLIT_TFLOPS if is_split else PEAK_F32_TFLOPS
             roof = {"kernel": sym, "ops": sorted(dom["ops"]), "bound": "mfma", "achieved": round(ach, 2),
                     "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "peak_note": ("fp32-equivalent FLOP/s; bound = dense bf16 MFMA peak (2500 TF) / 6 products per fp32 "
                                   "multiply-add of the exact 3-term split" if is_split else "f32-input MFMA peak"),
                     "frac_of_f32_mfma_peak": round(ach / PEAK_F32_TFLOPS, 4),
-                    "traffic": traffic, "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                     "alg_flop_per_launch": dom["flops"] / dom["launches"],
                     "launches_per_step": dom["launches"] / prof_steps,
                     "measured": f"HIP events, serialized pass of {prof_steps} steps right after the timed region "
                                 "(timed region itself: un-instrumented, wgrad kernels overlapped on a 2nd stream)"}
+        per_gpu = tiles_s / world
         out = {
             "metric": "DSM tiles/sec fwd+bwd (256x256, 3-ch, depth-5 U-Net)" if args.workload == "S" else
                       "DSM tiles/sec fwd+bwd (512x512, 2-ch, depth-6 U-Net)", "value": round(tiles_s, 2),
             "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",
-            "arithmetic": ("fp32 storage and accumulation; MFMA-class kernels multiply exactly-split operands "
-                           "(x = x1+x2+x3, bf16 terms) on v_mfma_f32_32x32x16_bf16, 6 products per multiply, error below one fp32 "
-                           "rounding -- same parity tolerances as the exact-f32 MFMA path (RD_MFMA=f32)"),
+            "arithmetic": ARITHMETIC,
             "data": ("synthetic rasters resident in HBM, a fresh augmented batch assembled on the GPU every step"
-                                     if args.from_rasters else
-                                     "synthetic (randn tiles resident in HBM, default-initialised weights)"),
+                     if args.from_rasters else "synthetic (randn tiles resident in HBM, default-initialised weights)"),
             "config": {"workload": wl["name"] + ", fwd+loss+bwd+Adam",
                        "tiles_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"dp{world}" + ("+syncbn" if args.sync_bn else ""),
                        "backward": "serial" if args.serial_backward else "two-stream (wgrad || dgrad+BN)"},
-            "e2e": {"tflops": round(tiles_s / world * wl["flop"] / 1e12, 2),
-                    "frac_f32_peak": round(tiles_s / world * wl["flop"] / 1e12 / PEAK_F32_TFLOPS, 4)},
+            "step_ms_median": round(_median(step_ms), 3),
+            "step_ms_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)],
+            "step_timing": "ms_per_step/value: wall clock over the K steps between barriers (max over ranks); step_ms_*: one HIP-event "
+                           "pair per step on the launch stream (rank 0)",
+            "e2e": {"tflops": round(per_gpu * wl["flop"] / 1e12, 2),
+                    "frac_f32_peak": round(per_gpu * wl["flop"] / 1e12 / PEAK_F32_TFLOPS, 4),
+                    "frac_split_mfma_bound": round(per_gpu * wl["flop"] / 1e12 / PEAK_SPLIT_TFLOPS, 4),
+                    "hbm_frac": round(per_gpu * wl["bytes_a"] / (PEAK_HBM_GBS * 1e9), 4),
+                    "hbm_frac_note": "tiles/s/GPU x op-level compulsory bytes per tile (SURVEY 8d model A) / 8 TB/s"},
             "roofline": roof,
             "kernels": kernels,
             "loss_first_last": [round(loss_vals[0], 6), round(loss_vals[-1], 6)] if loss_vals else None,
         }
+        if dist_info:
+            out["dist"] = dist_info
+        if world == 1 and not args.no_secondary and args.workload == "S" and not args.from_rasters and not use_dist:
+            out["secondary"] = secondary_measurements(args, dev, tb)
         if world == 1 and not args.no_cpu_baseline and args.workload == "S":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -67,7 +67,10 @@ class SyntheticRasterTiles(Dataset):
     (lib/DsmOrthoDataset.py:191-203), same sample dict; `shard=(rank, world)` keeps every world-th tile."""
 
     def __init__(self, rows: int, cols: int, n_input_channels: int = 3, tile_size: int = 256, stride=None,
-                 seed: int = 0, dsm_std: float = 3.0, shard=(0, 1)):
+                 seed: int = 0, dsm_std: float = 3.0, shard=(0, 1), areas=None):
+        """areas: optional list of ((x0, x1), (y0, y1)) inclusive pixel extents -- the reference sweeps every area of
+        its `allowed` regions with its own regular grid (lib/DsmOrthoDataset.py:96-104, lib/rasterutils.py:100-191);
+        None = one area covering the whole raster."""
         self.tile_size = int(tile_size)
         self.stride = int(tile_size // 2 if stride is None else stride)
         self.raster_shape = (int(rows), int(cols))
@@ -75,7 +78,9 @@ class SyntheticRasterTiles(Dataset):
         self.raster = torch.randn(n_input_channels, rows, cols, generator=g)
         self.raster[0] = self.raster[0] * dsm_std + 400.0
         self.dsm_std = float(dsm_std)
-        pos, reg = regular_grid([(0, cols - 1)], [(0, rows - 1)], self.tile_size, self.stride)
+        if areas is None:
+            areas = [((0, cols - 1), (0, rows - 1))]
+        pos, reg = regular_grid([a[0] for a in areas], [a[1] for a in areas], self.tile_size, self.stride)
         idx = list(range(shard[0], len(pos), shard[1]))
         self.pos = [pos[i] for i in idx]
         self.reg = [reg[i] for i in idx]
