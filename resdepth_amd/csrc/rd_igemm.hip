@@ -361,11 +361,11 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
     const int c4 = t & 3;
     const int r0 = wave * 16 + ((lane >> 5) << 3) + (((lane >> 2) & 3) << 1) + ((lane >> 4) & 1);
 
-    f32x16 acc[TM][1];
+    f32x16 acc[TM][1], lo[TM];       // hi / lo accumulators (rd_mfma_dev.h: PA6)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = lo[i][r] = 0.f;
 
     const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.Bsplit, p.b_bytes);
@@ -449,8 +449,6 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
         for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(stage + a_rd[i][q]);
     };
     // six products per (a, b) pair, smallest terms first; lane half g owns k = 8g .. 8g+7 (the same 8 k for A and B)
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-    constexpr int NT6 = 6;
     // One K-step.  Software pipeline per tile j:  global load (step j-4) -> split + LDS write (step j-2) -> fragment
     // read (step j-1, right after the MFMAs that last used the registers) -> MFMA (step j).  B: global load straight
     // into fragment registers at step j-3.  One barrier per step; LDS stage of tile j = j & 1.
@@ -465,10 +463,13 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 #pragma unroll
         for (int g = 0; g < TM; g += GP) {
 #pragma unroll
-            for (int t6 = 0; t6 < NT6; ++t6)
+            for (int t6 = 0; t6 < 5; ++t6)
 #pragma unroll
                 for (int i = g; i < g + GP; ++i)
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t6]], bf[PB[t6]], acc[i][0], 0, 0, 0);
+                    lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
+#pragma unroll
+            for (int i = g; i < g + GP; ++i)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][0], 0, 0, 0);
 #pragma unroll
             for (int i = g; i < g + GP; ++i) read_a(rstage, i);      // tile kt+1, consumed one step later
         }
@@ -498,6 +499,10 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
         step(kt + 2, ra0, b2, b1, st0, st1);
         step(kt + 3, ra1, b3, b2, st1, st0);
     }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = merge_hi_lo(acc[i][0][r], lo[i][r]);
     nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m);
 }
 
@@ -531,11 +536,11 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     const int wm = wave / WN, wn = wave % WN;
     (void)logW; (void)logH;
 
-    f32x16 acc[TM][1];
+    f32x16 acc[TM][1], lo[TM];       // hi / lo accumulators (rd_mfma_dev.h: PA6)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = lo[i][r] = 0.f;
 
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.Bsplit, p.b_bytes);
     // staging tasks: element e = t + 256 k -> halo pixel e >> 2, 16-byte quarter e & 3 of its 64-byte channel chunk
@@ -585,7 +590,6 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         a_rd[i] = ((row >> 4) * HW_ + (row & 15)) * RS + half * 4;
     }
     bf16x8 af[TM][3];
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
     constexpr int GP = TM >= 2 ? 2 : 1;
 
     float* stage_cur = smem;
@@ -615,10 +619,13 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
 #pragma unroll
         for (int g = 0; g < TM; g += GP) {
 #pragma unroll
-            for (int t6 = 0; t6 < 6; ++t6)
+            for (int t6 = 0; t6 < 5; ++t6)
 #pragma unroll
                 for (int i = g; i < g + GP; ++i)
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t6]], bf[PB[t6]], acc[i][0], 0, 0, 0);
+                    lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
+#pragma unroll
+            for (int i = g; i < g + GP; ++i)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][0], 0, 0, 0);
 #pragma unroll
             for (int i = g; i < g + GP; ++i)
 #pragma unroll
@@ -642,6 +649,10 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         float* tmp = stage_cur; stage_cur = stage_nxt; stage_nxt = tmp;
     }
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = merge_hi_lo(acc[i][0][r], lo[i][r]);
     const int m0 = ((img * H + y0) * W) + x0;
     nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m);
 }
@@ -1042,13 +1053,13 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
     const int b_shift = b_dy * W + b_dx;
     const int lds_row0 = (isA ? 0 : BM) + quad * 4;   // LDS rows of this task's 4 channels
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN], lo[TM][TN];       // hi / lo accumulators (rd_mfma_dev.h: PA6)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = lo[i][j][r] = 0.f;
 
     const long k_begin = (long)split * p.kchunk;
     long k_end = k_begin + p.kchunk;
@@ -1131,14 +1142,18 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 3; ++q) bf[j][q] = *reinterpret_cast<const bf16x8*>(stage + b_rd[j][q]);
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int t6 = 0; t6 < 6; ++t6)
+        for (int t6 = 0; t6 < 5; ++t6)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t6]], bf[j][PB[t6]], acc[i][j], 0, 0, 0);
+                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[j][PB6[t6]], lo[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
     };
 
     if (k_begin < k_end) {
@@ -1171,7 +1186,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.M) out[(long)m * p.N + n] = acc[i][j][r];
+                if (m < p.M) out[(long)m * p.N + n] = merge_hi_lo(acc[i][j][r], lo[i][j][r]);
             }
         }
 }

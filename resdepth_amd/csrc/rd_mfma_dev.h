@@ -26,10 +26,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int SK = 16;      // k-values per K-step
 constexpr int SROWB = 96;   // bytes of one (row, K-step) in the packed split-B tensor
 
-// x = h + m + l exactly; h, m, l have <= 8 significant bits (bf16-representable), returned as fp32 bit patterns
+// ---- the six products of a*b = (a1+a2+a3)(b1+b2+b3) that are kept, smallest first.  The five products of weight <= 2^-8
+// go into a SEPARATE accumulator (lo) and only a1*b1 into the main one (hi); the two are added once in the epilogue.
+// With a single accumulator a 2^-16-class group sum (8 products) that is below half an ulp of a large running sum is
+// rounded away EVERY time -- a one-sided loss of up to 2^-15 |ab| on same-sign data (measured 163 u rms at K = 4608,
+// u = 2^-24; scripts/split_numerics.py) -- whereas `lo` only ever holds terms of its own size.  `hi` then behaves like an
+// fp32 dot product with one rounding per 16 products.
+constexpr int PA6[6] = {2, 1, 0, 1, 0, 0}, PB6[6] = {0, 1, 2, 0, 1, 0};
+// hi + lo.  An infinite operand lives in its first term only (split3), so hi = Inf * b1 carries the correct +-Inf (or NaN
+// for Inf * 0 / Inf - Inf, as in fp32) while lo may have picked up Inf * 0 = NaN from a ZERO lower term of the other
+// operand: an infinite hi therefore wins.  (Only difference to an fp32 product left: Inf * b with 0 < |b| < 2^-133.)
+__device__ __forceinline__ float merge_hi_lo(float hi, float lo) { return __builtin_fabsf(hi) == __builtin_inff() ? hi : hi + lo; }
+
+// x = h + m + l exactly (|x| >= 2^-110; below that the third term is a bf16 subnormal and absorbs an absolute error
+// <= 2^-133); h, m, l have <= 8 significant bits (bf16-representable), returned as fp32 bit patterns.  Split by
+// truncation: m and l carry the sign of x, |m| < 2^-7 |x|, |l| < 2^-15 |x|.
+// Non-finite x: h = x and the residual x - h (Inf - Inf = NaN) is replaced by 0, so +-Inf stays one exact term (h) and
+// propagates through the products exactly like in an fp32 multiply (Inf * 0 = NaN, Inf + -Inf = NaN); NaN stays NaN.
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
     h = __float_as_uint(x) & 0xffff0000u;
-    const float r = x - __uint_as_float(h);
+    float r = x - __uint_as_float(h);
+    r = (r == r) ? r : 0.f;
     m = __float_as_uint(r) & 0xffff0000u;
     l = __float_as_uint(r - __uint_as_float(m));
 }

@@ -56,7 +56,7 @@ def nerr(out, ref, den):
 def conv_cases(fl, g, n=2, h=16, w=16, cin=512, cout=128):
     x = flavour(fl, (n, cin, h, w), g, "a")
     wt = flavour(fl, (cout, cin, 3, 3), g, "b")
-    gy = flavour(fl, (n, cout, h, w), g, "a")
+    gy = flavour("randn" if fl == "tiny" else fl, (n, cout, h, w), g, "a")      # tiny * tiny would underflow to 0
     xd, wd_, gd = x.double(), wt.double(), gy.double()
     ref = {"fwd": F.conv2d(xd, wd_, None, 1, 1), "dgrad": F.conv_transpose2d(gd, wd_, None, 1, 1),
            "wgrad": torch.nn.grad.conv2d_weight(xd, wt.shape, gd, stride=1, padding=1)}
@@ -73,7 +73,7 @@ def conv_cases(fl, g, n=2, h=16, w=16, cin=512, cout=128):
 def convt_cases(fl, g, n=2, h=16, w=16, c=512):
     x = flavour(fl, (n, c, h, w), g, "a")
     wt = flavour(fl, (c, c, 2, 2), g, "b")
-    gy = flavour(fl, (n, c, 2 * h, 2 * w), g, "a")
+    gy = flavour("randn" if fl == "tiny" else fl, (n, c, 2 * h, 2 * w), g, "a")
     xd, wd_, gd = x.double(), wt.double(), gy.double()
     ref = {"fwd": F.conv_transpose2d(xd, wd_, None, 2), "dgrad": F.conv2d(gd, wd_, None, 2),
            "wgrad": torch.nn.grad.conv2d_weight(gd, wt.shape, xd, stride=2)}
