@@ -42,6 +42,7 @@ enum TuneKey {
     TUNE_WG_STRIP,         // -1 auto | 0: never use the strip weight-gradient kernel
     TUNE_WG_MINBLOCKS,     // strip kernel: minimum blocks before image rows are chunked
     TUNE_WG_BLOCKS,        // strip kernel: target block count
+    TUNE_CONVT_PATCH,      // -1 auto | 0: never use the patch transposed-convolution kernels
     TUNE_ROWS_BLOCKS,      // first-stage blocks of the per-channel reductions
     TUNE_LAST_BLOCKS,      // first-stage blocks of the last-conv gradient kernels
     TUNE_COUNT
@@ -55,6 +56,11 @@ inline int mfma_split() { return !tune(TUNE_MFMA_F32); }
 int wgrad_strip_splits(int n, int h, int w, int cin, int cout);
 int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int h, int w, int cin, int cout, hipStream_t s,
                        int* splits_out, int* swapped_out);
+
+// transposed-convolution patch kernels (rd_convt.hip); *launched = 0 when the shape is left to the generic NT kernel
+int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, const float* bias, const float* skip,
+                     const float* sk_mean, const float* sk_invstd, const float* sk_gamma, const float* sk_beta, float sk_slope,
+                     const float* sk_slope_dev, float* out, int n, int h, int w, int cin, int cout, hipStream_t s, int* launched);
 
 inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;

@@ -1,0 +1,264 @@
+// ConvTranspose2d(k=2, s=2) family on the gfx950 matrix cores (split-bf16, hi/lo accumulators; rd_mfma_dev.h).
+// Replaces the ATen kernels behind nn.ConvTranspose2d forward / autograd and the SkipConnection ADD
+// (reference: lib/UNet.py:21, 63, 96-101, 181, 213-224).
+//
+// A k2s2 transposed convolution has no overlap between taps: out[2g+a][2x+b][co] = bias[co] + sum_ci x[g][x][ci] * W[ci][co][a][b]
+// (g = n*H + y: the images of a batch are stacked rows, so an image border needs no special case).  It is four 1x1
+// convolutions sharing the input; as a GEMM: M = input pixels, K = Cin, N' = (a, b, co).
+//
+// convt_fwd_kernel: block tile = a PATCH of TR x PW input pixels (32*TM rows) x 128 consecutive N' columns.  For Cout >= 128
+// the 128 columns are one (a, b) quadrant and 128 output channels; for Cout = 64 they are one output row parity `a` with both
+// `b` -- in both cases a tile row (one input pixel) owns 512 CONTIGUOUS bytes of the output, and for Cout = 64 the PW pixels
+// of a patch row own one contiguous PW * 512-byte segment of an output row (the generic NT kernel scattered 16-byte pieces).
+// The epilogue stages 32 rows x 128 columns through LDS and every lane moves 16 bytes: bias, skip tensor and the lazy
+// act(BN(z)) recomputation of the encoder skip ride the same pass; the skip loads are issued before the LDS round trip.
+// Main loop = the split NT pipeline of rd_igemm.hip (global load -> split + LDS write -> fragment read -> MFMA over four
+// K-steps, one barrier per 16-channel step, weights straight from global memory in fragment order).
+#include "rd_common.h"
+#include "rd_mfma_dev.h"
+
+namespace rd {
+
+struct CtParams {
+    const float* x;
+    const void* wsplit;      // split-bf16 fragment layout of wtf[(ab, co)][ci] (rd_pack_convt2x2_weight)
+    const float* bias;
+    const float* skip;
+    const float* sk_mean;    // non-null: `skip` is the pre-BatchNorm conv output z; skip value = act(gamma*(z-mean)*invstd + beta)
+    const float* sk_invstd;
+    const float* sk_gamma;
+    const float* sk_beta;
+    const float* sk_slope_dev;
+    float sk_slope;
+    float* out;
+    int G, W, Cin, Cout;     // G = N * H stacked input rows
+    int PW, logPW, TR;       // patch = TR rows x PW columns, TR * PW = 32 * TM
+    int tiles_x, ngroups, nk;
+    unsigned x_bytes, w_bytes;
+};
+
+__device__ __forceinline__ float ct_act(float y, float slope) { return y > 0.f ? y : y * slope; }
+
+template <int TM>
+__global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
+    constexpr int BM = 32 * TM, RS = 28;                  // LDS row = 3 terms x 16 bf16 + 16 B pad (conflict-free b128 reads)
+    constexpr int STAGE = BM * RS;
+    constexpr int NLD = (BM * 4 + 255) / 256;             // staging float4 per thread and K-step
+    constexpr int CS = 128 + 4;
+    constexpr int EPI_WORDS = 32 * CS;
+    constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int cg = lb % p.ngroups, tile_m = lb / p.ngroups;     // the column groups of one patch run back to back (A from L2)
+    const int tx = tile_m % p.tiles_x, ty = tile_m / p.tiles_x;
+    const int g0 = ty * p.TR, x0 = tx * p.PW;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int W = p.W, logPW = p.logPW, pwm = p.PW - 1;
+
+    f32x16 acc[TM], lo[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = lo[i][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.x, p.x_bytes), rsB = make_rsrc(p.wsplit, p.w_bytes);
+    unsigned s_off[NLD];
+    int s_lds[NLD];
+    const int c4 = t & 3;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int row = (t + 256 * k) >> 2;
+        const int g = g0 + (row >> logPW), xx = x0 + (row & pwm);
+        const bool ok = row < BM && g < p.G;
+        s_off[k] = ok ? (unsigned)((((long)g * W + xx) * p.Cin + c4 * 4) * 4) : kOOB;
+        s_lds[k] = row < BM ? row * RS + c4 * 2 : -1;
+    }
+    const int nb = cg * 4 + wave;                         // 32-column block of this wave
+    const unsigned b_off = (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16);
+
+    auto load_a = [&](int kt, float4 (&ra)[NLD]) {
+        const bool cok = kt < p.nk;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) ra[k] = buf_load4(rsA, cok ? s_off[k] : kOOB, (unsigned)(kt * SK * 4));
+    };
+    auto store_a = [&](float* stage, const float4 (&ra)[NLD]) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            if (s_lds[k] < 0) continue;
+            uint2 ph, pm, pl;
+            split_pack4(ra[k], ph, pm, pl);
+            float* row = stage + s_lds[k];
+            *reinterpret_cast<uint2*>(row) = ph;
+            *reinterpret_cast<uint2*>(row + 8) = pm;
+            *reinterpret_cast<uint2*>(row + 16) = pl;
+        }
+    };
+    auto load_b = [&](int kt, uint4 (&rb)[3]) {
+        const unsigned voff = kt < p.nk ? b_off : kOOB;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((kt * 3 + q) * 1024));
+    };
+    const int lrow = lane & 31, half = lane >> 5;
+    bf16x8 af[TM][3];
+    auto read_a = [&](const float* stage) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                af[i][q] = *reinterpret_cast<const bf16x8*>(stage + (i * 32 + lrow) * RS + half * 4 + q * 8);
+    };
+    constexpr int GP = TM >= 2 ? 2 : 1;
+    // One K-step (16 input channels).  Pipeline per tile j: global load (step j-3) -> split + LDS write (step j-1) ->
+    // fragment read (end of step j-1, after the barrier) -> MFMA (step j); LDS stage of tile j = j & 1.
+    auto step = [&](int kt, float4 (&ra)[NLD], uint4 (&bcur)[3], uint4 (&bnew)[3], float* stage_next) {
+        store_a(stage_next, ra);          // tile kt+1 (this stage was last read before the previous barrier)
+        load_a(kt + 3, ra);
+        load_b(kt + 2, bnew);             // into the register set of tile kt-1
+        bf16x8 bf[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bf[q] = __builtin_bit_cast(bf16x8, bcur[q]);
+#pragma unroll
+        for (int g = 0; g < TM; g += GP) {
+#pragma unroll
+            for (int t6 = 0; t6 < 5; ++t6)
+#pragma unroll
+                for (int i = g; i < g + GP; ++i)
+                    lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
+#pragma unroll
+            for (int i = g; i < g + GP; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
+        }
+        __syncthreads();
+        read_a(stage_next);               // tile kt+1, consumed by the next step
+    };
+
+    float* st0 = smem;
+    float* st1 = smem + STAGE;
+    float4 ra0[NLD], ra1[NLD];
+    uint4 b0[3], b1[3], b2[3];
+    load_a(0, ra0);
+    load_a(1, ra1);
+    load_b(0, b0);
+    load_b(1, b1);
+    store_a(st0, ra0);
+    load_a(2, ra0);
+    __syncthreads();
+    read_a(st0);
+    // A register sets alternate with period 2, B sets with period 3: the pattern repeats every 6 steps (nk is even)
+#pragma unroll 1
+    for (int kt = 0; kt < p.nk; kt += 6) {
+        step(kt, ra1, b0, b2, st1);
+        step(kt + 1, ra0, b1, b0, st0);
+        if (kt + 2 >= p.nk) break;
+        step(kt + 2, ra1, b2, b1, st1);
+        step(kt + 3, ra0, b0, b2, st0);
+        if (kt + 4 >= p.nk) break;
+        step(kt + 4, ra1, b1, b0, st1);
+        step(kt + 5, ra0, b2, b1, st0);
+    }
+    __syncthreads();
+
+    // ---- epilogue: 32-row passes through LDS; tile row r = (gy, px) owns 128 contiguous floats of the output
+    const int col0 = cg * 128;
+    const int ab0 = col0 / p.Cout, co0 = col0 - ab0 * p.Cout;
+    const long obase = (((long)(2 * g0 + (ab0 >> 1)) * (2 * W)) + 2 * x0 + (ab0 & 1)) * p.Cout + co0;
+    const long ystride = (long)4 * W * p.Cout;
+    const int xstride = 2 * p.Cout;
+    const int q4 = t & 31, erow = t >> 5;                 // this thread's 16-byte column and first row of a pass (rows erow + 8k)
+    int co = co0 + q4 * 4;
+    if (co >= p.Cout) co -= p.Cout;                       // Cout = 64: columns 64..127 are the b = 1 pixel
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + co);
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, slope = 0.f;
+    if (p.sk_mean) {
+        const float4 mu = *reinterpret_cast<const float4*>(p.sk_mean + co), is = *reinterpret_cast<const float4*>(p.sk_invstd + co);
+        const float4 ga = *reinterpret_cast<const float4*>(p.sk_gamma + co), be = *reinterpret_cast<const float4*>(p.sk_beta + co);
+        sc[0] = is.x * ga.x; sc[1] = is.y * ga.y; sc[2] = is.z * ga.z; sc[3] = is.w * ga.w;
+        sh[0] = be.x - mu.x * sc[0]; sh[1] = be.y - mu.y * sc[1]; sh[2] = be.z - mu.z * sc[2]; sh[3] = be.w - mu.w * sc[3];
+        slope = p.sk_slope_dev ? p.sk_slope_dev[0] : p.sk_slope;
+    }
+    float* Cs = smem;
+    // all skip loads of the tile go out first (the fragment / weight registers of the main loop are dead by now): the
+    // HBM latency is paid once per block instead of once per 32-row pass
+    long off[TM][4];
+    bool ok[TM][4];
+    float4 sk[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = i * 32 + erow + 8 * k;
+            const int gy = r >> logPW, px = r & pwm;
+            ok[i][k] = g0 + gy < p.G;
+            off[i][k] = obase + gy * ystride + px * xstride + q4 * 4;
+            sk[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.skip && ok[i][k]) sk[i][k] = *reinterpret_cast<const float4*>(p.skip + off[i][k]);
+        }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            Cs[((r & 3) + 8 * (r >> 2) + 4 * half) * CS + wave * 32 + lrow] = merge_hi_lo(acc[i][r], lo[i][r]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[i][k]) continue;
+            float4 v = *reinterpret_cast<const float4*>(&Cs[(erow + 8 * k) * CS + q4 * 4]);
+            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+            if (p.skip) {
+                float4 s4 = sk[i][k];
+                if (p.sk_mean) {
+                    s4.x = ct_act(fmaf(s4.x, sc[0], sh[0]), slope);
+                    s4.y = ct_act(fmaf(s4.y, sc[1], sh[1]), slope);
+                    s4.z = ct_act(fmaf(s4.z, sc[2], sh[2]), slope);
+                    s4.w = ct_act(fmaf(s4.w, sc[3], sh[3]), slope);
+                }
+                v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w;
+            }
+            *reinterpret_cast<float4*>(p.out + off[i][k]) = v;
+        }
+        __syncthreads();
+    }
+}
+
+// The patch kernel handles Cin % 32 == 0, Cout % 64 == 0, W a power of two >= 8; everything else stays on the generic NT
+// kernel (rd_igemm.hip).  Returns 0 when it did not launch.
+int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, const float* bias, const float* skip,
+                     const float* sk_mean, const float* sk_invstd, const float* sk_gamma, const float* sk_beta, float sk_slope,
+                     const float* sk_slope_dev, float* out, int n, int h, int w, int cin, int cout, hipStream_t s, int* launched) {
+    *launched = 0;
+    if (!mfma_split() || tune(TUNE_CONVT_PATCH) == 0) return RD_OK;
+    if (cin % 32 != 0 || cout % 64 != 0 || w < 8 || ilog2_exact(w) < 0) return RD_OK;     // nk = Cin/16 even
+    const double xb = 4.0 * n * h * (double)w * cin;
+    if (xb >= 4294967040.0 || (double)wsplit_bytes >= 4294967040.0) return RD_OK;
+    const long G = (long)n * h;
+    const long M = G * w;
+    const int tm = 4;       // 128-row tiles (a 64-row instantiation spilled under hipcc's scheduler at 168 registers)
+    CtParams p = {};
+    p.x = x; p.wsplit = wsplit; p.bias = bias; p.skip = skip; p.out = out;
+    p.sk_mean = sk_mean; p.sk_invstd = sk_invstd; p.sk_gamma = sk_gamma; p.sk_beta = sk_beta; p.sk_slope = sk_slope;
+    p.sk_slope_dev = sk_slope_dev;
+    p.G = (int)G; p.W = w; p.Cin = cin; p.Cout = cout;
+    p.PW = w < 16 ? w : 16;
+    p.logPW = ilog2_exact(p.PW);
+    p.TR = 32 * tm / p.PW;
+    p.tiles_x = w / p.PW;
+    p.ngroups = 4 * cout / 128;
+    p.nk = cin / 16;
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wsplit_bytes;
+    const long tiles_y = (G + p.TR - 1) / p.TR;
+    const long grid = tiles_y * p.tiles_x * p.ngroups;
+    if (grid >= (1L << 31)) return RD_OK;
+    char pcls[64];
+    snprintf(pcls, sizeof(pcls), "convt2x2_fwd|convt_fwd<%d>", tm);
+    ProfScope ps(s, pcls, 2.0 * M * 4.0 * cout * cin,
+                 4.0 * ((double)M * cin + 4.0 * cout * cin + (skip ? 2.0 : 1.0) * 4.0 * M * cout), true);
+    hipLaunchKernelGGL(convt_fwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, p);
+    RD_LAUNCH_CHECK("convt_fwd");
+    *launched = 1;
+    return RD_OK;
+}
+
+}  // namespace rd

@@ -1098,10 +1098,10 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
         unsigned h[4][4], m[4][4], l[4][4];     // [pixel j][channel c]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            split3(x[j].x, h[j][0], m[j][0], l[j][0]);
-            split3(x[j].y, h[j][1], m[j][1], l[j][1]);
-            split3(x[j].z, h[j][2], m[j][2], l[j][2]);
-            split3(x[j].w, h[j][3], m[j][3], l[j][3]);
+            split3<false>(x[j].x, h[j][0], m[j][0], l[j][0]);
+            split3<false>(x[j].y, h[j][1], m[j][1], l[j][1]);
+            split3<false>(x[j].z, h[j][2], m[j][2], l[j][2]);
+            split3<false>(x[j].w, h[j][3], m[j][3], l[j][3]);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1534,6 +1534,14 @@ int rd_convt2x2_fwd(const float* x, const float* wtf, const float* bias, const f
     if (int e = check_conv_args(n, h, w, cin, cout)) return e;
     RD_REQUIRE(x && wtf && out, "rd_convt2x2_fwd: null pointer");
     RD_REQUIRE(cin % 4 == 0, "rd_convt2x2_fwd: Cin must be a multiple of 4 (got %d)", cin);
+    {
+        int launched = 0;
+        const size_t sb = (size_t)rows32_of(4L * cout) * nk16_of(1, cin) * SROWB;
+        if (int e = convt_fwd_launch(x, (const char*)wtf + packed_f32_bytes(4L * cout, 1, cin), sb, bias, skip, nullptr, nullptr,
+                                     nullptr, nullptr, 0.f, nullptr, out, n, h, w, cin, cout, (hipStream_t)s, &launched))
+            return e;
+        if (launched) return RD_OK;
+    }
     NtParams p = {};
     p.A = x; p.B = wtf; p.C = out; p.bias = bias; p.skip = skip;
     p.M = n * h * w; p.N = 4 * cout; p.K = cin; p.Cin = cin; p.Cout = cout;
@@ -1547,6 +1555,14 @@ int rd_convt2x2_fwd_bnskip(const float* x, const float* wtf, const float* bias, 
     if (int e = check_conv_args(n, h, w, cin, cout)) return e;
     RD_REQUIRE(x && wtf && out && z_skip && mean && invstd && gamma && beta, "rd_convt2x2_fwd_bnskip: null pointer");
     RD_REQUIRE(cin % 4 == 0, "rd_convt2x2_fwd_bnskip: Cin must be a multiple of 4 (got %d)", cin);
+    {
+        int launched = 0;
+        const size_t sb = (size_t)rows32_of(4L * cout) * nk16_of(1, cin) * SROWB;
+        if (int e = convt_fwd_launch(x, (const char*)wtf + packed_f32_bytes(4L * cout, 1, cin), sb, bias, z_skip, mean, invstd,
+                                     gamma, beta, slope, slope_dev, out, n, h, w, cin, cout, (hipStream_t)s, &launched))
+            return e;
+        if (launched) return RD_OK;
+    }
     NtParams p = {};
     p.A = x; p.B = wtf; p.C = out; p.bias = bias; p.skip = z_skip;
     p.sk_mean = mean; p.sk_invstd = invstd; p.sk_gamma = gamma; p.sk_beta = beta; p.sk_slope = slope; p.sk_slope_dev = slope_dev;

@@ -43,10 +43,14 @@ __device__ __forceinline__ float merge_hi_lo(float hi, float lo) { return __buil
 // truncation: m and l carry the sign of x, |m| < 2^-7 |x|, |l| < 2^-15 |x|.
 // Non-finite x: h = x and the residual x - h (Inf - Inf = NaN) is replaced by 0, so +-Inf stays one exact term (h) and
 // propagates through the products exactly like in an fp32 multiply (Inf * 0 = NaN, Inf + -Inf = NaN); NaN stays NaN.
+// GUARD = false drops the non-finite handling (2 VALU per element): used by the weight-gradient staging, where every
+// VALU instruction costs ~3 cycles of MFMA time (scripts/ubench/mfma_shadow.hip) and the single accumulator could not
+// keep an Inf apart from Inf * 0 anyway -- there a non-finite operand yields NaN in every output it touches.
+template <bool GUARD = true>
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
     h = __float_as_uint(x) & 0xffff0000u;
     float r = x - __uint_as_float(h);
-    r = (r == r) ? r : 0.f;
+    if (GUARD) r = (r == r) ? r : 0.f;
     m = __float_as_uint(r) & 0xffff0000u;
     l = __float_as_uint(r - __uint_as_float(m));
 }

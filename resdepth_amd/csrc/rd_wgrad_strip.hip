@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void wgrad_strip_kernel(WsParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float xv = c == 0 ? v[j].x : c == 1 ? v[j].y : c == 2 ? v[j].z : v[j].w;
-                split3(xv, h[j], m[j], l[j]);
+                split3<false>(xv, h[j], m[j], l[j]);
             }
             const int flip = (c >> 1) * 4;  // next swizzle value = chunk index ^ 1 = word offset ^ 4
             float* rowp = region + c * 32;
