@@ -43,6 +43,7 @@ enum TuneKey {
     TUNE_WG_MINBLOCKS,     // strip kernel: minimum blocks before image rows are chunked
     TUNE_WG_BLOCKS,        // strip kernel: target block count
     TUNE_CONVT_PATCH,      // -1 auto | 0: never use the patch transposed-convolution kernels
+    TUNE_EDGE_CONV,        // -1 auto | 0: never use the tile kernels of the first / last convolution (rd_edge_conv.hip)
     TUNE_ROWS_BLOCKS,      // first-stage blocks of the per-channel reductions
     TUNE_LAST_BLOCKS,      // first-stage blocks of the last-conv gradient kernels
     TUNE_COUNT
@@ -61,6 +62,13 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
 int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, const float* bias, const float* skip,
                      const float* sk_mean, const float* sk_invstd, const float* sk_gamma, const float* sk_beta, float sk_slope,
                      const float* sk_slope_dev, float* out, int n, int h, int w, int cin, int cout, hipStream_t s, int* launched);
+
+// last convolution, tile kernels (rd_edge_conv.hip); *launched = 0 / blocks = 0 when the shape stays on the generic kernels
+int conv_last_fwd_launch(const float* s_in, const float* wt, const float* bias, const float* x_nchw, int xc, float* out, int n,
+                         int h, int w, int c, hipStream_t s, int* launched);
+int conv_last_dgrad_launch(const float* dout, const float* wt, float* ds, int n, int h, int w, int c, hipStream_t s, int* launched);
+int conv_last_wgrad_blocks(int n, int h, int w, int c);
+int conv_last_wgrad_launch(const float* s_in, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s);
 
 inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;

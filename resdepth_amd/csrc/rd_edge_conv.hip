@@ -1,0 +1,257 @@
+// Streaming kernels of the last convolution C -> 1 (+ bias + outer residual x[:, 0:1]) for the channel counts the network
+// uses (C = 16 / 32 / 64: one pixel = 4 / 8 / 16 lanes of 16 bytes).  Replaces the ATen kernels behind the reference's
+// `last_layer` + outer SkipConnection and their autograd (lib/UNet.py:184, 227-244).  All three are HBM-bound: they move
+// the 64-channel full-resolution tensor exactly once (537 MB at cfg-S) and nothing else of size.
+//
+//  forward   every input pixel is read ONCE as a whole C-channel row (256 contiguous bytes at C = 64; the previous kernel
+//            re-read a 10x34 halo per 16-channel chunk in 64-byte pieces: 1.78x the algorithmic HBM traffic).  The 8 lanes
+//            of a pixel (8 channels each) form its nine tap dot products V[q][tap] = sum_c s[q][c] w[c][tap] (weights in registers, lane
+//            reduction with DPP adds -- no LDS, no barrier), V goes to LDS (612 halo pixels x 9 floats per 16x32 tile), and
+//            out[p] = bias + x0[p] + sum_tap V[p + tap][tap] is nine conflict-free LDS reads per output pixel.
+//  dgrad     ds[q][c] = sum_tap dout[q - tap] w[c][tap]: the 1-channel dout tile (+ halo) sits in LDS, every lane keeps its
+//            4 channels x 9 taps of weights in registers and streams 16-byte stores (a wave writes 1 KB contiguous).
+//  wgrad     dw[c][tap] = sum_q s[q][c] dout[q - tap]: same LDS tile of dout, four 16-byte loads of s in flight per lane,
+//            36 accumulators per lane, ONE block-level reduction at the end (LDS, two barriers) instead of 9 x 2.
+#include "rd_common.h"
+
+namespace rd {
+
+constexpr int ET_H = 16, ET_W = 32, EH_W = ET_W + 2, EH_H = ET_H + 2, EH_NP = EH_H * EH_W;   // 16x32 tile, 612 halo pixels
+constexpr int EVS = 9;          // V row stride in floats (odd: column reads of one tap are bank-conflict free)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_xadd(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the LP consecutive lanes of a pixel (LP = 2, 4, 8, 16; groups are aligned inside a 16-lane DPP row); every lane
+// ends up with the total.  Fixed pairing order => deterministic.
+template <int LP>
+__device__ __forceinline__ float lane_group_sum(float v) {
+    v = dpp_xadd<0xB1>(v);                        // quad_perm [1,0,3,2]
+    if (LP >= 4) v = dpp_xadd<0x4E>(v);           // quad_perm [2,3,0,1]
+    if (LP >= 8) v = dpp_xadd<0x141>(v);          // row_half_mirror: quad 0 <-> quad 1
+    if (LP >= 16) v = dpp_xadd<0x140>(v);         // row_mirror: half 0 <-> half 1
+    return v;
+}
+
+// LP = lanes per pixel, each lane owns 8 consecutive channels (two 16-byte loads): C = 8 * LP
+template <int LP>
+__global__ __launch_bounds__(256) void conv_last_fwd_dpp_kernel(const float* __restrict__ s_in, const float* __restrict__ w,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ x_nchw, int xc,
+                                                                float* __restrict__ out, int N, int H, int W, int tiles_x,
+                                                                int tiles_y) {
+    constexpr int C = LP * 8, PPI = 256 / LP;     // pixels per block iteration
+    __shared__ float V[EH_NP * EVS];
+    const int t = threadIdx.x, q = t % LP, slot = t / LP;
+    const int tl = blockIdx.x;
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+    const int y0 = ty * ET_H, x0 = tx * ET_W;
+    float wr[9][8];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wr[tap][k] = w[(q * 8 + k) * 9 + tap];
+    constexpr int UN = 2;                          // pixels (2 x 16-byte loads each) in flight per lane
+    for (int p0 = 0; p0 < EH_NP; p0 += PPI * UN) {
+        float4 v[UN][2];
+        int hp[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            hp[u] = p0 + u * PPI + slot;
+            const int hy = hp[u] / EH_W, hx = hp[u] - hy * EH_W;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            v[u][0] = v[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding / tile overhang
+            if (hp[u] < EH_NP && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+                const float* src = s_in + (((long)n * H + gy) * W + gx) * C + q * 8;
+                v[u][0] = *reinterpret_cast<const float4*>(src);
+                v[u][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const float sv[8] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w, v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+            float pt[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                float a = sv[0] * wr[tap][0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) a = fmaf(sv[k], wr[tap][k], a);
+                pt[tap] = lane_group_sum<LP>(a);
+            }
+            if (q == 0 && hp[u] < EH_NP) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) V[hp[u] * EVS + tap] = pt[tap];
+            }
+        }
+    }
+    __syncthreads();
+    const float b0 = bias ? bias[0] : 0.f;
+    for (int e = t; e < ET_H * ET_W; e += 256) {
+        const int py = e / ET_W, px = e - py * ET_W;
+        const int gy = y0 + py, gx = x0 + px;
+        if (gy >= H || gx >= W) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) acc += V[((py + tap / 3) * EH_W + px + tap % 3) * EVS + tap];
+        acc += b0;
+        if (x_nchw) acc = x_nchw[(((long)n * xc) * H + gy) * W + gx] + acc;
+        out[((long)n * H + gy) * W + gx] = acc;
+    }
+}
+
+// dout tile (+ one-pixel halo, zero outside the image) -> LDS; D[hy][hx] = dout[y0 - 1 + hy][x0 - 1 + hx]
+__device__ __forceinline__ void load_dout_tile(float* D, const float* __restrict__ dout, int n, int y0, int x0, int H, int W,
+                                               int t) {
+    for (int e = t; e < EH_NP; e += 256) {
+        const int hy = e / EH_W, hx = e - hy * EH_W;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        D[e] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? dout[((long)n * H + gy) * W + gx] : 0.f;
+    }
+}
+
+// ds[q][c] = sum_tap dout[q - off(tap)] * w[c][tap], off(tap) = (tap/3 - 1, tap%3 - 1)
+__global__ __launch_bounds__(256) void conv_last_dgrad_tile_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                                   float* __restrict__ ds, int N, int H, int W, int C, int CQ,
+                                                                   int tiles_x, int tiles_y) {
+    __shared__ float D[EH_NP];
+    const int t = threadIdx.x, q = t % CQ, slot = t / CQ, PPI = 256 / CQ;
+    const int tl = blockIdx.x;
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+    const int y0 = ty * ET_H, x0 = tx * ET_W;
+    float wr[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wr[tap][k] = w[(q * 4 + k) * 9 + tap];
+    load_dout_tile(D, dout, n, y0, x0, H, W, t);
+    __syncthreads();
+    for (int e = slot; e < ET_H * ET_W; e += PPI) {
+        const int py = e / ET_W, px = e - py * ET_W;
+        const int gy = y0 + py, gx = x0 + px;
+        if (gy >= H || gx >= W) continue;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // dout at q - off(tap): halo coordinates (py + 1 - dy, px + 1 - dx) = (py + 2 - tap/3, px + 2 - tap%3)
+            const float d = D[(py + 2 - tap / 3) * EH_W + px + 2 - tap % 3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(d, wr[tap][k], acc[k]);
+        }
+        *reinterpret_cast<float4*>(ds + (((long)n * H + gy) * W + gx) * C + q * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// dw[c][tap] = sum_q s[q][c] * dout[q - off(tap)];  dbias = sum dout.  Persistent blocks over tiles; per block one partial
+// row [9][C] + [1] (doubles, layout of last_wgrad_reduce_kernel).
+__global__ __launch_bounds__(256) void conv_last_wgrad_tile_kernel(const float* __restrict__ s_in, const float* __restrict__ dout,
+                                                                   double* __restrict__ partial, int N, int H, int W, int C,
+                                                                   int CQ, int tiles_x, int tiles_y, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float esm[];     // D[EH_NP] (padded to 640), then the reduction scratch
+    float* D = esm;
+    float* red = esm + 640;                        // [PPI][9][C] floats
+    const int t = threadIdx.x, q = t % CQ, slot = t / CQ, PPI = 256 / CQ;
+    float acc[9][4];
+    float accb = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[tap][k] = 0.f;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+        const int y0 = ty * ET_H, x0 = tx * ET_W;
+        __syncthreads();
+        load_dout_tile(D, dout, n, y0, x0, H, W, t);
+        __syncthreads();
+        constexpr int UN = 4;
+        for (int e0 = 0; e0 < ET_H * ET_W; e0 += PPI * UN) {
+            float4 s4[UN];
+            int py[UN], px[UN];
+            bool ok[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int e = e0 + u * PPI + slot;
+                py[u] = e / ET_W;
+                px[u] = e - py[u] * ET_W;
+                ok[u] = y0 + py[u] < H && x0 + px[u] < W;
+                s4[u] = ok[u] ? *reinterpret_cast<const float4*>(s_in + (((long)n * H + y0 + py[u]) * W + x0 + px[u]) * C + q * 4)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const float sv[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w};
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float d = D[(py[u] + 2 - tap / 3) * EH_W + px[u] + 2 - tap % 3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[tap][k] = fmaf(sv[k], d, acc[tap][k]);
+                    if (tap == 4 && q == 0 && ok[u]) accb += d;
+                }
+            }
+        }
+    }
+    // one block-level reduction over the PPI pixel slots (fixed order)
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+        *reinterpret_cast<float4*>(red + ((slot * 9 + tap) * C) + q * 4) = make_float4(acc[tap][0], acc[tap][1], acc[tap][2], acc[tap][3]);
+    __syncthreads();
+    double* out = partial + (long)blockIdx.x * (9 * C + 1);
+    for (int e = t; e < 9 * C; e += 256) {
+        double sum = 0.0;
+        for (int sl = 0; sl < PPI; ++sl) sum += (double)red[sl * 9 * C + e];
+        out[e] = sum;
+    }
+    __syncthreads();
+    if (q == 0) red[slot] = accb;
+    __syncthreads();
+    if (t == 0) {
+        double sum = 0.0;
+        for (int sl = 0; sl < PPI; ++sl) sum += (double)red[sl];
+        out[9 * C] = sum;
+    }
+}
+
+static bool edge_shape_ok(int c) { return c == 16 || c == 32 || c == 64; }
+
+int conv_last_fwd_launch(const float* s_in, const float* wt, const float* bias, const float* x_nchw, int xc, float* out, int n,
+                         int h, int w, int c, hipStream_t s, int* launched) {
+    *launched = 0;
+    if (!edge_shape_ok(c) || tune(TUNE_EDGE_CONV) == 0) return RD_OK;
+    const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
+    const dim3 grid(n * tx * ty);
+    if (c == 64) hipLaunchKernelGGL(conv_last_fwd_dpp_kernel<8>, grid, dim3(256), 0, s, s_in, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    else if (c == 32) hipLaunchKernelGGL(conv_last_fwd_dpp_kernel<4>, grid, dim3(256), 0, s, s_in, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    else hipLaunchKernelGGL(conv_last_fwd_dpp_kernel<2>, grid, dim3(256), 0, s, s_in, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    RD_LAUNCH_CHECK("conv_last_fwd");
+    *launched = 1;
+    return RD_OK;
+}
+
+int conv_last_dgrad_launch(const float* dout, const float* wt, float* ds, int n, int h, int w, int c, hipStream_t s, int* launched) {
+    *launched = 0;
+    if (!edge_shape_ok(c) || tune(TUNE_EDGE_CONV) == 0) return RD_OK;
+    const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
+    hipLaunchKernelGGL(conv_last_dgrad_tile_kernel, dim3(n * tx * ty), dim3(256), 0, s, dout, wt, ds, n, h, w, c, c / 4, tx, ty);
+    RD_LAUNCH_CHECK("conv_last_dgrad");
+    *launched = 1;
+    return RD_OK;
+}
+
+int conv_last_wgrad_blocks(int n, int h, int w, int c) {       // 0 = shape not handled here
+    if (!edge_shape_ok(c) || tune(TUNE_EDGE_CONV) == 0) return 0;
+    const long nt = (long)n * cdiv(w, ET_W) * cdiv(h, ET_H);
+    return (int)(nt < 1024 ? nt : 1024);
+}
+
+int conv_last_wgrad_launch(const float* s_in, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s) {
+    const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
+    const int nb = conv_last_wgrad_blocks(n, h, w, c);
+    const size_t smem = (640 + (size_t)(256 / (c / 4)) * 9 * c) * sizeof(float);       // 640 + 9 * 256 * 4 floats = 39.4 KB
+    hipLaunchKernelGGL(conv_last_wgrad_tile_kernel, dim3(nb), dim3(256), smem, s, s_in, dout, partial, n, h, w, c, c / 4, tx, ty,
+                       n * tx * ty);
+    RD_LAUNCH_CHECK("conv_last_wgrad");
+    return RD_OK;
+}
+
+}  // namespace rd

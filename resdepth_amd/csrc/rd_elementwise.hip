@@ -1290,6 +1290,11 @@ int rd_conv3x3_last_fwd(const float* s_in, const float* wt, const float* bias, c
     RD_REQUIRE(c % 4 == 0 && c > 0, "rd_conv3x3_last_fwd: C must be a multiple of 4 (got %d)", c);
     const int tx = cdiv(w, LT_W), ty = cdiv(h, LT_H);
     ProfScope ps((hipStream_t)s, "conv_last_fwd", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(c + 2));
+    {
+        int launched = 0;
+        if (int e = conv_last_fwd_launch(s_in, wt, bias, x_nchw, x_channels, out, n, h, w, c, (hipStream_t)s, &launched)) return e;
+        if (launched) return RD_OK;
+    }
     hipLaunchKernelGGL(conv_last_fwd_kernel, dim3(n * tx * ty), dim3(256), 0, (hipStream_t)s, s_in, wt, bias, x_nchw,
                        x_channels, out, n, h, w, c, tx, ty);
     RD_LAUNCH_CHECK("conv_last_fwd");
@@ -1302,6 +1307,11 @@ int rd_conv3x3_last_bwd_data(const float* dout, const float* wt, float* ds, int 
     RD_REQUIRE(plan_rows((long)n * h * w, c, &pl, last_blocks()), "rd_conv3x3_last_bwd_data: C must be a multiple of 4, <= 1024");
     RD_REQUIRE((long)n * h * w < (1L << 31), "rd_conv3x3_last_bwd_data: pixel count must be < 2^31");
     ProfScope ps((hipStream_t)s, "conv_last_dgrad", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(c + 1));
+    {
+        int launched = 0;
+        if (int e = conv_last_dgrad_launch(dout, wt, ds, n, h, w, c, (hipStream_t)s, &launched)) return e;
+        if (launched) return RD_OK;
+    }
     hipLaunchKernelGGL(conv_last_dgrad_kernel, dim3(pl.nb), dim3(256), 0, (hipStream_t)s, dout, wt, ds, (long)n * h * w,
                        h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
     RD_LAUNCH_CHECK("conv_last_dgrad");
@@ -1309,6 +1319,7 @@ int rd_conv3x3_last_bwd_data(const float* dout, const float* wt, float* ds, int 
 }
 
 size_t rd_conv3x3_last_bwd_weight_ws_bytes(int n, int h, int w, int c) {
+    if (const int nb = conv_last_wgrad_blocks(n, h, w, c)) return (size_t)nb * (9 * c + 1) * sizeof(double);
     RowPlan pl;
     if (!plan_rows((long)n * h * w, c, &pl, last_blocks())) return 0;
     return (size_t)pl.nb * (9 * c + 1) * sizeof(double);
@@ -1320,12 +1331,19 @@ int rd_conv3x3_last_bwd_weight(const float* s_in, const float* dout, float* dw, 
     RowPlan pl;
     RD_REQUIRE(plan_rows((long)n * h * w, c, &pl, last_blocks()), "rd_conv3x3_last_bwd_weight: C must be a multiple of 4, <= 1024");
     RD_REQUIRE((long)n * h * w < (1L << 31), "rd_conv3x3_last_bwd_weight: pixel count must be < 2^31");
-    const size_t need = (size_t)pl.nb * (9 * c + 1) * sizeof(double);
+    const size_t need = rd_conv3x3_last_bwd_weight_ws_bytes(n, h, w, c);
     if (!ws || ws_bytes < need) {
         set_error("rd_conv3x3_last_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
         return RD_ERR_WS;
     }
     ProfScope ps((hipStream_t)s, "conv_last_wgrad", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(c + 1));
+    if (const int nb = conv_last_wgrad_blocks(n, h, w, c)) {
+        if (int e = conv_last_wgrad_launch(s_in, dout, (double*)ws, n, h, w, c, (hipStream_t)s)) return e;
+        hipLaunchKernelGGL(last_wgrad_reduce_kernel, dim3(cdiv(9 * c + 1, 16)), dim3(256), 0, (hipStream_t)s,
+                           (const double*)ws, dw, dbias, nb, c);
+        RD_LAUNCH_CHECK("conv_last_wgrad");
+        return RD_OK;
+    }
     hipLaunchKernelGGL(conv_last_wgrad_kernel, dim3(pl.nb), dim3(256), 0, (hipStream_t)s, s_in, dout, (double*)ws,
                        (long)n * h * w, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
     hipLaunchKernelGGL(last_wgrad_reduce_kernel, dim3(cdiv(9 * c + 1, 16)), dim3(256), 0, (hipStream_t)s,

@@ -214,7 +214,10 @@ def test_first_conv(n, h, w, cin, cout):
 
 
 @pytest.mark.parametrize("n,h,w,c,xc,bias", [(2, 32, 32, 8, 3, True), (1, 16, 16, 4, 1, False), (2, 64, 64, 64, 3, True),
-                                             (3, 8, 8, 20, 2, True)])
+                                             (3, 8, 8, 20, 2, True),
+                                             # tile kernels (C = 16 / 32 / 64): ragged tiles in both directions, one-tile images
+                                             (3, 40, 72, 64, 3, True), (1, 8, 8, 64, 1, False), (2, 24, 100, 32, 2, True),
+                                             (5, 16, 32, 16, 1, True), (1, 256, 256, 64, 3, True)])
 def test_last_conv(n, h, w, c, xc, bias):
     from resdepth_amd import ops
     g = torch.Generator().manual_seed(c)
