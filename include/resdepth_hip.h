@@ -68,6 +68,12 @@ int rd_conv3x3_fwd(const float* x, const float* wf, float* z, int n, int h, int 
 size_t rd_conv3x3_fwd_stats_ws_bytes(int n, int h, int w, int cin, int cout);
 int rd_conv3x3_fwd_stats(const float* x, const float* wf, float* z, double* sums, int n, int h, int w, int cin, int cout,
                          void* ws, size_t ws_bytes, rd_stream_t s);
+/* Convolution + the complete training-mode BatchNorm statistics step (lib/UNet.py:44-45) in two launches: the per-tile
+ * partials of the epilogue are reduced and turned into mean / invstd, the running statistics are updated
+ * (momentum, unbiased variance) and num_batches_tracked incremented (all three nullable).  count = N*H*W. */
+int rd_conv3x3_fwd_bn(const float* x, const float* wf, float* z, double count, float eps, float momentum, float* mean,
+                      float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int n, int h,
+                      int w, int cin, int cout, void* ws, size_t ws_bytes, rd_stream_t s);
 /* dx[N,H,W,Cin] = conv^T(dz)                     (autograd data gradient of the above) */
 int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int h, int w, int cin, int cout,
                         rd_stream_t s);
@@ -82,6 +88,10 @@ int rd_conv3x3_first_fwd(const float* x_nchw, const float* w_oihw, float* z, int
 size_t rd_conv3x3_first_fwd_stats_ws_bytes(int n, int h, int w, int cin, int cout);
 int rd_conv3x3_first_fwd_stats(const float* x_nchw, const float* w_oihw, float* z, double* sums, int n, int h, int w,
                                int cin, int cout, void* ws, size_t ws_bytes, rd_stream_t s);
+int rd_conv3x3_first_fwd_bn(const float* x_nchw, const float* w_oihw, float* z, double count, float eps, float momentum,
+                            float* mean, float* invstd, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, int n, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,
+                            rd_stream_t s);
 size_t rd_conv3x3_first_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout);
 int rd_conv3x3_first_bwd_weight(const float* x_nchw, const float* dz, float* dw_oihw, int n, int h, int w, int cin,
                                 int cout, void* ws, size_t ws_bytes, rd_stream_t s);
@@ -165,13 +175,15 @@ int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, c
  *            sum_{y<=0} g*y (per channel; its total is the gradient of nn.PReLU()'s single slope).
  * slope_dev (nullable): device pointer to a learnable PReLU slope (lib/UNet.py:29); when non-NULL it
  *            overrides the immediate `slope` (ReLU = 0, LeakyReLU = 0.01).
- * Phase 2 -> dz; dgamma/dbeta are sums[C..2C) / sums[0..C) (written by rd_bn_act_bwd_apply).
+ * Phase 2 -> dz; dgamma/dbeta are sums[C..2C) / sums[0..C): written as fp32 by whichever of the two calls is handed
+ *            non-NULL dgamma / dbeta (phase 1 saves a launch; phase 2 is for SyncBN, where the LOCAL sums are the parameter
+ *            gradients and the all-reduced ones feed dz).
  * training=0 treats mean/invstd as constants (eval-mode BN). */
 size_t rd_bn_act_bwd_ws_bytes(int n, int h, int w, int c);
 int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                          float slope, const float* slope_dev, const float* g_full, const float* g_pool,
-                         const uint8_t* idx, double* sums, int n, int h, int w, int c, void* ws, size_t ws_bytes,
-                         rd_stream_t s);
+                         const uint8_t* idx, double* sums, float* dgamma, float* dbeta, int n, int h, int w, int c, void* ws,
+                         size_t ws_bytes, rd_stream_t s);
 int rd_bn_act_bwd_apply(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                         float slope, const float* slope_dev, const float* g_full, const float* g_pool,
                         const uint8_t* idx, const double* sums, double count, int training, float* dz, float* dgamma,

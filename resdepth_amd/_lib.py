@@ -36,12 +36,14 @@ SIGNATURES = {
     "rd_conv3x3_fwd": (I, [P, P, P, I, I, I, I, I, P]),
     "rd_conv3x3_fwd_stats_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_conv3x3_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, P, SZ, P]),
+    "rd_conv3x3_fwd_bn": (I, [P, P, P, D, F, F, P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_conv3x3_bwd_data": (I, [P, P, P, I, I, I, I, I, P]),
     "rd_conv3x3_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_conv3x3_bwd_weight": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_conv3x3_first_fwd": (I, [P, P, P, I, I, I, I, I, P]),
     "rd_conv3x3_first_fwd_stats_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_conv3x3_first_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, P, SZ, P]),
+    "rd_conv3x3_first_fwd_bn": (I, [P, P, P, D, F, F, P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_conv3x3_first_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_conv3x3_first_bwd_weight": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_conv3x3_last_fwd": (I, [P, P, P, P, I, P, I, I, I, I, P]),
@@ -69,7 +71,7 @@ SIGNATURES = {
     "rd_bn_eval_stats": (I, [P, P, F, P, P, I, P]),
     "rd_bn_act_pool_fwd": (I, [P, P, P, P, P, F, P, P, P, P, I, I, I, I, P]),
     "rd_bn_act_bwd_ws_bytes": (SZ, [I, I, I, I]),
-    "rd_bn_act_bwd_reduce": (I, [P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, P, SZ, P]),
+    "rd_bn_act_bwd_reduce": (I, [P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, P, SZ, P]),
     "rd_bn_act_bwd_apply": (I, [P, P, P, P, P, F, P, P, P, P, P, D, I, P, P, P, I, I, I, I, P]),
     "rd_masked_l1_ws_bytes": (SZ, [LL]),
     "rd_masked_l1_partial": (I, [P, P, P, P, P, P, I, LL, P, SZ, P]),

@@ -27,6 +27,9 @@ struct ProfScope {
     }
 };
 
+// BN statistics: per-tile fp32 partials [nb][2][C] -> mean / invstd / running statistics in one launch (rd_elementwise.hip)
+int bn_reduce_finalize(const float* partial, int nb, int c, double count, float eps, float momentum, float* mean, float* invstd,
+                       float* rmean, float* rvar, int64_t* nbt, hipStream_t s);
 // second stage of the per-channel reductions (rd_elementwise.hip): sums[c] = sum_b partial[b*qc + c], fixed order
 int reduce_partials_f32(const float* partial, double* sums, int nb, int qc, hipStream_t s);
 

@@ -71,12 +71,20 @@ __device__ __forceinline__ double sliced_column_sum(const T* __restrict__ partia
 }
 
 // sums[q*C + c] = sum_b partial[(b*Q + q)*C + c]
+// dbeta / dgamma (nullable): the first two C-column groups of the BN-backward sums are the affine-parameter gradients
+// (sum g', sum g' * xhat) -- written here instead of by a separate launch
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const double* __restrict__ partial,
-                                                             double* __restrict__ sums, int nb, int QC) {
+                                                             double* __restrict__ sums, int nb, int QC, int C = 0,
+                                                             float* __restrict__ dbeta = nullptr,
+                                                             float* __restrict__ dgamma = nullptr) {
     __shared__ double red[256];
     const double r = sliced_column_sum<double>(partial, nb, QC, QC, red);
     const int col = blockIdx.x * 16 + threadIdx.x;
-    if (threadIdx.x < 16 && col < QC) sums[col] = r;
+    if (threadIdx.x < 16 && col < QC) {
+        sums[col] = r;
+        if (dbeta && col < C) dbeta[col] = (float)r;
+        if (dgamma && col >= C && col < 2 * C) dgamma[col - C] = (float)r;
+    }
 }
 
 __global__ __launch_bounds__(256) void partial_reduce_f32_kernel(const float* __restrict__ partial,
@@ -176,6 +184,58 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
         const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
     }
+}
+
+// BatchNorm batch statistics in ONE launch: per-tile partials [nb][2][C] (fp32, written by the convolution epilogues) ->
+// fixed-order fp64 column sums -> mean / invstd / running statistics (the arithmetic of bn_finalize_kernel).  One block =
+// 4 channels x (sum, sum of squares) x 32 row slices; replaces partial_reduce_f32_kernel + bn_finalize_kernel.
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* __restrict__ partial, int nb, int C, double count,
+                                                                 float eps, float momentum, float* __restrict__ mean,
+                                                                 float* __restrict__ invstd, float* __restrict__ rmean,
+                                                                 float* __restrict__ rvar, int64_t* nbt) {
+    __shared__ double red[256];
+    const int t = threadIdx.x, j = t & 7, slice = t >> 3;          // j: 0..3 sums, 4..7 sums of squares
+    const int c = blockIdx.x * 4 + (j & 3);
+    const long col = (j < 4 ? 0 : C) + c;
+    double sacc = 0.0;
+    if (c < C) {
+        int b = slice;
+        for (; b + 96 < nb; b += 128) {
+            const float v0 = partial[(long)b * 2 * C + col], v1 = partial[(long)(b + 32) * 2 * C + col];
+            const float v2 = partial[(long)(b + 64) * 2 * C + col], v3 = partial[(long)(b + 96) * 2 * C + col];
+            sacc += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; b < nb; b += 32) sacc += (double)partial[(long)b * 2 * C + col];
+    }
+    red[t] = sacc;
+    __syncthreads();
+    if (t == 0 && blockIdx.x == 0 && nbt) *nbt += 1;
+    if (t < 4 && c < C) {
+        double su = 0.0, sq = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < 32; ++sl) {
+            su += red[sl * 8 + t];
+            sq += red[sl * 8 + 4 + t];
+        }
+        const double m = su / count;
+        double var = sq / count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+        if (rvar) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    }
+}
+
+int bn_reduce_finalize(const float* partial, int nb, int c, double count, float eps, float momentum, float* mean, float* invstd,
+                       float* rmean, float* rvar, int64_t* nbt, hipStream_t s) {
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(c, 4)), dim3(256), 0, s, partial, nb, c, count, eps, momentum, mean,
+                       invstd, rmean, rvar, nbt);
+    RD_LAUNCH_CHECK("bn_reduce_finalize");
+    return RD_OK;
 }
 
 __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
@@ -1039,7 +1099,8 @@ int rd_channel_sum(const float* g, float* out, long long pixels, int c, void* ws
     double* sums = partial + (size_t)pl.nb * c;
     hipLaunchKernelGGL((channel_stats_kernel<false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, g, partial,
                        (long)pixels, c, pl.CQ, pl.RP, pl.rows_per_block);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(c, 16)), dim3(256), 0, (hipStream_t)s, partial, sums, pl.nb, c);
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(c, 16)), dim3(256), 0, (hipStream_t)s, partial, sums, pl.nb, c, 0,
+                       (float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, (float*)nullptr,
                        out, c);
     RD_LAUNCH_CHECK("channel_sum");
@@ -1066,7 +1127,7 @@ int rd_bn_stats_partial(const float* z, double* sums, long long pixels, int c, v
     hipLaunchKernelGGL((channel_stats_kernel<true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, (double*)ws,
                        (long)pixels, c, pl.CQ, pl.RP, pl.rows_per_block);
     hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(2 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
-                       sums, pl.nb, 2 * c);
+                       sums, pl.nb, 2 * c, 0, (float*)nullptr, (float*)nullptr);
     RD_LAUNCH_CHECK("bn_stats");
     return RD_OK;
 }
@@ -1120,8 +1181,8 @@ size_t rd_bn_act_bwd_ws_bytes(int n, int h, int w, int c) {
 
 int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                          float slope, const float* slope_dev, const float* g_full, const float* g_pool,
-                         const uint8_t* idx, double* sums, int n, int h, int w, int c, void* ws, size_t ws_bytes,
-                         rd_stream_t s) {
+                         const uint8_t* idx, double* sums, float* dgamma, float* dbeta, int n, int h, int w, int c, void* ws,
+                         size_t ws_bytes, rd_stream_t s) {
     RD_REQUIRE(z && mean && invstd && gamma && beta && sums, "rd_bn_act_bwd_reduce: null pointer");
     RD_REQUIRE(g_full || g_pool, "rd_bn_act_bwd_reduce: no gradient source");
     RD_REQUIRE(!g_pool || idx, "rd_bn_act_bwd_reduce: g_pool needs idx");
@@ -1145,7 +1206,7 @@ int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd,
                            invstd, gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
                            (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
     hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(4 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
-                       sums, pl.nb, 4 * c);
+                       sums, pl.nb, 4 * c, c, dbeta, dgamma);
     RD_LAUNCH_CHECK("bn_act_bwd_reduce");
     return RD_OK;
 }
@@ -1250,6 +1311,27 @@ int rd_conv3x3_first_fwd_stats(const float* x, const float* wt, float* z, double
     }
     if (sums) return reduce_partials_f32((const float*)ws, sums, grid, 2 * cout, (hipStream_t)s);
     return RD_OK;
+}
+
+int rd_conv3x3_first_fwd_bn(const float* x, const float* wt, float* z, double count, float eps, float momentum, float* mean,
+                            float* invstd, float* running_mean, float* running_var, int64_t* nbt, int n, int h, int w, int cin,
+                            int cout, void* ws, size_t ws_bytes, rd_stream_t s) {
+    RD_REQUIRE(x && wt && z && mean && invstd && count > 0, "rd_conv3x3_first_fwd_bn: bad arguments");
+    RD_REQUIRE(cout % 4 == 0 && cout / 4 <= 256 && cout > 0, "rd_conv3x3_first_fwd_bn: Cout must be a multiple of 4, <= 1024");
+    int tx, ty, nt;
+    const int grid = first_grid(n, h, w, &tx, &ty, &nt);
+    if (!ws || ws_bytes < (size_t)grid * 2 * cout * sizeof(float)) {
+        set_error("rd_conv3x3_first_fwd_bn: workspace too small");
+        return RD_ERR_WS;
+    }
+    {
+        ProfScope ps((hipStream_t)s, "conv_first_fwd", 2.0 * n * h * w * cout * 9.0 * cin, 4.0 * n * h * w * (double)(cin + cout));
+        if (int e = launch_first<false>(x, wt, z, nullptr, (float*)ws, n, h, w, cin, cout, grid, tx, ty, nt, (hipStream_t)s))
+            return e;
+        RD_LAUNCH_CHECK("conv_first_fwd");
+    }
+    return bn_reduce_finalize((const float*)ws, grid, cout, count, eps, momentum, mean, invstd, running_mean, running_var, nbt,
+                              (hipStream_t)s);
 }
 
 size_t rd_conv3x3_first_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout) {

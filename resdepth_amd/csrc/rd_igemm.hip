@@ -1473,6 +1473,27 @@ int rd_conv3x3_fwd_stats(const float* x, const float* wf, float* z, double* sums
     return RD_OK;
 }
 
+int rd_conv3x3_fwd_bn(const float* x, const float* wf, float* z, double count, float eps, float momentum, float* mean,
+                      float* invstd, float* running_mean, float* running_var, int64_t* nbt, int n, int h, int w, int cin,
+                      int cout, void* ws, size_t ws_bytes, rd_stream_t s) {
+    if (int e = check_conv_args(n, h, w, cin, cout)) return e;
+    RD_REQUIRE(x && wf && z && mean && invstd && count > 0, "rd_conv3x3_fwd_bn: bad arguments");
+    RD_REQUIRE(cin % 4 == 0, "rd_conv3x3_fwd_bn: Cin must be a multiple of 4 (got %d); use rd_conv3x3_first_fwd_bn", cin);
+    if (!ws || ws_bytes < rd_conv3x3_fwd_stats_ws_bytes(n, h, w, cin, cout)) {
+        set_error("rd_conv3x3_fwd_bn: workspace too small");
+        return RD_ERR_WS;
+    }
+    NtParams p = {};
+    p.A = x; p.B = wf; p.C = z;
+    p.M = n * h * w; p.N = cout; p.K = 9 * cin; p.Cin = cin;
+    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    p.stats = (float*)ws;
+    int tiles_m = 0;
+    if (int e = launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_fwd", &tiles_m)) return e;
+    return bn_reduce_finalize((const float*)ws, tiles_m, cout, count, eps, momentum, mean, invstd, running_mean, running_var, nbt,
+                              (hipStream_t)s);
+}
+
 int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int h, int w, int cin, int cout,
                         rd_stream_t s) {
     if (int e = check_conv_args(n, h, w, cin, cout)) return e;

@@ -65,6 +65,21 @@ def conv3x3_fwd_stats(x, wf):
     return z, sums
 
 
+def conv3x3_fwd_bn(x, wf, running_mean, running_var, num_batches_tracked, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """-> (z, mean, invstd): convolution + training-mode BatchNorm statistics (incl. the running-statistics update) in two
+    launches; the statistics come out of the GEMM epilogue."""
+    n, h, w, cin = x.shape
+    cout = wf.shape[0]
+    z = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
+    mean = torch.empty(cout, device=x.device, dtype=torch.float32)
+    invstd = torch.empty(cout, device=x.device, dtype=torch.float32)
+    ws = workspace(load().rd_conv3x3_fwd_stats_ws_bytes(n, h, w, cin, cout), x.device)
+    check(load().rd_conv3x3_fwd_bn(ptr(_f32(x, "x")), ptr(wf), ptr(z), float(n * h * w), eps, momentum, ptr(mean), ptr(invstd),
+                                   ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), n, h, w, cin, cout,
+                                   ws.data_ptr(), ws.numel(), stream_ptr()), "conv3x3_fwd_bn")
+    return z, mean, invstd
+
+
 def conv3x3_bwd_data(dz, wd):
     n, h, w, cout = dz.shape
     cin = wd.shape[0]
@@ -103,6 +118,19 @@ def conv3x3_first_fwd_stats(x_nchw, w):
     check(load().rd_conv3x3_first_fwd_stats(ptr(_f32(x_nchw, "x")), ptr(w.detach()), ptr(z), ptr(sums), n, h, wd_, cin,
                                             cout, ws.data_ptr(), ws.numel(), stream_ptr()), "conv3x3_first_fwd_stats")
     return z, sums
+
+
+def conv3x3_first_fwd_bn(x_nchw, w, running_mean, running_var, num_batches_tracked, eps=BN_EPS, momentum=BN_MOMENTUM):
+    n, cin, h, wd_ = x_nchw.shape
+    cout = w.shape[0]
+    z = torch.empty(n, h, wd_, cout, device=x_nchw.device, dtype=torch.float32)
+    mean = torch.empty(cout, device=z.device, dtype=torch.float32)
+    invstd = torch.empty(cout, device=z.device, dtype=torch.float32)
+    ws = workspace(load().rd_conv3x3_first_fwd_stats_ws_bytes(n, h, wd_, cin, cout), z.device)
+    check(load().rd_conv3x3_first_fwd_bn(ptr(_f32(x_nchw, "x")), ptr(w.detach()), ptr(z), float(n * h * wd_), eps, momentum,
+                                         ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var), ptr(num_batches_tracked),
+                                         n, h, wd_, cin, cout, ws.data_ptr(), ws.numel(), stream_ptr()), "conv3x3_first_fwd_bn")
+    return z, mean, invstd
 
 
 def conv3x3_first_bwd_weight(x_nchw, dz, out=None, ws_slot=0):
@@ -300,15 +328,17 @@ def bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, pool, slope_dev=None, w
     return a, pooled, idx
 
 
-def bn_act_bwd_reduce(z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx, slope_dev=None):
-    """-> sums [4*C] float64: sum g', sum g'*xhat, sum g_full, sum_{y<=0} g*y (PReLU slope gradient)."""
+def bn_act_bwd_reduce(z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx, slope_dev=None, dgamma=None, dbeta=None):
+    """-> sums [4*C] float64: sum g', sum g'*xhat, sum g_full, sum_{y<=0} g*y (PReLU slope gradient).
+    dgamma / dbeta (optional fp32 [C]): the affine-parameter gradients, written by the same reduction."""
     n, h, w, c = z.shape
     sums = torch.empty(4 * c, device=z.device, dtype=torch.float64)
     nb = load().rd_bn_act_bwd_ws_bytes(n, h, w, c)
     ws = workspace(nb, z.device)
     check(load().rd_bn_act_bwd_reduce(ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
                                       float(slope), ptr(slope_dev), ptr(g_full), ptr(g_pool), ptr(idx), ptr(sums),
-                                      n, h, w, c, ws.data_ptr(), ws.numel(), stream_ptr()), "bn_act_bwd_reduce")
+                                      ptr(dgamma), ptr(dbeta), n, h, w, c, ws.data_ptr(), ws.numel(), stream_ptr()),
+          "bn_act_bwd_reduce")
     return sums
 
 

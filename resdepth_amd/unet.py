@@ -270,7 +270,7 @@ class UNet(nn.Module):
             return 0.0, slope.detach()
         return slope, None
 
-    def _bn_forward(self, z, bn, slope, pool, training, sums=None, bias=None, want_a=True):
+    def _bn_forward(self, z, bn, slope, pool, training, sums=None, bias=None, want_a=True, stats=None):
         """-> (a | skip descriptor, pooled, idx, mean, invstd, count).  want_a=False (pooled levels): the full-resolution
         activation is not written; the first return value is then the descriptor the transposed convolution needs to
         recompute it from z in its epilogue."""
@@ -283,7 +283,10 @@ class UNet(nn.Module):
             if a is None:
                 a = {"z": z, "mean": mean, "invstd": invstd, "gamma": invstd, "beta": bias, "slope": slope, "slope_dev": sdev}
             return a, p, idx, mean, invstd, 1
-        if training:
+        if training and stats is not None:       # statistics already finalised by the convolution's second launch
+            mean, invstd = stats
+            count = z.numel() // c
+        elif training:
             if sums is None:
                 sums = ops.bn_stats_partial(z)
             count = z.numel() // c
@@ -304,36 +307,50 @@ class UNet(nn.Module):
         pk = self._packed()
         S = {"x": x, "enc": [], "dec": [], "training": training} if save else None
 
-        def conv_stats(inp, wf):
+        fused_stats = training and self.do_BN and not (self.sync_bn and self.grad_sync is not None)
+
+        def conv_stats(inp, wf, bn):
+            """-> (z, sums | None, (mean, invstd) | None).  Training: the BN statistics come out of the conv epilogue; when
+            no cross-rank exchange sits between the sums and their use they are finalised right there (2 launches)."""
+            if fused_stats:
+                z_, mean_, invstd_ = ops.conv3x3_fwd_bn(inp, wf, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                                        eps=bn.eps, momentum=bn.momentum)
+                return z_, None, (mean_, invstd_)
             if training and self.do_BN:
-                return ops.conv3x3_fwd_stats(inp, wf)
-            return ops.conv3x3_fwd(inp, wf), None
+                return ops.conv3x3_fwd_stats(inp, wf) + (None,)
+            return ops.conv3x3_fwd(inp, wf), None, None
 
         skips = []
         cur = None
         for i in range(d):
             blk = self.encoder[i][0]
-            sums = None                      # training: BN statistics come out of the conv kernel's epilogue
-            if i == 0:
-                z, sums = ops.conv3x3_first_fwd_stats(x, blk[0].weight) if (training and self.do_BN) else \
-                    (ops.conv3x3_first_fwd(x, blk[0].weight), None)
-            else:
-                z, sums = conv_stats(cur, pk.get(("enc", i - 1))[0])
+            sums = st = None                 # training: BN statistics come out of the conv kernel's epilogue
             bn, cbias = self._norm_of(blk)
+            if i == 0:
+                if fused_stats:
+                    z, m_, i_ = ops.conv3x3_first_fwd_bn(x, blk[0].weight, bn.running_mean, bn.running_var,
+                                                         bn.num_batches_tracked, eps=bn.eps, momentum=bn.momentum)
+                    st = (m_, i_)
+                elif training and self.do_BN:
+                    z, sums = ops.conv3x3_first_fwd_stats(x, blk[0].weight)
+                else:
+                    z = ops.conv3x3_first_fwd(x, blk[0].weight)
+            else:
+                z, sums, st = conv_stats(cur, pk.get(("enc", i - 1))[0], bn)
             # transposed up-mode: the skip activation is recomputed from z in the decoder's convT epilogue, not stored
             lazy_skip = self.up_mode == "transpose" and not keep_skips
             a, p, idx, mean, invstd, count = self._bn_forward(z, bn, self._act_of(blk, self.act_fn_encoder), True, training,
-                                                              sums, cbias, want_a=not lazy_skip)
+                                                              sums, cbias, want_a=not lazy_skip, stats=st)
             skips.append(a)
             if save:
                 S["enc"].append({"z": z, "idx": idx, "mean": mean, "invstd": invstd, "count": count, "p": p})
                 if keep_skips:               # tests only: the backward never needs the skip activations
                     S["enc"][-1]["a"] = a
             cur = p
-        zb, sums = conv_stats(cur, pk.get("bott")[0])
         bn, cbias = self._norm_of(self.bottleneck)
+        zb, sums, st = conv_stats(cur, pk.get("bott")[0], bn)
         ab, _, _, mean, invstd, count = self._bn_forward(zb, bn, self._act_of(self.bottleneck, self.act_fn_bottleneck),
-                                                         False, training, sums, cbias)
+                                                         False, training, sums, cbias, stats=st)
         if save:
             S["bott"] = {"z": zb, "mean": mean, "invstd": invstd, "count": count, "a": ab}
         cur = ab
@@ -343,10 +360,10 @@ class UNet(nn.Module):
             rec = {"s": s}
             if i < d - 1:
                 blk = self.decoder[i][1]
-                zd, sums = conv_stats(s, pk.get(("dec_c", i))[0])
                 bn, cbias = self._norm_of(blk)
+                zd, sums, st = conv_stats(s, pk.get(("dec_c", i))[0], bn)
                 ad, _, _, mean, invstd, count = self._bn_forward(zd, bn, self._act_of(blk, self.act_fn_decoder), False,
-                                                                 training, sums, cbias)
+                                                                 training, sums, cbias, stats=st)
                 rec.update(z=zd, mean=mean, invstd=invstd, count=count, a=ad)
                 cur = ad
             else:
@@ -471,8 +488,12 @@ class UNet(nn.Module):
                                           sums, 1.0, False, dgamma=None, dbeta=gv(cbias), slope_dev=sdev)
                 done(cbias, prelu_w, extra_bias)
                 return dz
-            sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
-                                         g_pool, idx, slope_dev=sdev)
+            if sync_bn:
+                sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
+                                             g_pool, idx, slope_dev=sdev)
+            else:       # the reduction writes dgamma / dbeta itself (no separate launch)
+                sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
+                                             g_pool, idx, slope_dev=sdev, dgamma=gv(bn.weight), dbeta=gv(bn.bias))
             side_grads(sums)
             if sync_bn:
                 local = sums[:2 * c].clone()
@@ -483,8 +504,7 @@ class UNet(nn.Module):
                                           g_pool, idx, sums, rec["count"], training, slope_dev=sdev)
             else:
                 dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
-                                          g_pool, idx, sums, rec["count"], training, dgamma=gv(bn.weight),
-                                          dbeta=gv(bn.bias), slope_dev=sdev)
+                                          g_pool, idx, sums, rec["count"], training, slope_dev=sdev)
             done(bn.weight, bn.bias, prelu_w, extra_bias)
             return dz
 

@@ -489,3 +489,17 @@ def test_conv_epilogue_statistics_match_separate_pass(n, h, w, cin, cout):
     z3, s3 = ops.conv3x3_first_fwd_stats(x3.to(dev()), w3.to(dev()))
     assert torch.equal(z3, ops.conv3x3_first_fwd(x3.to(dev()), w3.to(dev())))
     close(s3.cpu(), ops.bn_stats_partial(z3).cpu(), tol=1e-6, name="first conv fused vs separate")
+    # one-launch finalisation (conv + reduce/finalize): identical statistics, running buffers and counter as the two-step path
+    for fused, args in ((ops.conv3x3_fwd_bn, (nhwc(x), wf)), (ops.conv3x3_first_fwd_bn, (x3.to(dev()), w3.to(dev())))):
+        s_ref = sums if fused is ops.conv3x3_fwd_bn else s3
+        rm = torch.linspace(-1, 1, cout, device=dev()); rv = torch.linspace(0.5, 2, cout, device=dev())
+        nbt = torch.tensor(7, device=dev())
+        rm2, rv2, nbt2 = rm.clone(), rv.clone(), nbt.clone()
+        zf, mean, invstd = fused(*args, rm, rv, nbt)
+        m_ref, i_ref = ops.bn_stats_finalize(s_ref, n * h * w, rm2, rv2, nbt2)
+        assert torch.equal(zf, z if fused is ops.conv3x3_fwd_bn else z3)
+        close(mean.cpu(), m_ref.cpu(), tol=1e-6, name="fused mean")
+        close(invstd.cpu(), i_ref.cpu(), tol=1e-6, name="fused invstd")
+        close(rm.cpu(), rm2.cpu(), tol=1e-6, name="running mean")
+        close(rv.cpu(), rv2.cpu(), tol=1e-6, name="running var")
+        assert int(nbt) == 8 and int(nbt2) == 8
