@@ -102,6 +102,7 @@ def infer_main(args, world, rank, dev):
         dist.init_process_group("nccl")
     torch.manual_seed(0)
     model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).eval()
+    model.fold_eval_bn = not args.no_fold
     ds = SyntheticRasterTiles(args.raster, args.raster, 3, tile_size=256, seed=1, shard=(rank, world))
     # tiles are staged on the device once (the metric excludes host->device staging, as for training)
     batches = []
@@ -310,6 +311,7 @@ def main():
                     help="measure the tiled full-raster inference sweep instead (BASELINE configs[4], cfg-G: 3-ch tiles of "
                          "256x256 at stride 128 over a synthetic --raster x --raster DSM, eval-mode BN, linear blend)")
     ap.add_argument("--raster", type=int, default=4096)
+    ap.add_argument("--no-fold", action="store_true", help="--infer: keep eval-mode BN as separate kernels (A/B of the folded path)")
     ap.add_argument("--prof-all", action="store_true", help="(kept for scripts) same as the default full breakdown")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the data-parallel code path (RCCL process group, bucketed all-reduce) even at world size 1")

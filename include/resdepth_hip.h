@@ -55,6 +55,9 @@ size_t rd_packed_weight_bytes(int rows, int taps, int cin);
  *   wf[co][tap][ci]              B operand of the forward implicit GEMM
  *   wd[ci][tap][co] = w[co][ci][8-tap]   B operand of the data-gradient GEMM (nullable) */
 int rd_pack_conv3x3_weight(const float* w_oihw, float* wf, float* wd, int cout, int cin, rd_stream_t s);
+/* Inference: eval-mode BatchNorm folded into the forward operand -- wf[co][tap][ci] = w[co][ci][tap] * row_scale[co] with
+ * row_scale = gamma / sqrt(running_var + eps) (lib/UNet.py:45 in eval mode, reached from lib/evaluation.py:497). */
+int rd_pack_conv3x3_weight_folded(const float* w_oihw, const float* row_scale, float* wf, int cout, int cin, rd_stream_t s);
 /* nn.ConvTranspose2d weight [Cin][Cout][2][2] (lib/UNet.py:21) ->
  *   wtf[(a*2+b)*Cout + co][ci]   forward B operand
  *   wtd[ci][(a*2+b)*Cout + co]   data-gradient B operand (nullable) */
@@ -74,6 +77,11 @@ int rd_conv3x3_fwd_stats(const float* x, const float* wf, float* z, double* sums
 int rd_conv3x3_fwd_bn(const float* x, const float* wf, float* z, double count, float eps, float momentum, float* mean,
                       float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int n, int h,
                       int w, int cin, int cout, void* ws, size_t ws_bytes, rd_stream_t s);
+/* Inference (eval-mode BN folded, rd_pack_conv3x3_weight_folded): a = act(conv(x) + shift[co]), shift = beta -
+ * running_mean * row_scale; `pooled` (nullable, needs W >= 16, H >= 8) also receives MaxPool2d(2,2)(a) from the same epilogue:
+ * conv -> BN -> act -> pool of an encoder level (lib/UNet.py:201-207) in ONE kernel, no pre-BN tensor is ever written. */
+int rd_conv3x3_fwd_act(const float* x, const float* wf_folded, const float* shift, float slope, float* a, float* pooled, int n,
+                       int h, int w, int cin, int cout, rd_stream_t s);
 /* dx[N,H,W,Cin] = conv^T(dz)                     (autograd data gradient of the above) */
 int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int h, int w, int cin, int cout,
                         rd_stream_t s);
@@ -209,7 +217,8 @@ int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, 
                  float weight_decay, float step_size, float bc2_sqrt, float grad_scale, rd_stream_t s);
 
 /* ---- tiled inference: linear blend of overlapping tiles (lib/evaluation.py:460-567) ----------- */
-/* For every tile i (in order, one launch each => deterministic fp64 accumulation order, no atomics):
+/* For every tile i (in tile order per raster pixel => deterministic fp64 accumulation order, no atomics; batches of up to
+ * 64 tiles are ONE launch, larger ones one launch per tile):
  *   raster[y_i + r][x_i + c] += (double)(float)(pred[i][r][c] * std[i] + mean[i]) * w_i(r, c)
  * with w_i = the reference's _get_blend_weights(tile_size, stride, ulx, uly, lrx, lry) (separable linear ramps,
  * np.linspace(0,1,overlap)).  pos = int32 [n][2] (offset_y, offset_x); reg = int32 [n][4] (uly, ulx, lry, lrx). */

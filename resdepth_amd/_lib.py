@@ -32,11 +32,13 @@ SIGNATURES = {
     "rd_version": (I, []),
     "rd_last_error_string": (C.c_char_p, []),
     "rd_pack_conv3x3_weight": (I, [P, P, P, I, I, P]),
+    "rd_pack_conv3x3_weight_folded": (I, [P, P, P, I, I, P]),
     "rd_pack_convt2x2_weight": (I, [P, P, P, I, I, P]),
     "rd_conv3x3_fwd": (I, [P, P, P, I, I, I, I, I, P]),
     "rd_conv3x3_fwd_stats_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_conv3x3_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_conv3x3_fwd_bn": (I, [P, P, P, D, F, F, P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
+    "rd_conv3x3_fwd_act": (I, [P, P, P, F, P, P, I, I, I, I, I, P]),
     "rd_conv3x3_bwd_data": (I, [P, P, P, I, I, I, I, I, P]),
     "rd_conv3x3_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_conv3x3_bwd_weight": (I, [P, P, P, I, I, I, I, I, P, SZ, P]),

@@ -864,6 +864,37 @@ __global__ __launch_bounds__(256) void blend_tile_kernel(const float* __restrict
     raster[(long)y * cols + x] += (double)den * w;
 }
 
+// All tiles of a batch in ONE launch with the accumulation order of the per-tile launches (tile 0, 1, 2, ... per raster
+// pixel: the reference's order, lib/evaluation.py:497-511).  Thread (tile i, pixel e) OWNS its raster pixel iff no earlier
+// tile of the batch covers it; the owner adds the contributions of tiles i, i+1, ... that cover the pixel, in order, and
+// every other thread exits -- no atomics, no inter-thread ordering needed, any tile placement (overlapping areas, shifted
+// border tiles) works.
+__global__ __launch_bounds__(256) void blend_batch_kernel(const float* __restrict__ pred, const float* __restrict__ mean,
+                                                          const float* __restrict__ stdv, const int* __restrict__ pos,
+                                                          const int* __restrict__ reg, int n, int T, int stride,
+                                                          double* __restrict__ raster, int rows, int cols) {
+    const long e_all = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e_all >= (long)n * T * T) return;
+    const int i = (int)(e_all / ((long)T * T)), e = (int)(e_all - (long)i * T * T);
+    const int r = e / T, c = e - r * T;
+    const int y = pos[i * 2] + r, x = pos[i * 2 + 1] + c;
+    if ((unsigned)y >= (unsigned)rows || (unsigned)x >= (unsigned)cols) return;
+    for (int j = 0; j < i; ++j)
+        if ((unsigned)(y - pos[j * 2]) < (unsigned)T && (unsigned)(x - pos[j * 2 + 1]) < (unsigned)T) return;   // not the owner
+    const int overlap = T - stride;
+    const double step = overlap > 1 ? 1.0 / (double)(overlap - 1) : 0.0;
+    double acc = raster[(long)y * cols + x];
+    for (int j = i; j < n; ++j) {
+        const int rj = y - pos[j * 2], cj = x - pos[j * 2 + 1];
+        if ((unsigned)rj >= (unsigned)T || (unsigned)cj >= (unsigned)T) continue;
+        const double w = blend_axis(rj, reg[j * 4], reg[j * 4 + 2], T, overlap, step) *
+                         blend_axis(cj, reg[j * 4 + 1], reg[j * 4 + 3], T, overlap, step);
+        const float den = __fadd_rn(__fmul_rn(pred[((long)j * T + rj) * T + cj], stdv[j]), mean[j]);
+        acc += (double)den * w;
+    }
+    raster[(long)y * cols + x] = acc;
+}
+
 // ---- bilinear 2x upsampling (up_mode='bilinear', lib/UNet.py:20) ---------------------------------------------
 // nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False): src = max(0.5*(dst+0.5)-0.5, 0), i0 = floor(src),
 // i1 = i0 + (i0 < size-1), l1 = src - i0, l0 = 1 - l1   (same arithmetic as ATen's upsample_bilinear2d).
@@ -1486,6 +1517,13 @@ int rd_blend_accumulate(const float* pred, const float* mean, const float* stdv,
     RD_REQUIRE(n > 0 && tile_size > 0 && stride > 0 && stride <= tile_size && rows > 0 && cols > 0,
                "rd_blend_accumulate: bad shape (n=%d tile=%d stride=%d raster=%dx%d)", n, tile_size, stride, rows, cols);
     ProfScope ps((hipStream_t)s, "blend_accumulate", 0, 20.0 * n * tile_size * tile_size);
+    if (n <= 64) {      // one launch for the whole batch (owner threads walk the covering tiles in order)
+        const long total = (long)n * tile_size * tile_size;
+        hipLaunchKernelGGL(blend_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, pred, mean, stdv,
+                           pos, reg, n, tile_size, stride, raster, rows, cols);
+        RD_LAUNCH_CHECK("blend_accumulate");
+        return RD_OK;
+    }
     const int blocks = cdiv((long)tile_size * tile_size, 256);
     for (int i = 0; i < n; ++i)   // one launch per tile, in order: overlapping tiles never race, order is fixed
         hipLaunchKernelGGL(blend_tile_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, pred, mean, stdv, pos, reg, i,

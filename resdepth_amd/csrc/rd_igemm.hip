@@ -61,6 +61,11 @@ struct NtParams {
     int vec;  // epilogue may use 16-byte accesses (N % 4 == 0 and, for the transposed conv, Cout % 4 == 0)
     unsigned a_bytes, b_bytes;  // extents of the A / B tensors for the buffer descriptors
     float* stats;  // EPI_STORE only, nullable: per-(tile_m) column sums / sums of squares [tiles_m][2][N] (BN statistics)
+    // EPI_STORE, inference with eval-mode BatchNorm folded into the convolution (the weight rows carry gamma*invstd):
+    // C = act(acc + shift[n]); pool_out (patch kernels only) additionally receives the 2x2/2 max-pool of C
+    const float* shift;
+    float act_slope;
+    float* pool_out;
 };
 
 
@@ -70,7 +75,7 @@ __device__ __forceinline__ float skip_act(float y, float slope) { return y > 0.f
 // map is the same for the f32 and the bf16 MFMA shapes).
 template <int BM, int BN, int WM, int WN, int EPI, int SMEM_WORDS, int EB = BM / WM / 32>
 __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem, const NtParams& p,
-                                            int m0, int n0, int tile_m) {
+                                            int m0, int n0, int tile_m, long pool_base = -1) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -131,6 +136,11 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                 if (m >= p.M || n >= p.N) continue;
                 float4 v = *reinterpret_cast<const float4*>(&Cs[row * CS + q4 * 4]);
                 if (EPI == EPI_STORE) {
+                    if (p.shift) {
+                        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + n);
+                        v.x = skip_act(v.x + sh4.x, p.act_slope); v.y = skip_act(v.y + sh4.y, p.act_slope);
+                        v.z = skip_act(v.z + sh4.z, p.act_slope); v.w = skip_act(v.w + sh4.w, p.act_slope);
+                    }
                     *reinterpret_cast<float4*>(p.C + (long)m * p.N + n) = v;
                 } else {
                     const int ab = n / p.Cout, co = n - ab * p.Cout;
@@ -160,6 +170,27 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                     *reinterpret_cast<float4*>(p.C + o) = v;
                 }
             }
+            if (EPI == EPI_STORE && p.pool_out && pool_base >= 0) {
+                // this pass = two patch rows x 16 pixels = 8 complete 2x2 windows per channel quad (ROWS = 32)
+                for (int e = t; e < 8 * Q; e += 256) {
+                    const int j = e / Q, q4 = e - j * Q, n = n0 + q4 * 4;
+                    if (n >= p.N) continue;
+                    const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + n);
+                    float mx[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 c4 = *reinterpret_cast<const float4*>(&Cs[((k >> 1) * 16 + 2 * j + (k & 1)) * CS + q4 * 4]);
+                        const float y[4] = {skip_act(c4.x + sh4.x, p.act_slope), skip_act(c4.y + sh4.y, p.act_slope),
+                                            skip_act(c4.z + sh4.z, p.act_slope), skip_act(c4.w + sh4.w, p.act_slope)};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (k == 0 || y[q] > mx[q] || y[q] != y[q]) mx[q] = y[q];      // torch max_pool2d: NaN wins
+                    }
+                    // pooled pixel: patch origin + (pass, j); rowbase / 32 = pass index = pooled row inside the patch
+                    const long pp = pool_base + (long)(rowbase >> 5) * (p.W >> 1) + j;
+                    *reinterpret_cast<float4*>(p.pool_out + pp * p.N + n) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+                }
+            }
         } else {
             for (int e = t; e < ROWS * BN; e += 256) {
                 const int row = e / BN, c = e - row * BN;
@@ -167,6 +198,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                 if (m >= p.M || n >= p.N) continue;
                 float v = Cs[row * CS + c];
                 if (EPI == EPI_STORE) {
+                    if (p.shift) v = skip_act(v + p.shift[n], p.act_slope);
                     p.C[(long)m * p.N + n] = v;
                 } else {
                     const int ab = n / p.Cout, co = n - ab * p.Cout;
@@ -654,7 +686,8 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = merge_hi_lo(acc[i][0][r], lo[i][r]);
     const int m0 = ((img * H + y0) * W) + x0;
-    nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m);
+    const long pool_base = ((long)img * (H >> 1) + (y0 >> 1)) * (W >> 1) + (x0 >> 1);
+    nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m, pool_base);
 }
 
 // fp32 GEMM-layout B[N][K] (K = taps*Cin, tap-major) -> split-bf16 fragment layout
@@ -700,7 +733,7 @@ __global__ void split_pack_kernel(const float* __restrict__ B, uint4* __restrict
 //   pieces [Tf, Tf+Td)  data-gradient operand rows n = ci, k = (tap', co):   w[co0+j][ci][8-tap']
 // one thread per 16-byte fragment piece (row n, K-step kt = chunk*9 + tap, k-half g); gathered, cached loads.
 __global__ void split_pack_conv3x3_kernel(const float* __restrict__ w, uint4* __restrict__ outf, uint4* __restrict__ outd,
-                                          int cout, int cin) {
+                                          int cout, int cin, const float* __restrict__ row_scale) {
     const int nkf = 9 * ((cin + SK - 1) / SK), nkd = 9 * ((cout + SK - 1) / SK);
     const long rf = (long)((cout + 31) / 32) * 32, rd_ = (long)((cin + 31) / 32) * 32;
     const long Tf = rf * nkf * 2, Td = outd ? rd_ * nkd * 2 : 0;
@@ -718,6 +751,7 @@ __global__ void split_pack_conv3x3_kernel(const float* __restrict__ w, uint4* __
             const int c = c0 + j;
             float x = 0.f;
             if (n < N && c < Kc) x = fwd ? w[((long)n * cin + c) * 9 + tap] : w[((long)c * cin + n) * 9 + (8 - tap)];
+            if (fwd && row_scale && n < N) x *= row_scale[n];       // eval-mode BatchNorm folded into the forward operand
             v[j] = x;
         }
         unsigned h[8], m[8], l[8];
@@ -784,7 +818,8 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     if (split) {
         // split kernel: two 128x128 blocks (57 KB LDS each) per CU; measured per layer with scripts/bench_layers.py
         const bool halo_shape = AMODE == A_CONV3 && EPI == EPI_STORE && p.W >= 16 && p.H >= 8;
-        if (halo_shape && tiles_128x64 >= 512) cfg = (p.N >= 128 && tiles_128x64 >= 1024) ? 0 : 1;   // 16x16 levels: 128x64 patches
+        // (the pooling epilogue exists in the patch kernels only: small batches take them too)
+        if (halo_shape && (tiles_128x64 >= 512 || p.pool_out)) cfg = (p.N >= 128 && tiles_128x64 >= 1024) ? 0 : 1;   // 16x16 levels: 128x64 patches
         else if (p.M < 128 || tiles_128x64 < 1024) cfg = 2;
         else if (EPI == EPI_CONVT && p.K <= 256) cfg = 2;   // scatter epilogue dominates: small tiles keep more in flight
         else if (p.N >= 128) cfg = 0;
@@ -802,6 +837,10 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     if (force >= 0 && force <= 2 && !(force == 0 && p.N <= 64)) cfg = force;
     const int halo_force = tune(TUNE_NT_HALO);
     const bool halo = split && AMODE == A_CONV3 && EPI == EPI_STORE && p.W >= 16 && p.H >= 8 && cfg != 2 && halo_force != 0;
+    if (p.pool_out && !halo) {
+        set_error("%s: the pooling epilogue exists in the patch (halo) kernels only", cls);
+        return RD_ERR_ARG;
+    }
     char pcls[64];   // "<operation>|<kernel symbol>": the kernel symbol is what rocprofv3 reports
     if (halo)
         snprintf(pcls, sizeof(pcls), "%s|conv3_halo_split<%d>", cls, cfg == 0 ? 128 : 64);
@@ -1411,7 +1450,8 @@ int rd_pack_conv3x3_weight(const float* w, float* wf, float* wd, int cout, int c
         const long pieces = rows32_of(cout) * nk16_of(9, cin) * 2 + (wd ? rows32_of(cin) * nk16_of(9, cout) * 2 : 0);
         long g = (pieces + 255) / 256;
         if (g > 8192) g = 8192;
-        hipLaunchKernelGGL(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, od, cout, cin);
+        hipLaunchKernelGGL(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, od, cout, cin,
+                           (const float*)nullptr);
         RD_LAUNCH_CHECK("pack_conv3x3");
         return RD_OK;
     }
@@ -1425,6 +1465,20 @@ int rd_pack_conv3x3_weight(const float* w, float* wf, float* wd, int cout, int c
     RD_LAUNCH_CHECK("pack_conv3x3");
     if (int e = split_pack(wf, cout, 9, cin, (hipStream_t)s)) return e;
     if (wd) return split_pack(wd, cin, 9, cout, (hipStream_t)s);
+    return RD_OK;
+}
+
+int rd_pack_conv3x3_weight_folded(const float* w, const float* row_scale, float* wf, int cout, int cin, rd_stream_t s) {
+    RD_REQUIRE(w && wf && row_scale && cout > 0 && cin > 0, "rd_pack_conv3x3_weight_folded: bad arguments");
+    RD_REQUIRE(mfma_split(), "rd_pack_conv3x3_weight_folded: only the split-bf16 kernels implement the folded inference path");
+    ProfScope ps((hipStream_t)s, "pack_weights", 0, 10.0 * cout * cin * 9);
+    uint4* of = (uint4*)((char*)wf + packed_f32_bytes(cout, 9, cin));
+    const long pieces = rows32_of(cout) * nk16_of(9, cin) * 2;
+    long g = (pieces + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, (uint4*)nullptr, cout, cin,
+                       row_scale);
+    RD_LAUNCH_CHECK("pack_conv3x3_folded");
     return RD_OK;
 }
 
@@ -1492,6 +1546,21 @@ int rd_conv3x3_fwd_bn(const float* x, const float* wf, float* z, double count, f
     if (int e = launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_fwd", &tiles_m)) return e;
     return bn_reduce_finalize((const float*)ws, tiles_m, cout, count, eps, momentum, mean, invstd, running_mean, running_var, nbt,
                               (hipStream_t)s);
+}
+
+int rd_conv3x3_fwd_act(const float* x, const float* wf_folded, const float* shift, float slope, float* a, float* pooled, int n,
+                       int h, int w, int cin, int cout, rd_stream_t s) {
+    if (int e = check_conv_args(n, h, w, cin, cout)) return e;
+    RD_REQUIRE(x && wf_folded && shift && a, "rd_conv3x3_fwd_act: null pointer");
+    RD_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "rd_conv3x3_fwd_act: channels must be multiples of 4 (%d, %d)", cin, cout);
+    RD_REQUIRE(mfma_split(), "rd_conv3x3_fwd_act: only the split-bf16 kernels implement the folded inference path");
+    RD_REQUIRE(!pooled || (w >= 16 && h >= 8), "rd_conv3x3_fwd_act: the pooling epilogue needs W >= 16 and H >= 8 (got %dx%d)", h, w);
+    NtParams p = {};
+    p.A = x; p.B = wf_folded; p.C = a;
+    p.M = n * h * w; p.N = cout; p.K = 9 * cin; p.Cin = cin;
+    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    p.shift = shift; p.act_slope = slope; p.pool_out = pooled;
+    return launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_fwd");
 }
 
 int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int h, int w, int cin, int cout,

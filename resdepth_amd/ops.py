@@ -37,6 +37,15 @@ def pack_conv3x3_weight(w, need_dgrad=True):
     return wf, wd
 
 
+def pack_conv3x3_weight_folded(w, row_scale):
+    """Forward operand with eval-mode BatchNorm folded in: rows scaled by gamma / sqrt(running_var + eps)."""
+    cout, cin = w.shape[0], w.shape[1]
+    wf = _packed_buffer(cout, 9, cin, w.device)
+    check(load().rd_pack_conv3x3_weight_folded(ptr(w.detach()), ptr(_f32(row_scale, "row_scale")), ptr(wf), cout, cin,
+                                               stream_ptr()), "pack_conv3x3_folded")
+    return wf
+
+
 def pack_convt2x2_weight(w, need_dgrad=True):
     cin, cout = w.shape[0], w.shape[1]
     wtf = _packed_buffer(4 * cout, 1, cin, w.device)
@@ -63,6 +72,17 @@ def conv3x3_fwd_stats(x, wf):
     check(load().rd_conv3x3_fwd_stats(ptr(_f32(x, "x")), ptr(wf), ptr(z), ptr(sums), n, h, w, cin, cout, ws.data_ptr(),
                                       ws.numel(), stream_ptr()), "conv3x3_fwd_stats")
     return z, sums
+
+
+def conv3x3_fwd_act(x, wf_folded, shift, slope, pool=False):
+    """Inference: -> (a, pooled | None) with a = act(conv(x) + shift); the 2x2 max-pool comes out of the same epilogue."""
+    n, h, w, cin = x.shape
+    cout = wf_folded.shape[0]
+    a = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
+    pooled = torch.empty(n, h // 2, w // 2, cout, device=x.device, dtype=torch.float32) if pool else None
+    check(load().rd_conv3x3_fwd_act(ptr(_f32(x, "x")), ptr(wf_folded), ptr(shift), float(slope), ptr(a), ptr(pooled), n, h, w,
+                                    cin, cout, stream_ptr()), "conv3x3_fwd_act")
+    return a, pooled
 
 
 def conv3x3_fwd_bn(x, wf, running_mean, running_var, num_batches_tracked, eps=BN_EPS, momentum=BN_MOMENTUM):

@@ -133,6 +133,8 @@ class UNet(nn.Module):
         self.grad_sync = None        # optional resdepth_amd.dp.GradSync (data-parallel hooks)
         self.sync_bn = False
         self.two_stream_backward = True   # weight gradients on a second HIP stream, overlapping the dgrad/BN chain
+        self.fold_eval_bn = True          # inference: eval-mode BN folded into the packed conv weights + epilogue activation
+        self._bn_gen = 0                  # bumped by every training-mode forward (the kernels update running statistics in place)
         self._side_stream = None
 
     # ------------------------------------------------------------------------------------------
@@ -302,9 +304,75 @@ class UNet(nn.Module):
             a = {"z": z, "mean": mean, "invstd": invstd, "gamma": bn.weight, "beta": bn.bias, "slope": slope, "slope_dev": sdev}
         return a, p, idx, mean, invstd, count
 
-    def _engine_forward(self, x, training: bool, save: bool, keep_skips: bool = False):
+    # ---- inference: eval-mode BatchNorm folded into the convolutions ---------------------------------------------------
+    def _can_fold(self) -> bool:
+        return self.do_BN and self.up_mode == "transpose" and _lib.tune_get("mfma_f32") == 0 and self.fold_eval_bn
+
+    def _folded(self):
+        """Per conv block with BN (all but the first convolution): forward operand with the rows scaled by
+        gamma / sqrt(running_var + eps), the shift beta - running_mean * scale and the activation slope.  Rebuilt when a
+        parameter or a running statistic changed (lib/UNet.py:45,66,86 in eval mode)."""
+        blocks = [self.encoder[i][0] for i in range(1, self.depth)] + [self.bottleneck] + \
+                 [self.decoder[i][1] for i in range(self.depth - 1)]
+        acts = [self.act_fn_encoder] * (self.depth - 1) + [self.act_fn_bottleneck] + [self.act_fn_decoder] * (self.depth - 1)
+        key = (self._flat_param.data_ptr(), _lib.param_generation(self._flat_param.data_ptr()),
+               tuple(p._version for p in self.parameters()),
+               tuple((b[1].running_mean._version, b[1].running_var._version) for b in blocks), self._bn_gen)
+        if self.__dict__.get("_fold_key") == key:
+            return self.__dict__["_fold_cache"]
+        out = []
+        with torch.no_grad():
+            for blk, act in zip(blocks, acts):
+                bn = blk[1]
+                scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+                shift = (bn.bias - bn.running_mean * scale).contiguous()
+                a = self._act_of(blk, act)
+                slope = float(a.detach()) if isinstance(a, torch.Tensor) else a     # PReLU: one read-back per weight change
+                out.append((ops.pack_conv3x3_weight_folded(blk[0].weight, scale), shift, slope))
+        self.__dict__["_fold_key"], self.__dict__["_fold_cache"] = key, out
+        return out
+
+    def _conv_act(self, inp, folded, pool):
+        wf, shift, slope = folded
+        if pool and (inp.shape[2] < 16 or inp.shape[1] < 8):
+            # levels too small for the patch kernel's pooling epilogue: pool in a second (tiny) pass over the activation
+            a, _ = ops.conv3x3_fwd_act(inp, wf, shift, slope, pool=False)
+            c = a.shape[-1]
+            zero, one = self._const(c, 0.0, a.device), self._const(c, 1.0, a.device)
+            _, p, _ = ops.bn_act_pool_fwd(a, zero, one, one, zero, 1.0, True, want_a=False)     # identity BN / activation
+            return a, p
+        return ops.conv3x3_fwd_act(inp, wf, shift, slope, pool=pool)
+
+    def _engine_forward_folded(self, x):
+        """Eval-mode forward with no pre-BN tensor after level 0: conv -> (+shift, act[, pool]) in one kernel per block."""
         d = self.depth
         pk = self._packed()
+        fold = self._folded()
+        blk = self.encoder[0][0]
+        z0 = ops.conv3x3_first_fwd(x, blk[0].weight)
+        bn = blk[1]
+        skip0, cur, _, _, _, _ = self._bn_forward(z0, bn, self._act_of(blk, self.act_fn_encoder), True, False, want_a=False)
+        skips = [skip0]
+        for i in range(1, d):
+            a, cur = self._conv_act(cur, fold[i - 1], True)
+            skips.append(a)
+        cur, _ = self._conv_act(cur, fold[d - 1], False)
+        for i in range(d):
+            s = self._up_forward(cur, pk.get(("dec_t", i)), self._up_of(i), skips[d - 1 - i])
+            skips[d - 1 - i] = None
+            cur = self._conv_act(s, fold[d + i], False)[0] if i < d - 1 else s
+        x_res = x if self.do_outer_skip else None
+        if self.do_outer_skip and self.do_outer_skip_BN:
+            x_res, _ = self._outer_bn_forward(x, False)
+        return ops.conv3x3_last_fwd(cur, self.last_layer.weight, self.last_layer.bias, x_res)
+
+    def _engine_forward(self, x, training: bool, save: bool, keep_skips: bool = False):
+        if not training and not save and self._can_fold():
+            return self._engine_forward_folded(x), None
+        d = self.depth
+        pk = self._packed()
+        if training:
+            self._bn_gen += 1
         S = {"x": x, "enc": [], "dec": [], "training": training} if save else None
 
         fused_stats = training and self.do_BN and not (self.sync_bn and self.grad_sync is not None)

@@ -475,3 +475,37 @@ def test_edge_shapes_against_oracle(n, t, kw):
     assert abs(float(loss) - float(lo)) <= 1e-5 * abs(float(lo))
     for (k, p), gr in zip(model.named_parameters(), go):
         assert rel_l2(p.grad, gr) <= 2e-3, (k, rel_l2(p.grad, gr))
+
+
+def test_folded_eval_forward_equals_unfolded_and_tracks_running_statistics():
+    """Inference folds eval-mode BN into the packed weights (+ shift / activation / pool in the conv epilogue).  It must agree
+    with the unfolded engine to fp32 rounding, with and without the pooling epilogue (levels below 16x16 pool in a second
+    pass), and must notice running statistics that a training-mode forward changed through raw device writes."""
+    from resdepth_amd import UNet
+    for kw, n, t in ((dict(n_input_channels=3, start_kernel=16, depth=3, bias_conv_layer=True), 3, 64),
+                     (dict(n_input_channels=2, start_kernel=64, depth=4, act_fn_encoder="lrelu", act_fn_decoder="prelu"), 2, 128)):
+        torch.manual_seed(3)
+        model = UNet(**kw).to(DEV)
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn(n, kw["n_input_channels"], t, t, generator=g).to(DEV)
+        model.train()
+        with torch.no_grad():
+            model(x)                                    # moves the running statistics away from (0, 1)
+        model.eval()
+        with torch.no_grad():
+            y_fold = model(x)
+            model.fold_eval_bn = False
+            y_plain = model(x)
+            model.fold_eval_bn = True
+        assert float((y_fold - y_plain).abs().max()) <= 2e-5 * max(1.0, float(y_plain.abs().max()))
+        model.train()
+        with torch.no_grad():
+            model(x * 2.0 + 1.0)                        # running statistics change again (no optimizer step in between)
+        model.eval()
+        with torch.no_grad():
+            y2 = model(x)
+            model.fold_eval_bn = False
+            y2_plain = model(x)
+            model.fold_eval_bn = True
+        assert float((y2 - y_fold).abs().max()) > 1e-4, "running statistics did not move: test is vacuous"
+        assert float((y2 - y2_plain).abs().max()) <= 2e-5 * max(1.0, float(y2_plain.abs().max()))
