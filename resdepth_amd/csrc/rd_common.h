@@ -71,6 +71,11 @@ int conv_last_fwd_launch(const float* s_in, const float* wt, const float* bias, 
                          int h, int w, int c, hipStream_t s, int* launched);
 int conv_last_dgrad_launch(const float* dout, const float* wt, float* ds, int n, int h, int w, int c, hipStream_t s, int* launched);
 int conv_last_wgrad_blocks(int n, int h, int w, int c);
+// first convolution, segment kernels: tiles / blocks = 0 when the shape stays on the generic kernel
+int conv_first_seg_tiles(int n, int h, int w, int cin, int cout);
+int conv_first_wgrad_seg_blocks(int n, int h, int w, int cin, int cout);
+int conv_first_seg_launch(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
+                          int w, int cin, int cout, hipStream_t s);
 int conv_last_wgrad_launch(const float* s_in, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s);
 
 inline int ilog2_exact(int v) {

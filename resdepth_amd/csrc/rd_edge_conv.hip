@@ -212,6 +212,226 @@ __global__ __launch_bounds__(256) void conv_last_wgrad_tile_kernel(const float* 
     }
 }
 
+// ---- first convolution (NCHW input with 1..6 channels -> NHWC, Cout = 32 / 64 / 128) ---------------------------------------
+// Tile = 16 x 32 output pixels; the input halo (18 x 34 per channel plane, row pitch 36 floats = 16-byte aligned rows) sits in
+// LDS.  A thread owns 4 output channels (lane cq) and works on 8-pixel row SEGMENTS: per (ky, ci) it reads the 10 input
+// values the 8 pixels share with three LDS instructions (the old kernel read 27 scalars per pixel) and keeps the weights
+// (forward) or the 27 x 4 weight-gradient accumulators (wgrad) in registers.  Forward: 16-byte stores, the 16 lanes of a pixel
+// write its 256 contiguous bytes; BN statistics of the block leave through one LDS reduction.  Wgrad: the 8 dz loads of a
+// segment are issued before its arithmetic; one three-chunk LDS reduction per block at the end (was 27 x 2 barriers).
+constexpr int FP = 36;                      // LDS row pitch of the input halo, floats
+constexpr int FH_PLANE = EH_H * FP;         // floats per channel plane
+
+template <int CIN>
+__device__ __forceinline__ void load_x_halo(float* X, const float* __restrict__ x, int n, int y0, int x0, int H, int W, int t) {
+    for (int e = t; e < CIN * EH_NP; e += 256) {
+        const int ci = e / EH_NP, rem = e - ci * EH_NP, hy = rem / EH_W, hx = rem - hy * EH_W;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        X[ci * FH_PLANE + hy * FP + hx] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                                              ? x[(((long)n * CIN + ci) * H + gy) * W + gx] : 0.f;
+    }
+}
+
+// the 10 input values under an 8-pixel segment starting at halo column c0 (multiple of 8) of halo row hy, channel ci
+__device__ __forceinline__ void read_row10(const float* X, int ci, int hy, int c0, float (&v)[10]) {
+    const float* p = X + ci * FH_PLANE + hy * FP + c0;
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    const float2 c = *reinterpret_cast<const float2*>(p + 8);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; v[8] = c.x; v[9] = c.y;
+}
+
+template <int CIN, int CQ>
+__global__ __launch_bounds__(256, 4) void conv_first_fwd_seg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 float* __restrict__ z, float* __restrict__ partial, int N, int H,
+                                                                 int W, int tiles_x, int tiles_y) {
+    constexpr int Cout = CQ * 4, SLOTS = 256 / CQ, NSEG = (ET_H * ET_W / 8) / SLOTS;
+    // halo planes, then the statistics scratch [8][256], then the weights [tap * CIN + ci][Cout] (16-byte broadcast reads:
+    // with the weights in registers the kernel needed 256 VGPRs = one wave per SIMD)
+    __shared__ __attribute__((aligned(16))) float X[CIN * FH_PLANE + 8 * 256 + 9 * CIN * Cout];
+    float* Wl = X + CIN * FH_PLANE + 8 * 256;
+    const int t = threadIdx.x, cq = t % CQ, slot = t / CQ;
+    const int tl = blockIdx.x;
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+    const int y0 = ty * ET_H, x0 = tx * ET_W;
+    for (int e = t; e < 9 * CIN * Cout; e += 256) {
+        const int j = e / Cout, co = e - j * Cout;
+        Wl[e] = w[((long)co * CIN + j % CIN) * 9 + j / CIN];
+    }
+    load_x_halo<CIN>(X, x, n, y0, x0, H, W, t);
+    __syncthreads();
+    float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int sg = 0; sg < NSEG; ++sg) {
+        const int seg = sg * SLOTS + slot;         // 64 segments: row = seg / 4, first column = (seg % 4) * 8
+        const int py = seg >> 2, c0 = (seg & 3) * 8;
+        float acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky)             // not unrolled: fully unrolled, hipcc hoists all 27*CIN LDS reads and spills
+#pragma unroll 1
+            for (int ci = 0; ci < CIN; ++ci) {
+                float v[10];
+                read_row10(X, ci, py + ky, c0, v);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(Wl + ((ky * 3 + kx) * CIN + ci) * Cout + cq * 4);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        acc[i][0] = fmaf(v[i + kx], w4.x, acc[i][0]);
+                        acc[i][1] = fmaf(v[i + kx], w4.y, acc[i][1]);
+                        acc[i][2] = fmaf(v[i + kx], w4.z, acc[i][2]);
+                        acc[i][3] = fmaf(v[i + kx], w4.w, acc[i][3]);
+                    }
+                }
+            }
+        const int gy = y0 + py;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int gx = x0 + c0 + i;
+            if (gy < H && gx < W) {
+                *reinterpret_cast<float4*>(z + (((long)n * H + gy) * W + gx) * Cout + cq * 4) =
+                    make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    st_s[k] += acc[i][k];
+                    st_q[k] = fmaf(acc[i][k], acc[i][k], st_q[k]);
+                }
+            }
+        }
+    }
+    if (partial) {      // BN statistics of this tile: fixed-order sum over the pixel slots -> partial[tile][2][Cout]
+        float* red = X + CIN * FH_PLANE;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[k * 256 + t] = st_s[k];
+            red[(4 + k) * 256 + t] = st_q[k];
+        }
+        __syncthreads();
+        for (int e = t; e < 2 * Cout; e += 256) {
+            const int qq = e / Cout, c = e - qq * Cout, k = c & 3, lane_cq = c >> 2;
+            float sum = 0.f;
+            for (int sl = 0; sl < SLOTS; ++sl) sum += red[(qq * 4 + k) * 256 + sl * CQ + lane_cq];
+            partial[(long)tl * 2 * Cout + e] = sum;
+        }
+    }
+}
+
+template <int CIN, int CQ>
+__global__ __launch_bounds__(256, 2) void conv_first_wgrad_seg_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                   float* __restrict__ partial, int N, int H, int W, int tiles_x,
+                                                                   int tiles_y, int ntiles) {
+    constexpr int Cout = CQ * 4, SLOTS = 256 / CQ, NSEG = (ET_H * ET_W / 8) / SLOTS, NT = 9 * CIN;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];       // halo planes, then the reduction scratch [9][256][4]
+    float* X = fsm;
+    float* red = fsm + CIN * FH_PLANE;
+    const int t = threadIdx.x, cq = t % CQ, slot = t / CQ;
+    float wg[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wg[j][k] = 0.f;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+        const int y0 = ty * ET_H, x0 = tx * ET_W;
+        __syncthreads();
+        load_x_halo<CIN>(X, x, n, y0, x0, H, W, t);
+        __syncthreads();
+#pragma unroll 1
+        for (int sg = 0; sg < NSEG; ++sg) {
+            const int seg = sg * SLOTS + slot;
+            const int py = seg >> 2, c0 = (seg & 3) * 8;
+            const int gy = y0 + py;
+            float4 d[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {          // eight 16-byte loads of dz in flight
+                const int gx = x0 + c0 + i;
+                d[i] = (gy < H && gx < W) ? *reinterpret_cast<const float4*>(dz + (((long)n * H + gy) * W + gx) * Cout + cq * 4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    float v[10];
+                    read_row10(X, ci, py + ky, c0, v);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int j = (ky * 3 + kx) * CIN + ci;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            wg[j][0] = fmaf(v[i + kx], d[i].x, wg[j][0]);
+                            wg[j][1] = fmaf(v[i + kx], d[i].y, wg[j][1]);
+                            wg[j][2] = fmaf(v[i + kx], d[i].z, wg[j][2]);
+                            wg[j][3] = fmaf(v[i + kx], d[i].w, wg[j][3]);
+                        }
+                    }
+                }
+        }
+    }
+    // block reduction over the pixel slots in chunks of 9 (tap, ci) rows: partial[block][NT][Cout]
+    float* out = partial + (long)blockIdx.x * NT * Cout;
+#pragma unroll
+    for (int ch = 0; ch < CIN; ++ch) {
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 9; ++jj)
+            *reinterpret_cast<float4*>(red + (jj * 256 + t) * 4) = make_float4(wg[ch * 9 + jj][0], wg[ch * 9 + jj][1], wg[ch * 9 + jj][2], wg[ch * 9 + jj][3]);
+        __syncthreads();
+        for (int e = t; e < 9 * Cout; e += 256) {
+            const int jj = e / Cout, c = e - jj * Cout;
+            float sum = 0.f;
+            for (int sl = 0; sl < SLOTS; ++sl) sum += red[(jj * 256 + sl * CQ + (c >> 2)) * 4 + (c & 3)];
+            out[(long)(ch * 9 + jj) * Cout + c] = sum;
+        }
+    }
+}
+
+// (5 and 6 input channels would need > 256 registers for the 216 weight-gradient accumulators: they stay on the generic kernel)
+static bool first_shape_ok(int cin, int cout) { return cin >= 1 && cin <= 4 && (cout == 32 || cout == 64 || cout == 128); }
+
+int conv_first_seg_tiles(int n, int h, int w, int cin, int cout) {        // 0 = shape stays on the generic kernel
+    if (!first_shape_ok(cin, cout) || tune(TUNE_EDGE_CONV) == 0) return 0;
+    return n * cdiv(w, ET_W) * cdiv(h, ET_H);
+}
+
+int conv_first_wgrad_seg_blocks(int n, int h, int w, int cin, int cout) {
+    const int nt = conv_first_seg_tiles(n, h, w, cin, cout);
+    return nt < 1024 ? nt : 1024;
+}
+
+template <int CIN>
+static int launch_first_seg(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
+                            int w, int cout, hipStream_t s) {
+    const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H), nt = n * tx * ty;
+    if (!wgrad) {
+        if (cout == 64) hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 16>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
+        else if (cout == 32) hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 8>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
+        else hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 32>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
+    } else {
+        const int nb = nt < 1024 ? nt : 1024;
+        const size_t smem = (size_t)(CIN * FH_PLANE + 9 * 256 * 4) * sizeof(float);
+        if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 16>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt);
+        else if (cout == 32) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 8>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt);
+        else hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 32>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt);
+    }
+    RD_LAUNCH_CHECK("conv_first_seg");
+    return RD_OK;
+}
+
+// forward (partial = per-tile BN statistics [tiles][2][Cout], nullable) / weight gradient (partial = [blocks][9*Cin][Cout])
+int conv_first_seg_launch(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
+                          int w, int cin, int cout, hipStream_t s) {
+    switch (cin) {
+        case 1: return launch_first_seg<1>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s);
+        case 2: return launch_first_seg<2>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s);
+        case 3: return launch_first_seg<3>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s);
+        default: return launch_first_seg<4>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s);
+    }
+}
+
 static bool edge_shape_ok(int c) { return c == 16 || c == 32 || c == 64; }
 
 int conv_last_fwd_launch(const float* s_in, const float* wt, const float* bias, const float* x_nchw, int xc, float* out, int n,

@@ -1317,6 +1317,7 @@ int rd_conv3x3_first_fwd(const float* x, const float* wt, float* z, int n, int h
 }
 
 size_t rd_conv3x3_first_fwd_stats_ws_bytes(int n, int h, int w, int cin, int cout) {
+    if (const int nt2 = conv_first_seg_tiles(n, h, w, cin, cout)) return (size_t)nt2 * 2 * cout * sizeof(float);
     int tx, ty, nt;
     const int grid = first_grid(n, h, w, &tx, &ty, &nt);
     return (size_t)grid * 2 * cout * sizeof(float);
@@ -1327,12 +1328,18 @@ int rd_conv3x3_first_fwd_stats(const float* x, const float* wt, float* z, double
     RD_REQUIRE(x && wt && z, "rd_conv3x3_first_fwd: null pointer");
     RD_REQUIRE(cout % 4 == 0 && cout / 4 <= 256 && cout > 0, "rd_conv3x3_first_fwd: Cout must be a multiple of 4, <= 1024");
     int tx, ty, nt;
-    const int grid = first_grid(n, h, w, &tx, &ty, &nt);
+    int grid = first_grid(n, h, w, &tx, &ty, &nt);
+    const int seg_tiles = conv_first_seg_tiles(n, h, w, cin, cout);
+    if (seg_tiles) grid = seg_tiles;
     if (sums && (!ws || ws_bytes < (size_t)grid * 2 * cout * sizeof(float))) {
         set_error("rd_conv3x3_first_fwd_stats: workspace too small");
         return RD_ERR_WS;
     }
-    {
+    if (seg_tiles) {
+        ProfScope ps((hipStream_t)s, "conv_first_fwd", 2.0 * n * h * w * cout * 9.0 * cin, 4.0 * n * h * w * (double)(cin + cout));
+        if (int e = conv_first_seg_launch(false, x, wt, z, nullptr, sums ? (float*)ws : nullptr, n, h, w, cin, cout, (hipStream_t)s))
+            return e;
+    } else {
         ProfScope ps((hipStream_t)s, "conv_first_fwd", 2.0 * n * h * w * cout * 9.0 * cin,
                      4.0 * n * h * w * (double)(cin + cout));
         if (int e = launch_first<false>(x, wt, z, nullptr, sums ? (float*)ws : nullptr, n, h, w, cin, cout, grid, tx, ty,
@@ -1350,12 +1357,17 @@ int rd_conv3x3_first_fwd_bn(const float* x, const float* wt, float* z, double co
     RD_REQUIRE(x && wt && z && mean && invstd && count > 0, "rd_conv3x3_first_fwd_bn: bad arguments");
     RD_REQUIRE(cout % 4 == 0 && cout / 4 <= 256 && cout > 0, "rd_conv3x3_first_fwd_bn: Cout must be a multiple of 4, <= 1024");
     int tx, ty, nt;
-    const int grid = first_grid(n, h, w, &tx, &ty, &nt);
+    int grid = first_grid(n, h, w, &tx, &ty, &nt);
+    const int seg_tiles = conv_first_seg_tiles(n, h, w, cin, cout);
+    if (seg_tiles) grid = seg_tiles;
     if (!ws || ws_bytes < (size_t)grid * 2 * cout * sizeof(float)) {
         set_error("rd_conv3x3_first_fwd_bn: workspace too small");
         return RD_ERR_WS;
     }
-    {
+    if (seg_tiles) {
+        ProfScope ps((hipStream_t)s, "conv_first_fwd", 2.0 * n * h * w * cout * 9.0 * cin, 4.0 * n * h * w * (double)(cin + cout));
+        if (int e = conv_first_seg_launch(false, x, wt, z, nullptr, (float*)ws, n, h, w, cin, cout, (hipStream_t)s)) return e;
+    } else {
         ProfScope ps((hipStream_t)s, "conv_first_fwd", 2.0 * n * h * w * cout * 9.0 * cin, 4.0 * n * h * w * (double)(cin + cout));
         if (int e = launch_first<false>(x, wt, z, nullptr, (float*)ws, n, h, w, cin, cout, grid, tx, ty, nt, (hipStream_t)s))
             return e;
@@ -1366,6 +1378,7 @@ int rd_conv3x3_first_fwd_bn(const float* x, const float* wt, float* z, double co
 }
 
 size_t rd_conv3x3_first_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout) {
+    if (const int nb = conv_first_wgrad_seg_blocks(n, h, w, cin, cout)) return (size_t)nb * 9 * cin * cout * sizeof(float);
     int tx, ty, nt;
     const int grid = first_grid(n, h, w, &tx, &ty, &nt);
     return (size_t)grid * 9 * cin * cout * sizeof(float);
@@ -1377,7 +1390,9 @@ int rd_conv3x3_first_bwd_weight(const float* x, const float* dz, float* dw, int 
     RD_REQUIRE(cout % 4 == 0 && cout / 4 <= 256 && cout > 0,
                "rd_conv3x3_first_bwd_weight: Cout must be a multiple of 4, <= 1024");
     int tx, ty, nt;
-    const int grid = first_grid(n, h, w, &tx, &ty, &nt);
+    int grid = first_grid(n, h, w, &tx, &ty, &nt);
+    const int seg_blocks = conv_first_wgrad_seg_blocks(n, h, w, cin, cout);
+    if (seg_blocks) grid = seg_blocks;
     const size_t need = (size_t)grid * 9 * cin * cout * sizeof(float);
     if (!ws || ws_bytes < need) {
         set_error("rd_conv3x3_first_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -1385,6 +1400,13 @@ int rd_conv3x3_first_bwd_weight(const float* x, const float* dz, float* dw, int 
     }
     ProfScope ps((hipStream_t)s, "conv_first_wgrad", 2.0 * n * h * w * cout * 9.0 * cin,
                  4.0 * n * h * w * (double)(cin + cout));
+    if (seg_blocks) {
+        if (int e = conv_first_seg_launch(true, x, nullptr, nullptr, dz, (float*)ws, n, h, w, cin, cout, (hipStream_t)s)) return e;
+        hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 16)), dim3(256), 0, (hipStream_t)s,
+                           (const float*)ws, dw, grid, cin, cout);
+        RD_LAUNCH_CHECK("conv_first_wgrad");
+        return RD_OK;
+    }
     if (int e = launch_first<true>(x, nullptr, nullptr, dz, (float*)ws, n, h, w, cin, cout, grid, tx, ty, nt,
                                    (hipStream_t)s))
         return e;

@@ -142,3 +142,123 @@ def test_two_rank_gloo_gradient_sync_matches_single_device():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in results), results
+
+
+class _SyncBN(torch.autograd.Function):
+    """The engine's host-side SyncBN protocol (resdepth_amd/unet.py: _bn_forward / bn_backward with sync_bn) on CPU
+    tensors: forward exchanges (sum z, sum z^2) through GradSync.allreduce_stats, backward exchanges (sum g, sum g*xhat)
+    through GradSync.allreduce_sums; the affine-parameter gradients stay LOCAL (the gradient all-reduce sums them)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, gs):
+        c = z.shape[1]
+        sums = torch.cat([z.double().sum((0, 2, 3)), (z.double() ** 2).sum((0, 2, 3))])
+        count = gs.allreduce_stats(sums, z.numel() // c)
+        mean = (sums[:c] / count).float()
+        var = (sums[c:] / count - (sums[:c] / count) ** 2).clamp_min(0).float()
+        invstd = torch.rsqrt(var + 1e-5)
+        xhat = (z - mean.view(1, c, 1, 1)) * invstd.view(1, c, 1, 1)
+        ctx.save_for_backward(xhat, gamma, invstd)
+        ctx.gs, ctx.count = gs, count
+        return xhat * gamma.view(1, c, 1, 1) + beta.view(1, c, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        xhat, gamma, invstd = ctx.saved_tensors
+        c = g.shape[1]
+        sums = torch.cat([g.double().sum((0, 2, 3)), (g.double() * xhat.double()).sum((0, 2, 3))])
+        dbeta, dgamma = sums[:c].float().clone(), sums[c:].float().clone()          # local sums = parameter gradients
+        ctx.gs.allreduce_sums(sums)
+        k1 = (sums[:c] / ctx.count).float().view(1, c, 1, 1)
+        k2 = (sums[c:] / ctx.count).float().view(1, c, 1, 1)
+        dz = (gamma * invstd).view(1, c, 1, 1) * (g - k1 - xhat * k2)
+        return dz, dgamma, dbeta, None
+
+
+def _worker4(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        import torch.nn.functional as F
+        g = torch.Generator().manual_seed(11)
+        w1 = torch.randn(6, 2, 3, 3, generator=g) * 0.3
+        gamma, beta = torch.rand(6, generator=g) + 0.5, torch.randn(6, generator=g) * 0.1
+        w2 = torch.randn(1, 6, 3, 3, generator=g) * 0.3
+        b2 = torch.randn(1, generator=g)
+        full = O.synthetic_batch(8, 2, 16, seed=9)
+        full["dsm_std"] = torch.linspace(0.5, 3.0, 8)
+
+        def net(x, p, bn):
+            z = F.conv2d(x, p[0], None, 1, 1)
+            a = torch.relu(bn(z, p[1], p[2]))
+            return x[:, 0:1] + F.conv2d(a, p[3], p[4], 1, 1)
+
+        def loss_num(yp, b):
+            return (((yp - b["target"]) * b["dsm_std"].view(-1, 1, 1, 1)).abs() * b["loss_mask"]).sum()
+
+        # reference: one process, whole batch, torch's own training-mode batch norm
+        pr = [t.clone().requires_grad_(True) for t in (w1, gamma, beta, w2, b2)]
+        ref_loss = loss_num(net(full["input"], pr, lambda z, ga, be: F.batch_norm(z, None, None, ga, be, True, 0.1, 1e-5)), full) / \
+            full["loss_mask"].sum()
+        ref = torch.autograd.grad(ref_loss, pr)
+        # 4 ranks, 2 tiles each: SyncBN + global loss normaliser + bucketed gradient all-reduce
+        gs = dp.GradSync(bucket_bytes=64)                          # 16-float buckets: five parameters -> several buckets
+        local = dp.shard_batch(full, rank, world)
+        pl = [t.clone().requires_grad_(True) for t in (w1, gamma, beta, w2, b2)]
+        yp = net(local["input"], pl, lambda z, ga, be: _SyncBN.apply(z, ga, be, gs))
+        num = loss_num(yp, local)
+        sums = torch.stack([num.detach().double(), local["loss_mask"].sum().double()])
+        gs.allreduce_loss_sums(sums, local["target"].numel())
+        assert float(sums[1]) == float(full["loss_mask"].sum())
+        assert abs(float(sums[0] / sums[1]) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+        gl = torch.autograd.grad(num / sums[1].float(), pl)
+        model = FlatModel([tuple(t.shape) for t in pl])
+        for i, gr in enumerate(gl):
+            o = model._offsets[i]
+            model._flat_grad[o:o + gr.numel()] = gr.flatten()
+        # readiness arrives OUT of backward order (uneven completion): buckets fire as soon as all their members are in,
+        # in the same order on every rank because every rank makes the same calls
+        order = [2, 4, 0, 3, 1]
+        launched_before = []
+        for i in order:
+            gs.params_ready(model, [i])
+            launched_before.append(sum(gs._launched))
+        assert launched_before[-1] >= 1 and launched_before == sorted(launched_before)
+        gs.finish(model)
+        for i, gr in enumerate(ref):
+            o = model._offsets[i]
+            got = model._flat_grad[o:o + gr.numel()].view(gr.shape)
+            err = float((got - gr).norm() / (gr.norm() + 1e-30))
+            assert err < 2e-5, (i, err)
+        # a second step re-uses the plan (buckets reset by finish)
+        for i in range(5):
+            gs.params_ready(model, [4 - i])
+        gs.finish(model)
+        # unequal shards are refused on every rank instead of deadlocking later
+        gs.check_equal_across_ranks(7, "len(loader)")
+        try:
+            gs.check_equal_across_ranks(7 + (rank == 2), "len(loader)")
+            raise AssertionError("unequal loader lengths were accepted")
+        except RuntimeError as e:
+            assert "differs across ranks" in str(e)
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_rank_gloo_syncbn_uneven_bucket_order_matches_single_device():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in results), results

@@ -198,7 +198,10 @@ def test_conv_known_answer(g4):
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 32, 32, 3, 8), (1, 16, 16, 1, 4), (3, 8, 64, 2, 64), (2, 64, 64, 3, 64),
-                                            (1, 16, 16, 6, 12)])
+                                            (1, 16, 16, 6, 12),
+                                            # segment kernels (Cin <= 4, Cout = 32 / 64 / 128): ragged tiles, every Cin
+                                            (1, 40, 72, 4, 32), (2, 16, 32, 1, 128), (1, 256, 256, 3, 64), (3, 24, 8, 2, 64),
+                                            (2, 32, 32, 5, 64)])
 def test_first_conv(n, h, w, cin, cout):
     from resdepth_amd import ops
     g = torch.Generator().manual_seed(cin * 10 + cout)

@@ -509,3 +509,34 @@ def test_folded_eval_forward_equals_unfolded_and_tracks_running_statistics():
             model.fold_eval_bn = True
         assert float((y2 - y_fold).abs().max()) > 1e-4, "running statistics did not move: test is vacuous"
         assert float((y2 - y2_plain).abs().max()) <= 2e-5 * max(1.0, float(y2_plain.abs().max()))
+
+
+def test_data_parallel_overhead_at_full_batch_on_rccl_world1():
+    """cfg-S at batch 32 through the data-parallel code path on RCCL (world size 1: the only size one GPU offers): loss
+    normaliser all-reduce, four 16 MB gradient buckets launched from the weight-gradient stream, final wait -- and the same
+    with the 20 SyncBN statistic exchanges.  DESIGN.md section 6 claims 0.35 ms/step for the former; bound: 1 ms (8 % of the
+    step) resp. 2 ms with SyncBN, and identical losses (world 1: every collective is the identity)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "12", "--warmup", "4", "--no-cpu-baseline", "--no-secondary", "--no-prof"]
+
+    def run(extra, launcher):
+        cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", "29581"] if launcher else [sys.executable]) + [os.path.join(root, "bench.py"), "--gpus", "1"] + common + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    plain = run([], False)
+    dist_ = run(["--force-dist"], True)
+    sync = run(["--force-dist", "--sync-bn"], True)
+    assert dist_["dist"]["backend"] == "nccl" and dist_["dist"]["world_size_reported"] == 1
+    assert len(dist_["dist"]["per_rank_ms_per_step"]) == 1
+    assert dist_["loss_first_last"] == plain["loss_first_last"] == sync["loss_first_last"]
+    base = plain["step_ms_median"]
+    assert dist_["step_ms_median"] - base <= 1.0, (base, dist_["step_ms_median"])
+    assert sync["step_ms_median"] - base <= 2.0, (base, sync["step_ms_median"])
