@@ -14,6 +14,11 @@ for f in rd_runtime rd_igemm rd_convt rd_wgrad_strip rd_elementwise rd_edge_conv
   if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/rd_common.h" -nt "$HERE/obj/$f.o" ] \
      || [ "$HERE/rd_mfma_dev.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/resdepth_hip.h" -nt "$HERE/obj/$f.o" ]; then
     F="$FLAGS"; [ $f = rd_wgrad_strip ] && F="$BASE"     # 144 accumulator registers: AGPR-form MFMA (see the file header)
+    # rd_edge_conv: no SLP vectorisation = no v_pk_fma_f32.  With it, the last-conv weight-gradient kernel (operands
+    # from ds_read2_b32, consumed by v_pk_fma_f32 ... op_sel:[0,1,0]) produced wrong LOW-half results in single 16-lane
+    # rows whenever it ran concurrently with main-stream kernels of the two-stream backward (profiles/r02_notes.md,
+    # "packed-FMA corruption"); the scalar-FMA build is bit-stable and equally fast (the kernels are HBM-bound)
+    [ $f = rd_edge_conv ] && F="$FLAGS -fno-slp-vectorize"
     $HIPCC $F -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
     pids+=($!)
   fi

@@ -16,6 +16,12 @@
 
 namespace rd {
 
+// TUNE_EDGE_CONV: -1 all kernels of this file, else a bit mask (1 last fwd, 2 last dgrad, 4 last wgrad, 8 first fwd, 16 first wgrad)
+static bool edge_on(int bit) {
+    const int v = tune(TUNE_EDGE_CONV);
+    return v < 0 || (v & bit);
+}
+
 constexpr int ET_H = 16, ET_W = 32, EH_W = ET_W + 2, EH_H = ET_H + 2, EH_NP = EH_H * EH_W;   // 16x32 tile, 612 halo pixels
 constexpr int EVS = 9;          // V row stride in floats (odd: column reads of one tap are bank-conflict free)
 
@@ -393,12 +399,13 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_seg_kernel(const floa
 static bool first_shape_ok(int cin, int cout) { return cin >= 1 && cin <= 4 && (cout == 32 || cout == 64 || cout == 128); }
 
 int conv_first_seg_tiles(int n, int h, int w, int cin, int cout) {        // 0 = shape stays on the generic kernel
-    if (!first_shape_ok(cin, cout) || tune(TUNE_EDGE_CONV) == 0) return 0;
+    if (!first_shape_ok(cin, cout) || !edge_on(8)) return 0;
     return n * cdiv(w, ET_W) * cdiv(h, ET_H);
 }
 
 int conv_first_wgrad_seg_blocks(int n, int h, int w, int cin, int cout) {
-    const int nt = conv_first_seg_tiles(n, h, w, cin, cout);
+    if (!first_shape_ok(cin, cout) || !edge_on(16)) return 0;
+    const int nt = n * cdiv(w, ET_W) * cdiv(h, ET_H);
     return nt < 1024 ? nt : 1024;
 }
 
@@ -437,7 +444,7 @@ static bool edge_shape_ok(int c) { return c == 16 || c == 32 || c == 64; }
 int conv_last_fwd_launch(const float* s_in, const float* wt, const float* bias, const float* x_nchw, int xc, float* out, int n,
                          int h, int w, int c, hipStream_t s, int* launched) {
     *launched = 0;
-    if (!edge_shape_ok(c) || tune(TUNE_EDGE_CONV) == 0) return RD_OK;
+    if (!edge_shape_ok(c) || !edge_on(1)) return RD_OK;
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
     const dim3 grid(n * tx * ty);
     if (c == 64) hipLaunchKernelGGL(conv_last_fwd_dpp_kernel<8>, grid, dim3(256), 0, s, s_in, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
@@ -450,7 +457,7 @@ int conv_last_fwd_launch(const float* s_in, const float* wt, const float* bias, 
 
 int conv_last_dgrad_launch(const float* dout, const float* wt, float* ds, int n, int h, int w, int c, hipStream_t s, int* launched) {
     *launched = 0;
-    if (!edge_shape_ok(c) || tune(TUNE_EDGE_CONV) == 0) return RD_OK;
+    if (!edge_shape_ok(c) || !edge_on(2)) return RD_OK;
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
     hipLaunchKernelGGL(conv_last_dgrad_tile_kernel, dim3(n * tx * ty), dim3(256), 0, s, dout, wt, ds, n, h, w, c, c / 4, tx, ty);
     RD_LAUNCH_CHECK("conv_last_dgrad");
@@ -459,7 +466,7 @@ int conv_last_dgrad_launch(const float* dout, const float* wt, float* ds, int n,
 }
 
 int conv_last_wgrad_blocks(int n, int h, int w, int c) {       // 0 = shape not handled here
-    if (!edge_shape_ok(c) || tune(TUNE_EDGE_CONV) == 0) return 0;
+    if (!edge_shape_ok(c) || !edge_on(4)) return 0;
     const long nt = (long)n * cdiv(w, ET_W) * cdiv(h, ET_H);
     return (int)(nt < 1024 ? nt : 1024);
 }

@@ -32,6 +32,8 @@
 
 namespace rd {
 
+__host__ __device__ inline long rows32_of_dev(long rows) { return (rows + 31) / 32 * 32; }
+
 enum { A_CONV3 = 0, A_PLAIN = 1, A_UP2 = 2 };
 enum { EPI_STORE = 0, EPI_CONVT = 1 };
 
@@ -770,6 +772,93 @@ __global__ void split_pack_conv3x3_kernel(const float* __restrict__ w, uint4* __
     }
 }
 
+// ---- every packed operand of the network in ONE launch ------------------------------------------------------------------
+// The per-layer pack kernels were ~30 launches per step (9 conv3x3 layers, 5 transposed convolutions x 4 launches) of 4-60 us
+// each on the second stream.  Here a device-resident item table describes the layers and one grid covers all 16-byte
+// fragment pieces: thread -> (item, operand, row n, K-step kt, k-half g) -> gathers its 8 weights straight from the torch
+// layouts, splits them and writes the three fragment pieces.  Items (8 x int64 each): w pointer, forward-operand buffer,
+// data-gradient-operand buffer, kind (0 conv3x3, 1 convT2x2), Cout, Cin, first piece, write-f32-layout flag.
+struct PackItem {
+    long long w, outf, outd, kind, cout, cin, begin, f32;
+};
+
+__device__ __forceinline__ void write_split_piece(uint4* out, long n, int nk, int kt, int g, const float (&v)[8]) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
+    const long blk = ((n >> 5) * nk + kt) * 3;
+    const int lane = g * 32 + (int)(n & 31);
+    const unsigned sel = 0x07060302u;
+    out[blk * 64 + lane] = make_uint4(__builtin_amdgcn_perm(h[1], h[0], sel), __builtin_amdgcn_perm(h[3], h[2], sel),
+                                      __builtin_amdgcn_perm(h[5], h[4], sel), __builtin_amdgcn_perm(h[7], h[6], sel));
+    out[(blk + 1) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(m[1], m[0], sel), __builtin_amdgcn_perm(m[3], m[2], sel),
+                                            __builtin_amdgcn_perm(m[5], m[4], sel), __builtin_amdgcn_perm(m[7], m[6], sel));
+    out[(blk + 2) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(l[1], l[0], sel), __builtin_amdgcn_perm(l[3], l[2], sel),
+                                            __builtin_amdgcn_perm(l[5], l[4], sel), __builtin_amdgcn_perm(l[7], l[6], sel));
+}
+
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackItem* __restrict__ items, int n_items, long total) {
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        int it = 0;
+        while (it + 1 < n_items && items[it + 1].begin <= p) ++it;
+        const PackItem I = items[it];
+        const float* __restrict__ w = reinterpret_cast<const float*>(I.w);
+        const int cout = (int)I.cout, cin = (int)I.cin;
+        long e = p - I.begin;
+        float v[8];
+        if (I.kind == 0) {
+            // conv3x3 w[co][ci][3][3]: forward rows n = co, k = (tap, ci); data gradient rows n = ci, k = (8 - tap, co)
+            const int nkf = 9 * ((cin + SK - 1) / SK), nkd = 9 * ((cout + SK - 1) / SK);
+            const long Tf = rows32_of_dev(cout) * nkf * 2;
+            const bool fwd = e < Tf;
+            if (!fwd) e -= Tf;
+            const int nk = fwd ? nkf : nkd, N = fwd ? cout : cin, Kc = fwd ? cin : cout;
+            const int g = (int)(e & 1), kt = (int)((e >> 1) % nk);
+            const long n = (e >> 1) / nk;
+            const int chunk = kt / 9, tap = kt - chunk * 9, c0 = chunk * SK + g * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + j;
+                v[j] = (n < N && c < Kc) ? (fwd ? w[((long)n * cin + c) * 9 + tap] : w[((long)c * cin + n) * 9 + (8 - tap)]) : 0.f;
+            }
+            write_split_piece(reinterpret_cast<uint4*>(fwd ? I.outf : I.outd), n, nk, kt, g, v);
+        } else {
+            // convT2x2 w[ci][co][2][2]: forward rows n = (ab, co), k = ci; data gradient rows n = ci, k = (ab, co);
+            // optional third segment: the fp32 forward operand wtf[(ab, co)][ci] (exact-f32 kernel of the short-K levels)
+            const int nkf = (cin + SK - 1) / SK, nkd = 4 * ((cout + SK - 1) / SK);
+            const long Tf = rows32_of_dev(4L * cout) * nkf * 2, Td = rows32_of_dev(cin) * nkd * 2;
+            if (e < Tf) {
+                const int g = (int)(e & 1), kt = (int)((e >> 1) % nkf);
+                const long n = (e >> 1) / nkf;
+                const int ab = (int)(n / cout), co = (int)(n - (long)ab * cout), c0 = kt * SK + g * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (n < 4L * cout && c0 + j < cin) ? w[((long)(c0 + j) * cout + co) * 4 + ab] : 0.f;
+                write_split_piece(reinterpret_cast<uint4*>(I.outf), n, nkf, kt, g, v);
+            } else if (e < Tf + Td) {
+                e -= Tf;
+                const int g = (int)(e & 1), kt = (int)((e >> 1) % nkd);
+                const long n = (e >> 1) / nkd;
+                const int chunk = kt / 4, ab = kt - chunk * 4, c0 = chunk * SK + g * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (n < cin && c0 + j < cout) ? w[((long)n * cout + c0 + j) * 4 + ab] : 0.f;
+                write_split_piece(reinterpret_cast<uint4*>(I.outd), n, nkd, kt, g, v);
+            } else {
+                e -= Tf + Td;                    // 8 consecutive elements of wtf[(ab*Cout + co)][ci]
+                float* wtf = reinterpret_cast<float*>(I.f32);
+                const long tot = 4L * cout * cin;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const long q = e * 8 + j;
+                    if (q < tot) {
+                        const int ci = (int)(q % cin), co = (int)((q / cin) % cout), ab = (int)(q / ((long)cin * cout));
+                        wtf[q] = w[((long)ci * cout + co) * 4 + ab];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- packed weight buffers -------------------------------------------------------------------------------
 // One opaque buffer per GEMM operand B[rows][K = taps*Cin]:  [rows*K floats, fp32 GEMM layout] [pad to 16 B]
 // [rows * nk16 * 96 bytes, split-bf16 layout], nk16 = taps * ceil(Cin/16).  rd_packed_weight_bytes() sizes it.
@@ -1479,6 +1568,24 @@ int rd_pack_conv3x3_weight_folded(const float* w, const float* row_scale, float*
     hipLaunchKernelGGL(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, (uint4*)nullptr, cout, cin,
                        row_scale);
     RD_LAUNCH_CHECK("pack_conv3x3_folded");
+    return RD_OK;
+}
+
+long long rd_pack_item_pieces(int kind, int cout, int cin, int with_f32) {
+    if (cout <= 0 || cin <= 0) return 0;
+    if (kind == 0) return rows32_of(cout) * nk16_of(9, cin) * 2 + rows32_of(cin) * nk16_of(9, cout) * 2;
+    return rows32_of(4L * cout) * nk16_of(1, cin) * 2 + rows32_of(cin) * nk16_of(4, cout) * 2 + (with_f32 ? (4L * cout * cin + 7) / 8 : 0);
+}
+
+int rd_pack_weights_fused(const void* items_dev, int n_items, long long total_pieces, rd_stream_t s) {
+    RD_REQUIRE(items_dev && n_items > 0 && total_pieces > 0, "rd_pack_weights_fused: bad arguments");
+    RD_REQUIRE(mfma_split(), "rd_pack_weights_fused: the fused packer writes the split-bf16 operands only");
+    ProfScope ps((hipStream_t)s, "pack_weights", 0, 10.0 * 8.0 * (double)total_pieces);
+    long g = (total_pieces + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(pack_all_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items,
+                       (long)total_pieces);
+    RD_LAUNCH_CHECK("pack_weights_fused");
     return RD_OK;
 }
 

@@ -191,10 +191,10 @@ class UNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _packed(self):
-        """GEMM-layout copies of the conv / convT weights, rebuilt whenever a parameter changed.  The re-packing is a
-        string of small HBM/latency-bound kernels, so it runs on the second HIP stream in the order the forward uses
-        the layers and every layer carries an event the first consumer waits on: the first convolutions (MFMA-bound)
-        overlap with the packing of the later layers."""
+        """GEMM-layout copies of the conv / convT weights, rebuilt whenever a parameter changed, on the second HIP stream
+        (the first convolution and its BN pass do not need them and run meanwhile).  Split-bf16 mode: ONE launch over a
+        device-resident item table into persistent buffers (`_pack_plan`); exact-f32 / bilinear modes: one pack call per
+        layer in the order the forward uses them, each with its own ready event."""
         params = self._param_list()
         key = (self._flat_param.data_ptr(), _lib.param_generation(self._flat_param.data_ptr()),
                tuple(p._version for p in params))
@@ -208,6 +208,19 @@ class UNet(nn.Module):
             self._side_stream = torch.cuda.Stream(device=dev)
         side = self._side_stream
         side.wait_stream(main)                   # the parameters' last writer (optimizer step) ran on the main stream
+
+        if self.up_mode == "transpose" and _lib.tune_get("mfma_f32") == 0:
+            # split-bf16 mode: every operand of the network in ONE launch into persistent buffers (device item table)
+            plan = self._pack_plan()
+            with torch.cuda.stream(side):
+                _lib.check(_lib.load().rd_pack_weights_fused(plan["items"].data_ptr(), plan["n"], plan["total"],
+                                                             _lib.stream_ptr()), "pack_weights_fused")
+                ev = torch.cuda.Event()
+                ev.record(side)
+            for k, tensors in plan["buffers"].items():
+                pk.items[k], pk.events[k] = tensors, ev
+            self._pack_cache, self._pack_key = pk, key
+            return pk
 
         def put(k, tensors):
             for t_ in tensors:
@@ -229,6 +242,48 @@ class UNet(nn.Module):
                     put(("dec_c", i), ops.pack_conv3x3_weight(self.decoder[i][1][0].weight))
         self._pack_cache, self._pack_key = pk, key
         return pk
+
+    def _pack_plan(self):
+        """Persistent packed-operand buffers of every conv3x3 / ConvTranspose2d layer + the device-resident item table of
+        rd_pack_weights_fused (include/resdepth_hip.h).  Built once per flat parameter buffer."""
+        plan = self.__dict__.get("_pack_plan_cache")
+        if plan is not None and plan["flat"] == self._flat_param.data_ptr():
+            return plan
+        lib, dev, d = _lib.load(), self._flat_param.device, self.depth
+        rows, buffers, begin = [], {}, 0
+
+        def split_ptr(buf, nrows, taps, cin):
+            return buf.data_ptr() + (nrows * taps * cin * 4 + 15) // 16 * 16      # the split operand follows the fp32 layout
+
+        def conv(key, w):
+            nonlocal begin
+            cout, cin = w.shape[0], w.shape[1]
+            wf, wd = ops._packed_buffer(cout, 9, cin, dev), ops._packed_buffer(cin, 9, cout, dev)
+            buffers[key] = (wf, wd)
+            rows.append([w.data_ptr(), split_ptr(wf, cout, 9, cin), split_ptr(wd, cin, 9, cout), 0, cout, cin, begin, 0])
+            begin += lib.rd_pack_item_pieces(0, cout, cin, 0)
+
+        def convt(key, w):
+            nonlocal begin
+            cin, cout = w.shape[0], w.shape[1]
+            wtf, wtd = ops._packed_buffer(4 * cout, 1, cin, dev), ops._packed_buffer(cin, 4, cout, dev)
+            buffers[key] = (wtf, wtd)
+            f32 = 1 if cin <= 128 else 0       # short-K levels may run on the exact-f32 NT kernel (fp32 operand layout)
+            rows.append([w.data_ptr(), split_ptr(wtf, 4 * cout, 1, cin), split_ptr(wtd, cin, 4, cout), 1, cout, cin, begin,
+                         wtf.data_ptr() if f32 else 0])
+            begin += lib.rd_pack_item_pieces(1, cout, cin, f32)
+
+        for i in range(1, d):
+            conv(("enc", i - 1), self.encoder[i][0][0].weight)
+        conv("bott", self.bottleneck[0].weight)
+        for i in range(d):
+            convt(("dec_t", i), self._up_of(i).weight)
+            if i < d - 1:
+                conv(("dec_c", i), self.decoder[i][1][0].weight)
+        items = torch.tensor(rows, dtype=torch.int64).to(dev)
+        plan = {"flat": self._flat_param.data_ptr(), "items": items, "n": len(rows), "total": begin, "buffers": buffers}
+        self.__dict__["_pack_plan_cache"] = plan
+        return plan
 
     def _up_of(self, i):
         """The parameterised module of decoder level i's up-convolution: the ConvTranspose2d, or the conv1x1 behind the

@@ -1,6 +1,6 @@
 REPO="$(pwd)"; OUT="$REPO/gpurun_out/gaps"; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d "$OUT" -o g --output-format csv -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-prof > "$OUT/bench.json" 2> "$OUT/err.txt"
+rocprofv3 --kernel-trace -d "$OUT" -o g --output-format csv -- python $REPO/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-secondary --no-prof > "$OUT/bench.json" 2> "$OUT/err.txt"
 tail -c 300 "$OUT/bench.json"
 python - "$OUT" <<'PY'
 import csv, sys, glob

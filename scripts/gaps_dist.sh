@@ -1,7 +1,7 @@
 # GPU busy/idle analysis of the DP (RCCL, world 1) bench run
 REPO="$(pwd)"; OUT="$REPO/gpurun_out/gapsd"; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d "$OUT" -o g --output-format csv -- python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 $REPO/bench.py --gpus 1 --steps 8 --warmup 3 --force-dist --no-cpu-baseline --no-prof > "$OUT/bench.json" 2> "$OUT/err.txt"
+rocprofv3 --kernel-trace -d "$OUT" -o g --output-format csv -- python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 $REPO/bench.py --gpus 1 --steps 8 --warmup 3 --force-dist --no-cpu-baseline --no-secondary --no-prof > "$OUT/bench.json" 2> "$OUT/err.txt"
 tail -c 200 "$OUT/bench.json"
 python - "$OUT" <<'PY'
 import csv, sys, glob, collections
