@@ -224,6 +224,12 @@ int rd_masked_l1_finish(const float* yp, const float* y, const uint8_t* mask, co
 int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, double beta1, double beta2, float eps,
                  float weight_decay, float step_size, float bc2_sqrt, float grad_scale, rd_stream_t s);
 
+/* ---- torch.optim.SGD step over a flat buffer (lib/utils.py:332-334: SGD(lr, weight_decay)) ---- */
+/* g = grad_scale*g + wd*p;  momentum != 0: buf = first_step ? g : momentum*buf + (1-dampening)*g;  g = nesterov ? g + momentum*buf : buf;
+ * p -= lr*g.   momentum_buf may be NULL when momentum == 0 (the reference's configuration). */
+int rd_sgd_step(float* p, const float* g, float* momentum_buf, long long numel, float lr, float weight_decay, float momentum,
+                float dampening, int nesterov, int first_step, float grad_scale, rd_stream_t s);
+
 /* ---- tiled inference: linear blend of overlapping tiles (lib/evaluation.py:460-567) ----------- */
 /* For every tile i (in tile order per raster pixel => deterministic fp64 accumulation order, no atomics; batches of up to
  * 64 tiles are ONE launch, larger ones one launch per tile):

@@ -314,29 +314,59 @@ def adam_step(params: List[torch.Tensor], grads: List[torch.Tensor], exp_avg: Li
         p.addcdiv_(m, denom, value=-step_size)
 
 
+def sgd_step(params: List[torch.Tensor], grads: List[torch.Tensor], bufs: List[Optional[torch.Tensor]], lr: float,
+             weight_decay: float = 0.0, momentum: float = 0.0, dampening: float = 0.0, nesterov: bool = False) -> None:
+    """One torch.optim.SGD step (lib/utils.py:332-334 builds SGD(lr, weight_decay); momentum / dampening / nesterov are
+    torch's further options), in place.  Restated from the published algorithm (torch.optim.SGD, maximize=False):
+    g += wd * p;  momentum: buf = g on the first step, else buf = momentum * buf + (1 - dampening) * g, and
+    g = g + momentum * buf (nesterov) or buf;  p -= lr * g.  `bufs[i] is None` marks "no momentum buffer yet"; the list is
+    updated in place.  Pinned against torch.optim.SGD through tests/golden/g16_sgd.npz / g17_sgd_mom.npz."""
+    for i, (p, g) in enumerate(zip(params, grads)):
+        if weight_decay != 0.0:
+            g = g + weight_decay * p
+        if momentum != 0.0:
+            if bufs[i] is None:
+                bufs[i] = g.clone()
+            else:
+                bufs[i].mul_(momentum).add_(g, alpha=1.0 - dampening)
+            g = g + momentum * bufs[i] if nesterov else bufs[i]
+        p.add_(g, alpha=-lr)
+
+
 def param_keys(spec: Spec) -> List[str]:
     return [k for k, _, kind in param_layout(spec) if kind == "param"]
 
 
 def train_step(sd, batch, spec: Spec, opt_state: dict, lr=2e-4, betas=(0.9, 0.999), eps=1e-8,
-               weight_decay=1e-5, keep: Optional[dict] = None):
+               weight_decay=1e-5, keep: Optional[dict] = None, sgd: Optional[dict] = None):
     """One reference training iteration: Trainer.inference_one_batch('train') +
     optimizer.step() (lib/Trainer.py:159-199, 212-222).  Returns (loss, grads dict).
 
     `opt_state` = {'step': int, 'exp_avg': {key: t}, 'exp_avg_sq': {key: t}} (created
-    lazily like torch.optim.Adam does).
+    lazily like torch.optim.Adam does).  `sgd` = {'momentum', 'nesterov'} switches to torch.optim.SGD(lr,
+    weight_decay, ...) (opt_state then holds 'buf').  With `keep`, keep['grad_input'] = d loss / d input.
     """
     keys = param_keys(spec)
     leaves = {k_: sd[k_].detach().clone().requires_grad_(True) for k_ in keys}
     work = dict(sd)
     work.update(leaves)
-    y_pred = forward(work, batch["input"], spec, training=True, update_running=True, keep=keep)
+    x_in = batch["input"].detach().clone().requires_grad_(True) if keep is not None else batch["input"]
+    y_pred = forward(work, x_in, spec, training=True, update_running=True, keep=keep)
     # BN buffers are updated in place through `work` (it shares sd's buffer tensors)
     loss = masked_l1_loss(y_pred, batch["target"], batch["loss_mask"], batch["dsm_mean"], batch["dsm_std"])
-    glist = torch.autograd.grad(loss, [leaves[k_] for k_ in keys])
+    glist = torch.autograd.grad(loss, [leaves[k_] for k_ in keys] + ([x_in] if keep is not None else []))
     grads = dict(zip(keys, glist))
     if keep is not None:
         keep["y_pred"] = y_pred.detach()
+        keep["grad_input"] = glist[-1]
+    if sgd is not None:
+        if not opt_state:
+            opt_state.update(step=0, buf=[None] * len(keys))
+        opt_state["step"] += 1
+        with torch.no_grad():
+            sgd_step([sd[k_] for k_ in keys], [grads[k_] for k_ in keys], opt_state["buf"], lr, weight_decay,
+                     sgd.get("momentum", 0.0), sgd.get("dampening", 0.0), sgd.get("nesterov", False))
+        return float(loss.detach()), grads
     if not opt_state:
         opt_state.update(step=0, exp_avg={k_: torch.zeros_like(sd[k_]) for k_ in keys},
                          exp_avg_sq={k_: torch.zeros_like(sd[k_]) for k_ in keys})

@@ -81,6 +81,7 @@ SIGNATURES = {
     "rd_masked_l1_partial": (I, [P, P, P, P, P, P, I, LL, P, SZ, P]),
     "rd_masked_l1_finish": (I, [P, P, P, P, P, P, D, P, P, P, I, LL, P]),
     "rd_adam_step": (I, [P, P, P, P, LL, D, D, F, F, F, F, F, P]),
+    "rd_sgd_step": (I, [P, P, P, LL, F, F, F, F, I, I, F, P]),
     "rd_blend_accumulate": (I, [P, P, P, P, P, I, I, I, P, I, I, P]),
     "rd_patch_sums": (I, [P, LL, P, I, P, I, I, I, F, I, P, P]),
     "rd_assemble_patches": (I, [P, P, P, LL, P, I, P, P, P, F, P, F, F, I, I, I, P, P, P, P]),

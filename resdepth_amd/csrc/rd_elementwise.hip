@@ -828,6 +828,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// ---- SGD (torch.optim.SGD, lib/utils.py:332-334: lr + coupled weight decay; momentum / dampening / nesterov as torch) ----
+template <bool MOM>
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  long n, float lr, float wd, float momentum, float damp1, int nesterov,
+                                                  int first, float gscale) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const float pe = p[e];
+        float ge = g[e] * gscale;
+        ge = fmaf(wd, pe, ge);
+        if (MOM) {
+            // torch: buf = clone(g) on the first step, else buf = buf * momentum + (1 - dampening) * g
+            const float be = first ? ge : fmaf(damp1, ge, buf[e] * momentum);
+            buf[e] = be;
+            ge = nesterov ? fmaf(momentum, be, ge) : be;
+        }
+        p[e] = fmaf(-lr, ge, pe);
+    }
+}
+
 // ---- tiled inference: linear blend --------------------------------------------------------------
 __device__ __forceinline__ double blend_axis(int c, int lo, int hi, int T, int overlap, double step) {
     // np.linspace(0, 1, overlap): ramp[i] = i * step, last element exactly 1
@@ -1530,6 +1549,22 @@ int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, 
                        (long)numel, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, step_size, bc2_sqrt,
                        grad_scale);
     RD_LAUNCH_CHECK("adam");
+    return RD_OK;
+}
+
+int rd_sgd_step(float* p, const float* g, float* momentum_buf, long long numel, float lr, float weight_decay, float momentum,
+                float dampening, int nesterov, int first_step, float grad_scale, rd_stream_t s) {
+    RD_REQUIRE(p && g && numel > 0, "rd_sgd_step: bad arguments");
+    RD_REQUIRE(momentum == 0.f || momentum_buf, "rd_sgd_step: momentum != 0 needs a momentum buffer");
+    ProfScope ps((hipStream_t)s, "sgd", 0, (momentum != 0.f ? 20.0 : 12.0) * numel);
+    const dim3 grid(grid_cap((numel + 255) / 256, 8192));
+    if (momentum != 0.f)
+        hipLaunchKernelGGL(sgd_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, p, g, momentum_buf, (long)numel, lr, weight_decay,
+                           momentum, 1.f - dampening, nesterov, first_step, grad_scale);
+    else
+        hipLaunchKernelGGL(sgd_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, p, g, (float*)nullptr, (long)numel, lr,
+                           weight_decay, 0.f, 1.f, 0, 0, grad_scale);
+    RD_LAUNCH_CHECK("sgd");
     return RD_OK;
 }
 

@@ -402,6 +402,11 @@ def adam_step(p, g, m, v, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, 
                               bc2_sqrt, grad_scale, stream_ptr()), "adam_step")
 
 
+def sgd_step(p, g, buf, lr, weight_decay, momentum=0.0, dampening=0.0, nesterov=False, first_step=False, grad_scale=1.0):
+    check(load().rd_sgd_step(ptr(p), ptr(g), ptr(buf), p.numel(), lr, weight_decay, momentum, dampening,
+                             1 if nesterov else 0, 1 if first_step else 0, grad_scale, stream_ptr()), "sgd_step")
+
+
 def nchw_to_nhwc(x):
     n, c, h, w = x.shape
     out = torch.empty(n, h, w, c, device=x.device, dtype=torch.float32)

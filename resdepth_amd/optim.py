@@ -147,6 +147,112 @@ class FusedAdam(torch.optim.Optimizer):
                 st["exp_avg_sq"] = torch.zeros_like(p.data)
 
 
+class FusedSGD(torch.optim.Optimizer):
+    """torch.optim.SGD as the reference configures it (lib/utils.py:332-334: lr + coupled weight decay, momentum 0), with
+    torch's momentum / dampening / nesterov options and state key ('momentum_buffer') so optimizer state_dicts are
+    interchangeable.  One launch over the flat parameter buffer when parameters and gradients are views of flat
+    buffers (resdepth_amd.UNet arranges that), else one launch per tensor -- always the HIP kernel."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
+        if lr < 0 or momentum < 0 or weight_decay < 0:
+            raise ValueError("invalid SGD hyper-parameter")
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")      # torch's own message
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov,
+                        maximize=False, foreach=None, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        self._flat_state = {}      # group index -> (flat_ptr, momentum buffer or None, steps taken)
+        self.grad_scale = 1.0
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._flat_state = {}
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._flat_state = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"]]
+            if not params:
+                continue
+            with _lib.device_of(params[0]):
+                self._step_group(gi, group, params)
+        return loss
+
+    def _step_group(self, gi, group, params):
+        if any(not p.is_cuda for p in params):
+            raise RuntimeError("resdepth_amd.FusedSGD: parameters must live on a HIP device (no CPU fallback)")
+        if group.get("maximize"):
+            raise NotImplementedError("FusedSGD: maximize is not implemented")
+        lr, wd, mom = group["lr"], group["weight_decay"], group["momentum"]
+        damp, nest = group["dampening"], group["nesterov"]
+        pr = FusedAdam._flat_range([p.data for p in params])
+        gr = FusedAdam._flat_range([p.grad for p in params]) if all(p.grad is not None for p in params) else None
+        if pr is not None and gr is not None and gr[1] == pr[1]:
+            total = pr[1]
+            have = self._flat_state.get(gi)
+            buf, first = None, False
+            if mom != 0:
+                if have is None or have[0] != pr[0] or have[1] is None or have[1].numel() != total:
+                    buf = torch.zeros(total, device=params[0].device, dtype=torch.float32)
+                    # first = "no parameter has a momentum buffer yet" (torch initialises it with the gradient);
+                    # a loaded / per-tensor state is copied into the flat buffer
+                    first = not any("momentum_buffer" in self.state[p] and self.state[p]["momentum_buffer"] is not None
+                                    for p in params)
+                    off = 0
+                    for p in params:
+                        st, n = self.state[p], p.numel()
+                        if st.get("momentum_buffer") is not None:
+                            buf[off:off + n].copy_(st["momentum_buffer"].reshape(-1))
+                        st["momentum_buffer"] = buf[off:off + n].view(p.shape)
+                        off += n
+                    self._flat_state[gi] = (pr[0], buf)
+                else:
+                    buf = have[1]
+            ops.sgd_step(_as_flat(params[0].data, total), _as_flat(params[0].grad, total), buf, lr, wd, mom, damp, nest,
+                         first, self.grad_scale)
+            _lib.bump_param_generation(pr[0])
+            return
+        for p in params:
+            if p.grad is None:
+                continue                      # torch.optim.SGD skips parameters without gradient
+            st = self.state[p]
+            buf, first = None, False
+            if mom != 0:
+                if st.get("momentum_buffer") is None:
+                    st["momentum_buffer"] = torch.zeros_like(p.data, memory_format=torch.contiguous_format)
+                    first = True
+                buf = st["momentum_buffer"].view(-1)
+            g = p.grad.contiguous()
+            ops.sgd_step(p.data.view(-1) if p.data.is_contiguous() else p.data, g.view(-1), buf, lr, wd, mom, damp, nest,
+                         first, self.grad_scale)
+        _lib.bump_param_generation(None)
+
+
+def get_optimizer(cfg, model, logger=None):
+    """lib/utils.py:318-340 with the fused optimizers: cfg.optimizer.{name, learning_rate, weight_decay}; 'Adam' ->
+    FusedAdam, 'SGD' -> FusedSGD (torch defaults for everything else).  Unknown names log the reference's message and,
+    like the reference (which then hits an unbound local), raise."""
+    name = cfg.optimizer.name
+    if name == "Adam":
+        return FusedAdam(model.parameters(), lr=cfg.optimizer.learning_rate, weight_decay=cfg.optimizer.weight_decay)
+    if name == "SGD":
+        return FusedSGD(model.parameters(), lr=cfg.optimizer.learning_rate, weight_decay=cfg.optimizer.weight_decay)
+    msg = f"{name} optimizer is not implemented. Choose among ['Adam', 'SGD'].\n"
+    if logger:
+        logger.error(msg)
+    else:
+        print(f"ERROR: {msg}")
+    raise UnboundLocalError("local variable 'optimizer' referenced before assignment")
+
+
 def _as_flat(first: torch.Tensor, total: int) -> torch.Tensor:
     """A 1-D view of `total` fp32 elements starting at `first`'s storage position."""
     return torch.as_strided(first, (total,), (1,), first.storage_offset()) if first.storage_offset() + total <= \

@@ -138,12 +138,69 @@ class UNet(nn.Module):
         self._side_stream = None
 
     # ------------------------------------------------------------------------------------------
-    def _unsupported(self) -> Optional[str]:
-        if self.start_kernel % 4 != 0:
-            return "start_kernel not a multiple of 4"
-        if not 1 <= self.n_input_channels <= 6:
-            return "n_input_channels outside 1..6"
-        return None
+    def _first_generic(self) -> bool:
+        """More than 6 input channels: the first convolution runs as an ordinary NHWC conv3x3 (MFMA-class kernels, packed
+        operands) behind an NCHW -> NHWC transpose instead of the dedicated few-channel kernels."""
+        return self.n_input_channels > 6
+
+    def _needs_twin(self) -> bool:
+        """The kernels move channels in groups of four.  Constructor arguments outside that domain (start_kernel or
+        max_filter_depth not a multiple of 4, more than 6 input channels not a multiple of 4) run on a zero-padded twin
+        (`_twin`), which computes the same function."""
+        if any(c % 4 for c in self.filter_depths):
+            return True
+        return self.n_input_channels > 6 and self.n_input_channels % 4 != 0
+
+    def _twin(self):
+        """The channel-padded engine model of a UNet whose widths the kernels do not take directly: same architecture with
+        start_kernel / max_filter_depth / (n_input_channels > 6) rounded up to multiples of 4 (every layer then has at
+        least as many channels as this model's).  Parameters live in the leading channels; the padding channels carry
+        zero weights, BN (gamma, beta) = (1, 0) and zero biases, so their activations are exactly 0 in training and eval
+        mode and they neither influence a real channel nor receive a gradient through one."""
+        tw = self.__dict__.get("_twin_model")
+        dev = next(self.parameters()).device
+        if tw is None or next(tw.parameters()).device != dev:
+            up4 = lambda v: (v + 3) // 4 * 4
+            cin = up4(self.n_input_channels) if self.n_input_channels > 6 else self.n_input_channels
+            with torch.random.fork_rng(devices=[]):        # the twin's default init must not advance the caller's RNG stream
+                tw = UNet(cin, up4(self.start_kernel), up4(self.max_filter_depth), self.depth, self.act_fn_encoder,
+                          self.act_fn_decoder, self.act_fn_bottleneck, self.up_mode, self.do_BN, self.bias_conv_layer,
+                          self.do_outer_skip, self.do_outer_skip_BN).to(dev)
+            with torch.no_grad():
+                for name, t in list(tw.named_parameters()) + list(tw.named_buffers()):
+                    if name.endswith("num_batches_tracked"):
+                        continue
+                    is_bn_scale = t.dim() == 1 and (name.endswith(".1.weight") or name.endswith("running_var")
+                                                    or name == "layer_outer_skip.0.weight")
+                    t.fill_(1.0 if is_bn_scale else 0.0)
+            for q in tw.parameters():
+                q.requires_grad_(False)              # gradients come back through _TwinFunction, never through autograd
+            self.__dict__["_twin_model"] = tw         # not a registered sub-module: invisible to state_dict / parameters
+        return tw
+
+    @staticmethod
+    def _corner(small, big):
+        return big[tuple(slice(0, k) for k in small.shape)]
+
+    def _twin_load(self):
+        """Copy this model's parameters and BN buffers into the leading channels of the twin."""
+        tw = self._twin()
+        tw._ensure_flat()
+        with torch.no_grad():
+            for (_, a), (_, b) in zip(list(self.named_parameters()) + list(self.named_buffers()),
+                                      list(tw.named_parameters()) + list(tw.named_buffers())):
+                self._corner(a, b).copy_(a) if a.dim() else b.copy_(a)
+        tw.train(self.training)
+        tw.two_stream_backward, tw.fold_eval_bn = self.two_stream_backward, self.fold_eval_bn
+        tw.invalidate_packed()
+        _lib.bump_param_generation(None)
+        return tw
+
+    def _twin_store_buffers(self, tw):
+        """Running statistics / num_batches_tracked updated by a training-mode forward of the twin -> this model."""
+        with torch.no_grad():
+            for (_, a), (_, b) in zip(self.named_buffers(), tw.named_buffers()):
+                a.copy_(self._corner(a, b) if a.dim() else b)
 
     def _param_list(self) -> List[nn.Parameter]:
         return list(self.parameters())
@@ -231,6 +288,8 @@ class UNet(nn.Module):
             pk.items[k], pk.events[k] = tensors, ev
 
         with torch.cuda.stream(side):
+            if self._first_generic():
+                put("enc_first", ops.pack_conv3x3_weight(self.encoder[0][0][0].weight))
             for i in range(1, d):
                 put(("enc", i - 1), ops.pack_conv3x3_weight(self.encoder[i][0][0].weight))
             put("bott", ops.pack_conv3x3_weight(self.bottleneck[0].weight))
@@ -273,6 +332,8 @@ class UNet(nn.Module):
                          wtf.data_ptr() if f32 else 0])
             begin += lib.rd_pack_item_pieces(1, cout, cin, f32)
 
+        if self._first_generic():
+            conv("enc_first", self.encoder[0][0][0].weight)
         for i in range(1, d):
             conv(("enc", i - 1), self.encoder[i][0][0].weight)
         conv("bott", self.bottleneck[0].weight)
@@ -404,7 +465,10 @@ class UNet(nn.Module):
         pk = self._packed()
         fold = self._folded()
         blk = self.encoder[0][0]
-        z0 = ops.conv3x3_first_fwd(x, blk[0].weight)
+        if self._first_generic():
+            z0 = ops.conv3x3_fwd(ops.nchw_to_nhwc(x), pk.get("enc_first")[0])
+        else:
+            z0 = ops.conv3x3_first_fwd(x, blk[0].weight)
         bn = blk[1]
         skip0, cur, _, _, _, _ = self._bn_forward(z0, bn, self._act_of(blk, self.act_fn_encoder), True, False, want_a=False)
         skips = [skip0]
@@ -449,7 +513,12 @@ class UNet(nn.Module):
             blk = self.encoder[i][0]
             sums = st = None                 # training: BN statistics come out of the conv kernel's epilogue
             bn, cbias = self._norm_of(blk)
-            if i == 0:
+            if i == 0 and self._first_generic():
+                xh = ops.nchw_to_nhwc(x)
+                if save:
+                    S["xh"] = xh
+                z, sums, st = conv_stats(xh, pk.get("enc_first")[0], bn)
+            elif i == 0:
                 if fused_stats:
                     z, m_, i_ = ops.conv3x3_first_fwd_bn(x, blk[0].weight, bn.running_mean, bn.running_var,
                                                          bn.num_batches_tracked, eps=bn.eps, momentum=bn.momentum)
@@ -526,7 +595,32 @@ class UNet(nn.Module):
         y, _, _ = ops.bn_act_pool_fwd(v, mean4, inv4, g4, b4, 1.0, False)       # slope 1 = identity activation
         return y.view(n, 1, h, w), {"v": v, "mean": mean4, "invstd": inv4, "g4": g4, "b4": b4, "count": count}
 
-    def _engine_backward(self, S, dout):
+    def _input_grad(self, S, dz0, dout, pk):
+        """dL/dx [N, Cin, T, T] (lib/UNet.py:196-246 differentiated w.r.t. its input): the first convolution's data
+        gradient plus, on channel 0, the outer residual (through BatchNorm2d(1) when outer_skip_BN).  Off the training
+        path (the reference never asks for it); built from existing kernels."""
+        blk = self.encoder[0][0]
+        w = blk[0].weight.detach()
+        if self._first_generic():
+            dx = ops.nhwc_to_nchw(ops.conv3x3_bwd_data(dz0, pk.get("enc_first")[1]))
+        else:
+            # dx[ci] = sum_{co,tap} dz[p - off(tap)][co] w[co][ci][tap] = a C -> 1 convolution of dz with the flipped taps
+            planes = [ops.conv3x3_last_fwd(dz0, w[:, ci].flip(-1, -2).contiguous().unsqueeze(0), None, None)
+                      for ci in range(self.n_input_channels)]
+            dx = torch.cat(planes, 1) if len(planes) > 1 else planes[0]
+        if self.do_outer_skip:
+            if "outer_bn" in S:
+                ob = S["outer_bn"]
+                s12 = ob["s12"]
+                tot = torch.cat([s12[0:4].sum().expand(4), s12[4:8].sum().expand(4)]).contiguous()
+                g0 = ops.bn_act_bwd_apply(ob["v"], ob["mean"], ob["invstd"], ob["g4"], ob["b4"], 1.0, dout.view(ob["v"].shape),
+                                          None, None, tot, ob["count"], S["training"])
+                dx[:, 0:1] += g0.view(dout.shape)
+            else:
+                dx[:, 0:1] += dout
+        return dx
+
+    def _engine_backward(self, S, dout, want_dx=False):
         """Writes every parameter gradient into a flat gradient buffer; returns the list of views
         (state_dict / parameters() order).  Order of production: head, decoder levels d-1..0 + bottleneck,
         encoder levels d-1..0 -- i.e. from the END of the flat buffer towards its start, which is what the
@@ -644,6 +738,7 @@ class UNet(nn.Module):
             obn = self.layer_outer_skip[0]
             s12 = ops.bn_act_bwd_reduce(ob["v"], ob["mean"], ob["invstd"], ob["g4"], ob["b4"], 1.0,
                                         dout.view(ob["v"].shape), None, None)
+            ob["s12"] = s12
             gv(obn.bias).copy_(s12[0:4].sum().reshape(1))
             gv(obn.weight).copy_(s12[4:8].sum().reshape(1))
             done(obn.weight, obn.bias)
@@ -683,21 +778,21 @@ class UNet(nn.Module):
             if i > 0:
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][i - 1]["p"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
                 gp = ops.conv3x3_bwd_data(dz, pk.get(("enc", i - 1))[1])
+            elif self._first_generic():
+                wgrad(ops.conv3x3_bwd_weight, (dz,), S["xh"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
             else:
                 wgrad(ops.conv3x3_first_bwd_weight, (dz,), S["x"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
+        dx = self._input_grad(S, dz, dout, pk) if want_dx else None
         if side is not None:
             main.wait_stream(side)           # every weight gradient (and bucket launch) is ordered before what follows
         if sync is not None:
             sync.finish(self)
         elif self.grad_sync is not None:
             self.grad_sync.allreduce_unbucketed(flat)
-        return grads
+        return grads, dx
 
     # ------------------------------------------------------------------------------------------
     def forward(self, x):
-        why = self._unsupported()
-        if why is not None:
-            raise NotImplementedError(f"resdepth_amd.UNet: {why} is not implemented by the HIP engine yet")
         if not x.is_cuda:
             raise RuntimeError("resdepth_amd.UNet runs on MI355X only: move the model and the input to a HIP device "
                                "(there is no CPU fallback)")
@@ -706,17 +801,39 @@ class UNet(nn.Module):
         t = x.shape[2]
         if x.shape[3] != t or (t & (t - 1)) != 0 or t < 2 ** self.depth:
             raise ValueError(f"tile size must be a power of two >= 2^depth = {2 ** self.depth} (got {tuple(x.shape[2:])})")
+        if self.training and self.do_BN and x.shape[0] * (t >> self.depth) ** 2 == 1:
+            # torch.nn.functional.batch_norm's own check, hit by the reference at its bottleneck BatchNorm2d (lib/UNet.py:66)
+            raise ValueError("Expected more than 1 value per channel when training, got input size "
+                             f"torch.Size([1, {self.filter_depths[-1]}, 1, 1])")
         x = x.contiguous().float()
         with _lib.device_of(x):          # raw kernel launches go to the CURRENT device's stream: make it x's device
-            self._ensure_flat()
             params = self._param_list()
             if params[0].device != x.device:
                 raise RuntimeError(f"resdepth_amd.UNet: input on {x.device} but parameters on {params[0].device}")
-            need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+            need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+            if self._needs_twin():
+                if self.grad_sync is not None:
+                    raise NotImplementedError("resdepth_amd.UNet: data-parallel gradient hooks need channel counts that are "
+                                              "multiples of 4 (this configuration runs on the zero-padded twin)")
+                tw = self._twin_load()
+                if not need_grad:
+                    out, _ = tw._engine_forward(self._pad_input(x, tw), tw.training, save=False)
+                    if self.training:
+                        self._twin_store_buffers(tw)
+                    return out
+                return _TwinFunction.apply(x, self, tw, *params)
+            self._ensure_flat()
             if not need_grad:
                 out, _ = self._engine_forward(x, self.training, save=False)
                 return out
             return _UNetFunction.apply(x, self, *params)
+
+    @staticmethod
+    def _pad_input(x, tw):
+        extra = tw.n_input_channels - x.shape[1]
+        if extra == 0:
+            return x
+        return torch.cat([x, x.new_zeros(x.shape[0], extra, x.shape[2], x.shape[3])], 1)
 
     def invalidate_packed(self):
         """Drop the packed (GEMM-layout) weight copies; the next forward re-packs.  Needed only after writing parameters
@@ -739,6 +856,32 @@ class _UNetFunction(torch.autograd.Function):
         if S is None:
             raise RuntimeError("resdepth_amd.UNet: backward called twice (activations were released)")
         with _lib.device_of(dout):
-            grads = model._engine_backward(S, dout)
+            grads, dx = model._engine_backward(S, dout, want_dx=ctx.needs_input_grad[0])
         ctx.saved = None
-        return (None, None, *grads)
+        return (dx, None, *grads)
+
+
+class _TwinFunction(torch.autograd.Function):
+    """Forward / backward of a UNet whose channel counts are not multiples of 4, executed on its zero-padded twin
+    (UNet._twin): gradients are the leading-channel corners of the twin's."""
+
+    @staticmethod
+    def forward(ctx, x, model, twin, *params):
+        out, saved = twin._engine_forward(UNet._pad_input(x, twin), twin.training, save=True)
+        if model.training:
+            model._twin_store_buffers(twin)
+        ctx.model, ctx.twin, ctx.saved, ctx.cin = model, twin, saved, x.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, twin, S = ctx.model, ctx.twin, ctx.saved
+        if S is None:
+            raise RuntimeError("resdepth_amd.UNet: backward called twice (activations were released)")
+        with _lib.device_of(dout):
+            grads, dx = twin._engine_backward(S, dout, want_dx=ctx.needs_input_grad[0])
+            out = [UNet._corner(p, g).clone() if p.requires_grad else None for p, g in zip(model._param_list(), grads)]
+            if dx is not None:
+                dx = dx[:, :ctx.cin].contiguous()
+        ctx.saved = None
+        return (dx, None, None, *out)

@@ -434,6 +434,46 @@ def test_masked_l1_random_vs_oracle():
     np.testing.assert_allclose(ypd.grad.cpu().numpy(), 2.5 * yp.grad.numpy(), rtol=3e-6, atol=0)
 
 
+@pytest.mark.parametrize("momentum,dampening,nesterov", [(0.0, 0.0, False), (0.9, 0.0, False), (0.8, 0.1, False), (0.9, 0.0, True)])
+def test_sgd_against_torch_optim_sgd(momentum, dampening, nesterov):
+    """FusedSGD (lib/utils.py:332-334 configures SGD(lr, weight_decay); momentum variants are torch's) against
+    torch.optim.SGD on the host: flat single-launch path (two tensors tiling one buffer) and the per-tensor path, 4 steps;
+    state_dict round trip into torch.optim.SGD."""
+    from resdepth_amd import FusedSGD
+    g = torch.Generator().manual_seed(5)
+    flat = torch.randn(300, generator=g)
+    grads = torch.randn(4, 300, generator=g)
+    kw = dict(lr=0.05, weight_decay=1e-2, momentum=momentum, dampening=dampening, nesterov=nesterov)
+    rp = [torch.nn.Parameter(flat[:200].clone().view(10, 20)), torch.nn.Parameter(flat[200:].clone())]
+    ref = torch.optim.SGD(rp, **kw)
+    for mode in ("flat", "per_tensor"):
+        buf, gbuf = flat.clone().to(dev()), torch.zeros(300, device=dev())
+        if mode == "flat":
+            ps = [torch.nn.Parameter(buf[:200].view(10, 20)), torch.nn.Parameter(buf[200:])]
+        else:
+            ps = [torch.nn.Parameter(buf[:200].clone().view(10, 20)), torch.nn.Parameter(buf[200:].clone())]
+        opt = FusedSGD(ps, **kw)
+        rp[0].data.copy_(flat[:200].view(10, 20)); rp[1].data.copy_(flat[200:])
+        ref = torch.optim.SGD(rp, **kw)
+        for it in range(4):
+            gbuf.copy_(grads[it])
+            ps[0].grad, ps[1].grad = (gbuf[:200].view(10, 20), gbuf[200:]) if mode == "flat" else \
+                (gbuf[:200].clone().view(10, 20), gbuf[200:].clone())
+            rp[0].grad, rp[1].grad = grads[it][:200].clone().view(10, 20), grads[it][200:].clone()
+            opt.step(); ref.step()
+            for a, b in zip(ps, rp):
+                np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=3e-6, atol=1e-7, err_msg=f"{mode} step {it}")
+        if momentum:
+            assert (mode == "flat") == bool(opt._flat_state)
+            sd = opt.state_dict()
+            sd["state"] = {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()}
+            other = torch.optim.SGD([torch.nn.Parameter(torch.zeros(10, 20)), torch.nn.Parameter(torch.zeros(100))], **kw)
+            other.load_state_dict(sd)
+            for a, b in zip(other.param_groups[0]["params"], rp):
+                np.testing.assert_allclose(other.state[a]["momentum_buffer"].numpy(), ref.state[b]["momentum_buffer"].numpy(),
+                                           rtol=3e-6, atol=1e-7)
+
+
 def test_adam_known_answers(g4):
     from resdepth_amd import FusedAdam
     p = torch.nn.Parameter(torch.from_numpy(g4["adam/p0"].copy()).to(dev()))

@@ -11,6 +11,8 @@ from conftest import load_json, load_npz
 from oracle import unet_oracle as O
 
 TINY = ["g1_tiny3.npz", "g2a_tiny1.npz", "g2b_cap.npz", "g7_nobn.npz", "g8_lrelu_oskipbn.npz", "g11_prelu.npz", "g12_bilinear.npz"]
+# widened constructor domain + SGD (tests/golden/make_golden_wide.py): same keys + grad_input + opt_json, no pool indices
+WIDE = ["g13_sk6.npz", "g14_cin9.npz", "g15_cin8.npz", "g16_sgd.npz", "g17_sgd_mom.npz"]
 
 
 def _spec(kwargs):
@@ -29,11 +31,13 @@ def _sha_sd(sd):
     return h.hexdigest()
 
 
-@pytest.mark.parametrize("name", TINY)
+@pytest.mark.parametrize("name", TINY + WIDE)
 def test_tiny_net_matches_reference(name):
     g = load_npz(name)
     kwargs = json.loads(str(g["kwargs_json"]))
     meta = json.loads(str(g["meta_json"]))
+    opt = json.loads(str(g["opt_json"])) if "opt_json" in g else {"name": "adam"}
+    sgd = {"momentum": opt["momentum"], "nesterov": opt["nesterov"]} if opt["name"] == "sgd" else None
     spec = _spec(kwargs)
     sd = _sub(g, "init/")
     assert list(sd.keys()) == [k for k, _, _ in O.param_layout(spec)]
@@ -53,7 +57,7 @@ def test_tiny_net_matches_reference(name):
     losses = []
     for it in range(meta["adam_steps"]):
         loss, grads = O.train_step(sd, batch, spec, state, lr=meta["lr"], weight_decay=meta["wd"],
-                                   keep=keep if it == 0 else None)
+                                   keep=keep if it == 0 else None, sgd=sgd)
         losses.append(loss)
         if it == 0:
             np.testing.assert_allclose(keep["y_pred"].numpy(), g["y_train"], rtol=0, atol=1e-6)
@@ -64,7 +68,12 @@ def test_tiny_net_matches_reference(name):
                 den = np.linalg.norm(ref.astype(np.float64)) + 1e-30
                 assert num / den < 1e-5, (k, num / den)
             for i in range(spec.depth):
-                assert np.array_equal(keep[f"idx{i}"].numpy().astype(np.int32), g[f"poolidx/{i}"]), i
+                if f"poolidx/{i}" in g:
+                    assert np.array_equal(keep[f"idx{i}"].numpy().astype(np.int32), g[f"poolidx/{i}"]), i
+            if "grad_input" in g:
+                ref = g["grad_input"].astype(np.float64)
+                num = np.linalg.norm(keep["grad_input"].numpy().astype(np.float64) - ref)
+                assert num / (np.linalg.norm(ref) + 1e-30) < 1e-5
             for k, v in _sub(g, "bn_after1/").items():
                 np.testing.assert_allclose(sd[k].numpy(), v.numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
             for k, v in _sub(g, "after1/").items():

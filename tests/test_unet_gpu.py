@@ -40,12 +40,16 @@ def _train_iter(model, opt, batch):
 
 
 @pytest.mark.parametrize("name", ["g1_tiny3.npz", "g2a_tiny1.npz", "g2b_cap.npz", "g7_nobn.npz", "g8_lrelu_oskipbn.npz",
-                                  "g11_prelu.npz", "g12_bilinear.npz"])
+                                  "g11_prelu.npz", "g12_bilinear.npz",
+                                  # widened constructor domain (lib/UNet.py:105-107): start_kernel % 4 != 0, > 6 input
+                                  # channels, gradient w.r.t. the input; torch.optim.SGD (lib/utils.py:332-334)
+                                  "g13_sk6.npz", "g14_cin9.npz", "g15_cin8.npz", "g16_sgd.npz", "g17_sgd_mom.npz"])
 def test_tiny_net_against_reference_fixture(name):
-    from resdepth_amd import UNet, FusedAdam
+    from resdepth_amd import UNet, FusedAdam, FusedSGD
     g = load_npz(name)
     kwargs = json.loads(str(g["kwargs_json"]))
     meta = json.loads(str(g["meta_json"]))
+    optc = json.loads(str(g["opt_json"])) if "opt_json" in g else {"name": "adam"}
     model = UNet(**kwargs)
     model.load_state_dict(_sub(g, "init/"))
     model = model.to(DEV)
@@ -54,12 +58,26 @@ def test_tiny_net_against_reference_fixture(name):
     with torch.no_grad():
         y = model(batch["input"].to(DEV))
     assert float((y.cpu() - torch.from_numpy(g["y_eval_init"])).abs().max()) <= 1e-4
-    opt = FusedAdam(model.parameters(), lr=meta["lr"], weight_decay=meta["wd"])
+    if optc["name"] == "sgd":
+        opt = FusedSGD(model.parameters(), lr=meta["lr"], weight_decay=meta["wd"], momentum=optc["momentum"],
+                       nesterov=optc["nesterov"])
+    else:
+        opt = FusedAdam(model.parameters(), lr=meta["lr"], weight_decay=meta["wd"])
     losses = []
     for it in range(meta["adam_steps"]):
         for p in model.parameters():
             p.grad = None
-        y_pred, loss = _train_iter(model, opt, batch)
+        if it == 0 and "grad_input" in g:
+            from resdepth_amd import masked_l1_loss
+            model.train()
+            x_in = batch["input"].to(DEV).requires_grad_(True)
+            y_pred = model(x_in)
+            loss = masked_l1_loss(y_pred, batch["target"], batch["loss_mask"], batch["dsm_mean"], batch["dsm_std"])
+            loss.backward()
+            r = rel_l2(x_in.grad, g["grad_input"])
+            assert r <= 1e-3, ("grad_input", r)
+        else:
+            y_pred, loss = _train_iter(model, opt, batch)
         losses.append(float(loss))
         if it == 0:
             assert float((y_pred.detach().cpu() - torch.from_numpy(g["y_train"])).abs().max()) <= 1e-4
@@ -90,7 +108,8 @@ def test_tiny_net_against_reference_fixture(name):
     assert float((y.cpu() - torch.from_numpy(g[f"y_eval_after{meta['adam_steps']}"])).abs().max()) <= 2e-4
     # pooling indices of the first training forward are checked bit-exactly at op level
     # (tests/test_ops_gpu.py); here: every parameter gradient is a view of the flat buffer
-    assert opt._flat_state, "fused single-launch Adam path was not taken"
+    if not model._needs_twin() and (optc["name"] == "adam" or optc["momentum"] != 0):
+        assert opt._flat_state, "fused single-launch optimizer path was not taken"
 
 
 def test_full_size_against_oracle_and_reference_digest():
@@ -500,10 +519,13 @@ def test_other_baseline_configs_against_oracle(name, kw, n, t):
     (1, 32, dict(n_input_channels=1, start_kernel=4, depth=3, bias_conv_layer=True)),     # batch 1, smallest legal tile 2^(depth+2)
     (5, 8, dict(n_input_channels=4, start_kernel=12, depth=1, bias_conv_layer=False)),    # odd batch, non-power-of-two channels
     (2, 64, dict(n_input_channels=6, start_kernel=8, depth=4, max_filter_depth=16, bias_conv_layer=True, outer_skip=False)),
+    (2, 32, dict(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True)),    # cfg-S architecture (tile kernels of the first / last conv)
+    (3, 16, dict(n_input_channels=7, start_kernel=10, depth=2, max_filter_depth=18, act_fn_decoder="lrelu", outer_skip_BN=True)),  # zero-padded twin
+    (2, 32, dict(n_input_channels=12, start_kernel=32, depth=2, up_mode="bilinear")),     # > 6 input channels on the generic first conv
 ])
 def test_edge_shapes_against_oracle(n, t, kw):
-    """Ragged / extreme shapes: batch 1, tiny tiles, channel counts that are not powers of two, six input channels,
-    a filter-depth cap that makes every level equally wide."""
+    """Ragged / extreme shapes: batch 1, tiny tiles, channel counts that are not powers of two (or of 4: padded twin), six
+    and more input channels, a filter-depth cap that makes every level equally wide.  Also the gradient w.r.t. the input."""
     from resdepth_amd import UNet, masked_l1_loss
     spec = O.Spec(**{"depth": 8, **kw})
     torch.manual_seed(4)
@@ -511,19 +533,46 @@ def test_edge_shapes_against_oracle(n, t, kw):
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     b = O.synthetic_batch(n, kw["n_input_channels"], t, seed=31)
     model = model.to(DEV).train()
-    yp = model(b["input"].to(DEV))
+    x_in = b["input"].to(DEV).requires_grad_(True)
+    yp = model(x_in)
     loss = masked_l1_loss(yp, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
     loss.backward()
+    sd1 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     leaves = {k: sd0[k].clone().requires_grad_(True) for k in O.param_keys(spec)}
-    work = dict(sd0)
+    work = {k: v.clone() for k, v in sd0.items()}
     work.update(leaves)
-    yo = O.forward(work, b["input"], spec, training=True)
+    xo = b["input"].clone().requires_grad_(True)
+    yo = O.forward(work, xo, spec, training=True)
     lo = O.masked_l1_loss(yo, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
-    go = torch.autograd.grad(lo, list(leaves.values()))
+    go = torch.autograd.grad(lo, list(leaves.values()) + [xo])
     assert float((yp.detach().cpu() - yo.detach()).abs().max()) <= 1e-4
     assert abs(float(loss) - float(lo)) <= 1e-5 * abs(float(lo))
     for (k, p), gr in zip(model.named_parameters(), go):
-        assert rel_l2(p.grad, gr) <= 2e-3, (k, rel_l2(p.grad, gr))
+        assert tuple(p.grad.shape) == tuple(gr.shape) and rel_l2(p.grad, gr) <= 2e-3, (k, rel_l2(p.grad, gr))
+    assert tuple(x_in.grad.shape) == tuple(xo.shape) and rel_l2(x_in.grad, go[-1]) <= 2e-3, rel_l2(x_in.grad, go[-1])
+    for k, v in sd1.items():             # running statistics of the training-mode forward (also through the padded twin)
+        if "running" in k:
+            np.testing.assert_allclose(v.numpy(), work[k].detach().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+        elif "num_batches" in k:
+            assert int(v) == int(work[k]) == 1, k
+    model.eval()
+    with torch.no_grad():
+        ye = model(b["input"].to(DEV))
+    yeo = O.forward(work, b["input"], spec, training=False)
+    assert float((ye.cpu() - yeo.detach()).abs().max()) <= 1e-4
+
+
+def test_single_value_per_channel_in_training_raises_like_torch():
+    """N = 1 with a tile of 2^depth pixels leaves ONE value per channel at the bottleneck BatchNorm2d: the reference fails
+    in torch.nn.functional.batch_norm (ValueError); eval mode works."""
+    from resdepth_amd import UNet
+    model = UNet(n_input_channels=2, start_kernel=8, depth=3).to(DEV)
+    x = torch.randn(1, 2, 8, 8, device=DEV)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        model.train()(x)
+    with torch.no_grad():
+        assert model.eval()(x).shape == (1, 1, 8, 8)
+    assert model.train()(torch.randn(2, 2, 8, 8, device=DEV)).shape == (2, 1, 8, 8)
 
 
 def test_folded_eval_forward_equals_unfolded_and_tracks_running_statistics():
