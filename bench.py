@@ -35,9 +35,13 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA (2495 meas
 PEAK_SPLIT_TFLOPS = PEAK_BF16_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0
 # measured bounds: scripts/split_numerics.py / tests/test_split_numerics_gpu.py
-ARITHMETIC = ("fp32 storage and accumulation; MFMA-class kernels multiply exactly-split operands (x = x1+x2+x3, bf16 terms) on "
-              "v_mfma_f32_32x32x16_bf16, 6 of the 9 term products per multiply -- the three dropped products are below 2^-21 |ab| "
-              "(worst case); RD_MFMA=f32 selects the exact-f32 MFMA kernels")
+ARITHMETIC = ("fp32 storage and accumulation; MFMA-class kernels multiply exactly-split operands (x = x1+x2+x3, bf16 terms by "
+              "truncation) on v_mfma_f32_32x32x16_bf16, 6 of the 9 term products per multiply -- the three dropped products are "
+              "below 2^-21 |ab| (worst case); the leading product a1*b1 and the five low-order products accumulate in separate "
+              "fp32 accumulators merged once per output (measured on all-positive operands at K = 4608: 5.9 u rms / 27 u max, "
+              "u = 2^-24, vs 16 u / 75 u for the exact-f32 MFMA chain; tests/test_split_numerics_gpu.py); +-Inf / NaN operands "
+              "propagate exactly like fp32 in the forward / data-gradient kernels (weight gradients: same set of non-finite "
+              "outputs, an Inf may surface as NaN); RD_MFMA=f32 selects the exact-f32 MFMA kernels")
 MFMA_CLASSES = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "convt2x2_fwd", "convt2x2_dgrad", "convt2x2_wgrad")
 
 
@@ -423,13 +427,18 @@ def main():
         if by_sym:
             sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            traffic, traffic_src = None, None
+            traffic, traffic_src, pmc = None, None, None
             for name in ("r02_summary.json", "r01_summary.json"):
                 # HBM bytes per launch are NOT measured by this process: they come from the committed rocprofv3 PMC passes
                 # of this same command (scripts/profile.sh + scripts/summarize_prof.py; FETCH_SIZE doubled per the guide)
                 try:
                     with open(os.path.join(ROOT, "profiles", name)) as f:
-                        traffic = json.load(f)["kernels"][sym]["hbm_bytes_per_launch"]
+                        rec = json.load(f)["kernels"][sym]
+                    traffic = rec["hbm_bytes_per_launch"]
+                    # same passes: MFMA pipe busy fraction IN CYCLES and the effective clock (power-limited DVFS) -- the
+                    # product of the two, relative to 2.4 GHz, is what `frac` sees
+                    pmc = {"mfma_pipe_busy": rec.get("mfma_pipe_util"), "effective_clock_ghz": rec.get("clock_ghz_under_pmc"),
+                           "l2_hit_rate": rec.get("l2_hit_rate"), "source": f"profiles/{name}"}
                     traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, not this run)"
                     break
                 except Exception:       # noqa: BLE001
@@ -441,7 +450,7 @@ def main():
                     "peak_note": ("fp32-equivalent FLOP/s; bound = dense bf16 MFMA peak (2500 TF) / 6 products per fp32 "
                                   "multiply-add of the exact 3-term split" if is_split else "f32-input MFMA peak"),
                     "frac_of_f32_mfma_peak": round(ach / PEAK_F32_TFLOPS, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                    "traffic": traffic, "traffic_source": traffic_src, "pmc": pmc, "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                     "alg_flop_per_launch": dom["flops"] / dom["launches"],
                     "launches_per_step": dom["launches"] / prof_steps,
                     "measured": f"HIP events, serialized pass of {prof_steps} steps right after the timed region "

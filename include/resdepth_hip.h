@@ -193,13 +193,14 @@ int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, c
  *            overrides the immediate `slope` (ReLU = 0, LeakyReLU = 0.01).
  * Phase 2 -> dz; dgamma/dbeta are sums[C..2C) / sums[0..C): written as fp32 by whichever of the two calls is handed
  *            non-NULL dgamma / dbeta (phase 1 saves a launch; phase 2 is for SyncBN, where the LOCAL sums are the parameter
- *            gradients and the all-reduced ones feed dz).
+ *            gradients and the all-reduced ones feed dz).  dextra (phase 1, nullable): sums[2C..3C) as fp32, the bias gradient
+ *            of the ConvTranspose2d whose output was added to this block's activation.
  * training=0 treats mean/invstd as constants (eval-mode BN). */
 size_t rd_bn_act_bwd_ws_bytes(int n, int h, int w, int c);
 int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                          float slope, const float* slope_dev, const float* g_full, const float* g_pool,
-                         const uint8_t* idx, double* sums, float* dgamma, float* dbeta, int n, int h, int w, int c, void* ws,
-                         size_t ws_bytes, rd_stream_t s);
+                         const uint8_t* idx, double* sums, float* dgamma, float* dbeta, float* dextra, int n, int h, int w, int c,
+                         void* ws, size_t ws_bytes, rd_stream_t s);
 int rd_bn_act_bwd_apply(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                         float slope, const float* slope_dev, const float* g_full, const float* g_pool,
                         const uint8_t* idx, const double* sums, double count, int training, float* dz, float* dgamma,

@@ -75,7 +75,7 @@ SIGNATURES = {
     "rd_bn_eval_stats": (I, [P, P, F, P, P, I, P]),
     "rd_bn_act_pool_fwd": (I, [P, P, P, P, P, F, P, P, P, P, I, I, I, I, P]),
     "rd_bn_act_bwd_ws_bytes": (SZ, [I, I, I, I]),
-    "rd_bn_act_bwd_reduce": (I, [P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, P, SZ, P]),
+    "rd_bn_act_bwd_reduce": (I, [P, P, P, P, P, F, P, P, P, P, P, P, P, P, I, I, I, I, P, SZ, P]),
     "rd_bn_act_bwd_apply": (I, [P, P, P, P, P, F, P, P, P, P, P, D, I, P, P, P, I, I, I, I, P]),
     "rd_masked_l1_ws_bytes": (SZ, [LL]),
     "rd_masked_l1_partial": (I, [P, P, P, P, P, P, I, LL, P, SZ, P]),

@@ -71,12 +71,14 @@ __device__ __forceinline__ double sliced_column_sum(const T* __restrict__ partia
 }
 
 // sums[q*C + c] = sum_b partial[(b*Q + q)*C + c]
-// dbeta / dgamma (nullable): the first two C-column groups of the BN-backward sums are the affine-parameter gradients
-// (sum g', sum g' * xhat) -- written here instead of by a separate launch
+// dbeta / dgamma / dextra (nullable): the first three C-column groups of the BN-backward sums are parameter gradients
+// (sum g', sum g' * xhat, sum g_full = the bias gradient of the ConvTranspose2d feeding the skip add) -- written here
+// instead of by separate launches
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const double* __restrict__ partial,
                                                              double* __restrict__ sums, int nb, int QC, int C = 0,
                                                              float* __restrict__ dbeta = nullptr,
-                                                             float* __restrict__ dgamma = nullptr) {
+                                                             float* __restrict__ dgamma = nullptr,
+                                                             float* __restrict__ dextra = nullptr) {
     __shared__ double red[256];
     const double r = sliced_column_sum<double>(partial, nb, QC, QC, red);
     const int col = blockIdx.x * 16 + threadIdx.x;
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const double* __res
         sums[col] = r;
         if (dbeta && col < C) dbeta[col] = (float)r;
         if (dgamma && col >= C && col < 2 * C) dgamma[col - C] = (float)r;
+        if (dextra && col >= 2 * C && col < 3 * C) dextra[col - 2 * C] = (float)r;
     }
 }
 
@@ -1231,8 +1234,8 @@ size_t rd_bn_act_bwd_ws_bytes(int n, int h, int w, int c) {
 
 int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                          float slope, const float* slope_dev, const float* g_full, const float* g_pool,
-                         const uint8_t* idx, double* sums, float* dgamma, float* dbeta, int n, int h, int w, int c, void* ws,
-                         size_t ws_bytes, rd_stream_t s) {
+                         const uint8_t* idx, double* sums, float* dgamma, float* dbeta, float* dextra, int n, int h, int w, int c,
+                         void* ws, size_t ws_bytes, rd_stream_t s) {
     RD_REQUIRE(z && mean && invstd && gamma && beta && sums, "rd_bn_act_bwd_reduce: null pointer");
     RD_REQUIRE(g_full || g_pool, "rd_bn_act_bwd_reduce: no gradient source");
     RD_REQUIRE(!g_pool || idx, "rd_bn_act_bwd_reduce: g_pool needs idx");
@@ -1256,7 +1259,7 @@ int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd,
                            invstd, gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
                            (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
     hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(4 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
-                       sums, pl.nb, 4 * c, c, dbeta, dgamma);
+                       sums, pl.nb, 4 * c, c, dbeta, dgamma, dextra);
     RD_LAUNCH_CHECK("bn_act_bwd_reduce");
     return RD_OK;
 }

@@ -29,7 +29,8 @@ struct WsParams {
     unsigned a_bytes, b_bytes;
 };
 
-__global__ __launch_bounds__(256) void wgrad_strip_kernel(WsParams p) {
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void wgrad_strip_kernel(WsParams p) {
     constexpr int A_ROWS = 128, B_ROWS = 96;                   // LDS rows per A stage / per ring slot
     constexpr int RING0 = 2 * A_ROWS * 32;                     // word offset of the halo ring
     __shared__ __attribute__((aligned(16))) float smem[(2 * A_ROWS + 4 * B_ROWS) * 32];
@@ -274,7 +275,10 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     q.a_bytes = (unsigned)ab; q.b_bytes = (unsigned)bb;
     ProfScope ps(s, "conv3x3_wgrad|wgrad_strip", 2.0 * cout * 9.0 * cin * (double)n * h * w, ab + bb + 4.0 * cout * 9.0 * cin,
                  true);
-    hipLaunchKernelGGL(wgrad_strip_kernel, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
+    if (tune(TUNE_WG_OCC) == 2)
+        hipLaunchKernelGGL(wgrad_strip_kernel<2>, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
+    else
+        hipLaunchKernelGGL(wgrad_strip_kernel<1>, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
     RD_LAUNCH_CHECK("wgrad_strip");
     *splits_out = wp.splits;
     *swapped_out = wp.swapped;

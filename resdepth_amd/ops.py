@@ -348,16 +348,19 @@ def bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, pool, slope_dev=None, w
     return a, pooled, idx
 
 
-def bn_act_bwd_reduce(z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx, slope_dev=None, dgamma=None, dbeta=None):
+def bn_act_bwd_reduce(z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx, slope_dev=None, dgamma=None, dbeta=None,
+                      dextra=None):
     """-> sums [4*C] float64: sum g', sum g'*xhat, sum g_full, sum_{y<=0} g*y (PReLU slope gradient).
-    dgamma / dbeta (optional fp32 [C]): the affine-parameter gradients, written by the same reduction."""
+    dgamma / dbeta / dextra (optional fp32 [C]): the affine-parameter gradients and sum g_full (the bias gradient of the
+    transposed convolution feeding the skip add), written by the same reduction."""
     n, h, w, c = z.shape
     sums = torch.empty(4 * c, device=z.device, dtype=torch.float64)
     nb = load().rd_bn_act_bwd_ws_bytes(n, h, w, c)
     ws = workspace(nb, z.device)
     check(load().rd_bn_act_bwd_reduce(ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
                                       float(slope), ptr(slope_dev), ptr(g_full), ptr(g_pool), ptr(idx), ptr(sums),
-                                      ptr(dgamma), ptr(dbeta), n, h, w, c, ws.data_ptr(), ws.numel(), stream_ptr()),
+                                      ptr(dgamma), ptr(dbeta), ptr(dextra), n, h, w, c, ws.data_ptr(), ws.numel(),
+                                      stream_ptr()),
           "bn_act_bwd_reduce")
     return sums
 

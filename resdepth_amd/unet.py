@@ -688,10 +688,10 @@ class UNet(nn.Module):
             slope, sdev = self._split_slope(act)
             prelu_w = act if sdev is not None else None
 
+            dextra = gv(extra_bias) if extra_bias is not None else None     # ConvTranspose2d bias (skip add): by-product
+
             def side_grads(sums):
-                # by-products of the same reduction: ConvTranspose2d bias (skip add) and the PReLU slope
-                if extra_bias is not None:
-                    gv(extra_bias).copy_(sums[2 * c:3 * c])
+                # the other by-product of the same reduction: the PReLU slope
                 if prelu_w is not None:
                     gv(prelu_w).copy_(sums[3 * c:4 * c].sum().reshape(1))
 
@@ -699,7 +699,7 @@ class UNet(nn.Module):
                 # do_BN=False: a = act(z + bias); d bias = sum g', dz = g' (the "eval" form of the fused kernels)
                 one = self._const(c, 1.0, rec["z"].device)
                 sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], one, cbias, slope, g_full, g_pool, idx,
-                                             slope_dev=sdev)
+                                             slope_dev=sdev, dextra=dextra)
                 side_grads(sums)
                 dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], one, cbias, slope, g_full, g_pool, idx,
                                           sums, 1.0, False, dgamma=None, dbeta=gv(cbias), slope_dev=sdev)
@@ -707,10 +707,11 @@ class UNet(nn.Module):
                 return dz
             if sync_bn:
                 sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
-                                             g_pool, idx, slope_dev=sdev)
+                                             g_pool, idx, slope_dev=sdev, dextra=dextra)
             else:       # the reduction writes dgamma / dbeta itself (no separate launch)
                 sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
-                                             g_pool, idx, slope_dev=sdev, dgamma=gv(bn.weight), dbeta=gv(bn.bias))
+                                             g_pool, idx, slope_dev=sdev, dgamma=gv(bn.weight), dbeta=gv(bn.bias),
+                                             dextra=dextra)
             side_grads(sums)
             if sync_bn:
                 local = sums[:2 * c].clone()
