@@ -39,6 +39,7 @@ enum TuneKey {
     TUNE_MFMA_F32 = 0,     // 1: exact-f32 MFMA kernels instead of split-bf16 (also RD_MFMA=f32)
     TUNE_NT_TILE,          // -1 auto | 0: 128x128, 1: 128x64, 2: 64x64 tiles of the NT kernels
     TUNE_NT_HALO,          // -1 auto | 0: never use the halo-reuse conv3x3 kernel
+    TUNE_NT_SKEW,          // halo kernel: 1 = skewed halo-row pitch (no LDS bank conflicts) | 0 = plain pitch (r01 layout)
     TUNE_TN_TILE,          // -1 auto | bm*1000 + bn
     TUNE_TN_BLOCKS,        // target block count of the split-K TN kernels
     TUNE_TN_SPLIT,         // -1 auto | 0/1 force the split-bf16 TN kernel off/on
@@ -87,6 +88,36 @@ inline int ilog2_exact(int v) {
 }
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Division of 0 <= n < 2^31 by a launch-time constant d (image width, pixels per image) as one v_mul_hi + shift:
+// q = (n * mul) >> (32 + sh) with mul = ceil(2^(31+s) / d), s = ceil(log2 d), sh = s - 1  (error term n * e < 2^(31+s)
+// because e < d <= 2^s and n < 2^31).  Powers of two give mul = 2^31, i.e. a plain shift.  d = 1: sh = -1 (identity).
+struct FastDiv {
+    unsigned mul;
+    int sh;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f = {0u, -1};
+    if (d <= 1) return f;
+    int s = 0;
+    while ((1u << s) < d) ++s;
+    f.mul = (unsigned)((((unsigned long long)1 << (31 + s)) + d - 1) / d);
+    f.sh = s - 1;
+    return f;
+}
+// pixel index m of an [img][H][W] grid -> (img, y, x); hw = H * W
+struct PixDiv {
+    FastDiv w, hw;
+    int W, HW;
+};
+inline PixDiv make_pixdiv(int h, int w) {
+    PixDiv d;
+    d.w = make_fastdiv((unsigned)w);
+    d.hw = make_fastdiv((unsigned)h * (unsigned)w);
+    d.W = w;
+    d.HW = h * w;
+    return d;
+}
 
 #define RD_REQUIRE(cond, ...)              \
     do {                                   \

@@ -229,7 +229,7 @@ int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, co
                      const float* sk_slope_dev, float* out, int n, int h, int w, int cin, int cout, hipStream_t s, int* launched) {
     *launched = 0;
     if (!mfma_split() || tune(TUNE_CONVT_PATCH) == 0) return RD_OK;
-    if (cin % 32 != 0 || cout % 64 != 0 || w < 8 || ilog2_exact(w) < 0) return RD_OK;     // nk = Cin/16 even
+    if (cin % 32 != 0 || cout % 64 != 0 || (w != 8 && w % 16 != 0)) return RD_OK;     // nk = Cin/16 even; 16- (or 8-) pixel patch rows
     const double xb = 4.0 * n * h * (double)w * cin;
     if (xb >= 4294967040.0 || (double)wsplit_bytes >= 4294967040.0) return RD_OK;
     const long G = (long)n * h;

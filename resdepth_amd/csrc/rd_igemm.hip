@@ -55,7 +55,8 @@ struct NtParams {
     float sk_slope;
     int M, N, K;
     int Cin;  // channels per tap (A row length)
-    int H, W, logH, logW;
+    int H, W;
+    PixDiv pd;  // pixel index -> (img, y, x): tiles need not be powers of two
     int Cout;  // EPI_CONVT: channels per (a,b) quadrant
     int chunks, nk, taps;
     int tiles_n;
@@ -82,7 +83,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane & 31, half = lane >> 5;
-    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+    const int H = p.H, W = p.W;
     // ---- epilogue.  D[i][j]: lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5).  The accumulators
     // are staged through LDS (EB 32-row blocks of one wave row-band per pass) so that HBM sees 16 B per lane and whole
     // contiguous rows per wave; bias / skip-add of the transposed convolution ride the same pass.
@@ -146,7 +147,8 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                     *reinterpret_cast<float4*>(p.C + (long)m * p.N + n) = v;
                 } else {
                     const int ab = n / p.Cout, co = n - ab * p.Cout;
-                    const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+                    int jj, ii, img;
+                    pix_split(m, p.pd, img, ii, jj);
                     const long opix = ((long)img * (2 * H) + 2 * ii + (ab >> 1)) * (2 * W) + 2 * jj + (ab & 1);
                     const long o = opix * p.Cout + co;
                     if (p.bias) {
@@ -204,7 +206,8 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                     p.C[(long)m * p.N + n] = v;
                 } else {
                     const int ab = n / p.Cout, co = n - ab * p.Cout;
-                    const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+                    int jj, ii, img;
+                    pix_split(m, p.pd, img, ii, jj);
                     const long opix = ((long)img * (2 * H) + 2 * ii + (ab >> 1)) * (2 * W) + 2 * jj + (ab & 1);
                     const long o = opix * p.Cout + co;
                     if (p.bias) v += p.bias[co];
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[AI], rb[BI];
-    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+    const int H = p.H, W = p.W;
 
     // ---- operand addressing, hoisted out of the K loop.  Loads are raw buffer loads: every lane carries a
     // 32-bit byte offset, lanes that must read zero (image border taps, rows/columns beyond M/N/Cin) carry an
@@ -268,7 +271,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
         unsigned val = 0;
         long pix = m;
         if (AMODE == A_CONV3) {
-            const int y = (m >> logW) & (H - 1), x = m & (W - 1);
+            int y, x, img_;
+            pix_split(m, p.pd, img_, y, x);
 #pragma unroll
             for (int t9 = 0; t9 < 9; ++t9) {
                 const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
@@ -277,7 +281,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
         } else if (AMODE == A_PLAIN) {
             val = 1u;
         } else {
-            const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+            int jj, ii, img;
+                    pix_split(m, p.pd, img, ii, jj);
             pix = ((long)img * (2 * H) + 2 * ii) * (2 * W) + 2 * jj;
             val = 0xFu;
         }
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = lo[i][r] = 0.f;
 
-    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+    const int H = p.H, W = p.W;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.Bsplit, p.b_bytes);
     unsigned a_off[AI], a_val[AI];
     int a_wr[AI];       // LDS word address of this thread's 8 bytes of term 0 (terms 1, 2: chunk +2, +4 before the swizzle)
@@ -413,7 +418,8 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
         unsigned val = 0;
         long pix = m;
         if (AMODE == A_CONV3) {
-            const int y = (m >> logW) & (H - 1), x = m & (W - 1);
+            int y, x, img_;
+            pix_split(m, p.pd, img_, y, x);
 #pragma unroll
             for (int t9 = 0; t9 < 9; ++t9) {
                 const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
@@ -422,7 +428,8 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
         } else if (AMODE == A_PLAIN) {
             val = 1u;
         } else {
-            const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+            int jj, ii, img;
+                    pix_split(m, p.pd, img, ii, jj);
             pix = ((long)img * (2 * H) + 2 * ii) * (2 * W) + 2 * jj;
             val = 0xFu;
         }
@@ -547,13 +554,17 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 // stride -> the tap shift is an instruction immediate).  Activation staging (global loads, split arithmetic, LDS
 // writes) drops ~6x and there is one barrier per chunk instead of per K-step.  Weights: unchanged (pre-split fragment
 // layout straight from global memory, kt = chunk*9 + tap, three register sets).
-template <int BN, int WM, int WN, int EPI>
+template <int BN, int WM, int WN, int EPI, int SKEW = 8>
 __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     constexpr int BM = 128, PH = 8, PW = 16, HW_ = PW + 2, HROWS = (PH + 2) * HW_;   // 180 halo pixels
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(TN == 1, "one 32-column block per wave");
     constexpr int RS = 28;                            // LDS row stride in words (3 terms x 16 bf16 + 16 B pad)
-    constexpr int STAGE = HROWS * RS;
+    // halo-row pitch = 18 rows + 32 bytes of skew: a 16-lane group of a ds_read_b128 fragment read spans two patch rows
+    // (e.g. pixels 0-3,12-15 of row y and 4-11 of row y+1); with the plain pitch 18*RS two of its 16-byte slots fell
+    // into the same banks for ANY RS (SQ_LDS_BANK_CONFLICT 19 % of the kernel's cycles), with the skew all 16 differ
+    constexpr int HP = HW_ * RS + SKEW;
+    constexpr int STAGE = (PH + 2) * HP;
     constexpr int NLD = (HROWS * 4 + 255) / 256;      // staging float4 per thread and chunk
     constexpr int EPI_WORDS = 32 * (BN + 4) + 512;
     constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
@@ -562,13 +573,12 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
     const int n0 = tile_n * BN;
-    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+    const int H = p.H, W = p.W;
     const int pxs = W >> 4, pys = H >> 3;             // patches per image row / column
     const int pbx = tile_m % pxs, pby = (tile_m / pxs) % pys, img = tile_m / (pxs * pys);
     const int x0 = pbx * PW, y0 = pby * PH;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    (void)logW; (void)logH;
 
     f32x16 acc[TM][1], lo[TM];       // hi / lo accumulators (rd_mfma_dev.h: PA6)
 #pragma unroll
@@ -588,7 +598,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         const bool ok = hr < HROWS && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         s_off[k] = ok ? (unsigned)(((((long)img * H + y) * W + x) * p.Cin + c4 * 4) * 4) : kOOB;
-        s_lds[k] = hr < HROWS ? hr * RS + c4 * 2 : -1;
+        s_lds[k] = hr < HROWS ? hy * HP + hx * RS + c4 * 2 : -1;
     }
     const int nb = (n0 >> 5) + wn;
     const unsigned b_off = (nb * 32 < p.N) ? (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16) : kOOB;
@@ -621,7 +631,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = (wm * TM + i) * 32 + lrow;            // tile row -> patch pixel (row >> 4, row & 15)
-        a_rd[i] = ((row >> 4) * HW_ + (row & 15)) * RS + half * 4;
+        a_rd[i] = (row >> 4) * HP + (row & 15) * RS + half * 4;
     }
     bf16x8 af[TM][3];
     constexpr int GP = TM >= 2 ? 2 : 1;
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     // for the next step right after its last use (next tap of this chunk, or tap 0 of the next chunk's stage)
     auto tap_step = [&](int kt, auto tap_c, uint4 (&bcur)[3], uint4 (&bnew)[3]) {
         constexpr int TAP = decltype(tap_c)::value;
-        constexpr int NEXT = TAP == 8 ? 0 : ((TAP + 1) / 3 * HW_ + (TAP + 1) % 3) * RS;
+        constexpr int NEXT = TAP == 8 ? 0 : (TAP + 1) / 3 * HP + (TAP + 1) % 3 * RS;
         load_b(kt + 2, bnew);
         bf16x8 bf[3];
 #pragma unroll
@@ -906,7 +916,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     int cfg;
     if (split) {
         // split kernel: two 128x128 blocks (57 KB LDS each) per CU; measured per layer with scripts/bench_layers.py
-        const bool halo_shape = AMODE == A_CONV3 && EPI == EPI_STORE && p.W >= 16 && p.H >= 8;
+        const bool halo_shape = AMODE == A_CONV3 && EPI == EPI_STORE && p.W % 16 == 0 && p.H % 8 == 0;
         // (the pooling epilogue exists in the patch kernels only: small batches take them too)
         if (halo_shape && (tiles_128x64 >= 512 || p.pool_out)) cfg = (p.N >= 128 && tiles_128x64 >= 1024) ? 0 : 1;   // 16x16 levels: 128x64 patches
         else if (p.M < 128 || tiles_128x64 < 1024) cfg = 2;
@@ -925,7 +935,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     }
     if (force >= 0 && force <= 2 && !(force == 0 && p.N <= 64)) cfg = force;
     const int halo_force = tune(TUNE_NT_HALO);
-    const bool halo = split && AMODE == A_CONV3 && EPI == EPI_STORE && p.W >= 16 && p.H >= 8 && cfg != 2 && halo_force != 0;
+    const bool halo = split && AMODE == A_CONV3 && EPI == EPI_STORE && p.W % 16 == 0 && p.H % 8 == 0 && cfg != 2 && halo_force != 0;
     if (p.pool_out && !halo) {
         set_error("%s: the pooling epilogue exists in the patch (halo) kernels only", cls);
         return RD_ERR_ARG;
@@ -948,10 +958,16 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
         if (tiles_m_out) *tiles_m_out = tiles_m;
         if (cfg == 0) {
             p.tiles_n = cdiv(p.N, 128);
-            hipLaunchKernelGGL((conv3_halo_split_kernel<128, 1, 4, EPI_STORE>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
+            if (tune(TUNE_NT_SKEW) == 0)
+                hipLaunchKernelGGL((conv3_halo_split_kernel<128, 1, 4, EPI_STORE, 0>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
+            else
+                hipLaunchKernelGGL((conv3_halo_split_kernel<128, 1, 4, EPI_STORE>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
         } else {
             p.tiles_n = cdiv(p.N, 64);
-            hipLaunchKernelGGL((conv3_halo_split_kernel<64, 2, 2, EPI_STORE>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
+            if (tune(TUNE_NT_SKEW) == 0)
+                hipLaunchKernelGGL((conv3_halo_split_kernel<64, 2, 2, EPI_STORE, 0>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
+            else
+                hipLaunchKernelGGL((conv3_halo_split_kernel<64, 2, 2, EPI_STORE>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
         }
         RD_LAUNCH_CHECK(cls);
         return RD_OK;
@@ -982,7 +998,8 @@ struct TnParams {
     int M, N;
     long Kp;       // pixels reduced over
     int lda, ldb;  // channels per pixel of the A / B source tensors
-    int H, W, logH, logW;
+    int H, W;
+    PixDiv pd;
     int Cout;  // WA_UP2: channels per (a,b) quadrant of the A columns
     int Cin;   // WB_CONV3: channels per tap of the B columns
     int kchunk;  // pixels per split, multiple of 32
@@ -1009,7 +1026,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnParams p) {   // (256,3
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+    const int H = p.H, W = p.W;
 
     // per-thread fixed column descriptors
     const int ca = t % AQ, ra0 = t / AQ;
@@ -1056,7 +1073,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnParams p) {   // (256,3
             unsigned voff;
             if (AMODE == WA_UP2) {
                 const int m = (int)kbase + row;
-                const int j = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+                int j, ii, img;
+                pix_split(m, p.pd, img, ii, j);
                 const long src = ((long)img * (2 * H) + 2 * ii + a_qa) * (2 * W) + 2 * j + a_qb;
                 voff = (unsigned)((src * p.lda + a_col) * 4);
                 ra[i] = buf_load4(rsA, ok ? voff : kOOB, 0);
@@ -1071,7 +1089,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnParams p) {   // (256,3
             bool ok = b_ok && row < rem;
             if (BMODE == WB_CONV3) {
                 const int m = (int)kbase + row;
-                const int y = (m >> logW) & (H - 1), x = m & (W - 1);
+                int y, x, img_;
+            pix_split(m, p.pd, img_, y, x);
                 ok = ok && ((unsigned)(y + b_dy) < (unsigned)H) && ((unsigned)(x + b_dx) < (unsigned)W);
                 const unsigned voff = (unsigned)((((long)m + b_shift) * p.ldb + b_col) * 4);
                 rb[i] = buf_load4(rsB, ok ? voff : kOOB, 0);
@@ -1156,7 +1175,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int H = p.H, W = p.W, logW = p.logW, logH = p.logH;
+    const int H = p.H, W = p.W;
 
     // staging role of this thread
     const bool isA = t < BM, active = t < BM + BN;
@@ -1203,7 +1222,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
             if (isA) {
                 if (AMODE == WA_UP2) {
                     const int m = (int)kbase + row;
-                    const int jj = m & (W - 1), ii = (m >> logW) & (H - 1), img = m >> (logW + logH);
+                    int jj, ii, img;
+                    pix_split(m, p.pd, img, ii, jj);
                     const long src = ((long)img * (2 * H) + 2 * ii + a_qa) * (2 * W) + 2 * jj + a_qb;
                     x[j] = buf_load4(rsA, ok ? (unsigned)((src * p.lda + a_col) * 4) : kOOB, 0);
                 } else {
@@ -1212,7 +1232,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
             } else {
                 if (BMODE == WB_CONV3) {
                     const int m = (int)kbase + row;
-                    const int y = (m >> logW) & (H - 1), xx = m & (W - 1);
+                    int y, xx, img_;
+                    pix_split(m, p.pd, img_, y, xx);
                     const bool in = ok && ((unsigned)(y + b_dy) < (unsigned)H) && ((unsigned)(xx + b_dx) < (unsigned)W);
                     x[j] = buf_load4(rsB, in ? (unsigned)((((long)m + b_shift) * p.ldb + b_col) * 4) : kOOB, 0);
                 } else {
@@ -1514,7 +1535,6 @@ static int grid_for(long total, int block = 256, int cap = 4096) {
 static int check_conv_args(int n, int h, int w, int cin, int cout) {
     RD_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad conv shape n=%d h=%d w=%d cin=%d cout=%d", n, h, w,
                cin, cout);
-    RD_REQUIRE(ilog2_exact(h) >= 0 && ilog2_exact(w) >= 0, "H and W must be powers of two (got %dx%d)", h, w);
     RD_REQUIRE((long)n * h * w * 4L < (1L << 31), "pixel count too large for 32-bit tile indices");
     return RD_OK;
 }
@@ -1626,7 +1646,7 @@ int rd_conv3x3_fwd_stats(const float* x, const float* wf, float* z, double* sums
     NtParams p = {};
     p.A = x; p.B = wf; p.C = z;
     p.M = n * h * w; p.N = cout; p.K = 9 * cin; p.Cin = cin;
-    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     p.stats = sums ? (float*)ws : nullptr;
     int tiles_m = 0;
     if (int e = launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_fwd", &tiles_m)) return e;
@@ -1647,7 +1667,7 @@ int rd_conv3x3_fwd_bn(const float* x, const float* wf, float* z, double count, f
     NtParams p = {};
     p.A = x; p.B = wf; p.C = z;
     p.M = n * h * w; p.N = cout; p.K = 9 * cin; p.Cin = cin;
-    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     p.stats = (float*)ws;
     int tiles_m = 0;
     if (int e = launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_fwd", &tiles_m)) return e;
@@ -1661,11 +1681,12 @@ int rd_conv3x3_fwd_act(const float* x, const float* wf_folded, const float* shif
     RD_REQUIRE(x && wf_folded && shift && a, "rd_conv3x3_fwd_act: null pointer");
     RD_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "rd_conv3x3_fwd_act: channels must be multiples of 4 (%d, %d)", cin, cout);
     RD_REQUIRE(mfma_split(), "rd_conv3x3_fwd_act: only the split-bf16 kernels implement the folded inference path");
-    RD_REQUIRE(!pooled || (w >= 16 && h >= 8), "rd_conv3x3_fwd_act: the pooling epilogue needs W >= 16 and H >= 8 (got %dx%d)", h, w);
+    RD_REQUIRE(!pooled || (w % 16 == 0 && h % 8 == 0),
+               "rd_conv3x3_fwd_act: the pooling epilogue needs W a multiple of 16 and H a multiple of 8 (got %dx%d)", h, w);
     NtParams p = {};
     p.A = x; p.B = wf_folded; p.C = a;
     p.M = n * h * w; p.N = cout; p.K = 9 * cin; p.Cin = cin;
-    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     p.shift = shift; p.act_slope = slope; p.pool_out = pooled;
     return launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_fwd");
 }
@@ -1678,7 +1699,7 @@ int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int 
     NtParams p = {};
     p.A = dz; p.B = wd; p.C = dx;
     p.M = n * h * w; p.N = cin; p.K = 9 * cout; p.Cin = cout;
-    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     return launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_dgrad");
 }
 
@@ -1717,7 +1738,7 @@ int rd_conv3x3_bwd_weight(const float* x, const float* dz, float* dw, int n, int
     p.A = dz; p.B = x; p.slab = (float*)ws;
     p.M = cout; p.N = 9 * cin; p.Kp = (long)n * h * w;
     p.lda = cout; p.ldb = cin; p.Cin = cin; p.Cout = cout;
-    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     if (int e = launch_tn<WA_PLAIN, WB_CONV3>(p, pl, (hipStream_t)s, "conv3x3_wgrad")) return e;
     ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N / 4)), dim3(256), 0, (hipStream_t)s,
@@ -1742,7 +1763,7 @@ int rd_convt2x2_fwd(const float* x, const float* wtf, const float* bias, const f
     NtParams p = {};
     p.A = x; p.B = wtf; p.C = out; p.bias = bias; p.skip = skip;
     p.M = n * h * w; p.N = 4 * cout; p.K = cin; p.Cin = cin; p.Cout = cout;
-    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     return launch_nt<A_PLAIN, EPI_CONVT>(p, (hipStream_t)s, "convt2x2_fwd");
 }
 
@@ -1764,7 +1785,7 @@ int rd_convt2x2_fwd_bnskip(const float* x, const float* wtf, const float* bias, 
     p.A = x; p.B = wtf; p.C = out; p.bias = bias; p.skip = z_skip;
     p.sk_mean = mean; p.sk_invstd = invstd; p.sk_gamma = gamma; p.sk_beta = beta; p.sk_slope = slope; p.sk_slope_dev = slope_dev;
     p.M = n * h * w; p.N = 4 * cout; p.K = cin; p.Cin = cin; p.Cout = cout;
-    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     return launch_nt<A_PLAIN, EPI_CONVT>(p, (hipStream_t)s, "convt2x2_fwd");
 }
 
@@ -1776,7 +1797,7 @@ int rd_convt2x2_bwd_data(const float* dout, const float* wtd, float* dx, int n, 
     NtParams p = {};
     p.A = dout; p.B = wtd; p.C = dx;
     p.M = n * h * w; p.N = cin; p.K = 4 * cout; p.Cin = cout;
-    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     return launch_nt<A_UP2, EPI_STORE>(p, (hipStream_t)s, "convt2x2_dgrad");
 }
 
@@ -1801,7 +1822,7 @@ int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw, int n, 
     p.A = dout; p.B = x; p.slab = (float*)ws;
     p.M = 4 * cout; p.N = cin; p.Kp = (long)n * h * w;
     p.lda = cout; p.ldb = cin; p.Cin = cin; p.Cout = cout;
-    p.H = h; p.W = w; p.logH = ilog2_exact(h); p.logW = ilog2_exact(w);
+    p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     if (int e = launch_tn<WA_UP2, WB_PLAIN>(p, pl, (hipStream_t)s, "convt2x2_wgrad")) return e;
     ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N / 4)), dim3(256), 0, (hipStream_t)s,
@@ -1837,7 +1858,7 @@ int rd_conv1x1_fwd(const float* x, const float* w, float* out, long long pixels,
     NtParams p = {};
     p.A = x; p.B = w; p.C = out;
     p.M = (int)pixels; p.N = cout; p.K = cin; p.Cin = cin;
-    p.H = 1; p.W = 1; p.logH = 0; p.logW = 0;
+    p.H = 1; p.W = 1; p.pd = make_pixdiv(1, 1);
     return launch_nt<A_PLAIN, EPI_STORE>(p, (hipStream_t)s, "conv1x1_fwd");
 }
 
@@ -1848,7 +1869,7 @@ int rd_conv1x1_bwd_data(const float* dy, const float* wt, float* dx, long long p
     NtParams p = {};
     p.A = dy; p.B = wt; p.C = dx;
     p.M = (int)pixels; p.N = cin; p.K = cout; p.Cin = cout;
-    p.H = 1; p.W = 1; p.logH = 0; p.logW = 0;
+    p.H = 1; p.W = 1; p.pd = make_pixdiv(1, 1);
     return launch_nt<A_PLAIN, EPI_STORE>(p, (hipStream_t)s, "conv1x1_dgrad");
 }
 
@@ -1872,7 +1893,7 @@ int rd_conv1x1_bwd_weight(const float* x, const float* dy, float* dw, long long 
     p.A = dy; p.B = x; p.slab = (float*)ws;
     p.M = cout; p.N = cin; p.Kp = (long)pixels;
     p.lda = cout; p.ldb = cin; p.Cin = cin; p.Cout = cout;
-    p.H = 1; p.W = 1; p.logH = 0; p.logW = 0;
+    p.H = 1; p.W = 1; p.pd = make_pixdiv(1, 1);
     if (int e = launch_tn<WA_PLAIN, WB_PLAIN>(p, pl, (hipStream_t)s, "conv1x1_wgrad")) return e;
     ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N / 4)), dim3(256), 0, (hipStream_t)s,

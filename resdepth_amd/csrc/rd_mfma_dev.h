@@ -4,6 +4,15 @@
 
 namespace rd {
 
+__device__ __forceinline__ unsigned fd_div(unsigned n, FastDiv f) { return f.sh < 0 ? n : (__umulhi(n, f.mul) >> f.sh); }
+// pixel index m of an [img][H][W] grid (m < 2^31) -> img, y, x
+__device__ __forceinline__ void pix_split(int m, const PixDiv& d, int& img, int& y, int& x) {
+    img = (int)fd_div((unsigned)m, d.hw);
+    const int rem = m - img * d.HW;
+    y = (int)fd_div((unsigned)rem, d.w);
+    x = rem - y * d.W;
+}
+
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOOB = 0xFFFFFF00u;  // voffset beyond any descriptor extent: the hardware returns zeros
 

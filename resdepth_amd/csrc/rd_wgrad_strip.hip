@@ -23,7 +23,7 @@ struct WsParams {
     const float* x;
     float* slab;        // [splits][M][N]
     int Cin, Cout, M, N;
-    int H, W, logH, logW;
+    int H, W;
     int strips_x, chunks_y, rows_per_chunk, reps;
     int tiles_ci, tiles_mn;
     unsigned a_bytes, b_bytes;
@@ -218,7 +218,7 @@ struct WsPlan {
 static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
     WsPlan pl = {};
     const int force = tune(TUNE_WG_STRIP);
-    if (!mfma_split() || force == 0 || w < 16 || h < 4) return pl;
+    if (!mfma_split() || force == 0 || w % 16 != 0 || h < 4 || h % 2 != 0) return pl;   // 16-pixel strips, rows in pairs
     if (cout >= 128 && cout % 4 == 0 && cin % 32 == 0) {
         pl.swapped = 0;
     } else if (cin >= 128 && cin % 4 == 0 && cout % 32 == 0) {
@@ -234,7 +234,7 @@ static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
     const long base = (long)pl.tiles_m * pl.tiles_ci * n * pl.strips_x;
     int rows = h;
     const int minb = tune(TUNE_WG_MINBLOCKS);
-    while (base * (h / rows) < minb && rows > 32) rows >>= 1;
+    while (base * (h / rows) < minb && rows > 32 && rows % 4 == 0) rows >>= 1;   // chunks stay an even number of rows
     pl.rows_per_chunk = rows;
     pl.chunks_y = h / rows;
     // every split costs one [Cout][9*Cin] slab of HBM traffic (written here, read by the reduction): with more than
@@ -267,7 +267,7 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     WsParams q = {};
     q.dz = dz; q.x = x; q.slab = slab;
     q.Cin = cin; q.Cout = cout; q.M = cout; q.N = 9 * cin;
-    q.H = h; q.W = w; q.logH = ilog2_exact(h); q.logW = ilog2_exact(w);
+    q.H = h; q.W = w;
     q.strips_x = wp.strips_x; q.chunks_y = wp.chunks_y; q.rows_per_chunk = wp.rows_per_chunk; q.reps = wp.reps;
     q.tiles_ci = wp.tiles_ci; q.tiles_mn = wp.tiles_m * wp.tiles_ci;
     const double ab = 4.0 * n * h * w * (double)cout, bb = 4.0 * n * h * w * (double)cin;

@@ -450,7 +450,7 @@ class UNet(nn.Module):
 
     def _conv_act(self, inp, folded, pool):
         wf, shift, slope = folded
-        if pool and (inp.shape[2] < 16 or inp.shape[1] < 8):
+        if pool and (inp.shape[2] % 16 != 0 or inp.shape[1] % 8 != 0):
             # levels too small for the patch kernel's pooling epilogue: pool in a second (tiny) pass over the activation
             a, _ = ops.conv3x3_fwd_act(inp, wf, shift, slope, pool=False)
             c = a.shape[-1]
@@ -799,10 +799,12 @@ class UNet(nn.Module):
                                "(there is no CPU fallback)")
         if x.dim() != 4 or x.shape[1] != self.n_input_channels:
             raise ValueError(f"expected input [N, {self.n_input_channels}, T, T], got {tuple(x.shape)}")
-        t = x.shape[2]
-        if x.shape[3] != t or (t & (t - 1)) != 0 or t < 2 ** self.depth:
-            raise ValueError(f"tile size must be a power of two >= 2^depth = {2 ** self.depth} (got {tuple(x.shape[2:])})")
-        if self.training and self.do_BN and x.shape[0] * (t >> self.depth) ** 2 == 1:
+        th, tw = x.shape[2], x.shape[3]
+        q = 2 ** self.depth
+        if th < q or tw < q or th % q or tw % q:
+            # the reference fails later, in the first skip ADD whose pooled / up-sampled sizes disagree (lib/UNet.py:219)
+            raise ValueError(f"tile height and width must be multiples of 2^depth = {q} (got {tuple(x.shape[2:])})")
+        if self.training and self.do_BN and x.shape[0] * (th // q) * (tw // q) == 1:
             # torch.nn.functional.batch_norm's own check, hit by the reference at its bottleneck BatchNorm2d (lib/UNet.py:66)
             raise ValueError("Expected more than 1 value per channel when training, got input size "
                              f"torch.Size([1, {self.filter_depths[-1]}, 1, 1])")

@@ -54,6 +54,12 @@ CONV_SHAPES = [  # n, h, w, cin, cout
     (1, 256, 16, 32, 128),    # one 16-pixel strip, 8 row chunks per image (strip kernel split along y)
     (1, 64, 64, 64, 256),     # 4 strips x 2 row chunks, two output-channel tiles
     (2, 128, 128, 32, 128),   # halo kernel on a small batch (N = 128: one column tile), strip kernel with chunks
+    # tiles that are not powers of two (fast-division pixel indexing; lib/UNet.py is fully convolutional)
+    (2, 24, 40, 32, 64),      # generic kernels only (W % 16 != 0)
+    (3, 12, 20, 8, 24),       # odd quotients everywhere
+    (2, 48, 80, 64, 128),     # W % 16 == 0, H % 8 == 0: halo kernel + strip weight gradient on a 48 x 80 image
+    (1, 6, 48, 32, 128),      # strip kernel with 6 rows (even, not a multiple of 4: one chunk); H % 8 != 0: no halo kernel
+    (16, 40, 96, 24, 132),    # halo kernel <128> with 5 x 6 patches per image, ragged N tile
 ]
 
 
@@ -152,7 +158,8 @@ def test_convt2x2_adjoint_identities_at_full_size(h, c):
     assert abs(dot(w, dw) - ref) <= 1e-5 * scale, (ref, dot(w, dw))
 
 
-CONVT_SHAPES = [(2, 4, 8, 8, 12), (1, 2, 2, 4, 4), (4, 16, 16, 128, 128), (8, 32, 32, 64, 64), (2, 8, 8, 256, 256)]
+CONVT_SHAPES = [(2, 4, 8, 8, 12), (1, 2, 2, 4, 4), (4, 16, 16, 128, 128), (8, 32, 32, 64, 64), (2, 8, 8, 256, 256),
+                (2, 6, 10, 8, 12), (3, 12, 48, 64, 64), (2, 24, 40, 128, 128), (1, 5, 8, 32, 64)]     # not powers of two
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", CONVT_SHAPES)
@@ -244,7 +251,8 @@ def test_last_conv(n, h, w, c, xc, bias):
 
 @pytest.mark.parametrize("n,h,w,c,slope,pool", [(3, 8, 8, 8, 0.0, True), (2, 16, 32, 64, 0.0, True),
                                                 (2, 16, 16, 12, 0.01, True), (4, 8, 8, 512, 0.0, False),
-                                                (2, 4, 4, 32, 0.01, False)])
+                                                (2, 4, 4, 32, 0.01, False),
+                                                (2, 12, 20, 8, 0.0, True), (3, 6, 10, 12, 0.01, True), (1, 24, 40, 64, 0.0, False)])
 def test_bn_act_pool_forward_backward(n, h, w, c, slope, pool):
     from resdepth_amd import ops
     g = torch.Generator().manual_seed(c + n)
@@ -508,8 +516,9 @@ def test_errors_are_reported():
     from resdepth_amd import ops
     with pytest.raises(RuntimeError, match="multiple of 4"):
         ops.conv3x3_fwd(torch.zeros(1, 4, 4, 3, device=dev()), torch.zeros(8, 9, 3, device=dev()))
-    with pytest.raises(RuntimeError, match="powers of two"):
-        ops.conv3x3_fwd(torch.zeros(1, 6, 4, 4, device=dev()), torch.zeros(8, 9, 4, device=dev()))
+    with pytest.raises(RuntimeError, match="multiple of 16"):        # the pooling epilogue lives in the patch kernels
+        ops.conv3x3_fwd_act(torch.zeros(1, 12, 20, 4, device=dev()), ops.pack_conv3x3_weight_folded(
+            torch.zeros(8, 4, 3, 3, device=dev()), torch.ones(8, device=dev())), torch.zeros(8, device=dev()), 0.0, pool=True)
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 8, 16, 8, 24), (8, 64, 64, 32, 128), (3, 32, 32, 20, 36), (2, 16, 16, 128, 256)])

@@ -562,6 +562,55 @@ def test_edge_shapes_against_oracle(n, t, kw):
     assert float((ye.cpu() - yeo.detach()).abs().max()) <= 1e-4
 
 
+@pytest.mark.parametrize("n,th,tw,kw", [
+    (2, 48, 80, dict(n_input_channels=3, start_kernel=32, depth=3, bias_conv_layer=True)),      # halo / strip / convT patch kernels on 48 x 80
+    (3, 24, 40, dict(n_input_channels=2, start_kernel=8, depth=2, act_fn_encoder="lrelu", outer_skip_BN=True)),
+    (1, 96, 32, dict(n_input_channels=1, start_kernel=16, depth=4, up_mode="bilinear")),
+])
+def test_tiles_that_are_not_square_powers_of_two_against_oracle(n, th, tw, kw):
+    """lib/UNet.py is fully convolutional: any tile whose sides are multiples of 2^depth is valid.  Training step (forward,
+    loss, every parameter gradient and the input gradient, running statistics) and the folded eval forward vs the oracle."""
+    from resdepth_amd import UNet, masked_l1_loss
+    spec = O.Spec(**{"depth": 8, **kw})
+    torch.manual_seed(9)
+    model = UNet(**kw)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, kw["n_input_channels"], th, tw, generator=g)
+    y = x[:, 0:1] + 0.3 * torch.randn(n, 1, th, tw, generator=g)
+    mask = torch.rand(n, 1, th, tw, generator=g) > 0.05
+    mean = torch.randn(n, generator=g, dtype=torch.float64) * 50.0
+    std = torch.rand(n, generator=g) * 2.0 + 1.0
+    model = model.to(DEV).train()
+    x_in = x.to(DEV).requires_grad_(True)
+    yp = model(x_in)
+    loss = masked_l1_loss(yp, y, mask, mean, std)
+    loss.backward()
+    sd1 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    leaves = {k: sd0[k].clone().requires_grad_(True) for k in O.param_keys(spec)}
+    work = {k: v.clone() for k, v in sd0.items()}
+    work.update(leaves)
+    xo = x.clone().requires_grad_(True)
+    yo = O.forward(work, xo, spec, training=True)
+    lo = O.masked_l1_loss(yo, y, mask, mean, std)
+    go = torch.autograd.grad(lo, list(leaves.values()) + [xo])
+    assert tuple(yp.shape) == (n, 1, th, tw)
+    assert float((yp.detach().cpu() - yo.detach()).abs().max()) <= 1e-4
+    assert abs(float(loss.detach()) - float(lo)) <= 1e-5 * abs(float(lo))
+    for (k, p), gr in zip(model.named_parameters(), go):
+        assert rel_l2(p.grad, gr) <= 2e-3, (k, rel_l2(p.grad, gr))
+    assert rel_l2(x_in.grad, go[-1]) <= 2e-3
+    for k, v in sd1.items():
+        if "running" in k:
+            np.testing.assert_allclose(v.numpy(), work[k].detach().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    model.eval()
+    with torch.no_grad():
+        ye = model(x.to(DEV))
+    assert float((ye.cpu() - O.forward(work, x, spec, training=False).detach()).abs().max()) <= 1e-4
+    with pytest.raises(ValueError, match="multiples of 2\\^depth"):
+        model(torch.zeros(1, kw["n_input_channels"], th + 2 ** (spec.depth - 1), tw, device=DEV))
+
+
 def test_single_value_per_channel_in_training_raises_like_torch():
     """N = 1 with a tile of 2^depth pixels leaves ONE value per channel at the bottleneck BatchNorm2d: the reference fails
     in torch.nn.functional.batch_norm (ValueError); eval mode works."""
