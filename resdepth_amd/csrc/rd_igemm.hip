@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnParams p) {   // (256,3
             if (BMODE == WB_CONV3) {
                 const int m = (int)kbase + row;
                 int y, x, img_;
-            pix_split(m, p.pd, img_, y, x);
+                pix_split(m, p.pd, img_, y, x);
                 ok = ok && ((unsigned)(y + b_dy) < (unsigned)H) && ((unsigned)(x + b_dx) < (unsigned)W);
                 const unsigned voff = (unsigned)((((long)m + b_shift) * p.ldb + b_col) * 4);
                 rb[i] = buf_load4(rsB, ok ? voff : kOOB, 0);
@@ -1213,8 +1213,11 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
     if (k_end > p.Kp) k_end = p.Kp;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.B, p.b_bytes);
 
+    const bool w4 = (W & 3) == 0;     // the task's 4 consecutive pixels share an image row: one index decomposition
     auto load_task = [&](long kbase, float4 (&x)[4]) {
         const int rem = (int)(k_end - kbase);   // pixels of this K-step that exist (may be <= 0 past the end)
+        int img0 = 0, y0 = 0, x0 = 0;
+        if ((AMODE == WA_UP2 && isA) || (BMODE == WB_CONV3 && !isA)) pix_split((int)kbase + kq * 4, p.pd, img0, y0, x0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = kq * 4 + j;
@@ -1222,8 +1225,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
             if (isA) {
                 if (AMODE == WA_UP2) {
                     const int m = (int)kbase + row;
-                    int jj, ii, img;
-                    pix_split(m, p.pd, img, ii, jj);
+                    int jj = x0 + j, ii = y0, img = img0;
+                    if (!w4) pix_split(m, p.pd, img, ii, jj);
                     const long src = ((long)img * (2 * H) + 2 * ii + a_qa) * (2 * W) + 2 * jj + a_qb;
                     x[j] = buf_load4(rsA, ok ? (unsigned)((src * p.lda + a_col) * 4) : kOOB, 0);
                 } else {
@@ -1232,8 +1235,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
             } else {
                 if (BMODE == WB_CONV3) {
                     const int m = (int)kbase + row;
-                    int y, xx, img_;
-                    pix_split(m, p.pd, img_, y, xx);
+                    int y = y0, xx = x0 + j, img_ = img0;
+                    if (!w4) pix_split(m, p.pd, img_, y, xx);
                     const bool in = ok && ((unsigned)(y + b_dy) < (unsigned)H) && ((unsigned)(xx + b_dx) < (unsigned)W);
                     x[j] = buf_load4(rsB, in ? (unsigned)((((long)m + b_shift) * p.ldb + b_col) * 4) : kOOB, 0);
                 } else {
