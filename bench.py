@@ -301,6 +301,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the exact-f32 / cfg-M / cfg-G secondary measurements")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
+    ap.add_argument("--separate-bn-stats", action="store_true",
+                    help="A/B: BN-backward sums from the stand-alone reduction pass instead of the data-gradient epilogues")
     ap.add_argument("--serial-backward", action="store_true",
                     help="disable the two-stream backward (weight gradients overlapping the dgrad/BN chain) in the timed region")
     ap.add_argument("--prof-steps", type=int, default=5, help="steps of the serialized, instrumented roofline pass")
@@ -357,6 +359,7 @@ def main():
         dp.broadcast_parameters(tb.model, 0)
     tb.attach_optimizer()
     tb.model.two_stream_backward = not args.serial_backward
+    tb.model.fused_bn_bwd_stats = not args.separate_bn_stats
 
     def barrier():
         if use_dist:

@@ -179,10 +179,12 @@ int rd_bn_eval_stats(const float* running_mean, const float* running_var, float 
 /* a = act(gamma*(z-mean)*invstd + beta), act = LeakyReLU(slope) (slope 0 = ReLU, lib/UNet.py:27-33); with pooling
  * `a` may be NULL (the full-resolution activation is then not written, see rd_convt2x2_fwd_bnskip);
  * if pooled != NULL also the 2x2/2 max-pool of a (lib/UNet.py:161,167): pooled[N,H/2,W/2,C] and
- * idx (uint8, window position 0..3 = dy*2+dx; first maximum in row-major order, NaN wins). */
+ * idx (uint8, window position 0..3 = dy*2+dx; first maximum in row-major order, NaN wins).
+ * zpool (nullable, with pooling): z at the arg-max position [N,H/2,W/2,C] -- lets the backward take the pooled part of
+ * the BN statistics from quarter-size tensors (rd_conv3x3_bwd_data_bnstats, mode 2). */
 int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                       float slope, const float* slope_dev, float* a, float* pooled, uint8_t* idx, int n, int h, int w,
-                       int c, rd_stream_t s);
+                       float slope, const float* slope_dev, float* a, float* pooled, uint8_t* idx, float* zpool, int n, int h,
+                       int w, int c, rd_stream_t s);
 
 /* Backward of conv -> BN -> act [-> pool].  The gradient wrt `a` is g_full (same resolution,
  * nullable) + unpool(g_pool via idx) (nullable).
@@ -196,6 +198,30 @@ int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, c
  *            gradients and the all-reduced ones feed dz).  dextra (phase 1, nullable): sums[2C..3C) as fp32, the bias gradient
  *            of the ConvTranspose2d whose output was added to this block's activation.
  * training=0 treats mean/invstd as constants (eval-mode BN). */
+/* ---- BN-backward statistics WITHOUT their own pass over z and g: the kernels that PRODUCE the gradient operand g of a
+ * conv block (the 3x3 / transposed / last convolution's data gradient) read the block's pre-BN output z in their
+ * epilogue and emit per-tile partial rows [rows][4][C] of (sum g', sum g' xhat, sum g, sum_{y<=0} g y) -- the phase-1
+ * sums of rd_bn_act_bwd_reduce.  rd_bn_bwd_stats_finalize adds the rows of one or two producers (an encoder block has
+ * two: the un-pooled skip gradient, mode 1, and the pooled gradient, mode 2, whose `bn_z` is the `zpool` tensor of
+ * rd_bn_act_pool_fwd) in fixed order into `sums[4C]` (fp64) and writes the fp32 parameter gradients.
+ * `part` must hold rd_bn_bwd_part_floats(pixels of the OUTPUT, C) floats; *rows_out = rows written (0: this shape has no
+ * statistics epilogue -- then only the data gradient was computed and the caller runs rd_bn_act_bwd_reduce). */
+size_t rd_bn_bwd_part_floats(long long pixels, int c);
+int rd_conv3x3_bwd_data_bnstats(const float* dz, const float* wd, float* dx, int n, int h, int w, int cin, int cout,
+                                const float* bn_z, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, float slope, const float* slope_dev, int mode, float* part,
+                                size_t part_floats, int* rows_out, rd_stream_t s);
+int rd_convt2x2_bwd_data_bnstats(const float* dout, const float* wtd, float* dx, int n, int h, int w, int cin, int cout,
+                                 const float* bn_z, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, float slope, const float* slope_dev, float* part, size_t part_floats,
+                                 int* rows_out, rd_stream_t s);
+int rd_conv3x3_last_bwd_data_bnstats(const float* dout, const float* wt, float* ds, int n, int h, int w, int c,
+                                     const float* bn_z, const float* mean, const float* invstd, const float* gamma,
+                                     const float* beta, float slope, const float* slope_dev, float* part, size_t part_floats,
+                                     int* rows_out, rd_stream_t s);
+int rd_bn_bwd_stats_finalize(const float* part_a, int rows_a, const float* part_b, int rows_b, int c, double* sums,
+                             float* dgamma, float* dbeta, float* dextra, rd_stream_t s);
+
 size_t rd_bn_act_bwd_ws_bytes(int n, int h, int w, int c);
 int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                          float slope, const float* slope_dev, const float* g_full, const float* g_pool,

@@ -73,8 +73,13 @@ SIGNATURES = {
     "rd_bn_stats_partial": (I, [P, P, LL, I, P, SZ, P]),
     "rd_bn_stats_finalize": (I, [P, D, F, F, P, P, P, P, P, I, P]),
     "rd_bn_eval_stats": (I, [P, P, F, P, P, I, P]),
-    "rd_bn_act_pool_fwd": (I, [P, P, P, P, P, F, P, P, P, P, I, I, I, I, P]),
+    "rd_bn_act_pool_fwd": (I, [P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, P]),
     "rd_bn_act_bwd_ws_bytes": (SZ, [I, I, I, I]),
+    "rd_bn_bwd_part_floats": (SZ, [LL, I]),
+    "rd_conv3x3_bwd_data_bnstats": (I, [P, P, P, I, I, I, I, I, P, P, P, P, P, F, P, I, P, SZ, P, P]),
+    "rd_convt2x2_bwd_data_bnstats": (I, [P, P, P, I, I, I, I, I, P, P, P, P, P, F, P, P, SZ, P, P]),
+    "rd_conv3x3_last_bwd_data_bnstats": (I, [P, P, P, I, I, I, I, P, P, P, P, P, F, P, P, SZ, P, P]),
+    "rd_bn_bwd_stats_finalize": (I, [P, I, P, I, I, P, P, P, P, P]),
     "rd_bn_act_bwd_reduce": (I, [P, P, P, P, P, F, P, P, P, P, P, P, P, P, I, I, I, I, P, SZ, P]),
     "rd_bn_act_bwd_apply": (I, [P, P, P, P, P, F, P, P, P, P, P, D, I, P, P, P, I, I, I, I, P]),
     "rd_masked_l1_ws_bytes": (SZ, [LL]),

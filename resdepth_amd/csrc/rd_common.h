@@ -72,6 +72,9 @@ int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, co
 int conv_last_fwd_launch(const float* s_in, const float* wt, const float* bias, const float* x_nchw, int xc, float* out, int n,
                          int h, int w, int c, hipStream_t s, int* launched);
 int conv_last_dgrad_launch(const float* dout, const float* wt, float* ds, int n, int h, int w, int c, hipStream_t s, int* launched);
+int conv_last_dgrad_bn_launch(const float* dout, const float* wt, float* ds, int n, int h, int w, int c, const float* bn_z,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                              const float* slope_dev, float* part, hipStream_t s, int* rows);
 int conv_last_wgrad_blocks(int n, int h, int w, int c);
 // first convolution, segment kernels: tiles / blocks = 0 when the shape stays on the generic kernel
 int conv_first_seg_tiles(int n, int h, int w, int cin, int cout);

@@ -116,11 +116,26 @@ __device__ __forceinline__ void load_dout_tile(float* D, const float* __restrict
     }
 }
 
+// BN-backward statistics of the block whose activation gradient the kernel writes (the arithmetic of bn_act_bwd_kernel's
+// reduction: sum g', sum g' xhat, sum g, sum_{y<=0} g y per channel); per-tile partial rows [tile][4][C]
+struct BnHook {
+    const float* z;
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    const float* slope_dev;
+    float slope;
+    float* part;
+};
+
 // ds[q][c] = sum_tap dout[q - off(tap)] * w[c][tap], off(tap) = (tap/3 - 1, tap%3 - 1)
+template <bool BN>
 __global__ __launch_bounds__(256) void conv_last_dgrad_tile_kernel(const float* __restrict__ dout, const float* __restrict__ w,
                                                                    float* __restrict__ ds, int N, int H, int W, int C, int CQ,
-                                                                   int tiles_x, int tiles_y) {
+                                                                   int tiles_x, int tiles_y, BnHook bn) {
     __shared__ float D[EH_NP];
+    __shared__ float red[BN ? 256 * 16 : 1];
     const int t = threadIdx.x, q = t % CQ, slot = t / CQ, PPI = 256 / CQ;
     const int tl = blockIdx.x;
     const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
@@ -130,12 +145,32 @@ __global__ __launch_bounds__(256) void conv_last_dgrad_tile_kernel(const float* 
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
         for (int k = 0; k < 4; ++k) wr[tap][k] = w[(q * 4 + k) * 9 + tap];
+    float sc[4], sh[4], mu[4], is[4], bacc[16], slope = 0.f;
+    if (BN) {
+        slope = bn.slope_dev ? bn.slope_dev[0] : bn.slope;
+        const float4 m4 = *reinterpret_cast<const float4*>(bn.mean + q * 4), i4 = *reinterpret_cast<const float4*>(bn.invstd + q * 4);
+        const float4 g4 = *reinterpret_cast<const float4*>(bn.gamma + q * 4), b4 = *reinterpret_cast<const float4*>(bn.beta + q * 4);
+        const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mu[k] = mm[k];
+            is[k] = ii[k];
+            sc[k] = ii[k] * gg[k];
+            sh[k] = bb[k] - mm[k] * sc[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bacc[k] = 0.f;
+    }
     load_dout_tile(D, dout, n, y0, x0, H, W, t);
     __syncthreads();
     for (int e = slot; e < ET_H * ET_W; e += PPI) {
         const int py = e / ET_W, px = e - py * ET_W;
         const int gy = y0 + py, gx = x0 + px;
         if (gy >= H || gx >= W) continue;
+        const long o = (((long)n * H + gy) * W + gx) * C + q * 4;
+        float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (BN) z4 = *reinterpret_cast<const float4*>(bn.z + o);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -144,7 +179,32 @@ __global__ __launch_bounds__(256) void conv_last_dgrad_tile_kernel(const float* 
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] = fmaf(d, wr[tap][k], acc[k]);
         }
-        *reinterpret_cast<float4*>(ds + (((long)n * H + gy) * W + gx) * C + q * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(ds + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (BN) {
+            const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float y = fmaf(zz[k], sc[k], sh[k]);
+                const float gm = acc[k] * (y > 0.f ? 1.f : slope);
+                const float xh = (zz[k] - mu[k]) * is[k];
+                bacc[k] += gm;
+                bacc[4 + k] = fmaf(gm, xh, bacc[4 + k]);
+                bacc[8 + k] += acc[k];
+                if (!(y > 0.f)) bacc[12 + k] = fmaf(acc[k], y, bacc[12 + k]);
+            }
+        }
+    }
+    if (BN) {
+        // fixed-order combination of the PPI pixel slots of every channel quad
+#pragma unroll
+        for (int k = 0; k < 16; ++k) red[t * 16 + k] = bacc[k];
+        __syncthreads();
+        for (int o = t; o < 4 * C; o += 256) {
+            const int sidx = o / C, c = o - sidx * C;
+            float sum = 0.f;
+            for (int sl = 0; sl < PPI; ++sl) sum += red[(sl * CQ + (c >> 2)) * 16 + sidx * 4 + (c & 3)];
+            bn.part[((long)tl * 4 + sidx) * C + c] = sum;
+        }
     }
 }
 
@@ -459,9 +519,26 @@ int conv_last_dgrad_launch(const float* dout, const float* wt, float* ds, int n,
     *launched = 0;
     if (!edge_shape_ok(c) || !edge_on(2)) return RD_OK;
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
-    hipLaunchKernelGGL(conv_last_dgrad_tile_kernel, dim3(n * tx * ty), dim3(256), 0, s, dout, wt, ds, n, h, w, c, c / 4, tx, ty);
+    const BnHook none = {};
+    hipLaunchKernelGGL(conv_last_dgrad_tile_kernel<false>, dim3(n * tx * ty), dim3(256), 0, s, dout, wt, ds, n, h, w, c, c / 4, tx,
+                       ty, none);
     RD_LAUNCH_CHECK("conv_last_dgrad");
     *launched = 1;
+    return RD_OK;
+}
+
+// same + the BN-backward statistics of the last decoder level's consumer; *rows = partial rows written (0: shape not handled)
+int conv_last_dgrad_bn_launch(const float* dout, const float* wt, float* ds, int n, int h, int w, int c, const float* bn_z,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                              const float* slope_dev, float* part, hipStream_t s, int* rows) {
+    *rows = 0;
+    if (!edge_shape_ok(c) || !edge_on(2)) return RD_OK;
+    const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
+    const BnHook bn = {bn_z, mean, invstd, gamma, beta, slope_dev, slope, part};
+    hipLaunchKernelGGL(conv_last_dgrad_tile_kernel<true>, dim3(n * tx * ty), dim3(256), 0, s, dout, wt, ds, n, h, w, c, c / 4, tx,
+                       ty, bn);
+    RD_LAUNCH_CHECK("conv_last_dgrad");
+    *rows = n * tx * ty;
     return RD_OK;
 }
 

@@ -233,6 +233,63 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* __
     }
 }
 
+// BN-backward statistics from the dgrad epilogues: per-tile partials [rows][4][C] (fp32) of one or two producers (the
+// un-pooled and the pooled gradient operand) -> fixed-order fp64 column sums `sums[4C]` (layout of bn_act_bwd_kernel's
+// reduction) + the fp32 parameter gradients.  One block = one channel quad of one of the four sums; its 256 threads are
+// 256 row slices (16-byte loads), combined in slice order.
+__global__ __launch_bounds__(256) void bn_bwd_stats_finalize_kernel(const float* __restrict__ pa, int ra,
+                                                                    const float* __restrict__ pb, int rb, int C,
+                                                                    double* __restrict__ sums, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, float* __restrict__ dextra) {
+    __shared__ double red[256][4];
+    const int t = threadIdx.x, CQ = C >> 2;
+    const int sidx = blockIdx.x / CQ, cq = blockIdx.x - sidx * CQ;
+    const long col = (long)sidx * C + cq * 4, stride = 4L * C;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int src = 0; src < 2; ++src) {
+        const float* part = src ? pb : pa;
+        const int nb = src ? rb : ra;
+        if (!part) continue;
+        int b = t;
+        for (; b + 768 < nb; b += 1024) {
+            const float4 v0 = *reinterpret_cast<const float4*>(part + (long)b * stride + col);
+            const float4 v1 = *reinterpret_cast<const float4*>(part + (long)(b + 256) * stride + col);
+            const float4 v2 = *reinterpret_cast<const float4*>(part + (long)(b + 512) * stride + col);
+            const float4 v3 = *reinterpret_cast<const float4*>(part + (long)(b + 768) * stride + col);
+            a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+            a1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+            a2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+            a3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+        }
+        for (; b < nb; b += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (long)b * stride + col);
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        }
+    }
+    red[t][0] = a0; red[t][1] = a1; red[t][2] = a2; red[t][3] = a3;
+    __syncthreads();
+    // 256 slices -> 16 -> 1, fixed order
+    __shared__ double red2[16][4];
+    if (t < 64) {
+        const int k = t & 3, grp = t >> 2;
+        double r = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) r += red[grp * 16 + sl][k];
+        red2[grp][k] = r;
+    }
+    __syncthreads();
+    if (t < 4) {
+        double r = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) r += red2[g][t];
+        const int c = cq * 4 + t;
+        sums[col + t] = r;
+        if (sidx == 0 && dbeta) dbeta[c] = (float)r;
+        if (sidx == 1 && dgamma) dgamma[c] = (float)r;
+        if (sidx == 2 && dextra) dextra[c] = (float)r;
+    }
+}
+
 int bn_reduce_finalize(const float* partial, int nb, int c, double count, float eps, float momentum, float* mean, float* invstd,
                        float* rmean, float* rvar, int64_t* nbt, hipStream_t s) {
     hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(c, 4)), dim3(256), 0, s, partial, nb, c, count, eps, momentum, mean,
@@ -257,9 +314,10 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
                                                               const float* __restrict__ beta, float slope_val,
                                                               const float* __restrict__ slope_dev,
                                                               float* __restrict__ a, float* __restrict__ pooled,
-                                                              uint8_t* __restrict__ idx, long rows, int H, int W, int C,
-                                                              int CQ) {
-    // rows = pooled pixels (POOL) or pixels; one thread per (row, cq)
+                                                              uint8_t* __restrict__ idx, float* __restrict__ zpool, long rows,
+                                                              int H, int W, int C, int CQ) {
+    // rows = pooled pixels (POOL) or pixels; one thread per (row, cq).  zpool (nullable): z at the arg-max position -- the
+    // pooled part of the BN-backward statistics is then a pass over quarter-size tensors (rd_conv3x3_bwd_data_bnstats)
     const float slope = slope_dev ? slope_dev[0] : slope_val;   // PReLU: learnable slope read on the device
     const long total = rows * CQ;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -285,12 +343,13 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
             const int i = (int)((row / W2) % H2);
             const long img = row / ((long)W2 * H2);
             const long base = (img * H + 2 * i) * W + 2 * j;
-            float m[4];
+            float m[4], zm[4] = {0.f, 0.f, 0.f, 0.f};
             int mi[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const long pix = base + (k >> 1) * W + (k & 1);
                 const float4 x = *reinterpret_cast<const float4*>(z + pix * C + cq * 4);
+                const float xv[4] = {x.x, x.y, x.z, x.w};
                 float y[4];
                 y[0] = act_fn(fmaf(x.x, sc[0], sh[0]), slope);
                 y[1] = act_fn(fmaf(x.y, sc[1], sh[1]), slope);
@@ -303,10 +362,12 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
                     if (k == 0 || y[q] > m[q] || y[q] != y[q]) {
                         m[q] = y[q];
                         mi[q] = k;
+                        zm[q] = xv[q];
                     }
                 }
             }
             *reinterpret_cast<float4*>(pooled + row * C + cq * 4) = make_float4(m[0], m[1], m[2], m[3]);
+            if (zpool) *reinterpret_cast<float4*>(zpool + row * C + cq * 4) = make_float4(zm[0], zm[1], zm[2], zm[3]);
             *reinterpret_cast<uchar4*>(idx + row * C + cq * 4) =
                 make_uchar4((unsigned char)mi[0], (unsigned char)mi[1], (unsigned char)mi[2], (unsigned char)mi[3]);
         }
@@ -1204,8 +1265,8 @@ int rd_bn_eval_stats(const float* running_mean, const float* running_var, float 
 }
 
 int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                       float slope, const float* slope_dev, float* a, float* pooled, uint8_t* idx, int n, int h, int w,
-                       int c, rd_stream_t s) {
+                       float slope, const float* slope_dev, float* a, float* pooled, uint8_t* idx, float* zpool, int n, int h,
+                       int w, int c, rd_stream_t s) {
     RD_REQUIRE(z && mean && invstd && gamma && beta && (a || pooled), "rd_bn_act_pool_fwd: null pointer");
     RD_REQUIRE(c % 4 == 0 && c > 0, "rd_bn_act_pool_fwd: C must be a multiple of 4 (got %d)", c);
     const int CQ = c / 4;
@@ -1213,14 +1274,16 @@ int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, c
     if (pooled) {
         RD_REQUIRE(idx && h % 2 == 0 && w % 2 == 0, "rd_bn_act_pool_fwd: pooling needs idx and even H, W");
         const long rows = pixels / 4;
-        ProfScope ps((hipStream_t)s, "bn_act_pool_fwd", 0, 4.0 * pixels * c * (a ? 2.25 : 1.25) + 0.25 * pixels * c);
+        ProfScope ps((hipStream_t)s, "bn_act_pool_fwd", 0,
+                     4.0 * pixels * c * (a ? 2.25 : 1.25) + 0.25 * pixels * c + (zpool ? 1.0 * pixels * c : 0.0));
         hipLaunchKernelGGL((bn_act_pool_fwd_kernel<true>), dim3(grid_cap((rows * CQ + 255) / 256, 8192)), dim3(256), 0,
-                           (hipStream_t)s, z, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, idx, rows, h, w, c, CQ);
+                           (hipStream_t)s, z, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, idx, zpool, rows, h, w, c,
+                           CQ);
     } else {
         ProfScope ps((hipStream_t)s, "bn_act_fwd", 0, 8.0 * pixels * c);
         hipLaunchKernelGGL((bn_act_pool_fwd_kernel<false>), dim3(grid_cap((pixels * CQ + 255) / 256, 8192)), dim3(256),
                            0, (hipStream_t)s, z, mean, invstd, gamma, beta, slope, slope_dev, a, (float*)nullptr,
-                           (uint8_t*)nullptr, pixels, h, w, c, CQ);
+                           (uint8_t*)nullptr, (float*)nullptr, pixels, h, w, c, CQ);
     }
     RD_LAUNCH_CHECK("bn_act_pool_fwd");
     return RD_OK;
@@ -1261,6 +1324,16 @@ int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd,
     hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(4 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
                        sums, pl.nb, 4 * c, c, dbeta, dgamma, dextra);
     RD_LAUNCH_CHECK("bn_act_bwd_reduce");
+    return RD_OK;
+}
+
+int rd_bn_bwd_stats_finalize(const float* part_a, int rows_a, const float* part_b, int rows_b, int c, double* sums,
+                             float* dgamma, float* dbeta, float* dextra, rd_stream_t s) {
+    RD_REQUIRE(part_a && rows_a > 0 && sums && c > 0 && c % 4 == 0 && (!part_b || rows_b > 0), "rd_bn_bwd_stats_finalize: bad arguments");
+    ProfScope ps((hipStream_t)s, "bn_act_bwd_reduce", 0, 16.0 * c * ((double)rows_a + (part_b ? rows_b : 0)));
+    hipLaunchKernelGGL(bn_bwd_stats_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)s, part_a, rows_a, part_b,
+                       part_b ? rows_b : 0, c, sums, dgamma, dbeta, dextra);
+    RD_LAUNCH_CHECK("bn_bwd_stats_finalize");
     return RD_OK;
 }
 
@@ -1473,6 +1546,25 @@ int rd_conv3x3_last_bwd_data(const float* dout, const float* wt, float* ds, int 
                        h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
     RD_LAUNCH_CHECK("conv_last_dgrad");
     return RD_OK;
+}
+
+int rd_conv3x3_last_bwd_data_bnstats(const float* dout, const float* wt, float* ds, int n, int h, int w, int c,
+                                     const float* bn_z, const float* mean, const float* invstd, const float* gamma,
+                                     const float* beta, float slope, const float* slope_dev, float* part, size_t part_floats,
+                                     int* rows_out, rd_stream_t s) {
+    RD_REQUIRE(dout && wt && ds && bn_z && mean && invstd && gamma && beta && part && rows_out,
+               "rd_conv3x3_last_bwd_data_bnstats: null pointer");
+    RD_REQUIRE(part_floats >= rd_bn_bwd_part_floats((long long)n * h * w, c),
+               "rd_conv3x3_last_bwd_data_bnstats: statistics buffer too small");
+    {
+        ProfScope ps((hipStream_t)s, "conv_last_dgrad", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(2 * c + 1));
+        if (int e = conv_last_dgrad_bn_launch(dout, wt, ds, n, h, w, c, bn_z, mean, invstd, gamma, beta, slope, slope_dev, part,
+                                              (hipStream_t)s, rows_out))
+            return e;
+        if (*rows_out) return RD_OK;
+    }
+    // channel counts without a tile kernel: plain data gradient, the caller runs the stand-alone reduction
+    return rd_conv3x3_last_bwd_data(dout, wt, ds, n, h, w, c, s);
 }
 
 size_t rd_conv3x3_last_bwd_weight_ws_bytes(int n, int h, int w, int c) {

@@ -69,7 +69,24 @@ struct NtParams {
     const float* shift;
     float act_slope;
     float* pool_out;
+    // EPI_STORE, backward: C is the gradient g w.r.t. the activation a = act(BN(z)) of a conv block.  With bn_part != NULL
+    // the block's BN-backward statistics come out of this epilogue as per-(tile_m) column sums [tiles_m][4][N] of
+    //   g' = g act'(y),  g' xhat,  g,  g y [y <= 0]        (y = gamma xhat + beta, xhat = (z - mean) invstd)
+    // -- the arithmetic of bn_act_bwd_kernel<*, false>, whose pass over z and g this replaces.  bn_mode 1: bn_z = z at
+    // C's resolution; 2: C is the POOLED gradient and bn_z = z at the arg-max positions (rd_bn_act_pool_fwd zpool): the
+    // third sum is then left 0 (it belongs to the un-pooled operand only)
+    const float* bn_z;
+    const float* bn_mean;
+    const float* bn_invstd;
+    const float* bn_gamma;
+    const float* bn_beta;
+    const float* bn_slope_dev;
+    float bn_slope;
+    int bn_mode;
+    float* bn_part;
 };
+
+__device__ __forceinline__ float nt_act_grad(float y, float slope) { return y > 0.f ? 1.f : slope; }
 
 
 __device__ __forceinline__ float skip_act(float y, float slope) { return y > 0.f ? y : y * slope; }
@@ -94,9 +111,46 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
     float* Cs = smem;
     float* red = smem + ROWS * CS;          // 2 x 256 floats for the fused BatchNorm statistics
     float tot_s = 0.f, tot_q = 0.f;         // threads t < BN: column totals over the passes
+    // BN-backward statistics hook: a thread keeps one column quad (256 % Q == 0) over all passes
+    static_assert(256 % Q == 0, "a thread must keep its column quad across the store loop");
+    const bool bn_on = EPI == EPI_STORE && p.bn_part != nullptr;
+    float bsc[4] = {0, 0, 0, 0}, bsh[4] = {0, 0, 0, 0}, bmu[4] = {0, 0, 0, 0}, bis[4] = {0, 0, 0, 0}, bacc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bacc[k] = 0.f;
+    float bslope = 0.f;
+    if (bn_on) {
+        bslope = p.bn_slope_dev ? p.bn_slope_dev[0] : p.bn_slope;
+        const int n = n0 + (t % Q) * 4;
+        if (n < p.N) {
+            const float4 m4 = *reinterpret_cast<const float4*>(p.bn_mean + n), i4 = *reinterpret_cast<const float4*>(p.bn_invstd + n);
+            const float4 g4 = *reinterpret_cast<const float4*>(p.bn_gamma + n), b4 = *reinterpret_cast<const float4*>(p.bn_beta + n);
+            const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bmu[q] = mm[q];
+                bis[q] = ii[q];
+                bsc[q] = ii[q] * gg[q];
+                bsh[q] = bb[q] - mm[q] * bsc[q];
+            }
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < WM * PPB; ++pass) {
         const int rowbase = (pass / PPB) * (TM * 32) + (pass % PPB) * ROWS;   // first tile row of this pass
+        // BN-backward hook: this pass's z values are requested before the accumulators go through LDS, so their HBM
+        // latency hides behind the staging (element e = t + 256 k of the store loop below)
+        constexpr int NIT = (ROWS * Q + 255) / 256;
+        float4 zpre[NIT];
+        if (bn_on) {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int e = t + 256 * k, row = e / Q, q4 = e - row * Q;
+                const int m = row_to_m(rowbase + row), n = n0 + q4 * 4;
+                zpre[k] = (e < ROWS * Q && m < p.M && n < p.N) ? *reinterpret_cast<const float4*>(p.bn_z + (long)m * p.N + n)
+                                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         __syncthreads();
         if (wm == pass / PPB) {
 #pragma unroll
@@ -133,7 +187,10 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
             }
         }
         if (p.vec) {
-            for (int e = t; e < ROWS * Q; e += 256) {
+#pragma unroll
+            for (int kk = 0; kk < NIT; ++kk) {
+                const int e = t + 256 * kk;
+                if (e >= ROWS * Q) break;
                 const int row = e / Q, q4 = e - row * Q;
                 const int m = row_to_m(rowbase + row), n = n0 + q4 * 4;
                 if (m >= p.M || n >= p.N) continue;
@@ -145,6 +202,20 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                         v.z = skip_act(v.z + sh4.z, p.act_slope); v.w = skip_act(v.w + sh4.w, p.act_slope);
                     }
                     *reinterpret_cast<float4*>(p.C + (long)m * p.N + n) = v;
+                    if (bn_on) {
+                        const float4 z4 = zpre[kk];
+                        const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, gv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float y = fmaf(zz[q], bsc[q], bsh[q]);
+                            const float gm = gv[q] * nt_act_grad(y, bslope);
+                            const float xh = (zz[q] - bmu[q]) * bis[q];
+                            bacc[q] += gm;
+                            bacc[4 + q] = fmaf(gm, xh, bacc[4 + q]);
+                            if (p.bn_mode == 1) bacc[8 + q] += gv[q];
+                            if (!(y > 0.f)) bacc[12 + q] = fmaf(gv[q], y, bacc[12 + q]);
+                        }
+                    }
                 } else {
                     const int ab = n / p.Cout, co = n - ab * p.Cout;
                     int jj, ii, img;
@@ -229,6 +300,21 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
         float* out = p.stats + (long)tile_m * 2 * p.N;
         out[n0 + t] = tot_s;
         out[p.N + n0 + t] = tot_q;
+    }
+    if (bn_on) {
+        // combine the 256 / Q threads of each column quad in a fixed order; [tile_m][4][N]
+        static_assert(256 * 16 <= SMEM_WORDS, "BN-backward statistics scratch must fit the operand buffers");
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) smem[t * 16 + k] = bacc[k];
+        __syncthreads();
+        for (int o = t; o < 4 * BN; o += 256) {
+            const int sidx = o / BN, col = o - sidx * BN;
+            float sum = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < 256 / Q; ++g2) sum += smem[(g2 * Q + (col >> 2)) * 16 + sidx * 4 + (col & 3)];
+            if (n0 + col < p.N) p.bn_part[((long)tile_m * 4 + sidx) * p.N + n0 + col] = sum;
+        }
     }
 }
 
@@ -1706,6 +1792,37 @@ int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int 
     return launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_dgrad");
 }
 
+// BN-backward statistics from the epilogue of the kernel that produces the gradient operand (NtParams::bn_part)
+static int set_bn_hook(NtParams& p, const char* who, const float* bn_z, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, float slope, const float* slope_dev, int mode, float* part, size_t part_floats) {
+    RD_REQUIRE(bn_z && mean && invstd && gamma && beta && part && (mode == 1 || mode == 2), "%s: bad BN-statistics arguments", who);
+    RD_REQUIRE(p.N % 4 == 0, "%s: the BN-statistics epilogue needs a multiple of 4 channels (got %d)", who, p.N);
+    RD_REQUIRE(part_floats >= rd_bn_bwd_part_floats(p.M, p.N), "%s: statistics buffer too small (%zu < %zu floats)", who,
+               part_floats, rd_bn_bwd_part_floats(p.M, p.N));
+    p.bn_z = bn_z; p.bn_mean = mean; p.bn_invstd = invstd; p.bn_gamma = gamma; p.bn_beta = beta;
+    p.bn_slope = slope; p.bn_slope_dev = slope_dev; p.bn_mode = mode; p.bn_part = part;
+    return RD_OK;
+}
+
+size_t rd_bn_bwd_part_floats(long long pixels, int c) { return (size_t)cdiv(pixels, 64) * 4 * (size_t)c; }
+
+int rd_conv3x3_bwd_data_bnstats(const float* dz, const float* wd, float* dx, int n, int h, int w, int cin, int cout,
+                                const float* bn_z, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, float slope, const float* slope_dev, int mode, float* part,
+                                size_t part_floats, int* rows_out, rd_stream_t s) {
+    if (int e = check_conv_args(n, h, w, cin, cout)) return e;
+    RD_REQUIRE(dz && wd && dx && rows_out, "rd_conv3x3_bwd_data_bnstats: null pointer");
+    RD_REQUIRE(cout % 4 == 0, "rd_conv3x3_bwd_data_bnstats: Cout must be a multiple of 4 (got %d)", cout);
+    NtParams p = {};
+    p.A = dz; p.B = wd; p.C = dx;
+    p.M = n * h * w; p.N = cin; p.K = 9 * cout; p.Cin = cout;
+    p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
+    if (int e = set_bn_hook(p, "rd_conv3x3_bwd_data_bnstats", bn_z, mean, invstd, gamma, beta, slope, slope_dev, mode, part,
+                            part_floats))
+        return e;
+    return launch_nt<A_CONV3, EPI_STORE>(p, (hipStream_t)s, "conv3x3_dgrad", rows_out);
+}
+
 size_t rd_conv3x3_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout) {
     if (const int ss = wgrad_strip_splits(n, h, w, cin, cout)) return (size_t)ss * cout * 9 * cin * sizeof(float);
     TnPlan pl = plan_tn(cout, 9 * cin, (long)n * h * w);
@@ -1802,6 +1919,23 @@ int rd_convt2x2_bwd_data(const float* dout, const float* wtd, float* dx, int n, 
     p.M = n * h * w; p.N = cin; p.K = 4 * cout; p.Cin = cout;
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     return launch_nt<A_UP2, EPI_STORE>(p, (hipStream_t)s, "convt2x2_dgrad");
+}
+
+int rd_convt2x2_bwd_data_bnstats(const float* dout, const float* wtd, float* dx, int n, int h, int w, int cin, int cout,
+                                 const float* bn_z, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, float slope, const float* slope_dev, float* part, size_t part_floats,
+                                 int* rows_out, rd_stream_t s) {
+    if (int e = check_conv_args(n, h, w, cin, cout)) return e;
+    RD_REQUIRE(dout && wtd && dx && rows_out, "rd_convt2x2_bwd_data_bnstats: null pointer");
+    RD_REQUIRE(cout % 4 == 0, "rd_convt2x2_bwd_data_bnstats: Cout must be a multiple of 4 (got %d)", cout);
+    NtParams p = {};
+    p.A = dout; p.B = wtd; p.C = dx;
+    p.M = n * h * w; p.N = cin; p.K = 4 * cout; p.Cin = cout;
+    p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
+    if (int e = set_bn_hook(p, "rd_convt2x2_bwd_data_bnstats", bn_z, mean, invstd, gamma, beta, slope, slope_dev, 1, part,
+                            part_floats))
+        return e;
+    return launch_nt<A_UP2, EPI_STORE>(p, (hipStream_t)s, "convt2x2_dgrad", rows_out);
 }
 
 size_t rd_convt2x2_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout) {

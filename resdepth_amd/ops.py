@@ -7,6 +7,8 @@ Every call enqueues on torch's current HIP stream and never synchronises.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -100,12 +102,45 @@ def conv3x3_fwd_bn(x, wf, running_mean, running_var, num_batches_tracked, eps=BN
     return z, mean, invstd
 
 
-def conv3x3_bwd_data(dz, wd):
+class BnHook:
+    """The conv block whose activation gradient a data-gradient kernel produces: that kernel's epilogue then emits the
+    block's BN-backward statistics (include/resdepth_hip.h, rd_*_bwd_data_bnstats).  mode 1: z at the gradient's
+    resolution; mode 2: the gradient is the POOLED one and z holds the values at the arg-max positions (zpool)."""
+
+    def __init__(self, z, mean, invstd, gamma, beta, slope, slope_dev=None, mode=1):
+        self.z, self.mean, self.invstd, self.gamma, self.beta = z, mean, invstd, gamma.detach(), beta.detach()
+        self.slope, self.slope_dev, self.mode = float(slope), slope_dev, mode
+
+    def args(self):
+        return (ptr(self.z), ptr(self.mean), ptr(self.invstd), ptr(self.gamma), ptr(self.beta), self.slope, ptr(self.slope_dev))
+
+
+def _bn_part(pixels, c, device):
+    return torch.empty(load().rd_bn_bwd_part_floats(pixels, c), device=device, dtype=torch.float32)
+
+
+def conv3x3_bwd_data(dz, wd, bn=None):
+    """bn (BnHook, optional): also return (partial rows tensor, row count) of the BN-backward statistics; row count 0 =
+    this shape has no statistics epilogue."""
     n, h, w, cout = dz.shape
     cin = wd.shape[0]
     dx = torch.empty(n, h, w, cin, device=dz.device, dtype=torch.float32)
-    check(load().rd_conv3x3_bwd_data(ptr(dz), ptr(wd), ptr(dx), n, h, w, cin, cout, stream_ptr()), "conv3x3_bwd_data")
-    return dx
+    if bn is None:
+        check(load().rd_conv3x3_bwd_data(ptr(dz), ptr(wd), ptr(dx), n, h, w, cin, cout, stream_ptr()), "conv3x3_bwd_data")
+        return dx
+    part, rows = _bn_part(n * h * w, cin, dz.device), ctypes.c_int(0)
+    check(load().rd_conv3x3_bwd_data_bnstats(ptr(dz), ptr(wd), ptr(dx), n, h, w, cin, cout, *bn.args(), bn.mode, ptr(part),
+                                             part.numel(), ctypes.byref(rows), stream_ptr()), "conv3x3_bwd_data_bnstats")
+    return dx, (part, rows.value)
+
+
+def bn_bwd_stats_finalize(parts, c, dgamma=None, dbeta=None, dextra=None):
+    """parts: one or two (partial rows, row count) pairs -> sums [4*C] float64 (layout of bn_act_bwd_reduce)."""
+    (pa, ra), (pb, rb) = parts[0], (parts[1] if len(parts) > 1 else (None, 0))
+    sums = torch.empty(4 * c, device=pa.device, dtype=torch.float64)
+    check(load().rd_bn_bwd_stats_finalize(ptr(pa), ra, ptr(pb), rb, c, ptr(sums), ptr(dgamma), ptr(dbeta), ptr(dextra),
+                                          stream_ptr()), "bn_bwd_stats_finalize")
+    return sums
 
 
 def conv3x3_bwd_weight(x, dz, out=None, ws_slot=0):
@@ -174,12 +209,18 @@ def conv3x3_last_fwd(s, w, bias, x_nchw):
     return out
 
 
-def conv3x3_last_bwd_data(dout, w, c):
+def conv3x3_last_bwd_data(dout, w, c, bn=None):
     n, _, h, wd_ = dout.shape
     ds = torch.empty(n, h, wd_, c, device=dout.device, dtype=torch.float32)
-    check(load().rd_conv3x3_last_bwd_data(ptr(dout), ptr(w.detach()), ptr(ds), n, h, wd_, c, stream_ptr()),
-          "conv3x3_last_bwd_data")
-    return ds
+    if bn is None:
+        check(load().rd_conv3x3_last_bwd_data(ptr(dout), ptr(w.detach()), ptr(ds), n, h, wd_, c, stream_ptr()),
+              "conv3x3_last_bwd_data")
+        return ds
+    part, rows = _bn_part(n * h * wd_, c, dout.device), ctypes.c_int(0)
+    check(load().rd_conv3x3_last_bwd_data_bnstats(ptr(dout), ptr(w.detach()), ptr(ds), n, h, wd_, c, *bn.args(), ptr(part),
+                                                  part.numel(), ctypes.byref(rows), stream_ptr()),
+          "conv3x3_last_bwd_data_bnstats")
+    return ds, (part, rows.value)
 
 
 def conv3x3_last_bwd_weight(s, dout, dw=None, dbias=None, want_bias=True, ws_slot=0):
@@ -216,13 +257,19 @@ def convt2x2_fwd_bnskip(x, wtf, bias, z_skip, mean, invstd, gamma, beta, slope, 
     return out
 
 
-def convt2x2_bwd_data(dout, wtd):
+def convt2x2_bwd_data(dout, wtd, bn=None):
     n, h2, w2, cout = dout.shape
     cin = wtd.shape[0]
     dx = torch.empty(n, h2 // 2, w2 // 2, cin, device=dout.device, dtype=torch.float32)
-    check(load().rd_convt2x2_bwd_data(ptr(dout), ptr(wtd), ptr(dx), n, h2 // 2, w2 // 2, cin, cout, stream_ptr()),
-          "convt2x2_bwd_data")
-    return dx
+    if bn is None:
+        check(load().rd_convt2x2_bwd_data(ptr(dout), ptr(wtd), ptr(dx), n, h2 // 2, w2 // 2, cin, cout, stream_ptr()),
+              "convt2x2_bwd_data")
+        return dx
+    part, rows = _bn_part(n * (h2 // 2) * (w2 // 2), cin, dout.device), ctypes.c_int(0)
+    check(load().rd_convt2x2_bwd_data_bnstats(ptr(dout), ptr(wtd), ptr(dx), n, h2 // 2, w2 // 2, cin, cout, *bn.args(),
+                                              ptr(part), part.numel(), ctypes.byref(rows), stream_ptr()),
+          "convt2x2_bwd_data_bnstats")
+    return dx, (part, rows.value)
 
 
 def convt2x2_bwd_weight(x, dout, out=None, ws_slot=0):
@@ -332,19 +379,24 @@ def bn_eval_stats(running_mean, running_var, eps=BN_EPS):
     return mean, invstd
 
 
-def bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, pool, slope_dev=None, want_a=True):
+def bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, pool, slope_dev=None, want_a=True, want_zpool=False):
     """slope_dev: optional 1-element fp32 device tensor (nn.PReLU().weight) overriding `slope`.
-    want_a=False (pooling only): the full-resolution activation is not written (returned as None)."""
+    want_a=False (pooling only): the full-resolution activation is not written (returned as None).
+    want_zpool (pooling only): also return z at the arg-max positions as a 4th value."""
     n, h, w, c = z.shape
     a = torch.empty_like(z) if (want_a or not pool) else None
-    pooled = idx = None
+    pooled = idx = zpool = None
     if pool:
         pooled = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.float32)
         idx = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.uint8)
+        if want_zpool:
+            zpool = torch.empty_like(pooled)
     check(load().rd_bn_act_pool_fwd(ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
-                                    float(slope), ptr(slope_dev), ptr(a), ptr(pooled), ptr(idx), n, h, w, c,
+                                    float(slope), ptr(slope_dev), ptr(a), ptr(pooled), ptr(idx), ptr(zpool), n, h, w, c,
                                     stream_ptr()),
           "bn_act_pool_fwd")
+    if want_zpool:
+        return a, pooled, idx, zpool
     return a, pooled, idx
 
 

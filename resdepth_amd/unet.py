@@ -134,6 +134,7 @@ class UNet(nn.Module):
         self.sync_bn = False
         self.two_stream_backward = True   # weight gradients on a second HIP stream, overlapping the dgrad/BN chain
         self.fold_eval_bn = True          # inference: eval-mode BN folded into the packed conv weights + epilogue activation
+        self.fused_bn_bwd_stats = True    # BN-backward sums from the epilogues of the kernels producing the gradient operands
         self._bn_gen = 0                  # bumped by every training-mode forward (the kernels update running statistics in place)
         self._side_stream = None
 
@@ -388,8 +389,8 @@ class UNet(nn.Module):
             return 0.0, slope.detach()
         return slope, None
 
-    def _bn_forward(self, z, bn, slope, pool, training, sums=None, bias=None, want_a=True, stats=None):
-        """-> (a | skip descriptor, pooled, idx, mean, invstd, count).  want_a=False (pooled levels): the full-resolution
+    def _bn_forward(self, z, bn, slope, pool, training, sums=None, bias=None, want_a=True, stats=None, want_zpool=False):
+        """-> (a | skip descriptor, pooled, idx, mean, invstd, count[, zpool]).  want_a=False (pooled levels): the full-resolution
         activation is not written; the first return value is then the descriptor the transposed convolution needs to
         recompute it from z in its epilogue."""
         c = z.shape[-1]
@@ -397,10 +398,11 @@ class UNet(nn.Module):
         if bn is None:
             # do_BN=False: activation(conv + bias) == the fused BN-apply kernel with mean 0, invstd 1, gamma 1, beta = bias
             mean, invstd = self._const(c, 0.0, z.device), self._const(c, 1.0, z.device)
-            a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, invstd, bias, slope, pool, sdev, want_a=want_a)
+            a, p, idx, *zp = ops.bn_act_pool_fwd(z, mean, invstd, invstd, bias, slope, pool, sdev, want_a=want_a,
+                                                 want_zpool=want_zpool)
             if a is None:
                 a = {"z": z, "mean": mean, "invstd": invstd, "gamma": invstd, "beta": bias, "slope": slope, "slope_dev": sdev}
-            return a, p, idx, mean, invstd, 1
+            return (a, p, idx, mean, invstd, 1, *zp)
         if training and stats is not None:       # statistics already finalised by the convolution's second launch
             mean, invstd = stats
             count = z.numel() // c
@@ -415,10 +417,11 @@ class UNet(nn.Module):
         else:
             mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, eps=bn.eps)
             count = z.numel() // c
-        a, p, idx = ops.bn_act_pool_fwd(z, mean, invstd, bn.weight, bn.bias, slope, pool, sdev, want_a=want_a)
+        a, p, idx, *zp = ops.bn_act_pool_fwd(z, mean, invstd, bn.weight, bn.bias, slope, pool, sdev, want_a=want_a,
+                                             want_zpool=want_zpool)
         if a is None:
             a = {"z": z, "mean": mean, "invstd": invstd, "gamma": bn.weight, "beta": bn.bias, "slope": slope, "slope_dev": sdev}
-        return a, p, idx, mean, invstd, count
+        return (a, p, idx, mean, invstd, count, *zp)
 
     # ---- inference: eval-mode BatchNorm folded into the convolutions ---------------------------------------------------
     def _can_fold(self) -> bool:
@@ -531,11 +534,14 @@ class UNet(nn.Module):
                 z, sums, st = conv_stats(cur, pk.get(("enc", i - 1))[0], bn)
             # transposed up-mode: the skip activation is recomputed from z in the decoder's convT epilogue, not stored
             lazy_skip = self.up_mode == "transpose" and not keep_skips
-            a, p, idx, mean, invstd, count = self._bn_forward(z, bn, self._act_of(blk, self.act_fn_encoder), True, training,
-                                                              sums, cbias, want_a=not lazy_skip, stats=st)
+            want_zp = save and self.fused_bn_bwd_stats
+            a, p, idx, mean, invstd, count, *zp = self._bn_forward(z, bn, self._act_of(blk, self.act_fn_encoder), True,
+                                                                   training, sums, cbias, want_a=not lazy_skip, stats=st,
+                                                                   want_zpool=want_zp)
             skips.append(a)
             if save:
-                S["enc"].append({"z": z, "idx": idx, "mean": mean, "invstd": invstd, "count": count, "p": p})
+                S["enc"].append({"z": z, "idx": idx, "mean": mean, "invstd": invstd, "count": count, "p": p,
+                                 "zp": zp[0] if zp else None})
                 if keep_skips:               # tests only: the backward never needs the skip activations
                     S["enc"][-1]["a"] = a
             cur = p
@@ -681,12 +687,37 @@ class UNet(nn.Module):
                     t_.record_stream(side)
                 done(*ready)
 
-        def bn_backward(rec, block, act_name, g_full, g_pool, idx, extra_bias=None):
+        fused_stats = self.fused_bn_bwd_stats
+
+        def hook(rec, block, act_name, mode=1):
+            """ops.BnHook of a conv block (its saved z / statistics / affine parameters): handed to the kernel that
+            produces the gradient w.r.t. the block's activation, whose epilogue then emits the BN-backward sums."""
+            if not fused_stats or (mode == 2 and rec.get("zp") is None):
+                return None
+            bn, cbias = self._norm_of(block)
+            slope, sdev = self._split_slope(self._act_of(block, act_name))
+            z = rec["z"] if mode == 1 else rec["zp"]
+            if bn is None:
+                return ops.BnHook(z, rec["mean"], rec["invstd"], self._const(z.shape[-1], 1.0, z.device), cbias, slope, sdev, mode)
+            return ops.BnHook(z, rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, sdev, mode)
+
+        def with_stats(fn, *args, bn=None):
+            """fn(*args[, bn=hook]) -> (tensor, (partial rows, count) | None)"""
+            if bn is None:
+                return fn(*args), None
+            out, part = fn(*args, bn=bn)
+            return out, (part if part[1] > 0 else None)
+
+        def bn_backward(rec, block, act_name, g_full, g_pool, idx, extra_bias=None, pre=()):
             c = rec["z"].shape[-1]
             bn, cbias = self._norm_of(block)
             act = self._act_of(block, act_name)
             slope, sdev = self._split_slope(act)
             prelu_w = act if sdev is not None else None
+            # statistics that came out of the producers' epilogues (one per gradient operand); all must be there
+            operands = (g_full is not None) + (g_pool is not None)
+            pre = [q for q in pre if q is not None]
+            pre = pre if len(pre) == operands else None
 
             dextra = gv(extra_bias) if extra_bias is not None else None     # ConvTranspose2d bias (skip add): by-product
 
@@ -698,14 +729,20 @@ class UNet(nn.Module):
             if bn is None:
                 # do_BN=False: a = act(z + bias); d bias = sum g', dz = g' (the "eval" form of the fused kernels)
                 one = self._const(c, 1.0, rec["z"].device)
-                sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], one, cbias, slope, g_full, g_pool, idx,
-                                             slope_dev=sdev, dextra=dextra)
+                if pre:
+                    sums = ops.bn_bwd_stats_finalize(pre, c, dextra=dextra)
+                else:
+                    sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], one, cbias, slope, g_full, g_pool, idx,
+                                                 slope_dev=sdev, dextra=dextra)
                 side_grads(sums)
                 dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], one, cbias, slope, g_full, g_pool, idx,
                                           sums, 1.0, False, dgamma=None, dbeta=gv(cbias), slope_dev=sdev)
                 done(cbias, prelu_w, extra_bias)
                 return dz
-            if sync_bn:
+            if pre:
+                sums = ops.bn_bwd_stats_finalize(pre, c, dgamma=None if sync_bn else gv(bn.weight),
+                                                 dbeta=None if sync_bn else gv(bn.bias), dextra=dextra)
+            elif sync_bn:
                 sums = ops.bn_act_bwd_reduce(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
                                              g_pool, idx, slope_dev=sdev, dextra=dextra)
             else:       # the reduction writes dgamma / dbeta itself (no separate launch)
@@ -743,30 +780,37 @@ class UNet(nn.Module):
             gv(obn.bias).copy_(s12[0:4].sum().reshape(1))
             gv(obn.weight).copy_(s12[4:8].sum().reshape(1))
             done(obn.weight, obn.bias)
-        g = ops.conv3x3_last_bwd_data(dout, ll.weight, c0)
-        skipgrad = [None] * d
-        gp = None
+        # every data-gradient kernel below also emits the BN-backward sums of the block that consumes its output
+        # (`hook`): the skip gradient of encoder level j (full part), the pooled gradient (pooled part), the decoder /
+        # bottleneck block behind a transposed convolution
+        g, st = with_stats(ops.conv3x3_last_bwd_data, dout, ll.weight, c0, bn=hook(S["enc"][0], self.encoder[0][0], self.act_fn_encoder))
+        skipgrad, skipstat = [None] * d, [None] * d
+        gp = gpstat = None
         for i in reversed(range(d)):
             up = self._up_of(i)
             src = S["dec"][i - 1] if i > 0 else S["bott"]
             if self.up_mode == "bilinear":
                 dt = ops.upsample2x_bwd(g)            # adjoint of the interpolation; then the coarse-grid conv1x1
                 wgrad(ops.conv1x1_bwd_weight, (dt,), src["a"], dt, gv(up.weight), ready=(up.weight,))
-                dprev = ops.conv1x1_bwd_data(dt, pk.get(("dec_t", i))[1])
+                dprev, dstat = ops.conv1x1_bwd_data(dt, pk.get(("dec_t", i))[1]), None
             else:
                 wgrad(ops.convt2x2_bwd_weight, (g,), src["a"], g, gv(up.weight), ready=(up.weight,))
-                dprev = ops.convt2x2_bwd_data(g, pk.get(("dec_t", i))[1])
-            skipgrad[d - 1 - i] = g       # gradient wrt the encoder skip a_{d-1-i} (SkipConnection is an ADD)
+                sblk, sact = (self.decoder[i - 1][1], self.act_fn_decoder) if i > 0 else (self.bottleneck, self.act_fn_bottleneck)
+                dprev, dstat = with_stats(ops.convt2x2_bwd_data, g, pk.get(("dec_t", i))[1], bn=hook(src, sblk, sact))
+            skipgrad[d - 1 - i], skipstat[d - 1 - i] = g, st       # gradient wrt the encoder skip a_{d-1-i} (SkipConnection is an ADD)
             if i > 0:
                 blk = self.decoder[i - 1][1]
-                dz = bn_backward(src, blk, self.act_fn_decoder, dprev, None, None)
+                dz = bn_backward(src, blk, self.act_fn_decoder, dprev, None, None, pre=(dstat,))
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["dec"][i - 1]["s"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
-                g = ops.conv3x3_bwd_data(dz, pk.get(("dec_c", i - 1))[1])
+                j = d - i                 # encoder level whose skip a_j was added to this decoder level's up-convolution
+                g, st = with_stats(ops.conv3x3_bwd_data, dz, pk.get(("dec_c", i - 1))[1],
+                                   bn=hook(S["enc"][j], self.encoder[j][0], self.act_fn_encoder))
             else:
-                dz = bn_backward(src, self.bottleneck, self.act_fn_bottleneck, dprev, None, None)
+                dz = bn_backward(src, self.bottleneck, self.act_fn_bottleneck, dprev, None, None, pre=(dstat,))
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][d - 1]["p"], dz, gv(self.bottleneck[0].weight),
                       ready=(self.bottleneck[0].weight,))
-                gp = ops.conv3x3_bwd_data(dz, pk.get("bott")[1])
+                gp, gpstat = with_stats(ops.conv3x3_bwd_data, dz, pk.get("bott")[1],
+                                        bn=hook(S["enc"][d - 1], self.encoder[d - 1][0], self.act_fn_encoder, mode=2))
         for i in reversed(range(d)):
             e = S["enc"][i]
             blk = self.encoder[i][0]
@@ -774,11 +818,13 @@ class UNet(nn.Module):
             # ConvTranspose2d whose output was added to this skip (decoder level d-1-i)
             j = d - 1 - i
             up = self._up_of(j)
-            dz = bn_backward(e, blk, self.act_fn_encoder, skipgrad[i], gp, e["idx"], extra_bias=up.bias)
-            skipgrad[i] = None
+            dz = bn_backward(e, blk, self.act_fn_encoder, skipgrad[i], gp, e["idx"], extra_bias=up.bias,
+                             pre=(skipstat[i], gpstat))
+            skipgrad[i] = skipstat[i] = None
             if i > 0:
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][i - 1]["p"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
-                gp = ops.conv3x3_bwd_data(dz, pk.get(("enc", i - 1))[1])
+                gp, gpstat = with_stats(ops.conv3x3_bwd_data, dz, pk.get(("enc", i - 1))[1],
+                                        bn=hook(S["enc"][i - 1], self.encoder[i - 1][0], self.act_fn_encoder, mode=2))
             elif self._first_generic():
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["xh"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
             else:

@@ -512,6 +512,53 @@ def test_layout_roundtrip():
     assert torch.equal(ops.nhwc_to_nchw(y), x)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,mode,kind", [
+    (2, 32, 32, 64, 128, 1, "conv"), (8, 64, 64, 64, 128, 1, "conv"), (16, 64, 64, 128, 256, 2, "conv"), (2, 16, 16, 20, 36, 1, "conv"),
+    (3, 24, 40, 32, 64, 1, "conv"), (2, 48, 80, 64, 128, 2, "conv"), (4, 16, 16, 128, 128, 1, "convt"), (2, 8, 8, 256, 256, 1, "convt"),
+    (2, 6, 10, 8, 12, 1, "convt"), (2, 64, 64, 64, 1, 1, "last"), (1, 24, 40, 32, 1, 1, "last"), (2, 16, 16, 8, 1, 1, "last")])
+def test_bn_backward_statistics_from_the_data_gradient_epilogues(n, h, w, cin, cout, mode, kind):
+    """rd_*_bwd_data_bnstats: the data gradient is bit-identical to the plain entry point, and the per-tile partial rows,
+    summed by rd_bn_bwd_stats_finalize, equal the sums of the stand-alone reduction pass rd_bn_act_bwd_reduce over
+    (z, g) -- halo / generic / transposed / last-conv tile kernels, both modes, LeakyReLU slope."""
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + cin)
+    C = cin                                   # the BN block sits on the convolution's INPUT side
+    if kind == "conv":
+        dz = torch.randn(n, h, w, cout, generator=g).to(dev())
+        _, wd = ops.pack_conv3x3_weight((torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev()))
+        run = lambda **k: ops.conv3x3_bwd_data(dz, wd, **k)
+    elif kind == "convt":
+        dz = torch.randn(n, 2 * h, 2 * w, cout, generator=g).to(dev())
+        _, wd = ops.pack_convt2x2_weight((torch.randn(cin, cout, 2, 2, generator=g) * 0.05).to(dev()))
+        run = lambda **k: ops.convt2x2_bwd_data(dz, wd, **k)
+    else:
+        dz = torch.randn(n, 1, h, w, generator=g).to(dev())
+        wt = (torch.randn(1, cin, 3, 3, generator=g) * 0.1).to(dev())
+        run = lambda **k: ops.conv3x3_last_bwd_data(dz, wt, C, **k)
+    z = torch.randn(n, h, w, C, generator=g).to(dev())
+    mean, invstd = (torch.randn(C, generator=g) * 0.1).to(dev()), (torch.rand(C, generator=g) + 0.5).to(dev())
+    gamma, beta = torch.randn(C, generator=g).to(dev()), (torch.randn(C, generator=g) * 0.3).to(dev())
+    gout, part = run(bn=ops.BnHook(z, mean, invstd, gamma, beta, 0.01, None, mode))
+    assert torch.equal(gout, run())
+    if kind == "last" and C not in (16, 32, 64):
+        assert part[1] == 0                   # no tile kernel for this channel count: the caller runs the reduction pass
+        return
+    assert part[1] > 0
+    dg, db, de = (torch.empty(C, device=dev()) for _ in range(3))
+    sums = ops.bn_bwd_stats_finalize([part], C, dg, db, de)
+    ref = ops.bn_act_bwd_reduce(z, mean, invstd, gamma, beta, 0.01, gout, None, None)
+    if mode == 2:
+        ref[2 * C:3 * C] = 0                  # sum g belongs to the un-pooled operand only
+    scale = ref.abs().view(4, C).amax(1, keepdim=True).expand(4, C).reshape(-1) + 1e-30
+    assert float(((sums - ref).abs() / scale).max()) <= 1e-5
+    assert torch.allclose(db.double(), ref[:C], rtol=1e-5, atol=1e-5 * float(scale[0]))
+    assert torch.allclose(dg.double(), ref[C:2 * C], rtol=1e-5, atol=1e-5 * float(scale[C]))
+    assert torch.allclose(de.double(), ref[2 * C:3 * C], rtol=1e-5, atol=1e-5 * float(scale[2 * C]))
+    # two producers (an encoder block: un-pooled + pooled operand) add up
+    both = ops.bn_bwd_stats_finalize([part, part], C)
+    assert torch.allclose(both, 2 * sums, rtol=1e-12, atol=0)
+
+
 def test_errors_are_reported():
     from resdepth_amd import ops
     with pytest.raises(RuntimeError, match="multiple of 4"):
