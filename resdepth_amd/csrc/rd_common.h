@@ -46,7 +46,7 @@ enum TuneKey {
     TUNE_WG_STRIP,         // -1 auto | 0: never use the strip weight-gradient kernel
     TUNE_WG_MINBLOCKS,     // strip kernel: minimum blocks before image rows are chunked
     TUNE_WG_BLOCKS,        // strip kernel: target block count
-    TUNE_WG_OCC,           // strip kernel: 1 = one wave per SIMD (accumulators in AGPRs), 2 = register budget for two
+    TUNE_WG_OCC,           // strip kernel: 2 (default) = register budget for two waves per SIMD, 1 = one wave (accumulators in AGPRs)
     TUNE_CONVT_PATCH,      // -1 auto | 0: never use the patch transposed-convolution kernels
     TUNE_EDGE_CONV,        // -1 auto | 0: never use the tile kernels of the first / last convolution (rd_edge_conv.hip)
     TUNE_ROWS_BLOCKS,      // first-stage blocks of the per-channel reductions
