@@ -1509,25 +1509,42 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cl
 //  mode 2 (conv1x1): m = co, n = ci             ->  dw[co*Cin + ci]
 //  mode 3 (conv3x3, swapped strip kernel): m = ci, n = (8-tap)*Cout + co  ->  dw[(co*Cin + ci)*9 + tap]
 // One thread owns four consecutive n (16-byte coalesced slab reads, four splits in flight).
+// SPT = lanes that share one output quad: each sums the slabs s = part, part + SPT, ... in fp64 and the partial sums are
+// combined by a fixed butterfly (deterministic).  Few outputs x many slabs (e.g. the 64-channel transposed convolution:
+// 4096 quads x 256 slabs) would otherwise be a handful of latency-bound blocks.
+template <int SPT>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int M,
                                                           int N, int splits, int mode, int Cin, int Cout) {
     const long total = (long)M * N, quads = total >> 2;   // N % 4 == 0 (channels are multiples of 4)
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long)gridDim.x * blockDim.x) {
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    // lane groups are aligned (256 % SPT == 0, total thread count a multiple of SPT): the SPT lanes of a quad always
+    // run the same iterations, so the shuffles below only ever read live partners
+    for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < quads * SPT; gid += nthreads) {
+        const long q = gid / SPT;
+        const int part = (int)(gid - q * SPT);
         const float4* src = reinterpret_cast<const float4*>(slab) + q;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int s = 0;
-        for (; s + 3 < splits; s += 4) {
-            const float4 v0 = src[(long)s * quads], v1 = src[(long)(s + 1) * quads];
-            const float4 v2 = src[(long)(s + 2) * quads], v3 = src[(long)(s + 3) * quads];
+        int s = part;
+        for (; s + 3 * SPT < splits; s += 4 * SPT) {
+            const float4 v0 = src[(long)s * quads], v1 = src[(long)(s + SPT) * quads];
+            const float4 v2 = src[(long)(s + 2 * SPT) * quads], v3 = src[(long)(s + 3 * SPT) * quads];
             a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
             a1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
             a2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
             a3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
         }
-        for (; s < splits; ++s) {
+        for (; s < splits; s += SPT) {
             const float4 v = src[(long)s * quads];
             a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
         }
+#pragma unroll
+        for (int o = 1; o < SPT; o <<= 1) {
+            a0 += __shfl_xor(a0, o);
+            a1 += __shfl_xor(a1, o);
+            a2 += __shfl_xor(a2, o);
+            a3 += __shfl_xor(a3, o);
+        }
+        if (part != 0) continue;
         const long e = q << 2;
         const int m = (int)(e / N), n = (int)(e - (long)m * N);
         const float r[4] = {(float)a0, (float)a1, (float)a2, (float)a3};
@@ -1547,6 +1564,20 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
             for (int k = 0; k < 4; ++k) dw[((long)(n + k) * Cout + co) * 4 + ab] = r[k];
         }
     }
+}
+
+static int grid_for(long total, int block, int cap);
+
+static void launch_slab_reduce(const float* slab, float* dw, int M, int N, int splits, int mode, int Cin, int Cout, hipStream_t s) {
+    const long quads = (long)M * N / 4;
+    int spt = 1;
+    while (spt < 16 && quads * spt < 262144 && 2 * spt <= splits) spt *= 2;      // ~1024 blocks of work, at most 16 lanes per quad
+    const int grid = grid_for(quads * spt, 256, 4096);
+    if (spt == 1) hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
+    else if (spt == 2) hipLaunchKernelGGL(slab_reduce_kernel<2>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
+    else if (spt == 4) hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
+    else if (spt == 8) hipLaunchKernelGGL(slab_reduce_kernel<8>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
+    else hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
 }
 
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd,
@@ -1845,11 +1876,9 @@ int rd_conv3x3_bwd_weight(const float* x, const float* dz, float* dw, int n, int
     if (strip_splits > 0) {
         ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (strip_splits + 1) * (double)cout * 9 * cin);
         if (strip_swapped)
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)cout * 9 * cin / 4)), dim3(256), 0, (hipStream_t)s,
-                               (const float*)ws, dw, cin, 9 * cout, strip_splits, 3, cin, cout);
+            launch_slab_reduce((const float*)ws, dw, cin, 9 * cout, strip_splits, 3, cin, cout, (hipStream_t)s);
         else
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)cout * 9 * cin / 4)), dim3(256), 0, (hipStream_t)s,
-                               (const float*)ws, dw, cout, 9 * cin, strip_splits, 0, cin, cout);
+            launch_slab_reduce((const float*)ws, dw, cout, 9 * cin, strip_splits, 0, cin, cout, (hipStream_t)s);
         RD_LAUNCH_CHECK("slab_reduce");
         return RD_OK;
     }
@@ -1861,8 +1890,7 @@ int rd_conv3x3_bwd_weight(const float* x, const float* dz, float* dw, int n, int
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     if (int e = launch_tn<WA_PLAIN, WB_CONV3>(p, pl, (hipStream_t)s, "conv3x3_wgrad")) return e;
     ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N / 4)), dim3(256), 0, (hipStream_t)s,
-                       (const float*)ws, dw, p.M, p.N, pl.splits, 0, cin, cout);
+    launch_slab_reduce((const float*)ws, dw, p.M, p.N, pl.splits, 0, cin, cout, (hipStream_t)s);
     RD_LAUNCH_CHECK("slab_reduce");
     return RD_OK;
 }
@@ -1962,8 +1990,7 @@ int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw, int n, 
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
     if (int e = launch_tn<WA_UP2, WB_PLAIN>(p, pl, (hipStream_t)s, "convt2x2_wgrad")) return e;
     ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N / 4)), dim3(256), 0, (hipStream_t)s,
-                       (const float*)ws, dw, p.M, p.N, pl.splits, 1, cin, cout);
+    launch_slab_reduce((const float*)ws, dw, p.M, p.N, pl.splits, 1, cin, cout, (hipStream_t)s);
     RD_LAUNCH_CHECK("slab_reduce");
     return RD_OK;
 }
@@ -2033,8 +2060,7 @@ int rd_conv1x1_bwd_weight(const float* x, const float* dy, float* dw, long long 
     p.H = 1; p.W = 1; p.pd = make_pixdiv(1, 1);
     if (int e = launch_tn<WA_PLAIN, WB_PLAIN>(p, pl, (hipStream_t)s, "conv1x1_wgrad")) return e;
     ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (pl.splits + 1) * (double)p.M * p.N);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for((long)p.M * p.N / 4)), dim3(256), 0, (hipStream_t)s,
-                       (const float*)ws, dw, p.M, p.N, pl.splits, 2, cin, cout);
+    launch_slab_reduce((const float*)ws, dw, p.M, p.N, pl.splits, 2, cin, cout, (hipStream_t)s);
     RD_LAUNCH_CHECK("slab_reduce");
     return RD_OK;
 }
