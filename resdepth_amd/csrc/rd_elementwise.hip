@@ -235,14 +235,16 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* __
 
 // BN-backward statistics from the dgrad epilogues: per-tile partials [rows][4][C] (fp32) of one or two producers (the
 // un-pooled and the pooled gradient operand) -> fixed-order fp64 column sums `sums[4C]` (layout of bn_act_bwd_kernel's
-// reduction) + the fp32 parameter gradients.  One block = one channel quad of one of the four sums; its 256 threads are
-// 256 row slices (16-byte loads), combined in slice order.
-__global__ __launch_bounds__(256) void bn_bwd_stats_finalize_kernel(const float* __restrict__ pa, int ra,
-                                                                    const float* __restrict__ pb, int rb, int C,
-                                                                    double* __restrict__ sums, float* __restrict__ dgamma,
-                                                                    float* __restrict__ dbeta, float* __restrict__ dextra) {
-    __shared__ double red[256][4];
-    const int t = threadIdx.x, CQ = C >> 2;
+// reduction) + the fp32 parameter gradients.  One WAVE = one channel quad of one of the four sums, its 64 lanes are 64 row
+// slices (16-byte loads) combined by a fixed shuffle butterfly.  No LDS and < 32 registers on purpose: this kernel sits on
+// the critical path of the backward while the two-waves-per-SIMD weight-gradient kernel holds all of a CU's LDS and all but
+// 38 of its registers -- a kernel that needs neither still finds a slot (the LDS version took 42 us per launch under
+// overlap against 12 us alone).
+__global__ __launch_bounds__(64) void bn_bwd_stats_finalize_kernel(const float* __restrict__ pa, int ra,
+                                                                   const float* __restrict__ pb, int rb, int C,
+                                                                   double* __restrict__ sums, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, float* __restrict__ dextra) {
+    const int lane = threadIdx.x, CQ = C >> 2;
     const int sidx = blockIdx.x / CQ, cq = blockIdx.x - sidx * CQ;
     const long col = (long)sidx * C + cq * 4, stride = 4L * C;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -250,40 +252,31 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_finalize_kernel(const float*
         const float* part = src ? pb : pa;
         const int nb = src ? rb : ra;
         if (!part) continue;
-        int b = t;
-        for (; b + 768 < nb; b += 1024) {
+        int b = lane;
+        for (; b + 64 < nb; b += 128) {
             const float4 v0 = *reinterpret_cast<const float4*>(part + (long)b * stride + col);
-            const float4 v1 = *reinterpret_cast<const float4*>(part + (long)(b + 256) * stride + col);
-            const float4 v2 = *reinterpret_cast<const float4*>(part + (long)(b + 512) * stride + col);
-            const float4 v3 = *reinterpret_cast<const float4*>(part + (long)(b + 768) * stride + col);
-            a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
-            a1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
-            a2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
-            a3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
+            const float4 v1 = *reinterpret_cast<const float4*>(part + (long)(b + 64) * stride + col);
+            a0 += (double)v0.x + (double)v1.x;
+            a1 += (double)v0.y + (double)v1.y;
+            a2 += (double)v0.z + (double)v1.z;
+            a3 += (double)v0.w + (double)v1.w;
         }
-        for (; b < nb; b += 256) {
+        if (b < nb) {
             const float4 v = *reinterpret_cast<const float4*>(part + (long)b * stride + col);
             a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
         }
     }
-    red[t][0] = a0; red[t][1] = a1; red[t][2] = a2; red[t][3] = a3;
-    __syncthreads();
-    // 256 slices -> 16 -> 1, fixed order
-    __shared__ double red2[16][4];
-    if (t < 64) {
-        const int k = t & 3, grp = t >> 2;
-        double r = 0.0;
 #pragma unroll
-        for (int sl = 0; sl < 16; ++sl) r += red[grp * 16 + sl][k];
-        red2[grp][k] = r;
+    for (int o = 1; o < 64; o <<= 1) {
+        a0 += __shfl_xor(a0, o);
+        a1 += __shfl_xor(a1, o);
+        a2 += __shfl_xor(a2, o);
+        a3 += __shfl_xor(a3, o);
     }
-    __syncthreads();
-    if (t < 4) {
-        double r = 0.0;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) r += red2[g][t];
-        const int c = cq * 4 + t;
-        sums[col + t] = r;
+    if (lane < 4) {
+        const double r = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a3;
+        const int c = cq * 4 + lane;
+        sums[col + lane] = r;
         if (sidx == 0 && dbeta) dbeta[c] = (float)r;
         if (sidx == 1 && dgamma) dgamma[c] = (float)r;
         if (sidx == 2 && dextra) dextra[c] = (float)r;
@@ -1331,7 +1324,7 @@ int rd_bn_bwd_stats_finalize(const float* part_a, int rows_a, const float* part_
                              float* dgamma, float* dbeta, float* dextra, rd_stream_t s) {
     RD_REQUIRE(part_a && rows_a > 0 && sums && c > 0 && c % 4 == 0 && (!part_b || rows_b > 0), "rd_bn_bwd_stats_finalize: bad arguments");
     ProfScope ps((hipStream_t)s, "bn_act_bwd_reduce", 0, 16.0 * c * ((double)rows_a + (part_b ? rows_b : 0)));
-    hipLaunchKernelGGL(bn_bwd_stats_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)s, part_a, rows_a, part_b,
+    hipLaunchKernelGGL(bn_bwd_stats_finalize_kernel, dim3(c), dim3(64), 0, (hipStream_t)s, part_a, rows_a, part_b,
                        part_b ? rows_b : 0, c, sums, dgamma, dbeta, dextra);
     RD_LAUNCH_CHECK("bn_bwd_stats_finalize");
     return RD_OK;
