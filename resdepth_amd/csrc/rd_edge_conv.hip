@@ -1,5 +1,6 @@
 // Streaming kernels of the last convolution C -> 1 (+ bias + outer residual x[:, 0:1]) for the channel counts the network
-// uses (C = 16 / 32 / 64: one pixel = 4 / 8 / 16 lanes of 16 bytes).  Replaces the ATen kernels behind the reference's
+// uses (C = 16 / 32 / 64: in the forward a pixel is 2 / 4 / 8 lanes of 8 channels, in the gradients 4 / 8 / 16 lanes of 4),
+// and of the first convolution (1..4 input channels -> 32 / 64 / 128, segment kernels further down).  Replaces the ATen kernels behind the reference's
 // `last_layer` + outer SkipConnection and their autograd (lib/UNet.py:184, 227-244).  All three are HBM-bound: they move
 // the 64-channel full-resolution tensor exactly once (537 MB at cfg-S) and nothing else of size.
 //
@@ -10,6 +11,7 @@
 //            out[p] = bias + x0[p] + sum_tap V[p + tap][tap] is nine conflict-free LDS reads per output pixel.
 //  dgrad     ds[q][c] = sum_tap dout[q - tap] w[c][tap]: the 1-channel dout tile (+ halo) sits in LDS, every lane keeps its
 //            4 channels x 9 taps of weights in registers and streams 16-byte stores (a wave writes 1 KB contiguous).
+//            Template BN = true: it also reads the consumer block's z and emits that block's BN-backward sums (BnHook).
 //  wgrad     dw[c][tap] = sum_q s[q][c] dout[q - tap]: same LDS tile of dout, four 16-byte loads of s in flight per lane,
 //            36 accumulators per lane, ONE block-level reduction at the end (LDS, two barriers) instead of 9 x 2.
 #include "rd_common.h"
