@@ -12,7 +12,7 @@ mkdir -p "$HERE/obj"
 pids=()
 for f in rd_runtime rd_igemm rd_convt rd_wgrad_strip rd_elementwise rd_edge_conv rd_stats; do
   if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/rd_common.h" -nt "$HERE/obj/$f.o" ] \
-     || [ "$HERE/rd_mfma_dev.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/resdepth_hip.h" -nt "$HERE/obj/$f.o" ]; then
+     || [ "$HERE/rd_mfma_dev.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/rd_nt.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/resdepth_hip.h" -nt "$HERE/obj/$f.o" ]; then
     F="$FLAGS"; [ $f = rd_wgrad_strip ] && F="$BASE"     # 144 accumulator registers: AGPR-form MFMA (see the file header)
     # rd_edge_conv: no SLP vectorisation = no v_pk_fma_f32.  With it, the last-conv weight-gradient kernel (operands
     # from ds_read2_b32, consumed by v_pk_fma_f32 ... op_sel:[0,1,0]) produced wrong LOW-half results in single 16-lane
