@@ -10,7 +10,7 @@ BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unu
 FLAGS="$BASE -mllvm -amdgpu-mfma-vgpr-form"
 mkdir -p "$HERE/obj"
 pids=()
-for f in rd_runtime rd_igemm rd_convt rd_wgrad_strip rd_wino rd_elementwise rd_edge_conv rd_stats; do
+for f in rd_runtime rd_igemm rd_convt rd_wgrad_strip rd_elementwise rd_edge_conv rd_stats; do
   if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/rd_common.h" -nt "$HERE/obj/$f.o" ] \
      || [ "$HERE/rd_mfma_dev.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/rd_nt.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/resdepth_hip.h" -nt "$HERE/obj/$f.o" ]; then
     F="$FLAGS"; [ $f = rd_wgrad_strip ] && F="$BASE"     # 144 accumulator registers: AGPR-form MFMA (see the file header)
@@ -24,5 +24,5 @@ for f in rd_runtime rd_igemm rd_convt rd_wgrad_strip rd_wino rd_elementwise rd_e
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj/rd_runtime.o "$HERE"/obj/rd_igemm.o "$HERE"/obj/rd_convt.o "$HERE"/obj/rd_wgrad_strip.o "$HERE"/obj/rd_wino.o "$HERE"/obj/rd_elementwise.o "$HERE"/obj/rd_edge_conv.o "$HERE"/obj/rd_stats.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj/rd_runtime.o "$HERE"/obj/rd_igemm.o "$HERE"/obj/rd_convt.o "$HERE"/obj/rd_wgrad_strip.o "$HERE"/obj/rd_elementwise.o "$HERE"/obj/rd_edge_conv.o "$HERE"/obj/rd_stats.o
 echo "built $OUT"

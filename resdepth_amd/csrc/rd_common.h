@@ -39,7 +39,6 @@ enum TuneKey {
     TUNE_MFMA_F32 = 0,     // 1: exact-f32 MFMA kernels instead of split-bf16 (also RD_MFMA=f32)
     TUNE_NT_TILE,          // -1 auto | 0: 128x128, 1: 128x64, 2: 64x64 tiles of the NT kernels
     TUNE_NT_HALO,          // -1 auto | 0: never use the halo-reuse conv3x3 kernel
-    TUNE_NT_WINO,          // 3x3 forward / data gradient: -1 auto (Winograd F(2x2,3x3) where the shape allows) | 0 never
     TUNE_NT_SKEW,          // halo kernel: 1 = skewed halo-row pitch (no LDS bank conflicts) | 0 = plain pitch (r01 layout)
     TUNE_TN_TILE,          // -1 auto | bm*1000 + bn
     TUNE_TN_BLOCKS,        // target block count of the split-K TN kernels

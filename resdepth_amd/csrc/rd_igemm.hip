@@ -545,24 +545,12 @@ __global__ void split_pack_kernel(const float* __restrict__ B, uint4* __restrict
 //   pieces [0, Tf)      forward operand   rows n = co, k = (tap, ci):        w[co][ci0+j][tap]
 //   pieces [Tf, Tf+Td)  data-gradient operand rows n = ci, k = (tap', co):   w[co0+j][ci][8-tap']
 // one thread per 16-byte fragment piece (row n, K-step kt = chunk*9 + tap, k-half g); gathered, cached loads.
-// Winograd operand pieces of one direction: piece e -> (position xi, row n, K-step kt, k-half g); U = G g G^T of the 3x3 filter
-// between input channel k and output row n.  fwd: g = w[n][k][.];  data gradient: g[tap] = w[k][n][8 - tap].
-__device__ __forceinline__ void write_wino_piece(const float* __restrict__ w, uint4* out_wino, long e, int N, int Kc, int cin_w,
-                                                 bool fwd, const float* __restrict__ row_scale);
-
 __global__ void split_pack_conv3x3_kernel(const float* __restrict__ w, uint4* __restrict__ outf, uint4* __restrict__ outd,
                                           int cout, int cin, const float* __restrict__ row_scale) {
     const int nkf = 9 * ((cin + SK - 1) / SK), nkd = 9 * ((cout + SK - 1) / SK);
     const long rf = (long)((cout + 31) / 32) * 32, rd_ = (long)((cin + 31) / 32) * 32;
     const long Tf = rf * nkf * 2, Td = outd ? rd_ * nkd * 2 : 0;
-    const long Wf = wino_shape(cout, cin) ? 16 * rf * (nkf / 9) * 2 : 0, Wd = (outd && wino_shape(cin, cout)) ? 16 * rd_ * (nkd / 9) * 2 : 0;
-    for (long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x; e0 < Tf + Td + Wf + Wd; e0 += (long)gridDim.x * blockDim.x) {
-        if (e0 >= Tf + Td) {        // Winograd sections (behind the nine-tap split operand of their buffer)
-            const bool wf_ = e0 < Tf + Td + Wf;
-            if (wf_) write_wino_piece(w, outf + rf * nkf * 3 * 2, e0 - Tf - Td, cout, cin, cin, true, row_scale);
-            else write_wino_piece(w, outd + rd_ * nkd * 3 * 2, e0 - Tf - Td - Wf, cin, cout, cin, false, nullptr);
-            continue;
-        }
+    for (long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x; e0 < Tf + Td; e0 += (long)gridDim.x * blockDim.x) {
         const bool fwd = e0 < Tf;
         const long e = fwd ? e0 : e0 - Tf;
         const int nk = fwd ? nkf : nkd, N = fwd ? cout : cin, Kc = fwd ? cin : cout;
@@ -620,34 +608,6 @@ __device__ __forceinline__ void write_split_piece(uint4* out, long n, int nk, in
                                             __builtin_amdgcn_perm(l[5], l[4], sel), __builtin_amdgcn_perm(l[7], l[6], sel));
 }
 
-__device__ __forceinline__ void write_wino_piece(const float* __restrict__ w, uint4* out_wino, long e, int N, int Kc, int cin_w,
-                                                 bool fwd, const float* __restrict__ row_scale) {
-    const long r32 = rows32_of_dev(N);
-    const int nk1 = (Kc + SK - 1) / SK;
-    const int g = (int)(e & 1);
-    long q = e >> 1;
-    const int kt = (int)(q % nk1);
-    q /= nk1;
-    const long n = q % r32;
-    const int xi = (int)(q / r32), r = xi >> 2, c = xi & 3, c0 = kt * SK + g * 8;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = c0 + j;
-        float x = 0.f;
-        if (n < N && k < Kc) {
-            float gg[9];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-                gg[tap] = fwd ? w[((long)n * cin_w + k) * 9 + tap] : w[((long)k * cin_w + n) * 9 + (8 - tap)];
-            x = wino_u(gg, r, c);
-            if (row_scale) x *= row_scale[n];
-        }
-        v[j] = x;
-    }
-    write_split_piece(out_wino + (long)xi * (r32 >> 5) * nk1 * 3 * 64, n, nk1, kt, g, v);
-}
-
 __global__ __launch_bounds__(256) void pack_all_kernel(const PackItem* __restrict__ items, int n_items, long total) {
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
         int it = 0;
@@ -660,14 +620,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackItem* __restric
         if (I.kind == 0) {
             // conv3x3 w[co][ci][3][3]: forward rows n = co, k = (tap, ci); data gradient rows n = ci, k = (8 - tap, co)
             const int nkf = 9 * ((cin + SK - 1) / SK), nkd = 9 * ((cout + SK - 1) / SK);
-            const long Tf = rows32_of_dev(cout) * nkf * 2, Td = rows32_of_dev(cin) * nkd * 2;
-            if (e >= Tf + Td) {       // Winograd operands (only counted for qualifying channel counts: rd_pack_item_pieces)
-                const long Wf = wino_shape(cout, cin) ? 16 * rows32_of_dev(cout) * (nkf / 9) * 2 : 0;
-                e -= Tf + Td;
-                if (e < Wf) write_wino_piece(w, reinterpret_cast<uint4*>(I.outf) + rows32_of_dev(cout) * nkf * 6, e, cout, cin, cin, true, nullptr);
-                else write_wino_piece(w, reinterpret_cast<uint4*>(I.outd) + rows32_of_dev(cin) * nkd * 6, e - Wf, cin, cout, cin, false, nullptr);
-                continue;
-            }
+            const long Tf = rows32_of_dev(cout) * nkf * 2;
             const bool fwd = e < Tf;
             if (!fwd) e -= Tf;
             const int nk = fwd ? nkf : nkd, N = fwd ? cout : cin, Kc = fwd ? cin : cout;
@@ -724,12 +677,8 @@ static inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 static inline int nk16_of(int taps, int cin) { return taps * cdiv(cin, SK); }
 static inline size_t packed_f32_bytes(long rows, int taps, int cin) { return align16((size_t)rows * taps * cin * 4); }
 static inline long rows32_of(long rows) { return (rows + 31) / 32 * 32; }
-static inline size_t wino_bytes(long rows, int cin) {      // 16 positions x split fragments of a [rows][cin] operand
-    return wino_shape((int)rows, cin) ? (size_t)16 * rows32_of(rows) * nk16_of(1, cin) * SROWB : 0;
-}
 static inline size_t packed_bytes(long rows, int taps, int cin) {
-    return packed_f32_bytes(rows, taps, cin) + (size_t)rows32_of(rows) * nk16_of(taps, cin) * SROWB +
-           (taps == 9 ? wino_bytes(rows, cin) : 0);
+    return packed_f32_bytes(rows, taps, cin) + (size_t)rows32_of(rows) * nk16_of(taps, cin) * SROWB;
 }
 
 static int split_pack(const float* b_f32, long rows, int taps, int cin, hipStream_t s) {
@@ -763,21 +712,6 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     p.a_bytes = (unsigned)a_bytes;
     p.b_bytes = (unsigned)b_bytes;
     p.Bsplit = (const char*)p.B + packed_f32_bytes(p.N, taps, p.Cin);
-    if (split && AMODE == A_CONV3 && EPI == EPI_STORE && taps == 9 && !p.pool_out && wino_channels_ok(p.N, p.Cin) &&
-        p.W % 16 == 0 && p.H % 8 == 0 && (long)p.M % 128 == 0) {
-        // Winograd F(2x2,3x3): 2.25x fewer MFMA products; its operand sits behind the nine-tap split operand
-        p.Bwino = (const char*)p.Bsplit + (size_t)rows32_of(p.N) * p.nk * SROWB;
-        const double wb = (double)wino_bytes(p.N, p.Cin);
-        if (wb < 4294967040.0) {
-            p.b_bytes = (unsigned)wb;
-            p.a_bytes = (unsigned)a_bytes;
-            char pcls[64];
-            snprintf(pcls, sizeof(pcls), "%s|conv3_wino", cls);
-            ProfScope ps(s, pcls, (double)flops, bytes, true);
-            if (tiles_m_out) *tiles_m_out = p.M / 128;
-            return wino_launch(p, s);
-        }
-    }
     const int force = tune(TUNE_NT_TILE);
     const int tiles_128x64 = cdiv(p.M, 128) * cdiv(p.N, 64);
     int cfg;
@@ -1457,9 +1391,7 @@ int rd_pack_conv3x3_weight(const float* w, float* wf, float* wd, int cout, int c
     if (mfma_split()) {     // split kernels only: both fragment tensors in one launch, fp32 GEMM layouts left unwritten
         uint4* of = (uint4*)((char*)wf + packed_f32_bytes(cout, 9, cin));
         uint4* od = wd ? (uint4*)((char*)wd + packed_f32_bytes(cin, 9, cout)) : nullptr;
-        const long pieces = rows32_of(cout) * nk16_of(9, cin) * 2 + (wd ? rows32_of(cin) * nk16_of(9, cout) * 2 : 0) +
-                            (wino_shape(cout, cin) ? 16 * rows32_of(cout) * nk16_of(1, cin) * 2 : 0) +
-                            ((wd && wino_shape(cin, cout)) ? 16 * rows32_of(cin) * nk16_of(1, cout) * 2 : 0);
+        const long pieces = rows32_of(cout) * nk16_of(9, cin) * 2 + (wd ? rows32_of(cin) * nk16_of(9, cout) * 2 : 0);
         long g = (pieces + 255) / 256;
         if (g > 8192) g = 8192;
         hipLaunchKernelGGL(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, od, cout, cin,
@@ -1485,7 +1417,7 @@ int rd_pack_conv3x3_weight_folded(const float* w, const float* row_scale, float*
     RD_REQUIRE(mfma_split(), "rd_pack_conv3x3_weight_folded: only the split-bf16 kernels implement the folded inference path");
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 10.0 * cout * cin * 9);
     uint4* of = (uint4*)((char*)wf + packed_f32_bytes(cout, 9, cin));
-    const long pieces = rows32_of(cout) * nk16_of(9, cin) * 2 + (wino_shape(cout, cin) ? 16 * rows32_of(cout) * nk16_of(1, cin) * 2 : 0);
+    const long pieces = rows32_of(cout) * nk16_of(9, cin) * 2;
     long g = (pieces + 255) / 256;
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, (uint4*)nullptr, cout, cin,
@@ -1496,10 +1428,7 @@ int rd_pack_conv3x3_weight_folded(const float* w, const float* row_scale, float*
 
 long long rd_pack_item_pieces(int kind, int cout, int cin, int with_f32) {
     if (cout <= 0 || cin <= 0) return 0;
-    if (kind == 0)
-        return rows32_of(cout) * nk16_of(9, cin) * 2 + rows32_of(cin) * nk16_of(9, cout) * 2 +
-               (wino_shape(cout, cin) ? 16 * rows32_of(cout) * nk16_of(1, cin) * 2 : 0) +
-               (wino_shape(cin, cout) ? 16 * rows32_of(cin) * nk16_of(1, cout) * 2 : 0);
+    if (kind == 0) return rows32_of(cout) * nk16_of(9, cin) * 2 + rows32_of(cin) * nk16_of(9, cout) * 2;
     return rows32_of(4L * cout) * nk16_of(1, cin) * 2 + rows32_of(cin) * nk16_of(4, cout) * 2 + (with_f32 ? (4L * cout * cin + 7) / 8 : 0);
 }
 

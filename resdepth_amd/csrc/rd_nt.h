@@ -36,9 +36,7 @@ struct NtParams {
     int Cout;  // EPI_CONVT: channels per (a,b) quadrant
     int chunks, nk, taps;
     int tiles_n;
-    int patch;  // 1 (halo kernel): tile rows are an 8x16-pixel patch (row r -> pixel m0 + (r >> 4) * W + (r & 15));
-                // 2 (Winograd kernel): row r = output position (i, j) = r >> 5 of Winograd tile (ty, tx) = r & 31 of the patch
-    const void* Bwino;  // Winograd operand U = G g G^T, split-bf16 fragments [16 positions][N/32][Cin/16][3][64 x 16 B]
+    int patch;  // halo kernel: tile rows are an 8x16-pixel patch (row r -> pixel m0 + (r >> 4) * W + (r & 15))
     int vec;  // epilogue may use 16-byte accesses (N % 4 == 0 and, for the transposed conv, Cout % 4 == 0)
     unsigned a_bytes, b_bytes;  // extents of the A / B tensors for the buffer descriptors
     float* stats;  // EPI_STORE only, nullable: per-(tile_m) column sums / sums of squares [tiles_m][2][N] (BN statistics)
@@ -82,13 +80,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
     // ---- epilogue.  D[i][j]: lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5).  The accumulators
     // are staged through LDS (EB 32-row blocks of one wave row-band per pass) so that HBM sees 16 B per lane and whole
     // contiguous rows per wave; bias / skip-add of the transposed convolution ride the same pass.
-    auto row_to_m = [&](int r) {
-        if (p.patch == 2) {
-            const int set = r >> 5, tile = r & 31;
-            return m0 + (2 * (tile >> 3) + (set >> 1)) * W + 2 * (tile & 7) + (set & 1);
-        }
-        return p.patch ? m0 + (r >> 4) * W + (r & 15) : m0 + r;
-    };
+    auto row_to_m = [&](int r) { return p.patch ? m0 + (r >> 4) * W + (r & 15) : m0 + r; };
     constexpr int CS = BN + 4, ROWS = EB * 32, Q = BN / 4, PPB = TM / EB;   // PPB passes per wave row-band
     static_assert(TM % EB == 0, "EB must divide TM");
     static_assert(ROWS * CS + 512 <= SMEM_WORDS, "epilogue staging (+ statistics scratch) must fit the operand buffers");
@@ -301,19 +293,5 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
         }
     }
 }
-
-// rd_wino.hip: Winograd F(2x2,3x3) variant of the 3x3 forward / data gradient (N % 128 == 0, Cin % 32 == 0, W % 16 == 0, H % 8 == 0).
-// Its operand U = G g G^T is packed behind the nine-tap split operand for every layer whose channel counts qualify.
-__host__ __device__ inline bool wino_shape(int n, int k) { return n % 128 == 0 && k % 32 == 0; }
-// element (r, c) of G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], g row-major 3x3
-__host__ __device__ inline float wino_u(const float (&g)[9], int r, int c) {
-    float t[3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-        t[b] = r == 0 ? g[b] : (r == 3 ? g[6 + b] : 0.5f * ((g[b] + (r == 1 ? g[3 + b] : -g[3 + b])) + g[6 + b]));
-    return c == 0 ? t[0] : (c == 3 ? t[2] : 0.5f * ((t[0] + (c == 1 ? t[1] : -t[1])) + t[2]));
-}
-bool wino_channels_ok(int n, int cin);
-int wino_launch(NtParams p, hipStream_t s);
 
 }  // namespace rd
