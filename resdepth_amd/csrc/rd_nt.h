@@ -1,5 +1,5 @@
 // NT-kernel parameter block and the epilogue shared by the implicit-GEMM kernels (rd_igemm.hip: exact-f32 / split / halo
-// kernels; rd_wino.hip: Winograd F(2x2,3x3) kernel) -- staging through LDS for 16-byte row-contiguous stores, fused BatchNorm
+// kernels) -- staging through LDS for 16-byte row-contiguous stores, fused BatchNorm
 // forward statistics, transposed-convolution scatter + bias + skip, inference shift / activation / pooling, BN-backward
 // statistics hook.
 #pragma once
