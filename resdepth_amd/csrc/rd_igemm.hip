@@ -722,7 +722,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
         if (halo_shape && (tiles_128x64 >= 512 || p.pool_out)) cfg = (p.N >= 128 && tiles_128x64 >= 1024) ? 0 : 1;   // 16x16 levels: 128x64 patches
         else if (p.M < 128 || tiles_128x64 < 1024) cfg = 2;
         else if (EPI == EPI_CONVT && p.K <= 256) cfg = 2;   // scatter epilogue dominates: small tiles keep more in flight
-        else if (p.N >= 128) cfg = 0;
+        else if (p.N >= 128) cfg = AMODE == A_UP2 ? 1 : 0;  // gathered operand (convT data gradient): 128x64 runs two waves per SIMD (0.130 -> 0.116 ms)
         else cfg = 1;
     } else {
         // Tile choice (measured per layer on MI355X, scripts/bench_layers.py): with the lean buffer-load loader the
@@ -1019,17 +1019,25 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
         const int rem = (int)(k_end - kbase);   // pixels of this K-step that exist (may be <= 0 past the end)
         int img0 = 0, y0 = 0, x0 = 0;
         if ((AMODE == WA_UP2 && isA) || (BMODE == WB_CONV3 && !isA)) pix_split((int)kbase + kq * 4, p.pd, img0, y0, x0);
+        // WA_UP2, image width a multiple of 4: the task's four coarse pixels are consecutive in one row, their fine-grid
+        // sources two pixels apart -- one address, then a constant stride
+        unsigned up_off0 = 0;
+        const unsigned up_step = (unsigned)(2 * p.lda * 4);
+        if (AMODE == WA_UP2 && isA && w4)
+            up_off0 = (unsigned)(((((long)img0 * (2 * H) + 2 * y0 + a_qa) * (2 * W) + 2 * x0 + a_qb) * p.lda + a_col) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = kq * 4 + j;
             const bool ok = col_ok && row < rem;
             if (isA) {
                 if (AMODE == WA_UP2) {
-                    const int m = (int)kbase + row;
-                    int jj = x0 + j, ii = y0, img = img0;
-                    if (!w4) pix_split(m, p.pd, img, ii, jj);
-                    const long src = ((long)img * (2 * H) + 2 * ii + a_qa) * (2 * W) + 2 * jj + a_qb;
-                    x[j] = buf_load4(rsA, ok ? (unsigned)((src * p.lda + a_col) * 4) : kOOB, 0);
+                    unsigned off = up_off0 + j * up_step;
+                    if (!w4) {
+                        int jj, ii, img;
+                        pix_split((int)kbase + row, p.pd, img, ii, jj);
+                        off = (unsigned)(((((long)img * (2 * H) + 2 * ii + a_qa) * (2 * W) + 2 * jj + a_qb) * p.lda + a_col) * 4);
+                    }
+                    x[j] = buf_load4(rsA, ok ? off : kOOB, 0);
                 } else {
                     x[j] = buf_load4(rsA, ok ? (unsigned)((row * p.lda + a_col) * 4) : kOOB, (unsigned)(kbase * p.lda * 4));
                 }
