@@ -1,0 +1,133 @@
+"""One rank of a world-size-N run of the HIP engine with TWO (or more) PROCESSES SHARING cuda:0 -- the only way
+to execute resdepth_amd's data-parallel path at world size > 1 on a one-GPU box (RCCL refuses duplicate devices).
+torch.distributed backend: gloo; device-tensor collectives either natively (if this torch build's gloo takes them)
+or through tests/host_staged_collectives.py (same stream semantics as RCCL).  Driven by tests/test_dp_world2_gpu.py.
+
+modes:
+  probe  -- one tiny device all-reduce through the chosen collectives (exit 0 = works)
+  train  -- cfg-S architecture, global batch B cut into contiguous shards (dp.shard_batch), dp.attach (+/- SyncBN),
+            two-stream backward, FusedAdam, K steps; rank != 0 starts from DIFFERENT weights and adopts rank 0's through
+            dp.broadcast_parameters.  Writes losses, step-0 gradients (after the all-reduce), final parameters + buffers.
+  infer  -- cfg-G: predict_linear_blend over this rank's tile shard, rasters summed on rank 0 (torch.distributed.reduce)
+"""
+import argparse
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+CFG_S = dict(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True)
+
+
+def make_batch(n, step, t=256, c=3):
+    """Global batch of step `step`: per-sample dsm_std varies so that a wrong shard <-> std pairing shows."""
+    from resdepth_amd import synthetic_batch
+    b = synthetic_batch(n, c, t, seed=4000 + step)
+    b["dsm_std"] = torch.linspace(0.5, 3.0, n)
+    return b
+
+
+def make_infer_model(dev):
+    from resdepth_amd import UNet
+    torch.manual_seed(11)
+    model = UNet(**CFG_S)
+    sd = model.state_dict()
+    g = torch.Generator().manual_seed(12)
+    for k in [k for k in sd if k.endswith("running_mean")]:
+        pre = k[:-len("running_mean")]
+        sd[k] = torch.randn(sd[k].shape, generator=g) * 0.2
+        sd[pre + "running_var"] = torch.rand(sd[k].shape, generator=g) * 0.8 + 0.4
+    model.load_state_dict(sd)
+    return model.to(dev).eval()
+
+
+INFER_RASTER = dict(rows=640, cols=900, areas=[((0, 559), (0, 383)), ((300, 899), (200, 639))])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="train")
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, default=2)
+    ap.add_argument("--port", type=int, required=True)
+    ap.add_argument("--coll", default="staged", choices=["native", "staged"])
+    ap.add_argument("--sync-bn", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--tile", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--bucket-mb", type=int, default=16)
+    ap.add_argument("--serial-backward", type=int, default=0)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(a.port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
+    try:
+        if a.coll == "staged":
+            import host_staged_collectives
+            host_staged_collectives.install()
+        if a.mode == "probe":
+            t = torch.full((1 << 20,), float(a.rank + 1), device=dev)
+            h = dist.all_reduce(t, async_op=True)
+            h.wait()
+            torch.cuda.synchronize()
+            want = a.world * (a.world + 1) / 2
+            assert float(t[0]) == want and float(t[-1]) == want, (float(t[0]), want)
+            r = torch.full((8,), float(a.rank + 1), device=dev, dtype=torch.float64)
+            dist.reduce(r, dst=0)
+            torch.cuda.synchronize()
+            assert a.rank != 0 or float(r[0]) == want
+            torch.save({"ok": True}, a.out)
+            return
+        from resdepth_amd import UNet, FusedAdam, masked_l1_loss, dp
+        if a.mode == "train":
+            torch.manual_seed(100 + a.rank)              # rank 0's seed-100 weights win through the broadcast
+            model = UNet(**CFG_S).to(dev).train()
+            model.two_stream_backward = not a.serial_backward
+            gs = dp.attach(model, sync_bn=bool(a.sync_bn), bucket_bytes=a.bucket_mb << 20)
+            dp.broadcast_parameters(model, 0)
+            opt = FusedAdam(model.parameters(), lr=2e-4, weight_decay=1e-5)
+            losses, grads0, bufs0 = [], None, None
+            n_buckets = None
+            for step in range(a.steps):
+                local = dp.shard_batch(make_batch(a.batch, step, a.tile), a.rank, a.world)
+                y = model(local["input"].to(dev))
+                loss = masked_l1_loss(y, local["target"], local["loss_mask"], local["dsm_mean"], local["dsm_std"], grad_sync=gs)
+                loss.backward()
+                if step == 0:
+                    grads0 = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+                    bufs0 = {k: v.detach().cpu().clone() for k, v in model.named_buffers()}
+                    n_buckets = len(gs._buckets)
+                opt.step()
+                for p in model.parameters():
+                    p.grad = None
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            torch.save({"losses": losses, "grads0": grads0, "bufs0": bufs0, "n_buckets": n_buckets,
+                        "state": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}, a.out)
+        elif a.mode == "infer":
+            from torch.utils.data import DataLoader
+            from resdepth_amd import SyntheticRasterTiles, predict_linear_blend
+            model = make_infer_model(dev)
+            ds = SyntheticRasterTiles(INFER_RASTER["rows"], INFER_RASTER["cols"], 3, tile_size=256, seed=5,
+                                      areas=INFER_RASTER["areas"], shard=(a.rank, a.world))
+            out = predict_linear_blend(DataLoader(ds, batch_size=5, shuffle=False), model)      # reduce_to_rank0 default
+            torch.save({"raster": torch.from_numpy(out.copy()), "n_tiles": len(ds)}, a.out)
+        else:
+            raise SystemExit(f"unknown mode {a.mode}")
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,12 +99,14 @@ def test_predict_linear_blend_full_architecture_multi_area():
     out = predict_linear_blend(DataLoader(ds, batch_size=5, shuffle=False), model)
     ref = np.zeros((rows, cols))
     torch.set_num_threads(min(16, torch.get_num_threads()))
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}     # fp64 oracle: no noise of its own
     for i in range(len(ds)):
         smp = ds[i]
         with torch.no_grad():
-            yp = O.forward(dict(sd), smp["input"][None], spec, training=False)
+            yp = O.forward(dict(sd64), smp["input"][None].double(), spec, training=False)
         B.accumulate(ref, yp.numpy(), [float(smp["dsm_mean"])], [float(smp["dsm_std"])], [ds.pos[i]], [ds.reg[i]], 256, 128)
-    # metres: forward noise (~1e-5 normalised at this depth) x std 3 x blend weights (each area is a partition of unity)
-    assert np.abs(out - ref).max() <= 3e-4, np.abs(out - ref).max()
+    # north_star: <= 1e-4 residual-height deviation, in metres (forward noise ~1e-5 normalised x std 3; where the two
+    # areas overlap the raster holds the sum of two partitions of unity)
+    assert np.abs(out - ref).max() <= 1e-4, np.abs(out - ref).max()
     again = predict_linear_blend(DataLoader(ds, batch_size=32, shuffle=False), model)
     assert np.abs(out - again).max() <= 1e-9                 # one full batch == ragged batches (tiles independent in eval)

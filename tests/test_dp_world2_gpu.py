@@ -1,0 +1,274 @@
+"""The HIP engine at WORLD SIZE 2 on one GPU (-m gpu): two processes share cuda:0, torch.distributed over gloo
+(device tensors natively where the build's gloo takes them, and always through the host-staged shim of
+tests/host_staged_collectives.py, which keeps RCCL's stream semantics).  What world size 1 cannot show -- a wrong
+`count * world`, a mis-scaled loss normaliser, a bucket launched before its side-stream producer, the SyncBN `sums`
+slicing, parameter broadcast -- shows here:
+
+  * SyncBN on : global batch 8 as 4 + 4 == ONE process at batch 8 (loss, every gradient, BN buffers, weights after 2 steps)
+  * SyncBN off: == the sum of the two shards' local-BN gradients under the global normaliser (HIP, one process, tight)
+                and == the ORACLE's local-BN data-parallel result (lib/Trainer.py:98 with the global count)
+  * cfg-G     : rasters of tile shards (0,2) + (1,2) == the unsharded raster, in one process and through the
+                2-process torch.distributed.reduce (lib/evaluation.py:510-511)
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "dp_world2_worker.py")
+# Gradients of a 4 + 4 run against one process at 8 tiles.  The arithmetic differs only in summation grouping (per-rank
+# split-K slabs, then the all-reduce; BN statistics from fp64 sums added in a different order): 2e-5-class differences.
+# But the forward values then differ in their last bits, so now and then ONE discrete decision (a ReLU at ~0, a pool tie,
+# sign(p - t) of an L1 pixel at rounding level) falls the other way, which moves every gradient upstream of it by 1e-4..1e-3
+# rel-L2 (measured over repeated runs: 2.2e-5 .. 1.6e-4; DESIGN.md section 4 "identical decisions").  The HIP engine cannot
+# take imposed decisions, so the bar is SURVEY 8c's free-running gradient bar.  What this test is after -- x world, / world,
+# a missed or stale bucket, wrong SyncBN slices -- is O(1) on the tensors it touches.
+GRAD_TOL = 1e-3
+sys.path.insert(0, HERE)
+import dp_world2_worker as W  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def run_world(tmp_path, mode, world=2, timeout=600, **kw):
+    """Launch `world` worker processes on cuda:0; -> list of their saved outputs (raises with the workers' stderr)."""
+    port = _free_port()
+    outs = [str(tmp_path / f"{mode}_{kw.get('coll', 'staged')}_{kw.get('sync_bn', 0)}_r{r}.pt") for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(world):
+        cmd = [sys.executable, WORKER, "--mode", mode, "--rank", str(r), "--world", str(world), "--port", str(port),
+               "--out", outs[r]]
+        for k, v in kw.items():
+            cmd += ["--" + k.replace("_", "-"), str(v)]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    errs, failed = [], False
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()                      # exactly the PIDs started above
+            _, err = p.communicate()
+            err = "TIMEOUT\n" + (err or "")
+            failed = True
+        errs.append(err)
+        failed = failed or p.returncode != 0
+    if failed:
+        raise RuntimeError("\n----\n".join(e[-3000:] for e in errs))
+    return [torch.load(o, weights_only=False) for o in outs]
+
+
+_NATIVE = {}
+
+
+def _collectives(tmp_path, coll):
+    """'staged' always works; 'native' (gloo on device tensors) is probed once per session with a short timeout."""
+    if coll == "staged":
+        return
+    if "ok" not in _NATIVE:
+        try:
+            run_world(tmp_path, "probe", timeout=180, coll="native")
+            _NATIVE["ok"] = True
+        except RuntimeError as e:
+            _NATIVE["ok"], _NATIVE["why"] = False, str(e)[-300:]
+    if not _NATIVE["ok"]:
+        pytest.skip("this torch build's gloo backend does not take device tensors: " + _NATIVE.get("why", ""))
+
+
+def test_host_staged_collectives_probe(tmp_path):
+    run_world(tmp_path, "probe", timeout=180, coll="staged")
+
+
+def _single_process(batch, steps, tile=256):
+    """ONE process, whole batch, no data-parallel hooks: the reference semantics (lib/Trainer.py:159-222)."""
+    from resdepth_amd import UNet, FusedAdam, masked_l1_loss
+    torch.manual_seed(100)
+    model = UNet(**W.CFG_S).to(DEV).train()
+    opt = FusedAdam(model.parameters(), lr=2e-4, weight_decay=1e-5)
+    losses, grads0, bufs0 = [], None, None
+    for step in range(steps):
+        b = W.make_batch(batch, step, tile)
+        y = model(b["input"].to(DEV))
+        loss = masked_l1_loss(y, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
+        loss.backward()
+        if step == 0:
+            grads0 = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+            bufs0 = {k: v.detach().cpu().clone() for k, v in model.named_buffers()}
+        opt.step()
+        for p in model.parameters():
+            p.grad = None
+        losses.append(float(loss))
+    return {"losses": losses, "grads0": grads0, "bufs0": bufs0,
+            "state": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}
+
+
+@pytest.mark.parametrize("coll", ["staged", "native"])
+@pytest.mark.parametrize("serial", [0, 1])
+def test_world2_syncbn_equals_one_process_at_the_global_batch(tmp_path, coll, serial):
+    """cfg-S architecture, global batch 8 = 4 + 4, SyncBN on, two-stream (serial=0) / serial backward, 16 MB buckets
+    launched from the weight-gradient stream, FusedAdam, 2 steps -- against ONE process at batch 8."""
+    if serial and coll == "native":
+        pytest.skip("covered by the staged run")
+    _collectives(tmp_path, coll)
+    outs = run_world(tmp_path, "train", coll=coll, sync_bn=1, batch=8, steps=2, serial_backward=serial)
+    ref = _single_process(8, 2)
+    assert outs[0]["n_buckets"] >= 3                      # 50.5 MB of gradients in 16 MB buckets
+    for r, o in enumerate(outs):
+        for s in range(2):
+            assert abs(o["losses"][s] - ref["losses"][s]) <= 1e-6 * abs(ref["losses"][s]), (r, s, o["losses"], ref["losses"])
+        for k, g in ref["grads0"].items():
+            e = rel_l2(o["grads0"][k], g)
+            assert e <= GRAD_TOL, (r, k, e)
+        for k, v in ref["bufs0"].items():
+            if v.dtype.is_floating_point:
+                assert rel_l2(o["bufs0"][k], v) <= 1e-5, (r, k)
+            else:
+                assert torch.equal(o["bufs0"][k], v), (r, k)
+        for k, v in ref["state"].items():
+            if v.dtype.is_floating_point:
+                assert rel_l2(o["state"][k], v) <= 1e-5, (r, k, rel_l2(o["state"][k], v))
+    # the all-reduced gradients and the weights after two steps are the SAME BITS on both ranks
+    for k in outs[0]["grads0"]:
+        assert torch.equal(outs[0]["grads0"][k], outs[1]["grads0"][k]), k
+    for k, v in outs[0]["state"].items():
+        if "running_" not in k and "num_batches" not in k:
+            assert torch.equal(v, outs[1]["state"][k]), k
+
+
+class _OtherShard:
+    """grad_sync stand-in for ONE process replaying a rank: adds the other shard's (sum |d|, #valid) to the loss
+    normaliser exactly where GradSync.allreduce_loss_sums would (resdepth_amd/loss.py)."""
+
+    def __init__(self, other, world):
+        self.other, self.world = other, world
+
+    def allreduce_loss_sums(self, sums, numel):
+        sums += self.other
+        return numel * self.world
+
+
+def _local_bn_dp_in_one_process(batch, tile=256):
+    """The data-parallel result WITHOUT SyncBN, replayed in one process on the HIP engine: every shard runs with its own
+    batch statistics, the loss normaliser is global, the gradients add up.  -> (loss, gradient dict, per-rank buffers)"""
+    from resdepth_amd import UNet, masked_l1_loss, ops, dp
+    from resdepth_amd.loss import _prep
+    torch.manual_seed(100)
+    model = UNet(**W.CFG_S).to(DEV).train()
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    full = W.make_batch(batch, 0, tile)
+    shards = [dp.shard_batch(full, r, 2) for r in range(2)]
+    sums = []
+    for sh in shards:                                   # pass 1: every shard's partial loss sums
+        model.load_state_dict(sd0)
+        with torch.no_grad():
+            y = model(sh["input"].to(DEV))
+            sums.append(ops.masked_l1_partial(*_prep(y, sh["target"], sh["loss_mask"], sh["dsm_mean"], sh["dsm_std"])).clone())
+    total, bufs, loss = None, [], None
+    for r, sh in enumerate(shards):                     # pass 2: gradients under the global normaliser
+        model.load_state_dict(sd0)
+        y = model(sh["input"].to(DEV))
+        loss = masked_l1_loss(y, sh["target"], sh["loss_mask"], sh["dsm_mean"], sh["dsm_std"],
+                              grad_sync=_OtherShard(sums[1 - r], 2))
+        loss.backward()
+        g = {k: p.grad.detach().double().cpu() for k, p in model.named_parameters()}
+        total = g if total is None else {k: total[k] + g[k] for k in g}
+        bufs.append({k: v.detach().cpu().clone() for k, v in model.named_buffers()})
+        for p in model.parameters():
+            p.grad = None
+    return float(loss), total, bufs, {k: v.cpu() for k, v in sd0.items()}, full, shards
+
+
+def test_world2_local_bn_equals_the_shard_sum_and_the_oracle(tmp_path):
+    """SyncBN off (plain DDP semantics): every rank normalises with its own shard's statistics."""
+    outs = run_world(tmp_path, "train", coll="staged", sync_bn=0, batch=8, steps=1)
+    loss, total, bufs, sd0, full, shards = _local_bn_dp_in_one_process(8)
+    for r, o in enumerate(outs):
+        assert abs(o["losses"][0] - loss) <= 1e-6 * abs(loss), (r, o["losses"], loss)
+        for k, g in total.items():
+            e = rel_l2(o["grads0"][k], g)
+            assert e <= GRAD_TOL, (r, k, e)
+        for k, v in bufs[r].items():                    # running statistics are per rank (its own shard)
+            if v.dtype.is_floating_point:
+                assert rel_l2(o["bufs0"][k], v) <= 1e-6, (r, k)
+    # ... and against the oracle (fp32 torch-CPU, its own discrete decisions: the 1e-3 gradient contract of SURVEY 8c)
+    spec = O.Spec(**W.CFG_S)
+    keys = O.param_keys(spec)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    cnt = full["loss_mask"].sum().float()
+    ref, num_tot = None, 0.0
+    for r, sh in enumerate(shards):
+        work = {k: v.clone() for k, v in sd0.items()}
+        leaves = {k: work[k].requires_grad_(True) for k in keys}
+        yp = O.forward(work, sh["input"], spec, training=True)
+        mean, std = sh["dsm_mean"].float().view(-1, 1, 1, 1), sh["dsm_std"].view(-1, 1, 1, 1)
+        d = ((yp * std + mean) - (sh["target"] * std + mean)) * sh["loss_mask"]
+        num = d.abs().sum()
+        g = torch.autograd.grad(num / cnt, [leaves[k] for k in keys])
+        ref = [x.double() for x in g] if ref is None else [a + x.double() for a, x in zip(ref, g)]
+        num_tot += float(num.double())
+        for k, v in outs[r]["bufs0"].items():           # per-rank running statistics == the oracle's on that shard
+            if v.dtype.is_floating_point:
+                assert rel_l2(v, work[k].detach()) <= 1e-5, (r, k, rel_l2(v, work[k].detach()))
+    ref_loss = num_tot / float(cnt)
+    assert abs(outs[0]["losses"][0] - ref_loss) <= 1e-5 * abs(ref_loss), (outs[0]["losses"], ref_loss)
+    for k, g in zip(keys, ref):
+        e = rel_l2(outs[0]["grads0"][k], g)
+        assert e <= 1e-3, (k, e)
+
+
+def test_world2_small_buckets_and_four_ranks(tmp_path):
+    """4 ranks on the one GPU (2 tiles each), 2 MB buckets (9 collectives issued while the backward still runs),
+    SyncBN on: same answer as one process at batch 8."""
+    outs = run_world(tmp_path, "train", world=4, coll="staged", sync_bn=1, batch=8, steps=1, bucket_mb=2, timeout=900)
+    ref = _single_process(8, 1)
+    assert outs[0]["n_buckets"] >= 8                       # three 9.4 MB conv weights are buckets of their own
+    for r, o in enumerate(outs):
+        assert abs(o["losses"][0] - ref["losses"][0]) <= 1e-6 * abs(ref["losses"][0])
+        for k, g in ref["grads0"].items():
+            e = rel_l2(o["grads0"][k], g)
+            assert e <= GRAD_TOL, (r, k, e)
+
+
+def test_cfg_g_tile_shards_sum_to_the_unsharded_raster(tmp_path):
+    """cfg-G's multi-rank leg (BASELINE.json configs[4]): every rank sweeps every world-th tile into a private raster,
+    rank 0 receives the sum (lib/evaluation.py:460-513 runs the whole list on one device)."""
+    from torch.utils.data import DataLoader
+    from resdepth_amd import SyntheticRasterTiles, predict_linear_blend
+    model = W.make_infer_model(torch.device(DEV))
+    R = W.INFER_RASTER
+
+    def sweep(shard):
+        ds = SyntheticRasterTiles(R["rows"], R["cols"], 3, tile_size=256, seed=5, areas=R["areas"], shard=shard)
+        return predict_linear_blend(DataLoader(ds, batch_size=5, shuffle=False), model, reduce_to_rank0=False), len(ds)
+
+    full, n = sweep((0, 1))
+    a, na = sweep((0, 2))
+    b, nb = sweep((1, 2))
+    assert na + nb == n and na > 0 and nb > 0
+    assert np.abs(a + b - full).max() <= 1e-9, np.abs(a + b - full).max()
+    outs = run_world(tmp_path, "infer", coll="staged")
+    assert outs[0]["n_tiles"] == na and outs[1]["n_tiles"] == nb
+    got = outs[0]["raster"].numpy()
+    assert np.abs(got - full).max() <= 1e-9, np.abs(got - full).max()
+    assert np.abs(outs[1]["raster"].numpy() - b).max() <= 1e-9       # a non-destination rank keeps its own partial raster

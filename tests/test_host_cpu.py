@@ -80,3 +80,16 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_shipped_code_objects_hold_no_packed_f32_valu_and_no_spills():
+    """csrc/build.sh builds every translation unit with -fno-slp-vectorize: r02 traced a data corruption of the
+    two-stream backward to `v_pk_fma_f32 ... op_sel` fed by ds_read2_b32 under co-execution (no root cause), so the
+    instruction must not come back through a compiler / flag change in ANY kernel.  scripts/check_isa.sh disassembles the
+    built library (llvm-objdump, no GPU needed)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from resdepth_amd import _lib
+    r = subprocess.run(["bash", os.path.join(root, "scripts", "check_isa.sh"), _lib.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "packed-f32 VALU 0, scratch 0" in r.stdout

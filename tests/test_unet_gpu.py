@@ -8,6 +8,7 @@ units), loss rel 1e-5, gradients rel-L2 <= 1e-3 per tensor (sign() in the L1 gra
 element-wise checks), BN running stats rel 1e-5, weights after k Adam steps rel-L2 <= 1e-4.
 """
 import json
+import os
 
 import numpy as np
 import pytest
@@ -151,7 +152,7 @@ def test_full_size_against_oracle_and_reference_digest():
     go = torch.autograd.grad(lo, list(leaves.values()))
     assert float((ypc - yo.detach()).abs().max()) <= 1e-4
     dev_m = float(((ypc - yo.detach()).abs() * std.view(-1, 1, 1, 1)).max())
-    assert dev_m <= 3e-4, f"residual-height deviation {dev_m} m"
+    assert dev_m <= 1e-4, f"residual-height deviation {dev_m} m"      # north_star: <= 1e-4 m
     # ReLU masks / pool arg-max are discrete: ONE flipped decision in a 10^6-element layer moves the rel-L2 of
     # everything upstream by ~1e-3 (measured: 0-1 flips per layer between this path and torch-CPU; torch fp32 vs
     # fp64 shows the same jumps).  So (a) the decisions themselves must agree up to a vanishing fraction, and
@@ -456,9 +457,73 @@ def test_data_parallel_code_path_on_rccl_world1():
         assert o["loss_first_last"] == plain["loss_first_last"], (o["loss_first_last"], plain["loss_first_last"])
 
 
+def _hip_decisions(model, x_dev, spec):
+    """The HIP path's own discrete decisions on input x (ReLU / PReLU branch masks, pool arg-max as flat H*W indices, NCHW,
+    cropped to the model's real channels when it runs on its zero-padded twin) in the form oracle.forward(decisions=) takes.
+    Runs one more training-mode engine forward; the BN buffers are restored afterwards."""
+    eng, xin = model, x_dev
+    if model._needs_twin():
+        eng = model._twin_load()
+        xin = model._pad_input(x_dev, eng)
+    with torch.no_grad():
+        bufs = [(v, v.clone()) for v in eng.buffers()]
+        _, S = eng._engine_forward(xin.detach(), True, save=True, keep_skips=True)
+        for v, old in bufs:                  # the probe must not advance the running statistics a second time
+            v.copy_(old)
+    fd = spec.filter_depths()
+    nchw = lambda t, c: t.permute(0, 3, 1, 2)[:, :c].contiguous().cpu()
+    dec = {}
+    for i, e in enumerate(S["enc"]):
+        pos = nchw(e["idx"], fd[i]).long()
+        H2, W2 = pos.shape[2], pos.shape[3]
+        ii = torch.arange(H2).view(1, 1, H2, 1)
+        jj = torch.arange(W2).view(1, 1, 1, W2)
+        dec[f"mask_e{i}"] = nchw(e["a"], fd[i]) > 0
+        dec[f"idx{i}"] = (2 * ii + pos // 2) * (2 * W2) + 2 * jj + pos % 2
+    dec["mask_b"] = nchw(S["bott"]["a"], fd[-1]) > 0
+    up = list(reversed(fd))
+    for i in range(spec.depth - 1):
+        dec[f"mask_d{i}"] = nchw(S["dec"][i]["a"], up[i + 1]) > 0
+    return dec
+
+
+def _oracle_fp64_under_hip_decisions(model, sd0, spec, x, y, mask, mean, std, yp, want_dx=False):
+    """fp64 oracle forward / loss / gradients with the HIP path's discrete decisions imposed (masks, arg-max, and the
+    sign(p - t) of the L1 loss evaluated with the kernel's own fp32 de-normalisation, lib/data_normalization.py:29-38),
+    after checking that those decisions differ from the oracle's OWN in at most a vanishing fraction of the places.
+    -> (y_oracle, loss_oracle, [parameter gradients in O.param_keys order (+ d loss / d x)], work state dict)"""
+    dec = _hip_decisions(model, x.to(DEV), spec)
+    keep = {}
+    with torch.no_grad():
+        O.forward({k: v.clone() for k, v in sd0.items()}, x, spec, training=True, update_running=False, keep=keep)
+    own = {f"mask_e{i}": keep[f"a{i}"] > 0 for i in range(spec.depth)}
+    own.update({f"idx{i}": keep[f"idx{i}"] for i in range(spec.depth)})
+    own["mask_b"] = keep["ab"] > 0
+    own.update({f"mask_d{i}": keep[f"ad{i}"] > 0 for i in range(spec.depth - 1)})
+    flips = sum(int((dec[k] != own[k]).sum()) for k in dec)
+    total = sum(v.numel() for v in dec.values())
+    assert flips <= max(2, 1e-5 * total), (flips, total)
+    leaves = {k: sd0[k].double().requires_grad_(True) for k in O.param_keys(spec)}
+    work = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    work.update(leaves)
+    xo = x.double().requires_grad_(want_dx)
+    yo = O.forward(work, xo, spec, training=True, decisions=dec)
+    s32 = torch.tensor(torch.as_tensor(std).flatten().tolist(), dtype=torch.float32).view(-1, 1, 1, 1)
+    m32 = torch.tensor(torch.as_tensor(mean).flatten().tolist(), dtype=torch.float32).view(-1, 1, 1, 1)
+    ypc = yp.detach().cpu()
+    sg = torch.sign((ypc * s32 + m32) - (y * s32 + m32)) * mask
+    sg_or = torch.sign((yo.detach().float() * s32 + m32) - (y * s32 + m32)) * mask
+    assert int((sg != sg_or).sum()) <= max(2, 2e-6 * sg.numel()), int((sg != sg_or).sum())
+    lo = O.masked_l1_loss(yo, y.double(), mask, mean, std, sign=sg)
+    go = torch.autograd.grad(lo, list(leaves.values()) + ([xo] if want_dx else []))
+    return yo.detach(), float(lo), go, work
+
+
 @pytest.mark.parametrize("name,kw,n,t", [
     ("cfg-0 (config_ResDepth-0: DSM only, batch 4)", dict(n_input_channels=1, start_kernel=64, depth=5, bias_conv_layer=True), 4, 256),
     ("cfg-M (config_ResDepth-mono: 2-ch 512x512, depth 6)", dict(n_input_channels=2, start_kernel=64, depth=6, bias_conv_layer=True), 1, 512),
+    # ... and at batch 4: BN statistics over several 512^2 tiles, multi-strip weight-gradient schedules at 512^2
+    ("cfg-M (config_ResDepth-mono) at batch 4", dict(n_input_channels=2, start_kernel=64, depth=6, bias_conv_layer=True), 4, 512),
     # BASELINE.json configs[1] at its FULL batch: BN statistics over 32 tiles, the >=512-block strip weight-gradient
     # schedules with several strips per block, the <128> halo kernel on every big layer, fused single-launch reductions
     ("cfg-S (config_ResDepth-stereo: 3-ch 256x256, depth 5) at batch 32", dict(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True), 32, 256),
@@ -477,37 +542,13 @@ def test_other_baseline_configs_against_oracle(name, kw, n, t):
     loss = masked_l1_loss(yp, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
     loss.backward()
     sd1 = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    with torch.no_grad():
-        _, S = model._engine_forward(b["input"].to(DEV), True, save=True, keep_skips=True)
-    nchw = lambda x: x.permute(0, 3, 1, 2).contiguous().cpu()
-    dec = {}
-    for i, e in enumerate(S["enc"]):
-        pos = nchw(e["idx"]).long()
-        H2, W2 = pos.shape[2], pos.shape[3]
-        ii = torch.arange(H2).view(1, 1, H2, 1)
-        jj = torch.arange(W2).view(1, 1, 1, W2)
-        dec[f"mask_e{i}"] = nchw(e["a"]) > 0
-        dec[f"idx{i}"] = (2 * ii + pos // 2) * (2 * W2) + 2 * jj + pos % 2
-    dec["mask_b"] = nchw(S["bott"]["a"]) > 0
-    for i in range(spec.depth - 1):
-        dec[f"mask_d{i}"] = nchw(S["dec"][i]["a"]) > 0
-    leaves = {k: sd0[k].double().requires_grad_(True) for k in O.param_keys(spec)}          # fp64 oracle
-    work = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
-    work.update(leaves)
-    yo = O.forward(work, b["input"].double(), spec, training=True, decisions=dec)
-    # the L1 loss is one more discrete decision per pixel: sign(p - t), taken from the HIP path's own prediction with the
-    # kernel's arithmetic (de-normalise with two fp32 roundings, lib/data_normalization.py:29-38).  It must agree with the
-    # oracle's own sign on all but a vanishing fraction of the pixels.
-    s32 = torch.tensor(b["dsm_std"].tolist(), dtype=torch.float32).view(-1, 1, 1, 1)
-    m32 = torch.tensor(b["dsm_mean"].tolist(), dtype=torch.float32).view(-1, 1, 1, 1)
-    ypc = yp.detach().cpu()
-    sg = torch.sign((ypc * s32 + m32) - (b["target"] * s32 + m32)) * b["loss_mask"]
-    sg_or = torch.sign((yo.detach().float() * s32 + m32) - (b["target"] * s32 + m32)) * b["loss_mask"]
-    assert int((sg != sg_or).sum()) <= max(2, 2e-6 * sg.numel()), (name, int((sg != sg_or).sum()))
-    lo = O.masked_l1_loss(yo, b["target"].double(), b["loss_mask"], b["dsm_mean"], b["dsm_std"], sign=sg)
-    go = torch.autograd.grad(lo, list(leaves.values()))
-    assert float((yp.detach().cpu().double() - yo.detach()).abs().max()) <= 1e-4, name
-    assert abs(float(loss) - float(lo)) <= 1e-5 * abs(float(lo)), name
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    yo, lo, go, work = _oracle_fp64_under_hip_decisions(model, sd0, spec, b["input"], b["target"], b["loss_mask"],
+                                                        b["dsm_mean"], b["dsm_std"], yp)
+    assert float((yp.detach().cpu().double() - yo).abs().max()) <= 1e-4, name
+    dev_m = float(((yp.detach().cpu().double() - yo).abs() * b["dsm_std"].double().view(-1, 1, 1, 1)).max())
+    assert dev_m <= 1e-4, f"{name}: residual-height deviation {dev_m} m"        # north_star: <= 1e-4 m
+    assert abs(float(loss) - lo) <= 1e-5 * abs(lo), name
     for (k, p), gr in zip(model.named_parameters(), go):
         assert rel_l2(p.grad, gr) <= 1e-4, (name, k, rel_l2(p.grad, gr))
     for k in sd1:
@@ -538,18 +579,16 @@ def test_edge_shapes_against_oracle(n, t, kw):
     loss = masked_l1_loss(yp, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
     loss.backward()
     sd1 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    leaves = {k: sd0[k].clone().requires_grad_(True) for k in O.param_keys(spec)}
-    work = {k: v.clone() for k, v in sd0.items()}
-    work.update(leaves)
-    xo = b["input"].clone().requires_grad_(True)
-    yo = O.forward(work, xo, spec, training=True)
-    lo = O.masked_l1_loss(yo, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
-    go = torch.autograd.grad(lo, list(leaves.values()) + [xo])
-    assert float((yp.detach().cpu() - yo.detach()).abs().max()) <= 1e-4
-    assert abs(float(loss) - float(lo)) <= 1e-5 * abs(float(lo))
+    # gradients under the HIP path's own discrete decisions (ReLU masks, arg-max, L1 sign) against the fp64 oracle: the
+    # contract bar of SURVEY 8c (rel-L2 <= 1e-3) without the flipped-decision jumps a free-running comparison shows
+    yo, lo, go, work = _oracle_fp64_under_hip_decisions(model, sd0, spec, b["input"], b["target"], b["loss_mask"],
+                                                        b["dsm_mean"], b["dsm_std"], yp, want_dx=True)
+    assert float((yp.detach().cpu().double() - yo).abs().max()) <= 1e-4
+    assert abs(float(loss) - lo) <= 1e-5 * abs(lo)
     for (k, p), gr in zip(model.named_parameters(), go):
-        assert tuple(p.grad.shape) == tuple(gr.shape) and rel_l2(p.grad, gr) <= 2e-3, (k, rel_l2(p.grad, gr))
-    assert tuple(x_in.grad.shape) == tuple(xo.shape) and rel_l2(x_in.grad, go[-1]) <= 2e-3, rel_l2(x_in.grad, go[-1])
+        assert tuple(p.grad.shape) == tuple(gr.shape) and rel_l2(p.grad, gr) <= 1e-3, (k, rel_l2(p.grad, gr))
+    assert tuple(x_in.grad.shape) == tuple(go[-1].shape) and rel_l2(x_in.grad, go[-1]) <= 1e-3, rel_l2(x_in.grad, go[-1])
+    work = {k: (v.detach().float() if v.is_floating_point() else v) for k, v in work.items()}
     for k, v in sd1.items():             # running statistics of the training-mode forward (also through the padded twin)
         if "running" in k:
             np.testing.assert_allclose(v.numpy(), work[k].detach().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
@@ -587,19 +626,14 @@ def test_tiles_that_are_not_square_powers_of_two_against_oracle(n, th, tw, kw):
     loss = masked_l1_loss(yp, y, mask, mean, std)
     loss.backward()
     sd1 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    leaves = {k: sd0[k].clone().requires_grad_(True) for k in O.param_keys(spec)}
-    work = {k: v.clone() for k, v in sd0.items()}
-    work.update(leaves)
-    xo = x.clone().requires_grad_(True)
-    yo = O.forward(work, xo, spec, training=True)
-    lo = O.masked_l1_loss(yo, y, mask, mean, std)
-    go = torch.autograd.grad(lo, list(leaves.values()) + [xo])
+    yo, lo, go, work = _oracle_fp64_under_hip_decisions(model, sd0, spec, x, y, mask, mean, std, yp, want_dx=True)
     assert tuple(yp.shape) == (n, 1, th, tw)
-    assert float((yp.detach().cpu() - yo.detach()).abs().max()) <= 1e-4
-    assert abs(float(loss.detach()) - float(lo)) <= 1e-5 * abs(float(lo))
+    assert float((yp.detach().cpu().double() - yo).abs().max()) <= 1e-4
+    assert abs(float(loss.detach()) - lo) <= 1e-5 * abs(lo)
     for (k, p), gr in zip(model.named_parameters(), go):
-        assert rel_l2(p.grad, gr) <= 2e-3, (k, rel_l2(p.grad, gr))
-    assert rel_l2(x_in.grad, go[-1]) <= 2e-3
+        assert rel_l2(p.grad, gr) <= 1e-3, (k, rel_l2(p.grad, gr))           # SURVEY 8c bar, identical decisions
+    assert rel_l2(x_in.grad, go[-1]) <= 1e-3
+    work = {k: (v.detach().float() if v.is_floating_point() else v) for k, v in work.items()}
     for k, v in sd1.items():
         if "running" in k:
             np.testing.assert_allclose(v.numpy(), work[k].detach().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
