@@ -16,6 +16,7 @@
 // K-steps, one barrier per 16-channel step, weights straight from global memory in fragment order).
 #include "rd_common.h"
 #include "rd_mfma_dev.h"
+#include "rd_nt.h"
 
 namespace rd {
 
@@ -220,6 +221,185 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
         }
         __syncthreads();
     }
+}
+
+// ---- data gradient:  dx[p][ci] = sum_{a,b,co} dout[2g+a][2x+b][co] * W[ci][co][a][b]   (p = (g, x), g = n*H + y) --------
+// GEMM with M = coarse pixels, N = Cin, K = (a, b, co).  For a fixed `a` the K range (b, co) of pixel (g, x) is the 2*Cd
+// CONTIGUOUS floats dout[2g+a][2x .. 2x+1][:] -- and consecutive x continue the same run -- so with K ordered (a, b, co)
+// ("tap outer") the A operand is a plain row-major matrix per `a`: every staging load is 64 contiguous bytes per row and
+// consecutive K-steps walk along the same DRAM rows (the generic NT kernel orders K chunk-outer / tap-inner, which makes
+// consecutive K-steps of a row jump by Cd floats and 2*W*Cd floats).  The packed weights keep their chunk-outer order
+// (rd_pack_convt2x2_weight: kt' = chunk * 4 + tap); this kernel just asks for fragment kt' when it is at (tap, chunk).
+// Pipeline = convt_fwd_kernel's (global load -> split + LDS write -> fragment read -> MFMA, one barrier per K-step, weight
+// fragments straight from global memory into a three-deep register ring); epilogue = the shared NT epilogue (rd_nt.h:
+// 16-byte row-contiguous stores through LDS + the BatchNorm-backward statistics hook).
+//   <TM=4, WM=1, WN=4>: 128 pixels x 128 channels (Cin >= 128)
+//   <TM=4, WM=2, WN=2>: 256 pixels x 64 channels (Cin = 64: the 128^2 -> 256^2 level, HBM-bound)
+// (64-row variants -- TM = 2 -- spill under hipcc's scheduler, like convt_fwd_kernel<2>: 256 VGPRs + scratch)
+template <int TM, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * WN, RS = 28;
+    constexpr int STAGE = BM * RS;
+    constexpr int NLD = (BM * 4 + 255) / 256;
+    constexpr int EPI_WORDS = 32 * (BN + 4) + 512;
+    constexpr int SM0 = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
+    constexpr int SMEM = SM0 > 4096 ? SM0 : 4096;           // BN-backward statistics scratch of the epilogue
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;    // the column groups of one pixel tile run back to back
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int Cd = p.Cin, W = p.W;                          // Cd = channels of dout (the transposed convolution's Cout)
+
+    f32x16 acc[TM][1], lo[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = lo[i][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.Bsplit, p.b_bytes);
+    unsigned s_off[NLD];
+    int s_lds[NLD];
+    const int c4 = t & 3;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int row = (t + 256 * k) >> 2;
+        const int m = m0 + row;
+        const int g = (int)fd_div((unsigned)m, p.pd.w), x = m - g * W;       // stacked image rows: g = n*H + y
+        const bool ok = row < BM && m < p.M;
+        s_off[k] = ok ? (unsigned)((((long)(4 * g) * W + 2 * x) * Cd + c4 * 4) * 4) : kOOB;
+        s_lds[k] = row < BM ? row * RS + c4 * 2 : -1;
+    }
+    const int nb = (n0 >> 5) + wn;                          // 32-column block of this wave
+    const unsigned b_off = (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16);
+    const int cpt = p.chunks;                               // 16-channel chunks per tap
+    const int half_nk = 2 * cpt;
+    const unsigned arow = (unsigned)(2 * W * Cd * 4);       // bytes from fine row 2g to fine row 2g+1
+
+    auto load_a = [&](int kt, float4 (&ra)[NLD]) {
+        const bool cok = kt < p.nk;
+        const int a = kt >= half_nk ? 1 : 0;
+        const unsigned soff = (unsigned)(a ? arow : 0u) + (unsigned)((kt - a * half_nk) * (SK * 4));
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) ra[k] = buf_load4(rsA, cok ? s_off[k] : kOOB, cok ? soff : 0u);
+    };
+    auto store_a = [&](float* stage, const float4 (&ra)[NLD]) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            if (s_lds[k] < 0) continue;
+            uint2 ph, pm, pl;
+            split_pack4(ra[k], ph, pm, pl);
+            float* row = stage + s_lds[k];
+            *reinterpret_cast<uint2*>(row) = ph;
+            *reinterpret_cast<uint2*>(row + 8) = pm;
+            *reinterpret_cast<uint2*>(row + 16) = pl;
+        }
+    };
+    // weight fragments: K-step kt = (tap, chunk) in tap-outer order lives at kt' = chunk * 4 + tap of the packed operand
+    int b_tap = 0, b_chunk = 0;                             // position of the NEXT load_b call (called with kt = 0, 1, 2, ...)
+    auto load_b = [&](int kt, uint4 (&rb)[3]) {
+        const unsigned voff = kt < p.nk ? b_off : kOOB;
+        const int ktp = kt < p.nk ? b_chunk * 4 + b_tap : 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((ktp * 3 + q) * 1024));
+        if (++b_chunk == cpt) { b_chunk = 0; ++b_tap; }
+    };
+    const int lrow = lane & 31, half = lane >> 5;
+    bf16x8 af[TM][3];
+    auto read_a = [&](const float* stage) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                af[i][q] = *reinterpret_cast<const bf16x8*>(stage + ((wm * TM + i) * 32 + lrow) * RS + half * 4 + q * 8);
+    };
+    constexpr int GP = TM >= 2 ? 2 : 1;
+    auto step = [&](int kt, float4 (&ra)[NLD], uint4 (&bcur)[3], uint4 (&bnew)[3], float* stage_next) {
+        store_a(stage_next, ra);          // tile kt+1 (this stage was last read before the previous barrier)
+        load_a(kt + 3, ra);
+        load_b(kt + 2, bnew);
+        bf16x8 bf[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bf[q] = __builtin_bit_cast(bf16x8, bcur[q]);
+#pragma unroll
+        for (int g = 0; g < TM; g += GP) {
+#pragma unroll
+            for (int t6 = 0; t6 < 5; ++t6)
+#pragma unroll
+                for (int i = g; i < g + GP; ++i)
+                    lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
+#pragma unroll
+            for (int i = g; i < g + GP; ++i)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][0], 0, 0, 0);
+        }
+        __syncthreads();
+        read_a(stage_next);               // tile kt+1, consumed by the next step
+    };
+
+    float* st0 = smem;
+    float* st1 = smem + STAGE;
+    float4 ra0[NLD], ra1[NLD];
+    uint4 b0[3], b1[3], b2[3];
+    load_a(0, ra0);
+    load_a(1, ra1);
+    load_b(0, b0);
+    load_b(1, b1);
+    store_a(st0, ra0);
+    load_a(2, ra0);
+    __syncthreads();
+    read_a(st0);
+#pragma unroll 1
+    for (int kt = 0; kt < p.nk; kt += 6) {       // nk = 4 * cpt is even; A sets alternate with period 2, B sets with period 3
+        step(kt, ra1, b0, b2, st1);
+        step(kt + 1, ra0, b1, b0, st0);
+        if (kt + 2 >= p.nk) break;
+        step(kt + 2, ra1, b2, b1, st1);
+        step(kt + 3, ra0, b0, b2, st0);
+        if (kt + 4 >= p.nk) break;
+        step(kt + 4, ra1, b1, b0, st1);
+        step(kt + 5, ra0, b2, b1, st0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = merge_hi_lo(acc[i][0][r], lo[i][r]);
+    nt_epilogue<BM, BN, WM, WN, EPI_STORE, SMEM, 1>(acc, smem, p, m0, n0, tile_m);
+}
+
+// p: A = dout, Bsplit / b_bytes = the split operand of wtd[ci][(ab, co)], C = dx, M = coarse pixels, N = Cin, Cin = Cd (channels
+// of dout), H, W, pd = coarse grid, bn_* hook optional.  *launched = 0: shape left to the generic NT kernel.
+int convt_dgrad_launch(NtParams p, hipStream_t s, int* launched, int* tiles_m_out) {
+    *launched = 0;
+    if (!mfma_split() || tune(TUNE_CONVT_PATCH) == 0) return RD_OK;
+    const int Cd = p.Cin;
+    if (Cd % 16 != 0 || Cd < 64 || p.N % 32 != 0 || p.N < 64 || p.M < 2048) return RD_OK;
+    const double ab = 16.0 * (double)p.M * Cd;
+    if (ab >= 4294967040.0) return RD_OK;
+    p.taps = 4;
+    p.chunks = Cd / 16;
+    p.nk = 4 * p.chunks;
+    p.K = 4 * Cd;
+    p.vec = 1;
+    p.patch = 0;
+    p.a_bytes = (unsigned)ab;
+    const int cfg = p.N < 128 ? 2 : 0;
+    const int bm = cfg == 2 ? 256 : 128, bn = cfg == 2 ? 64 : 128;
+    p.tiles_n = cdiv(p.N, bn);
+    const long tiles_m = cdiv(p.M, bm);
+    const long grid = tiles_m * p.tiles_n;
+    if (grid >= (1L << 31)) return RD_OK;
+    if (tiles_m_out) *tiles_m_out = (int)tiles_m;
+    char pcls[64];
+    snprintf(pcls, sizeof(pcls), "convt2x2_dgrad|convt_dgrad<%d,%d>", bm, bn);
+    ProfScope ps(s, pcls, 2.0 * p.M * (double)p.N * p.K, 4.0 * (4.0 * p.M * Cd + (double)p.N * p.K + (double)p.M * p.N * (p.bn_part ? 2 : 1)), true);
+    if (cfg == 0) hipLaunchKernelGGL((convt_dgrad_kernel<4, 1, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((convt_dgrad_kernel<4, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    RD_LAUNCH_CHECK("convt_dgrad");
+    *launched = 1;
+    return RD_OK;
 }
 
 // The patch kernel handles Cin % 32 == 0, Cout % 64 == 0, W a power of two >= 8; everything else stays on the generic NT

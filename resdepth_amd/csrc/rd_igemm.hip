@@ -1660,6 +1660,18 @@ int rd_convt2x2_fwd_bnskip(const float* x, const float* wtf, const float* bias, 
     return launch_nt<A_PLAIN, EPI_CONVT>(p, (hipStream_t)s, "convt2x2_fwd");
 }
 
+// dedicated transposed-convolution data-gradient kernel (rd_convt.hip): -1 = launched, 0 = not handled, > 0 = error code
+static int convt_dgrad_try(NtParams p, hipStream_t s, int* rows_out) {
+    const int taps = 4;
+    const double b_bytes = (double)rows32_of(p.N) * (taps * cdiv(p.Cin, SK)) * SROWB;
+    if (b_bytes >= 4294967040.0) return 0;
+    p.b_bytes = (unsigned)b_bytes;
+    p.Bsplit = (const char*)p.B + packed_f32_bytes(p.N, taps, p.Cin);
+    int launched = 0;
+    if (int e = convt_dgrad_launch(p, s, &launched, rows_out)) return e;
+    return launched ? -1 : 0;
+}
+
 int rd_convt2x2_bwd_data(const float* dout, const float* wtd, float* dx, int n, int h, int w, int cin, int cout,
                          rd_stream_t s) {
     if (int e = check_conv_args(n, h, w, cin, cout)) return e;
@@ -1669,6 +1681,7 @@ int rd_convt2x2_bwd_data(const float* dout, const float* wtd, float* dx, int n, 
     p.A = dout; p.B = wtd; p.C = dx;
     p.M = n * h * w; p.N = cin; p.K = 4 * cout; p.Cin = cout;
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
+    if (int e = convt_dgrad_try(p, (hipStream_t)s, nullptr)) return e > 0 ? e : RD_OK;
     return launch_nt<A_UP2, EPI_STORE>(p, (hipStream_t)s, "convt2x2_dgrad");
 }
 
@@ -1686,6 +1699,7 @@ int rd_convt2x2_bwd_data_bnstats(const float* dout, const float* wtd, float* dx,
     if (int e = set_bn_hook(p, "rd_convt2x2_bwd_data_bnstats", bn_z, mean, invstd, gamma, beta, slope, slope_dev, 1, part,
                             part_floats))
         return e;
+    if (int e = convt_dgrad_try(p, (hipStream_t)s, rows_out)) return e > 0 ? e : RD_OK;
     return launch_nt<A_UP2, EPI_STORE>(p, (hipStream_t)s, "convt2x2_dgrad", rows_out);
 }
 

@@ -62,6 +62,9 @@ struct NtParams {
     float* bn_part;
 };
 
+// transposed-convolution data gradient (rd_convt.hip); *launched = 0 when the shape is left to the generic NT kernel
+int convt_dgrad_launch(NtParams p, hipStream_t s, int* launched, int* tiles_m_out);
+
 __device__ __forceinline__ float nt_act_grad(float y, float slope) { return y > 0.f ? 1.f : slope; }
 
 

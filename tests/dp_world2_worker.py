@@ -64,8 +64,11 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--bucket-mb", type=int, default=16)
     ap.add_argument("--serial-backward", type=int, default=0)
+    ap.add_argument("--tune", default="", help="RD_TUNE string (kernel-selection knobs), applied before the library loads")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
+    if a.tune:
+        os.environ["RD_TUNE"] = a.tune
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(a.port)
@@ -105,6 +108,7 @@ def main():
                 loss = masked_l1_loss(y, local["target"], local["loss_mask"], local["dsm_mean"], local["dsm_std"], grad_sync=gs)
                 loss.backward()
                 if step == 0:
+                    y0 = y.detach().cpu().clone()
                     grads0 = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
                     bufs0 = {k: v.detach().cpu().clone() for k, v in model.named_buffers()}
                     n_buckets = len(gs._buckets)
@@ -113,7 +117,7 @@ def main():
                     p.grad = None
                 losses.append(float(loss))
             torch.cuda.synchronize()
-            torch.save({"losses": losses, "grads0": grads0, "bufs0": bufs0, "n_buckets": n_buckets,
+            torch.save({"losses": losses, "y0": y0, "grads0": grads0, "bufs0": bufs0, "n_buckets": n_buckets,
                         "state": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}, a.out)
         elif a.mode == "infer":
             from torch.utils.data import DataLoader

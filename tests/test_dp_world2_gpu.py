@@ -25,14 +25,23 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "dp_world2_worker.py")
-# Gradients of a 4 + 4 run against one process at 8 tiles.  The arithmetic differs only in summation grouping (per-rank
-# split-K slabs, then the all-reduce; BN statistics from fp64 sums added in a different order): 2e-5-class differences.
-# But the forward values then differ in their last bits, so now and then ONE discrete decision (a ReLU at ~0, a pool tie,
-# sign(p - t) of an L1 pixel at rounding level) falls the other way, which moves every gradient upstream of it by 1e-4..1e-3
-# rel-L2 (measured over repeated runs: 2.2e-5 .. 1.6e-4; DESIGN.md section 4 "identical decisions").  The HIP engine cannot
-# take imposed decisions, so the bar is SURVEY 8c's free-running gradient bar.  What this test is after -- x world, / world,
-# a missed or stale bucket, wrong SyncBN slices -- is O(1) on the tensors it touches.
-GRAD_TOL = 1e-3
+# How tight can "4 + 4 tiles on two ranks == 8 tiles in one process" be?  The engine picks kernels by problem size (halo-patch
+# vs generic NT kernel, 64- vs 128-row tiles, patch vs generic transposed convolution), so a rank holding 4 tiles and a
+# process holding 8 do not run the same kernels: K is summed in a different order, BN partial sums cover different row
+# groups, the forward differs by <= 5e-7 -- and among 5e7 activations a handful of discrete decisions at |y| ~ 1e-7 (ReLU,
+# pool arg-max, sign(p - t) of the L1 loss) fall the other way.  Measured (scripts/diag_world2.py): ONE flipped ReLU in the
+# 8x8 bottleneck moves bottleneck.0.weight / bottleneck.1.bias by 2.2e-3 and the encoder gradients upstream of it by
+# 8e-4 .. 2e-5, while the decoder gradients (computed before it) agree to 3e-7 ("identical decisions").
+# So every comparison runs twice:
+#  * PINNED kernel selection (RD_TUNE = PIN: generic NT kernel with 64-row tiles everywhere, generic transposed convolution)
+#    on both sides: the per-element arithmetic no longer depends on the batch, mean / invstd come out as the same fp32 bits,
+#    the forward is BIT-IDENTICAL, every decision is the same and gradients differ by summation order only: TIGHT bars
+#    (loss 1e-6, gradients GRAD_TOL).  This is the test of the data-parallel machinery proper.
+#  * DEFAULT kernel selection: LOOSE bar FLIP_TOL -- x world, / world, a missed or stale bucket, wrong SyncBN slices are O(1)
+#    on the tensors they touch.
+PIN = "nt_halo=0,nt_tile=2,convt_patch=0"
+GRAD_TOL = 1e-5
+FLIP_TOL = 1e-2
 sys.path.insert(0, HERE)
 import dp_world2_worker as W  # noqa: E402
 
@@ -100,8 +109,31 @@ def test_host_staged_collectives_probe(tmp_path):
     run_world(tmp_path, "probe", timeout=180, coll="staged")
 
 
-def _single_process(batch, steps, tile=256):
+class _pinned:
+    """Context manager: kernel-selection knobs of PIN in THIS process (rd_tune_set), restored on exit."""
+
+    def __init__(self, spec):
+        self.kv = [kv.split("=") for kv in spec.split(",")] if spec else []
+
+    def __enter__(self):
+        from resdepth_amd import _lib
+        self.old = [(k, _lib.tune_get(k)) for k, _ in self.kv]
+        for k, v in self.kv:
+            _lib.tune_set(k, int(v))
+
+    def __exit__(self, *exc):
+        from resdepth_amd import _lib
+        for k, v in self.old:
+            _lib.tune_set(k, v)
+
+
+def _single_process(batch, steps, tile=256, tune=""):
     """ONE process, whole batch, no data-parallel hooks: the reference semantics (lib/Trainer.py:159-222)."""
+    with _pinned(tune):
+        return _single_process_(batch, steps, tile)
+
+
+def _single_process_(batch, steps, tile):
     from resdepth_amd import UNet, FusedAdam, masked_l1_loss
     torch.manual_seed(100)
     model = UNet(**W.CFG_S).to(DEV).train()
@@ -113,13 +145,14 @@ def _single_process(batch, steps, tile=256):
         loss = masked_l1_loss(y, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
         loss.backward()
         if step == 0:
+            y0 = y.detach().cpu().clone()
             grads0 = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
             bufs0 = {k: v.detach().cpu().clone() for k, v in model.named_buffers()}
         opt.step()
         for p in model.parameters():
             p.grad = None
         losses.append(float(loss))
-    return {"losses": losses, "grads0": grads0, "bufs0": bufs0,
+    return {"losses": losses, "y0": y0, "grads0": grads0, "bufs0": bufs0,
             "state": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}
 
 
@@ -131,29 +164,36 @@ def test_world2_syncbn_equals_one_process_at_the_global_batch(tmp_path, coll, se
     if serial and coll == "native":
         pytest.skip("covered by the staged run")
     _collectives(tmp_path, coll)
-    outs = run_world(tmp_path, "train", coll=coll, sync_bn=1, batch=8, steps=2, serial_backward=serial)
-    ref = _single_process(8, 2)
-    assert outs[0]["n_buckets"] >= 3                      # 50.5 MB of gradients in 16 MB buckets
-    for r, o in enumerate(outs):
-        for s in range(2):
-            assert abs(o["losses"][s] - ref["losses"][s]) <= 1e-6 * abs(ref["losses"][s]), (r, s, o["losses"], ref["losses"])
-        for k, g in ref["grads0"].items():
-            e = rel_l2(o["grads0"][k], g)
-            assert e <= GRAD_TOL, (r, k, e)
-        for k, v in ref["bufs0"].items():
-            if v.dtype.is_floating_point:
-                assert rel_l2(o["bufs0"][k], v) <= 1e-5, (r, k)
-            else:
-                assert torch.equal(o["bufs0"][k], v), (r, k)
-        for k, v in ref["state"].items():
-            if v.dtype.is_floating_point:
-                assert rel_l2(o["state"][k], v) <= 1e-5, (r, k, rel_l2(o["state"][k], v))
-    # the all-reduced gradients and the weights after two steps are the SAME BITS on both ranks
-    for k in outs[0]["grads0"]:
-        assert torch.equal(outs[0]["grads0"][k], outs[1]["grads0"][k]), k
-    for k, v in outs[0]["state"].items():
-        if "running_" not in k and "num_batches" not in k:
-            assert torch.equal(v, outs[1]["state"][k]), k
+    for tune, tol in ((PIN, GRAD_TOL), ("", FLIP_TOL)):
+        outs = run_world(tmp_path, "train", coll=coll, sync_bn=1, batch=8, steps=2, serial_backward=serial, **({"tune": tune} if tune else {}))
+        ref = _single_process(8, 2, tune=tune)
+        assert outs[0]["n_buckets"] >= 3                      # 50.5 MB of gradients in 16 MB buckets
+        y = torch.cat([o["y0"] for o in outs])
+        if tune:
+            assert torch.equal(y, ref["y0"]), float((y - ref["y0"]).abs().max())      # bit-identical forward
+        assert float((y - ref["y0"]).abs().max()) <= 2e-6
+        for r, o in enumerate(outs):
+            for s_ in range(2):
+                assert abs(o["losses"][s_] - ref["losses"][s_]) <= 2e-6 * abs(ref["losses"][s_]), (tune, r, s_, o["losses"], ref["losses"])
+            for k, g in ref["grads0"].items():
+                e = rel_l2(o["grads0"][k], g)
+                assert e <= tol, (tune, r, k, e)
+            for k, v in ref["bufs0"].items():
+                if v.dtype.is_floating_point:
+                    assert rel_l2(o["bufs0"][k], v) <= 1e-5, (tune, r, k)
+                else:
+                    assert torch.equal(o["bufs0"][k], v), (r, k)
+            # weights after two Adam steps: step 2 runs on weights that differ in their last bits, so its forward is no
+            # longer bit-identical (flip noise, see above), and zero-initialised biases consist of the two updates only
+            for k, v in ref["state"].items():
+                if v.dtype.is_floating_point and "running_" not in k:
+                    assert rel_l2(o["state"][k], v) <= (1e-3 if tune else 5e-2), (tune, r, k, rel_l2(o["state"][k], v))
+        # the all-reduced gradients and the weights after two steps are the SAME BITS on both ranks
+        for k in outs[0]["grads0"]:
+            assert torch.equal(outs[0]["grads0"][k], outs[1]["grads0"][k]), k
+        for k, v in outs[0]["state"].items():
+            if "running_" not in k and "num_batches" not in k:
+                assert torch.equal(v, outs[1]["state"][k]), k
 
 
 class _OtherShard:
@@ -240,8 +280,8 @@ def test_world2_local_bn_equals_the_shard_sum_and_the_oracle(tmp_path):
 def test_world2_small_buckets_and_four_ranks(tmp_path):
     """4 ranks on the one GPU (2 tiles each), 2 MB buckets (9 collectives issued while the backward still runs),
     SyncBN on: same answer as one process at batch 8."""
-    outs = run_world(tmp_path, "train", world=4, coll="staged", sync_bn=1, batch=8, steps=1, bucket_mb=2, timeout=900)
-    ref = _single_process(8, 1)
+    outs = run_world(tmp_path, "train", world=4, coll="staged", sync_bn=1, batch=8, steps=1, bucket_mb=2, timeout=900, tune=PIN)
+    ref = _single_process(8, 1, tune=PIN)
     assert outs[0]["n_buckets"] >= 8                       # three 9.4 MB conv weights are buckets of their own
     for r, o in enumerate(outs):
         assert abs(o["losses"][0] - ref["losses"][0]) <= 1e-6 * abs(ref["losses"][0])

@@ -470,7 +470,7 @@ def _hip_decisions(model, x_dev, spec):
         _, S = eng._engine_forward(xin.detach(), True, save=True, keep_skips=True)
         for v, old in bufs:                  # the probe must not advance the running statistics a second time
             v.copy_(old)
-    fd = spec.filter_depths()
+    fd = spec.filter_depths
     nchw = lambda t, c: t.permute(0, 3, 1, 2)[:, :c].contiguous().cpu()
     dec = {}
     for i, e in enumerate(S["enc"]):
