@@ -68,6 +68,11 @@ int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, co
                      const float* sk_mean, const float* sk_invstd, const float* sk_gamma, const float* sk_beta, float sk_slope,
                      const float* sk_slope_dev, float* out, int n, int h, int w, int cin, int cout, hipStream_t s, int* launched);
 
+// transposed-convolution weight gradient (rd_convt.hip): workspace of its split-K slabs (0: shape left to the generic TN kernel)
+size_t convt_wgrad_ws_bytes(int n, int h, int w, int cin, int cout);
+int convt_wgrad_launch(const float* x, const float* dout, float* slab, int n, int h, int w, int cin, int cout, hipStream_t s,
+                       int* splits_out);
+
 // last convolution, tile kernels (rd_edge_conv.hip); *launched = 0 / blocks = 0 when the shape stays on the generic kernels
 int conv_last_fwd_launch(const float* s_in, const float* wt, const float* bias, const float* x_nchw, int xc, float* out, int n,
                          int h, int w, int c, hipStream_t s, int* launched);

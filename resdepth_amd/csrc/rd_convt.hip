@@ -233,9 +233,8 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
 // Pipeline = convt_fwd_kernel's (global load -> split + LDS write -> fragment read -> MFMA, one barrier per K-step, weight
 // fragments straight from global memory into a three-deep register ring); epilogue = the shared NT epilogue (rd_nt.h:
 // 16-byte row-contiguous stores through LDS + the BatchNorm-backward statistics hook).
-//   <TM=4, WM=1, WN=4>: 128 pixels x 128 channels (Cin >= 128)
-//   <TM=4, WM=2, WN=2>: 256 pixels x 64 channels (Cin = 64: the 128^2 -> 256^2 level, HBM-bound)
-// (64-row variants -- TM = 2 -- spill under hipcc's scheduler, like convt_fwd_kernel<2>: 256 VGPRs + scratch)
+//   <TM=4, WM=1, WN=4>: 128 pixels x 128 channels (Cin >= 128, big grids)     <TM=2, WM=1, WN=4>: 64 x 128 (small grids)
+//   <TM=2, WM=2, WN=2>: 128 pixels x 64 channels (Cin = 64: the 128^2 -> 256^2 level, HBM-bound)
 template <int TM, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * WN, RS = 28;
@@ -276,14 +275,17 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
     const unsigned b_off = (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16);
     const int cpt = p.chunks;                               // 16-channel chunks per tap
     const int half_nk = 2 * cpt;
-    const unsigned arow = (unsigned)(2 * W * Cd * 4);       // bytes from fine row 2g to fine row 2g+1
+    const unsigned arow = (unsigned)__builtin_amdgcn_readfirstlane(2 * W * Cd * 4);     // bytes from fine row 2g to fine row 2g+1
 
     auto load_a = [&](int kt, float4 (&ra)[NLD]) {
         const bool cok = kt < p.nk;
         const int a = kt >= half_nk ? 1 : 0;
-        const unsigned soff = (unsigned)(a ? arow : 0u) + (unsigned)((kt - a * half_nk) * (SK * 4));
+        // (readfirstlane: the scalar offset must be an SGPR -- left to its divergence analysis hipcc computed it in a VGPR and
+        // wrapped every load in a waterfall loop)
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(
+            cok ? (int)((a ? arow : 0u) + (unsigned)((kt - a * half_nk) * (SK * 4))) : 0);
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) ra[k] = buf_load4(rsA, cok ? s_off[k] : kOOB, cok ? soff : 0u);
+        for (int k = 0; k < NLD; ++k) ra[k] = buf_load4(rsA, cok ? s_off[k] : kOOB, soff);
     };
     auto store_a = [&](float* stage, const float4 (&ra)[NLD]) {
 #pragma unroll
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
     int b_tap = 0, b_chunk = 0;                             // position of the NEXT load_b call (called with kt = 0, 1, 2, ...)
     auto load_b = [&](int kt, uint4 (&rb)[3]) {
         const unsigned voff = kt < p.nk ? b_off : kOOB;
-        const int ktp = kt < p.nk ? b_chunk * 4 + b_tap : 0;
+        const int ktp = __builtin_amdgcn_readfirstlane(kt < p.nk ? b_chunk * 4 + b_tap : 0);
 #pragma unroll
         for (int q = 0; q < 3; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((ktp * 3 + q) * 1024));
         if (++b_chunk == cpt) { b_chunk = 0; ++b_tap; }
@@ -316,10 +318,28 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
                 af[i][q] = *reinterpret_cast<const bf16x8*>(stage + ((wm * TM + i) * 32 + lrow) * RS + half * 4 + q * 8);
     };
     constexpr int GP = TM >= 2 ? 2 : 1;
-    auto step = [&](int kt, float4 (&ra)[NLD], uint4 (&bcur)[3], uint4 (&bnew)[3], float* stage_next) {
-        store_a(stage_next, ra);          // tile kt+1 (this stage was last read before the previous barrier)
-        load_a(kt + 3, ra);
-        load_b(kt + 2, bnew);
+
+    float* st0 = smem;
+    float* st1 = smem + STAGE;
+    // A register sets alternate with period 2; weight-fragment ring of NB sets: 3 for the 128-row tiles (period 6, exits
+    // after every pair of steps: nk = 4 * cpt is even) -- the 64-row tiles take 4 (period 4 divides nk, no exit inside the
+    // loop body): with the exits hipcc failed to coalesce their four accumulators across the steps (12 accumulator register
+    // blocks, 256 VGPRs + scratch)
+    constexpr int NB = TM >= 4 ? 3 : 4, PER = TM >= 4 ? 6 : 4;
+    float4 ra[2][NLD];
+    uint4 bq[NB][3];
+    load_a(0, ra[0]);
+    load_a(1, ra[1]);
+#pragma unroll
+    for (int j = 0; j < NB - 1; ++j) load_b(j, bq[j]);
+    store_a(st0, ra[0]);
+    load_a(2, ra[0]);
+    __syncthreads();
+    read_a(st0);
+    auto step = [&](int kt, float4 (&ra_)[NLD], uint4 (&bcur)[3], uint4 (&bnew)[3], float* stage_next) {
+        store_a(stage_next, ra_);         // tile kt+1 (this stage was last read before the previous barrier)
+        load_a(kt + 3, ra_);
+        load_b(kt + NB - 1, bnew);
         bf16x8 bf[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) bf[q] = __builtin_bit_cast(bf16x8, bcur[q]);
@@ -337,29 +357,13 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
         __syncthreads();
         read_a(stage_next);               // tile kt+1, consumed by the next step
     };
-
-    float* st0 = smem;
-    float* st1 = smem + STAGE;
-    float4 ra0[NLD], ra1[NLD];
-    uint4 b0[3], b1[3], b2[3];
-    load_a(0, ra0);
-    load_a(1, ra1);
-    load_b(0, b0);
-    load_b(1, b1);
-    store_a(st0, ra0);
-    load_a(2, ra0);
-    __syncthreads();
-    read_a(st0);
 #pragma unroll 1
-    for (int kt = 0; kt < p.nk; kt += 6) {       // nk = 4 * cpt is even; A sets alternate with period 2, B sets with period 3
-        step(kt, ra1, b0, b2, st1);
-        step(kt + 1, ra0, b1, b0, st0);
-        if (kt + 2 >= p.nk) break;
-        step(kt + 2, ra1, b2, b1, st1);
-        step(kt + 3, ra0, b0, b2, st0);
-        if (kt + 4 >= p.nk) break;
-        step(kt + 4, ra1, b1, b0, st1);
-        step(kt + 5, ra0, b2, b1, st0);
+    for (int kt = 0; kt < p.nk; kt += PER) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (NB == 3 && u > 0 && (u & 1) == 0 && kt + u >= p.nk) break;
+            step(kt + u, ra[(u + 1) & 1], bq[u % NB], bq[(u + NB - 1) % NB], (u & 1) ? st0 : st1);
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -375,7 +379,7 @@ int convt_dgrad_launch(NtParams p, hipStream_t s, int* launched, int* tiles_m_ou
     *launched = 0;
     if (!mfma_split() || tune(TUNE_CONVT_PATCH) == 0) return RD_OK;
     const int Cd = p.Cin;
-    if (Cd % 16 != 0 || Cd < 64 || p.N % 32 != 0 || p.N < 64 || p.M < 2048) return RD_OK;
+    if (Cd % 16 != 0 || Cd < 64 || p.N % 32 != 0 || p.N < 64 || p.M < 4096) return RD_OK;
     const double ab = 16.0 * (double)p.M * Cd;
     if (ab >= 4294967040.0) return RD_OK;
     p.taps = 4;
@@ -385,8 +389,11 @@ int convt_dgrad_launch(NtParams p, hipStream_t s, int* launched, int* tiles_m_ou
     p.vec = 1;
     p.patch = 0;
     p.a_bytes = (unsigned)ab;
-    const int cfg = p.N < 128 ? 2 : 0;
-    const int bm = cfg == 2 ? 256 : 128, bn = cfg == 2 ? 64 : 128;
+    // 64-row tiles (152 VGPRs: three waves per SIMD) beat 128-row tiles at every cfg-S level (r03: 176 vs 165 TFLOP/s at
+    // 32^2 x 256, equal at 64^2 x 128; profiles/r03_notes.md); convt_patch = 3 forces the 128-row variant for A/B runs
+    int cfg = p.N < 128 ? 2 : 1;
+    if (p.N >= 128 && tune(TUNE_CONVT_PATCH) == 3) cfg = 0;
+    const int bm = cfg == 1 ? 64 : 128, bn = cfg == 2 ? 64 : 128;
     p.tiles_n = cdiv(p.N, bn);
     const long tiles_m = cdiv(p.M, bm);
     const long grid = tiles_m * p.tiles_n;
@@ -396,9 +403,271 @@ int convt_dgrad_launch(NtParams p, hipStream_t s, int* launched, int* tiles_m_ou
     snprintf(pcls, sizeof(pcls), "convt2x2_dgrad|convt_dgrad<%d,%d>", bm, bn);
     ProfScope ps(s, pcls, 2.0 * p.M * (double)p.N * p.K, 4.0 * (4.0 * p.M * Cd + (double)p.N * p.K + (double)p.M * p.N * (p.bn_part ? 2 : 1)), true);
     if (cfg == 0) hipLaunchKernelGGL((convt_dgrad_kernel<4, 1, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((convt_dgrad_kernel<4, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    else if (cfg == 1) hipLaunchKernelGGL((convt_dgrad_kernel<2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((convt_dgrad_kernel<2, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, p);
     RD_LAUNCH_CHECK("convt_dgrad");
     *launched = 1;
+    return RD_OK;
+}
+
+// ---- weight gradient:  dW[ci][co][a][b] = sum_p x[p][ci] * dout[2g+a][2x+b][co] -----------------------------------------------
+// TN GEMM  C[(ab, co)][ci] = sum over coarse pixels, split-K slabs + the fixed-order slab reduction of rd_igemm.hip.
+// Both operands are activations, so BOTH are split into bf16 terms on the way into LDS (no pre-split weights here): the cost
+// per MFMA is set by how many MFMAs consume one staged element.  The generic TN kernel (128 x 128 tile, 4 waves, hi / lo
+// accumulators) stages 4096 elements per 96 MFMAs; this kernel takes a 256 x (64 * TN') tile with EIGHT waves and one
+// accumulator per 32 x 32 block (like wgrad_strip_kernel): 8192 elements per 384 MFMAs at TN = 4 -- half the split
+// arithmetic, LDS writes and barriers per MFMA.
+//   tile rows   = the four (a, b) quadrants x 64 output channels: wave row wm IS quadrant ab, and the A operand of a K-step
+//                 (16 consecutive coarse pixels of one coarse row) is two runs of 32 fine pixels x 256 contiguous bytes;
+//   tile cols   = 64 * (BN / 64) input channels; K-step = 16 coarse pixels; staging task = 4 pixels x 4 channels (register
+//                 transpose, as in the other weight-gradient kernels); waves 0-3 stage A, waves 4-7 stage B;
+//   LDS         = 128-byte rows [chunk = 2 * term + k-half], XOR-swizzled (conflict-free b64 writes / b128 reads), two stages.
+struct CtwParams {
+    const float* dout;
+    const float* x;
+    float* slab;             // [splits][4 * Cd][Cin]
+    int Cd, Cin;             // channels of dout (transposed convolution's Cout) / of x
+    int W;                   // coarse width (multiple of 16)
+    int spr;                 // K-steps per coarse row = W / 16
+    int total_ks, kps;       // K-steps in all / per split
+    int tiles_n, tiles_mn;
+    unsigned a_bytes, b_bytes;
+};
+
+template <int TN>
+__global__ __launch_bounds__(512, 2) void convt_wgrad_kernel(CtwParams p) {
+    constexpr int BM = 256, BN = 64 * TN, ROWS = BM + BN;
+    constexpr int STAGE = ROWS * 32;                         // words
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int gb = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = gb / p.tiles_mn;
+    const int lb = gb - split * p.tiles_mn;
+    const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
+    const int co0 = tile_m * 64, ci0 = tile_n * BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int Cd = p.Cd, Cin = p.Cin, W = p.W;
+
+    // ---- staging role (wave-uniform): waves 0-3 the dout tile (wave = quadrant ab), waves 4-7 the x tile
+    const bool isA = __builtin_amdgcn_readfirstlane(t) < 256;
+    const int idx = isA ? t : t - 256;
+    const int kq = idx & 3, rq = idx >> 2;                   // pixel quarter of the K-step, row quad of the operand tile
+    const bool active = isA || rq * 4 < BN;
+    const int lds_row0 = isA ? rq * 4 : BM + rq * 4;
+    unsigned voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int px = kq * 4 + j;                           // coarse pixel within the K-step
+        if (isA) {
+            const int ab = rq >> 4, cq = rq & 15;
+            voff[j] = (unsigned)(((((ab >> 1) * 2 * W + 2 * px + (ab & 1)) * Cd) + co0 + cq * 4) * 4);
+        } else {
+            voff[j] = active ? (unsigned)((px * Cin + ci0 + rq * 4) * 4) : kOOB;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.dout, p.a_bytes), rsB = make_rsrc(p.x, p.b_bytes);
+    const int ks0 = split * p.kps;
+    const int ks1 = ks0 + p.kps < p.total_ks ? ks0 + p.kps : p.total_ks;
+
+    auto load_task = [&](int ks, float4 (&v)[4]) {
+        // K-step ks = 16 coarse pixels starting at (g, x0): g = ks / spr stacked coarse row, x0 = 16 * (ks % spr)
+        const bool ok = ks < ks1;
+        const int g = ks / p.spr, x0 = (ks - g * p.spr) * 16;
+        const unsigned soffA = (unsigned)__builtin_amdgcn_readfirstlane(ok ? (int)(((unsigned)(4 * g) * W + 2 * x0) * (unsigned)Cd * 4u) : 0);
+        const unsigned soffB = (unsigned)__builtin_amdgcn_readfirstlane(ok ? (int)(((unsigned)g * W + x0) * (unsigned)Cin * 4u) : 0);
+        if (isA) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = buf_load4(rsA, ok ? voff[j] : kOOB, soffA);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = buf_load4(rsB, ok ? voff[j] : kOOB, soffB);
+        }
+    };
+    int wr_e[3];
+    {
+        const int sw = (lds_row0 >> 1) & 7, hi = kq >> 1;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wr_e[q] = lds_row0 * 32 + (kq & 1) * 2 + ((2 * q + hi) ^ sw) * 4;
+    }
+    // one channel (c = 0..3) of a staging task: 4 pixels -> three 8-byte pieces of that channel's LDS row.  The four pieces
+    // of a task are issued BETWEEN the MFMA groups of a K-step (mma_tile): all eight waves leave the barrier together, so a
+    // store phase in front of the MFMAs would idle the matrix pipe of every SIMD at the same time, while VALU work
+    // interleaved with MFMAs is nearly free up to ~1 instruction per MFMA (profiles/r02_notes.md section 1)
+    auto store_piece = [&](float* stage, const float4 (&v)[4], int c) {
+        if (!active) return;
+        const unsigned sel = 0x07060302u;
+        unsigned h[4], m[4], l[4];          // the 4 pixels of channel c
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xv = c == 0 ? v[j].x : c == 1 ? v[j].y : c == 2 ? v[j].z : v[j].w;
+            split3<false>(xv, h[j], m[j], l[j]);
+        }
+        const int flip = (c >> 1) * 4;      // rows lds_row0 + 2, + 3 carry the next swizzle value (chunk index ^ 1)
+        float* rowp = stage + c * 32;
+        *reinterpret_cast<uint2*>(rowp + (wr_e[0] ^ flip)) =
+            make_uint2(__builtin_amdgcn_perm(h[1], h[0], sel), __builtin_amdgcn_perm(h[3], h[2], sel));
+        *reinterpret_cast<uint2*>(rowp + (wr_e[1] ^ flip)) =
+            make_uint2(__builtin_amdgcn_perm(m[1], m[0], sel), __builtin_amdgcn_perm(m[3], m[2], sel));
+        *reinterpret_cast<uint2*>(rowp + (wr_e[2] ^ flip)) =
+            make_uint2(__builtin_amdgcn_perm(l[1], l[0], sel), __builtin_amdgcn_perm(l[3], l[2], sel));
+    };
+    auto store_task = [&](float* stage, const float4 (&v)[4]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) store_piece(stage, v, c);
+    };
+
+    const int lrow = lane & 31, half = lane >> 5;
+    int a_rd[2][3], b_rd[TN][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wm * 2 + i) * 32 + lrow;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a_rd[i][q] = row * 32 + ((2 * q + half) ^ ((row >> 1) & 7)) * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = BM + (wn * TN + j) * 32 + lrow;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b_rd[j][q] = row * 32 + ((2 * q + half) ^ ((row >> 1) & 7)) * 4;
+    }
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // one K-step: multiply stage `cur`; meanwhile split + store the next tile (registers v) into stage `nxt`, one channel
+    // piece after each group of 48 / 4 MFMAs
+    auto mma_tile = [&](const float* cur, float* nxt, const float4 (&v)[4]) {
+        // (TN < 4: 12 / 24 MFMAs per wave and K-step -- interleaving measured slower there: 133 vs 154 and 89 vs 98 TFLOP/s
+        // at the 64^2 x 128 / 128^2 x 64 levels, where it gains 165 -> 175 at 16^2 x 512; the whole task goes first)
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(cur + a_rd[i][q]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bf[0][q] = *reinterpret_cast<const bf16x8*>(cur + b_rd[0][q]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (j + 1 < TN) {                                // next column block's fragments while this one multiplies
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bf[(j + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(cur + b_rd[j + 1][q]);
+            }
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[j & 1][PB6[t6]], acc[i][j], 0, 0, 0);
+            }
+            if (TN == 4) store_piece(nxt, v, j);
+        }
+    };
+
+    if (ks0 < ks1) {
+        float* st0 = smem;
+        float* st1 = smem + STAGE;
+        float4 v0[4], v1[4];
+        load_task(ks0, v0);
+        load_task(ks0 + 1, v1);
+        store_task(st0, v0);
+        load_task(ks0 + 2, v0);
+        __syncthreads();
+        // step i multiplies stage i & 1, splits + stores tile i + 1 into the other stage between its MFMAs and then requests
+        // tile i + 3 into the registers just consumed.  Steps come in pairs with no exit in between (an odd count
+        // multiplies one all-zero tile: loads past ks1 return zeros) -- an exit inside the body made hipcc keep several
+        // copies of the accumulators (cf. convt_dgrad_kernel)
+        for (int ks = ks0; ks < ks1; ks += 2) {
+            if (TN < 4) {                    // whole task first, and the next global loads go out before the MFMAs
+                store_task(st1, v1);
+                load_task(ks + 3, v1);
+            }
+            mma_tile(st0, st1, v1);
+            if (TN == 4) load_task(ks + 3, v1);
+            __syncthreads();
+            if (TN < 4) {
+                store_task(st0, v0);
+                load_task(ks + 4, v0);
+            }
+            mma_tile(st1, st0, v0);
+            if (TN == 4) load_task(ks + 4, v0);
+            __syncthreads();
+        }
+    }
+
+    // slab rows: m' = ab * Cd + co (wave row wm = quadrant ab), columns ci
+    float* out = p.slab + (long)split * (4L * Cd) * Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = ci0 + (wn * TN + j) * 32 + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * Cd + co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                out[(long)m * Cin + n] = acc[i][j][r];
+            }
+        }
+}
+
+struct CtwPlan {
+    int ok, tn, tiles_m, tiles_n, splits, kps, total_ks;
+};
+
+static CtwPlan plan_convt_wgrad(int n, int h, int w, int cin, int cout) {
+    CtwPlan pl = {};
+    if (!mfma_split() || tune(TUNE_CONVT_PATCH) == 0) return pl;
+    if (w % 16 != 0 || cout % 64 != 0 || cin % 64 != 0) return pl;
+    if (16.0 * n * h * (double)w * cout >= 4294967040.0 || 4.0 * n * h * (double)w * cin >= 4294967040.0) return pl;
+    pl.tn = cin % 256 == 0 ? 4 : cin % 128 == 0 ? 2 : 1;
+    pl.tiles_m = cout / 64;
+    pl.tiles_n = cin / (64 * pl.tn);
+    const long total = (long)n * h * (w / 16);
+    if (total >= (1L << 30)) return pl;
+    pl.total_ks = (int)total;
+    // one 8-wave block per CU: aim at ~256 blocks (more splits = more slab traffic), at most 128 K-steps (2048 pixels) per
+    // block so that the single accumulator sums a bounded number of products (rd_mfma_dev.h: hi / lo discussion)
+    const int tiles = pl.tiles_m * pl.tiles_n;
+    long splits = cdiv(pl.tn == 1 ? 512 : 256, tiles);      // TN = 1: 80 KB of LDS, 123 VGPRs -- two blocks per CU
+    if (splits < cdiv(total, 128)) splits = cdiv(total, 128);
+    if (splits > total) splits = total;
+    pl.kps = (int)cdiv(total, splits);
+    pl.splits = (int)cdiv(total, pl.kps);
+    pl.ok = 1;
+    return pl;
+}
+
+size_t convt_wgrad_ws_bytes(int n, int h, int w, int cin, int cout) {
+    const CtwPlan pl = plan_convt_wgrad(n, h, w, cin, cout);
+    return pl.ok ? (size_t)pl.splits * 4 * cout * cin * sizeof(float) : 0;
+}
+
+// *splits_out = 0: shape left to the generic TN kernel; else the slab [splits][4 * cout][cin] was written
+int convt_wgrad_launch(const float* x, const float* dout, float* slab, int n, int h, int w, int cin, int cout, hipStream_t s,
+                       int* splits_out) {
+    *splits_out = 0;
+    const CtwPlan pl = plan_convt_wgrad(n, h, w, cin, cout);
+    if (!pl.ok) return RD_OK;
+    CtwParams q = {};
+    q.dout = dout; q.x = x; q.slab = slab;
+    q.Cd = cout; q.Cin = cin; q.W = w; q.spr = w / 16;
+    q.total_ks = pl.total_ks; q.kps = pl.kps;
+    q.tiles_n = pl.tiles_n; q.tiles_mn = pl.tiles_m * pl.tiles_n;
+    q.a_bytes = (unsigned)(16.0 * n * h * (double)w * cout);
+    q.b_bytes = (unsigned)(4.0 * n * h * (double)w * cin);
+    const double px = (double)n * h * w;
+    char pcls[64];
+    snprintf(pcls, sizeof(pcls), "convt2x2_wgrad|convt_wgrad<%d>", pl.tn);
+    ProfScope ps(s, pcls, 2.0 * 4.0 * cout * cin * px, 4.0 * px * (4.0 * cout + cin) + 4.0 * pl.splits * 4.0 * cout * cin, true);
+    const dim3 grid((unsigned)(q.tiles_mn * pl.splits));
+    if (pl.tn == 4) hipLaunchKernelGGL(convt_wgrad_kernel<4>, grid, dim3(512), 0, s, q);
+    else if (pl.tn == 2) hipLaunchKernelGGL(convt_wgrad_kernel<2>, grid, dim3(512), 0, s, q);
+    else hipLaunchKernelGGL(convt_wgrad_kernel<1>, grid, dim3(512), 0, s, q);
+    RD_LAUNCH_CHECK("convt_wgrad");
+    *splits_out = pl.splits;
     return RD_OK;
 }
 

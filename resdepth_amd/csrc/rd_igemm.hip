@@ -1704,6 +1704,7 @@ int rd_convt2x2_bwd_data_bnstats(const float* dout, const float* wtd, float* dx,
 }
 
 size_t rd_convt2x2_bwd_weight_ws_bytes(int n, int h, int w, int cin, int cout) {
+    if (const size_t own = convt_wgrad_ws_bytes(n, h, w, cin, cout)) return own;
     TnPlan pl = plan_tn(4 * cout, cin, (long)n * h * w);
     return (size_t)pl.splits * 4 * cout * cin * sizeof(float);
 }
@@ -1718,6 +1719,16 @@ int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw, int n, 
     if (ws_bytes < need || !ws) {
         set_error("rd_convt2x2_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
         return RD_ERR_WS;
+    }
+    {
+        int splits = 0;
+        if (int e = convt_wgrad_launch(x, dout, (float*)ws, n, h, w, cin, cout, (hipStream_t)s, &splits)) return e;
+        if (splits > 0) {
+            ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (splits + 1) * 4.0 * cout * cin);
+            launch_slab_reduce((const float*)ws, dw, 4 * cout, cin, splits, 1, cin, cout, (hipStream_t)s);
+            RD_LAUNCH_CHECK("slab_reduce");
+            return RD_OK;
+        }
     }
     TnPlan pl = plan_tn(4 * cout, cin, (long)n * h * w);
     TnParams p = {};
