@@ -195,7 +195,12 @@ class FusedSGD(torch.optim.Optimizer):
         damp, nest = group["dampening"], group["nesterov"]
         pr = FusedAdam._flat_range([p.data for p in params])
         gr = FusedAdam._flat_range([p.grad for p in params]) if all(p.grad is not None for p in params) else None
-        if pr is not None and gr is not None and gr[1] == pr[1]:
+        # mixed momentum state (some parameters have a buffer, others do not: partial load_state_dict, steps taken while some
+        # gradients were None): torch starts the missing buffers as clone(grad), which one `first` flag for the whole group
+        # cannot express -- this step goes per tensor (below), after which every parameter has a buffer
+        n_buf = sum(1 for p in params if self.state[p].get("momentum_buffer") is not None) if mom != 0 else 0
+        mixed = 0 < n_buf < len(params)
+        if pr is not None and gr is not None and gr[1] == pr[1] and not mixed:
             total = pr[1]
             have = self._flat_state.get(gi)
             buf, first = None, False

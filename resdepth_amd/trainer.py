@@ -146,9 +146,12 @@ class Trainer:
                 if self.loader[phase] is not None:
                     self.grad_sync.check_equal_across_ranks(len(self.loader[phase]), f"len({phase} loader)")
             self.grad_sync.check_equal_across_ranks(self.batch_size, "batch size")
+            # equal loader lengths + equal first-batch size leave one way for per-rank batch sizes to differ: a ragged LAST
+            # batch (drop_last=False).  Its size is what has to agree -- shards of different length that yield the same
+            # number of equally sized batches (drop_last=True) are legitimate
             ds = getattr(self.loader["train"], "dataset", None)
-            if ds is not None and hasattr(ds, "__len__"):
-                self.grad_sync.check_equal_across_ranks(len(ds), "len(train dataset shard)")
+            if ds is not None and hasattr(ds, "__len__") and not getattr(self.loader["train"], "drop_last", False):
+                self.grad_sync.check_equal_across_ranks(len(ds) % self.batch_size, "size of the last (ragged) train batch")
         self.hparams = {"batch_size": self.batch_size, "lr_initial": self._get_lr(),
                         "optimizer": type(self.optimizer).__name__, "scheduler": "None", "patience": -1, "step_size": -1}
         if self.scheduler is not None:

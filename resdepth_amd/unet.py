@@ -187,21 +187,34 @@ class UNet(nn.Module):
         """Copy this model's parameters and BN buffers into the leading channels of the twin."""
         tw = self._twin()
         tw._ensure_flat()
-        with torch.no_grad():
-            for (_, a), (_, b) in zip(list(self.named_parameters()) + list(self.named_buffers()),
-                                      list(tw.named_parameters()) + list(tw.named_buffers())):
-                self._corner(a, b).copy_(a) if a.dim() else b.copy_(a)
         tw.train(self.training)
         tw.two_stream_backward, tw.fold_eval_bn = self.two_stream_backward, self.fold_eval_bn
+        src = list(self.named_parameters()) + list(self.named_buffers())
+        # nothing to do when the source values are the ones already loaded (eval sweeps, repeated forwards)
+        key = self._twin_src_key(tw)
+        if self.__dict__.get("_twin_key") == key:
+            return tw
+        with torch.no_grad():
+            for (_, a), (_, b) in zip(src, list(tw.named_parameters()) + list(tw.named_buffers())):
+                self._corner(a, b).copy_(a) if a.dim() else b.copy_(a)
         tw.invalidate_packed()
-        _lib.bump_param_generation(None)
+        _lib.bump_param_generation(tw._flat_param.data_ptr())      # the twin's own caches only, not every model's
+        self.__dict__["_twin_key"] = key
         return tw
+
+    def _twin_src_key(self, tw):
+        """Identity of this model's parameter / buffer values as the twin last saw them: autograd versions + the raw-pointer
+        generation (optimizers that write through .data bump the global one)."""
+        return (tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers())),
+                _lib.param_generation(0), id(tw))
 
     def _twin_store_buffers(self, tw):
         """Running statistics / num_batches_tracked updated by a training-mode forward of the twin -> this model."""
         with torch.no_grad():
             for (_, a), (_, b) in zip(self.named_buffers(), tw.named_buffers()):
                 a.copy_(self._corner(a, b) if a.dim() else b)
+        if "_twin_key" in self.__dict__:       # model and twin are in sync again: these copies are not a change of the source
+            self.__dict__["_twin_key"] = self._twin_src_key(tw)
 
     def _param_list(self) -> List[nn.Parameter]:
         return list(self.parameters())
@@ -253,9 +266,7 @@ class UNet(nn.Module):
         (the first convolution and its BN pass do not need them and run meanwhile).  Split-bf16 mode: ONE launch over a
         device-resident item table into persistent buffers (`_pack_plan`); exact-f32 / bilinear modes: one pack call per
         layer in the order the forward uses them, each with its own ready event."""
-        params = self._param_list()
-        key = (self._flat_param.data_ptr(), _lib.param_generation(self._flat_param.data_ptr()),
-               tuple(p._version for p in params))
+        key = self._current_pack_key()
         if self._pack_key == key and self._pack_cache is not None:
             return self._pack_cache
         d = self.depth
@@ -302,6 +313,13 @@ class UNet(nn.Module):
                     put(("dec_c", i), ops.pack_conv3x3_weight(self.decoder[i][1][0].weight))
         self._pack_cache, self._pack_key = pk, key
         return pk
+
+    def _current_pack_key(self):
+        """Identity of the parameter values the packed operands were built from: flat buffer, its raw-pointer generation
+        (FusedAdam / broadcast write through `.data`), the autograd versions, and the arithmetic mode (the split-bf16 and the
+        exact-f32 kernels read different layouts of the packed buffers; only the active one is written)."""
+        return (self._flat_param.data_ptr(), _lib.param_generation(self._flat_param.data_ptr()),
+                tuple(p._version for p in self._param_list()), _lib.tune_get("mfma_f32"))
 
     def _pack_plan(self):
         """Persistent packed-operand buffers of every conv3x3 / ConvTranspose2d layer + the device-resident item table of
@@ -434,8 +452,7 @@ class UNet(nn.Module):
         blocks = [self.encoder[i][0] for i in range(1, self.depth)] + [self.bottleneck] + \
                  [self.decoder[i][1] for i in range(self.depth - 1)]
         acts = [self.act_fn_encoder] * (self.depth - 1) + [self.act_fn_bottleneck] + [self.act_fn_decoder] * (self.depth - 1)
-        key = (self._flat_param.data_ptr(), _lib.param_generation(self._flat_param.data_ptr()),
-               tuple(p._version for p in self.parameters()),
+        key = (self._current_pack_key(),
                tuple((b[1].running_mean._version, b[1].running_var._version) for b in blocks), self._bn_gen)
         if self.__dict__.get("_fold_key") == key:
             return self.__dict__["_fold_cache"]
@@ -495,7 +512,7 @@ class UNet(nn.Module):
         pk = self._packed()
         if training:
             self._bn_gen += 1
-        S = {"x": x, "enc": [], "dec": [], "training": training} if save else None
+        S = {"x": x, "enc": [], "dec": [], "training": training, "pack_key": self._pack_key} if save else None
 
         fused_stats = training and self.do_BN and not (self.sync_bn and self.grad_sync is not None)
 
@@ -632,6 +649,12 @@ class UNet(nn.Module):
         encoder levels d-1..0 -- i.e. from the END of the flat buffer towards its start, which is what the
         data-parallel bucketing in resdepth_amd.dp relies on for overlap."""
         d = self.depth
+        if S.get("pack_key") is not None and self._current_pack_key() != S["pack_key"]:
+            # the packed operands live in persistent buffers that a later forward re-packs in place: the data gradients
+            # of THIS graph would silently use the new weights.  torch raises in the same situation ("one of the variables
+            # needed for gradient computation has been modified by an inplace operation")
+            raise RuntimeError("resdepth_amd.UNet: a parameter was modified (optimizer step / load_state_dict / .data write) "
+                               "between this graph's forward and its backward")
         pk = self._packed()
         training = S["training"]
         params = self._param_list()

@@ -14,20 +14,23 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
 def sym(name):
-    """rocprof kernel name -> the short symbol used by rd_prof / bench.py."""
+    """rocprof kernel name -> key of the summary: the symbol WITH its template arguments (two instantiations of one kernel
+    -- bn_act_bwd_kernel<true, true> / <false, true> -- are different rows; r02 keyed by the bare name and one overwrote the
+    other), namespace / `void` / argument list stripped, the long NT / TN argument lists abbreviated as rd_prof prints them."""
+    name = name.strip()
     m = re.match(r"void rd::igemm_nt(_split)?_kernel<(\d+), (\d+), \d+, \d+, (\d+), (\d+)>", name)
     if m:
         return "igemm_nt%s<%s,%s,%s,%s>" % (m.group(1) or "", m.group(2), m.group(3), m.group(4), m.group(5))
     m = re.match(r"void rd::wgrad_tn(_split)?_kernel<(\d+), (\d+), \d+, \d+, (\d+), (\d+)>", name)
     if m:
         return "wgrad_tn%s<%s,%s,%s,%s>" % (m.group(1) or "", m.group(2), m.group(3), m.group(4), m.group(5))
-    m = re.match(r"void rd::conv3_halo_split_kernel<(\d+),", name)
+    m = re.match(r"void rd::conv3_halo_split_kernel<(\d+), \d+, \d+, (\d+)", name)
     if m:
         return "conv3_halo_split<%s>" % m.group(1)
-    m = re.match(r"(?:void )?rd::(\w+)", name)
+    m = re.match(r"(?:void )?rd::(\w+?)(?:_kernel)?(<[^(]*>)?\(", name) or re.match(r"(?:void )?rd::(\w+?)(?:_kernel)?(<.*>)?$", name)
     if m:
-        return m.group(1)[:-7] if m.group(1) == "wgrad_strip_kernel" else m.group(1)
-    return name[:40]
+        return m.group(1) + (m.group(2) or "").replace(" ", "")
+    return name[:60]
 
 
 def per_dispatch(path):
@@ -61,6 +64,11 @@ l2 = per_dispatch(os.path.join(SRC, "pmc_l2", "bench_counter_collection.csv"))
 hit, miss = mean_by_sym(l2, "TCC_HIT_sum"), mean_by_sym(l2, "TCC_MISS_sum")
 sq = per_dispatch(os.path.join(SRC, "pmc_sq", "bench_counter_collection.csv"))
 gui, dur, mf = mean_by_sym(sq, "GRBM_GUI_ACTIVE"), mean_by_sym(sq, "dur"), mean_by_sym(sq, "SQ_VALU_MFMA_BUSY_CYCLES")
+n_mfma = mean_by_sym(sq, "SQ_INSTS_MFMA")
+lds_path = os.path.join(SRC, "pmc_lds", "bench_counter_collection.csv")
+lds = per_dispatch(lds_path) if os.path.exists(lds_path) else {}
+n_valu, n_lds, n_vmem = mean_by_sym(lds, "SQ_INSTS_VALU"), mean_by_sym(lds, "SQ_INSTS_LDS"), mean_by_sym(lds, "SQ_INSTS_VMEM")
+bank, lds_act = mean_by_sym(lds, "SQ_LDS_BANK_CONFLICT"), mean_by_sym(lds, "SQ_LDS_IDX_ACTIVE")
 out = {"note": "FETCH_SIZE/WRITE_SIZE are KiB counters; fetch is doubled (gfx950 rocprofv3 tallies 128-B requests at 64 B "
                "for 16-B/lane coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE is uncalibrated. "
                "GRBM_GUI_ACTIVE is summed over the 8 XCDs (clock = GUI/8/duration). MFMA pipe utilisation = "
@@ -75,9 +83,18 @@ for k, st in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"]):
     if k in hit:
         e["l2_hit_rate"] = hit[k] / (hit[k] + miss[k] + 1e-9)
     if k in gui and dur.get(k):
-        e["clock_ghz_under_pmc"] = gui[k] / 8 / dur[k]
+        # GRBM_GUI_ACTIVE / 8 XCDs / duration is an effective clock only when the kernel fills the chip for most of its
+        # duration: below ~100 us the ramp-up / drain and the counter's own granularity dominate (r02 showed 2.6-13 "GHz")
+        if dur[k] >= 100e3:
+            e["clock_ghz_under_pmc"] = gui[k] / 8 / dur[k]
         if mf.get(k):
             e["mfma_pipe_util"] = mf[k] / (gui[k] / 8 * 1024)
+    if n_mfma.get(k) and k in n_valu:      # instruction mix per MFMA (both counters are per-wave instruction counts)
+        e["valu_per_mfma"] = n_valu[k] / n_mfma[k]
+        e["lds_inst_per_mfma"] = n_lds.get(k, 0.0) / n_mfma[k]
+        e["vmem_inst_per_mfma"] = n_vmem.get(k, 0.0) / n_mfma[k]
+    if lds_act.get(k):
+        e["lds_bank_conflict_frac"] = bank.get(k, 0.0) / lds_act[k]
     out["kernels"][k] = e
 json.dump(out, open(os.path.join(DST, f"{TAG}_summary.json"), "w"), indent=1)
 print("wrote", DST, "top kernels:")

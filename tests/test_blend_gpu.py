@@ -110,3 +110,25 @@ def test_predict_linear_blend_full_architecture_multi_area():
     assert np.abs(out - ref).max() <= 1e-4, np.abs(out - ref).max()
     again = predict_linear_blend(DataLoader(ds, batch_size=32, shuffle=False), model)
     assert np.abs(out - again).max() <= 1e-9                 # one full batch == ragged batches (tiles independent in eval)
+
+
+def test_sweep_reduce_on_rccl_world1_equals_the_plain_sweep():
+    """cfg-G's rank-sharded sweep ends in torch.distributed.reduce on RCCL (resdepth_amd/inference.py); with one GPU the
+    only RCCL world is 1, where the reduce must be the identity: same raster checksum as the sweep without a process group.
+    (World sizes 2 and 4 run on one GPU over gloo: tests/test_dp_world2_gpu.py.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = [os.path.join(root, "bench.py"), "--infer", "--gpus", "1", "--raster", "1024", "--steps", "1", "--warmup", "1", "--no-prof"]
+    outs = []
+    for cmd in ([sys.executable] + common,
+                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                 "--master-port", "29583"] + common + ["--force-dist"]):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[1]["dist"] == {"backend": "nccl", "world_size_reported": 1} and outs[0]["dist"] is None
+    assert outs[0]["raster_checksum"] == outs[1]["raster_checksum"]

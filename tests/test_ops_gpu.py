@@ -602,3 +602,41 @@ def test_conv_epilogue_statistics_match_separate_pass(n, h, w, cin, cout):
         close(rm.cpu(), rm2.cpu(), tol=1e-6, name="running mean")
         close(rv.cpu(), rv2.cpu(), tol=1e-6, name="running var")
         assert int(nbt) == 8 and int(nbt2) == 8
+
+
+def test_fused_sgd_mixed_momentum_state_matches_torch():
+    """Some parameters already have a momentum buffer, others do not (a step taken while their gradient was None): torch
+    starts the missing buffers as clone(grad).  With dampening != 0 a single `first` flag for the flat group got that wrong."""
+    from resdepth_amd import FusedSGD
+    g = torch.Generator().manual_seed(5)
+    shapes = [(8, 4), (16,), (3, 3, 2)]
+    flat = torch.randn(sum(int(np.prod(s)) for s in shapes), generator=g).to(DEV)
+    init = flat.clone()
+    kw = dict(lr=0.1, momentum=0.9, dampening=0.3, weight_decay=1e-2)
+
+    def make(base):
+        ps, o = [], 0
+        for s in shapes:
+            n = int(np.prod(s))
+            ps.append(torch.nn.Parameter(base[o:o + n].view(s)))
+            o += n
+        return ps
+
+    ours, ref = make(flat), [torch.nn.Parameter(p.detach().cpu().clone()) for p in make(init.clone())]
+    oo, ro = FusedSGD(ours, **kw), torch.optim.SGD(ref, **kw)
+    gflat = torch.zeros_like(flat)
+    for step in range(3):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        o = 0
+        for i, (p, r, gr) in enumerate(zip(ours, ref, grads)):
+            n = gr.numel()
+            if step == 0 and i == 1:             # step 0: the middle parameter has no gradient -> no buffer yet
+                p.grad, r.grad = None, None
+            else:
+                gflat[o:o + n] = gr.flatten().to(DEV)
+                p.grad, r.grad = gflat[o:o + n].view(gr.shape), gr.clone()
+            o += n
+        oo.step()
+        ro.step()
+    for p, r in zip(ours, ref):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), rtol=2e-6, atol=1e-7)

@@ -230,20 +230,32 @@ def test_determinism_and_tile_independence_at_full_batch():
     assert full.shape == (32, 1, 256, 256)
 
 
-def test_two_stream_backward_is_bit_identical_to_serial_over_many_steps():
-    """The side-stream weight gradients overlap main-stream kernels; the overlap must never change a bit: 12 optimizer
-    steps at the BASELINE batch, twice with the two-stream backward and once serial, compared through the loss bits,
-    plus repeated single backwards compared per parameter.  (Round 2 found a kernel whose packed-FP32 FMAs went wrong
-    only under cross-stream co-execution -- resdepth_amd/csrc/build.sh, rd_edge_conv -- which a single pair of repeat
-    runs did not catch.)"""
+@pytest.mark.parametrize("n,cin,th,tw,sk,depth,steps", [
+    (32, 3, 256, 256, 64, 5, 12),      # BASELINE batch: segment kernels of the first conv, tile kernels of the last one
+    (32, 5, 256, 256, 64, 5, 6),       # 5 / 6 input channels: conv_first_kernel<5|6, true> is the side-stream weight gradient
+    (32, 6, 256, 256, 64, 5, 6),
+    (32, 1, 256, 256, 64, 5, 6),       # cfg-0's DSM-only input
+    (16, 3, 192, 320, 32, 4, 6),       # non-square tiles, 32-channel first level
+    (16, 4, 256, 128, 16, 5, 6),       # 16-channel first level
+    (8, 8, 128, 128, 64, 4, 6),        # > 6 input channels: generic NHWC first conv (MFMA weight gradient on the side stream)
+])
+def test_two_stream_backward_is_bit_identical_to_serial_over_many_steps(n, cin, th, tw, sk, depth, steps):
+    """The side-stream weight gradients overlap main-stream kernels; the overlap must never change a bit: several optimizer
+    steps, twice with the two-stream backward and once serial, compared through the loss bits, plus repeated single backwards
+    compared per parameter.  (Round 2 found a kernel whose packed-FP32 FMAs went wrong only under cross-stream co-execution --
+    profiles/r02_notes.md; since r03 no kernel of the library contains a packed-f32 instruction, csrc/build.sh +
+    scripts/check_isa.sh -- which a single pair of repeat runs did not catch.  The parameter sets cover every first-conv
+    kernel family that can run on the weight-gradient stream, first-level widths of 16 / 32 / 64 and non-square tiles.)"""
     from resdepth_amd import UNet, FusedAdam, masked_l1_loss
-    b = O.synthetic_batch(32, 3, 256, seed=1234)
-    x, y, mk = b["input"].to(DEV), b["target"].to(DEV), b["loss_mask"].to(DEV)
-    me, sd = b["dsm_mean"].float().to(DEV), b["dsm_std"].to(DEV)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(n, cin, th, tw, generator=g).to(DEV)
+    y = (x[:, 0:1].cpu() + 0.3 * torch.randn(n, 1, th, tw, generator=g)).to(DEV)
+    mk = (torch.rand(n, 1, th, tw, generator=g) > 0.05).to(DEV)
+    me, sd = (torch.randn(n, generator=g) * 50.0).to(DEV), torch.full((n,), 3.0, device=DEV)
 
-    def train(two_stream, steps=12):
+    def train(two_stream, steps=steps):
         torch.manual_seed(0)
-        m = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(DEV).train()
+        m = UNet(n_input_channels=cin, start_kernel=sk, depth=depth, bias_conv_layer=True).to(DEV).train()
         m.two_stream_backward = two_stream
         opt = FusedAdam(m.parameters(), lr=2e-4, weight_decay=1e-5)
         bits = []
@@ -274,7 +286,7 @@ def test_two_stream_backward_is_bit_identical_to_serial_over_many_steps():
 
     m.eval()                    # frozen statistics: every backward sees the same forward
     ref = grads(False)
-    for rep in range(8):
+    for rep in range(8 if cin == 3 and sk == 64 else 4):
         bad = [n for n, g, r in zip(names, grads(True), ref) if not torch.equal(g, r)]
         assert not bad, f"rep {rep}: two-stream gradients differ from serial for {bad}"
 
@@ -721,3 +733,68 @@ def test_data_parallel_overhead_at_full_batch_on_rccl_world1():
     base = plain["step_ms_median"]
     assert dist_["step_ms_median"] - base <= 1.0, (base, dist_["step_ms_median"])
     assert sync["step_ms_median"] - base <= 2.0, (base, sync["step_ms_median"])
+
+
+def test_arithmetic_mode_flip_rebuilds_the_packed_operands():
+    """The split-bf16 and the exact-f32 kernels read different layouts of the packed weight buffers and only the active
+    one is written: flipping `mfma_f32` without invalidate_packed() must re-pack (the cache key carries the mode), not read
+    a layout that was never filled."""
+    from resdepth_amd import UNet, _lib
+    torch.manual_seed(2)
+    model = UNet(n_input_channels=3, start_kernel=64, depth=3, bias_conv_layer=True).to(DEV).eval()
+    model.fold_eval_bn = False
+    x = torch.randn(2, 3, 64, 64, device=DEV)
+    try:
+        with torch.no_grad():
+            y_split = model(x)
+            _lib.tune_set("mfma_f32", 1)
+            y_f32 = model(x)
+            _lib.tune_set("mfma_f32", 0)
+            y_again = model(x)
+    finally:
+        _lib.tune_set("mfma_f32", 0)
+    assert torch.isfinite(y_f32).all()
+    assert float((y_f32 - y_split).abs().max()) <= 1e-4
+    assert torch.equal(y_again, y_split)
+
+
+def test_backward_after_a_parameter_update_raises_instead_of_using_the_new_weights():
+    """forward -> optimizer step -> backward of that forward: torch raises (a tensor needed for the backward was modified in
+    place); the engine's packed operands are persistent buffers re-packed in place, so it must refuse as well."""
+    from resdepth_amd import UNet, FusedAdam, masked_l1_loss
+    torch.manual_seed(2)
+    model = UNet(n_input_channels=2, start_kernel=16, depth=2, bias_conv_layer=True).to(DEV).train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    b = O.synthetic_batch(2, 2, 32, seed=3)
+    loss1 = masked_l1_loss(model(b["input"].to(DEV)), b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
+    loss2 = masked_l1_loss(model(b["input"].to(DEV)), b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
+    loss2.backward()
+    opt.step()                                   # parameters change while loss1's graph is still alive
+    with pytest.raises(RuntimeError, match="modified"):
+        loss1.backward()
+
+
+def test_twin_forward_does_not_reload_unchanged_parameters_nor_invalidate_other_models():
+    """A model on the zero-padded twin (channel counts not multiples of 4) used to copy every parameter into the twin,
+    re-pack it and bump the GLOBAL parameter generation on every forward -- which also forced every other UNet of the
+    process to re-pack."""
+    from resdepth_amd import UNet
+    torch.manual_seed(1)
+    odd = UNet(n_input_channels=2, start_kernel=6, depth=2).to(DEV).eval()
+    other = UNet(n_input_channels=2, start_kernel=8, depth=2).to(DEV).eval()
+    x = torch.randn(2, 2, 16, 16, device=DEV)
+    with torch.no_grad():
+        other(x)
+        cache = other._pack_cache
+        y1 = odd(x)
+        key = odd.__dict__["_twin_key"]
+        tw_cache = odd._twin()._pack_cache
+        y2 = odd(x)
+        other(x)
+    assert odd.__dict__["_twin_key"] == key and odd._twin()._pack_cache is tw_cache      # no reload, no re-pack
+    assert other._pack_cache is cache                                                  # the other model's cache survived
+    assert torch.equal(y1, y2)
+    with torch.no_grad():
+        odd.encoder[0][0][0].weight.mul_(2.0)    # a real change is picked up
+        y3 = odd(x)
+    assert not torch.equal(y3, y1)
