@@ -604,6 +604,9 @@ def test_conv_epilogue_statistics_match_separate_pass(n, h, w, cin, cout):
         assert int(nbt) == 8 and int(nbt2) == 8
 
 
+DEV = "cuda:0"
+
+
 def test_fused_sgd_mixed_momentum_state_matches_torch():
     """Some parameters already have a momentum buffer, others do not (a step taken while their gradient was None): torch
     starts the missing buffers as clone(grad).  With dampening != 0 a single `first` flag for the flat group got that wrong."""
