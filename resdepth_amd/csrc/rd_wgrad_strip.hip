@@ -207,6 +207,188 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_kernel(WsParams p) {
     }
 }
 
+
+// ---- the same strip schedule with the gfx950 transpose read (ds_read_b64_tr_b16) ------------------------------------------
+// wgrad_strip_kernel transposes pixel-major data into k-contiguous LDS rows in registers, which forces the x halo row to be
+// staged (and split) once per dx: the bf16 fragments need 16-byte aligned k, so a one-pixel shift is another image.  Here both
+// operands are stored in their NATURAL [pixel][term][channel] order (straight 8-byte copies of split float4s) and the
+// transposition happens in the fragment read: a 16-lane group of ds_read_b64_tr_b16 reads a [4 pixels][16 channels] bf16 block
+// (lane i: 8 bytes at its own address = pixel i >> 2, channels 4 (i & 3) ..) and returns column i to lane i -- two reads give
+// the 8 consecutive k (pixels) of a lane's MFMA row.  A horizontal tap shift is then just a pixel-row offset:
+//   * the x halo row (18 pixels x 32 ci) is staged ONCE instead of three times: 2624 instead of 3584 split elements per
+//     K-step (54 MFMAs per wave), and every staging load is a coalesced run (512 B per dz pixel, 128 B per x pixel);
+//   * LDS: pixel strides of 832 B (dz, 64 B pad) and 192 B (x) put the four pixel rows of a transpose read 16 banks apart --
+//     the two 16-lane groups of a 32-lane half then cover all 64 banks; 40 KB per block instead of 80.
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_tr2(const float* smem_base, int byte_off, int second) {
+    // two transpose reads (k = 0..3 and 4..7 of the lane's octet) -> one 8 x bf16 MFMA operand
+    typedef __attribute__((address_space(3))) v4s16* lds_p;
+    const char* b = reinterpret_cast<const char*>(smem_base) + byte_off;
+    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(b));
+    const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(b + second));
+    typedef short v8s16 __attribute__((ext_vector_type(8)));
+    const v8s16 r = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
+    constexpr int APX = 832, ASTAGE = 16 * APX;                // bytes per dz pixel row (3 x 256 + 64 pad) / per stage
+    constexpr int BPX = 192, BSLOT = 18 * BPX;                 // bytes per x halo pixel (3 x 64) / per ring slot
+    constexpr int RINGB = 2 * ASTAGE;                          // byte offset of the halo ring
+    __shared__ __attribute__((aligned(16))) float smem[(2 * ASTAGE + 4 * BSLOT) / 4];
+
+    const int gb = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = gb / p.tiles_mn;
+    const int lb = gb - split * p.tiles_mn;
+    const int tile_ci = lb % p.tiles_ci, tile_m = lb / p.tiles_ci;
+    const int m0 = tile_m * 128, ci0 = tile_ci * 32;
+    int img = 0, x0 = 0, ya = 0, yb = 0;
+    const int H = p.H, W = p.W;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    // staging items (one float4 = 4 channels of one pixel each): dz row 16 px x 32 quads = 512 items -> e = t, t + 256;
+    // x halo row 18 px x 8 quads = 144 items -> threads t < 144
+    const int a_cq = t & 31, a_p = t >> 5;                     // second item: pixel a_p + 8
+    const bool a_ok = m0 + a_cq * 4 < p.Cout;
+    const int b_cq = t & 7, b_hp = t >> 3;
+    const bool b_act = t < 144;
+    const bool b_ok = b_act && ci0 + b_cq * 4 < p.Cin;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.dz, p.a_bytes), rsB = make_rsrc(p.x, p.b_bytes);
+    const unsigned rowA = (unsigned)W * p.Cout * 4, rowB = (unsigned)W * p.Cin * 4;
+    unsigned baseA = 0, baseB = 0, voffA[2], voffB = kOOB;
+    auto set_strip = [&](int sid) {
+        const int sx = sid % p.strips_x;
+        const int cy = (sid / p.strips_x) % p.chunks_y;
+        img = sid / (p.strips_x * p.chunks_y);
+        x0 = sx * 16;
+        ya = cy * p.rows_per_chunk;
+        yb = ya + p.rows_per_chunk;
+        baseA = (unsigned)img * H * rowA;
+        baseB = (unsigned)img * H * rowB;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) voffA[k] = a_ok ? (unsigned)(((x0 + a_p + 8 * k) * p.Cout + m0 + a_cq * 4) * 4) : kOOB;
+        const int px = x0 - 1 + b_hp;
+        voffB = (b_ok && (unsigned)px < (unsigned)W) ? (unsigned)((px * p.Cin + ci0 + b_cq * 4) * 4) : kOOB;
+    };
+    // virtual step yy stages T(yy) = { dz row yy+1, x halo row yy+2 } and multiplies row yy
+    auto load_task = [&](int yy, float4 (&v)[3]) {
+        const int ra = yy + 1, rb = yy + 2;
+        const bool oka = ra >= ya && ra < yb, okb = rb >= 0 && rb < H && rb <= yb;
+        const unsigned sa = (unsigned)__builtin_amdgcn_readfirstlane(oka ? (int)(baseA + (unsigned)ra * rowA) : 0);
+        const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane(okb ? (int)(baseB + (unsigned)rb * rowB) : 0);
+        v[0] = buf_load4(rsA, oka ? voffA[0] : kOOB, sa);
+        v[1] = buf_load4(rsA, oka ? voffA[1] : kOOB, sa);
+        v[2] = buf_load4(rsB, okb ? voffB : kOOB, sb);
+    };
+    const int a_wr = a_p * APX + a_cq * 8, b_wr = b_hp * BPX + b_cq * 8;
+    auto put = [&](char* dst, const float4 x) {
+        uint2 ph, pm, pl;
+        unsigned h0, m0_, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+        split3<false>(x.x, h0, m0_, l0);
+        split3<false>(x.y, h1, m1, l1);
+        split3<false>(x.z, h2, m2, l2);
+        split3<false>(x.w, h3, m3, l3);
+        const unsigned sel = 0x07060302u;
+        ph = make_uint2(__builtin_amdgcn_perm(h1, h0, sel), __builtin_amdgcn_perm(h3, h2, sel));
+        pm = make_uint2(__builtin_amdgcn_perm(m1, m0_, sel), __builtin_amdgcn_perm(m3, m2, sel));
+        pl = make_uint2(__builtin_amdgcn_perm(l1, l0, sel), __builtin_amdgcn_perm(l3, l2, sel));
+        *reinterpret_cast<uint2*>(dst) = ph;
+        return make_uint4(pm.x, pm.y, pl.x, pl.y);
+    };
+    auto store_task = [&](int yy, const float4 (&v)[3]) {
+        char* sa = reinterpret_cast<char*>(smem) + ((yy + 1) & 1) * ASTAGE + a_wr;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            char* d = sa + k * 8 * APX;
+            const uint4 r = put(d, v[k]);
+            *reinterpret_cast<uint2*>(d + 256) = make_uint2(r.x, r.y);
+            *reinterpret_cast<uint2*>(d + 512) = make_uint2(r.z, r.w);
+        }
+        if (b_act) {
+            char* d = reinterpret_cast<char*>(smem) + RINGB + ((yy + 3) & 3) * BSLOT + b_wr;
+            const uint4 r = put(d, v[2]);
+            *reinterpret_cast<uint2*>(d + 64) = make_uint2(r.x, r.y);
+            *reinterpret_cast<uint2*>(d + 128) = make_uint2(r.z, r.w);
+        }
+    };
+
+    // fragment addressing: lane -> 16-lane group g (n-block nb = g & 1, k-octet h = g >> 1), i = lane & 15
+    const int li = lane & 15, lg = lane >> 4, nb = lg & 1, hk = lg >> 1;
+    const int a_rd = (8 * hk + (li >> 2)) * APX + (32 * wave + 16 * nb + 4 * (li & 3)) * 2;
+    const int b_rd = (8 * hk + (li >> 2)) * BPX + (16 * nb + 4 * (li & 3)) * 2;
+    const int lrow = lane & 31, half = lane >> 5;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    auto mma_row = [&](int y) {
+        const int a_stage = (y & 1) * ASTAGE;
+        bf16x8 af[3], bf[2][3][3];
+        auto read_b = [&](int dy, bf16x8 (&dst)[3][3]) {
+            const int slot = RINGB + ((y + dy) & 3) * BSLOT;    // image row y+dy-1 lives in slot (row+1)&3
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dst[d][q] = lds_tr2(smem, slot + b_rd + d * BPX + q * 64, 4 * BPX);
+        };
+#pragma unroll
+        for (int q = 0; q < 3; ++q) af[q] = lds_tr2(smem, a_stage + a_rd + q * 256, 4 * APX);
+        read_b(0, bf[0]);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            if (dy < 2) read_b(dy + 1, bf[(dy + 1) & 1]);
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    acc[dy * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t6]], bf[dy & 1][d][PB[t6]], acc[dy * 3 + d], 0, 0, 0);
+        }
+    };
+
+    float4 v0[3], v1[3];
+    for (int rep = 0; rep < p.reps; ++rep) {
+        set_strip(split * p.reps + rep);
+        const int ys = ya - 3;                   // three warm-up steps fill the halo ring and the first dz row
+        load_task(ys, v0);
+        load_task(ys + 1, v1);
+        store_task(ys, v0);
+        load_task(ys + 2, v0);
+        __syncthreads();
+        store_task(ys + 1, v1);
+        load_task(ys + 3, v1);
+        __syncthreads();
+        store_task(ys + 2, v0);
+        load_task(ys + 4, v0);
+        __syncthreads();
+        for (int yy = ya; yy < yb; yy += 2) {    // rows_per_chunk is even; no branches around the MFMAs
+            store_task(yy, v1);
+            load_task(yy + 2, v1);
+            mma_row(yy);
+            __syncthreads();
+            store_task(yy + 1, v0);
+            load_task(yy + 3, v0);
+            mma_row(yy + 1);
+            __syncthreads();
+        }
+    }
+
+    float* out = p.slab + (long)split * p.M * p.N;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        const int n = tp * p.Cin + ci0 + lrow;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < p.M) out[(long)m * p.N + n] = acc[tp][r];
+        }
+    }
+}
+
 struct WsPlan {
     int ok, swapped, rows_per_chunk, chunks_y, strips_x, tiles_m, tiles_ci, reps, splits;
 };
@@ -275,7 +457,14 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     q.a_bytes = (unsigned)ab; q.b_bytes = (unsigned)bb;
     ProfScope ps(s, "conv3x3_wgrad|wgrad_strip", 2.0 * cout * 9.0 * cin * (double)n * h * w, ab + bb + 4.0 * cout * 9.0 * cin,
                  true);
-    if (tune(TUNE_WG_OCC) == 2)
+    // transpose-read variant by default (r03: 2.80 -> 2.69 ms over the nine layers alone, +0.8 % end to end, VALU per MFMA
+    // 2.9 -> see profiles/r03_summary.json); wg_strip = 1 selects the register-transpose kernel for A/B runs
+    const bool tr = tune(TUNE_WG_STRIP) != 1;
+    if (tr && tune(TUNE_WG_OCC) == 2)
+        hipLaunchKernelGGL(wgrad_strip_tr_kernel<2>, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
+    else if (tr)
+        hipLaunchKernelGGL(wgrad_strip_tr_kernel<1>, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
+    else if (tune(TUNE_WG_OCC) == 2)
         hipLaunchKernelGGL(wgrad_strip_kernel<2>, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
     else
         hipLaunchKernelGGL(wgrad_strip_kernel<1>, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
