@@ -231,32 +231,56 @@ __device__ __forceinline__ bf16x8 lds_tr2(const float* smem_base, int byte_off, 
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int OCC>
+// NCO x NCI = 4 waves: wave (cw, cb) owns output channels [32 cw, +32) x input channels [32 cb, +32) of the block tile.
+//   <4, 1>: 128 co x 32 ci (the r02 tile): 2048 + 576 = 2624 staged elements per K-step
+//   <2, 2>:  64 co x 64 ci               : 1024 + 1152 = 2176 (-17 %), needs Cin % 64 == 0
+template <int OCC, int NCO, int NCI>
 __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
-    constexpr int APX = 832, ASTAGE = 16 * APX;                // bytes per dz pixel row (3 x 256 + 64 pad) / per stage
-    constexpr int BPX = 192, BSLOT = 18 * BPX;                 // bytes per x halo pixel (3 x 64) / per ring slot
+    static_assert(NCO * NCI == 4, "four waves");
+    constexpr int TA = 64 * NCO, TB = 64 * NCI;                // bytes of one term of one pixel (32 channels x 2 B per wave column)
+    // pixel strides: 3 terms + padding so that (stride / 4) mod 64 is 16 or 48 -- the four pixel rows of a transpose read then
+    // sit 16 banks apart and the two 16-lane groups of a 32-lane half cover all 64 banks
+    constexpr int APX = 3 * TA + (NCO == 4 ? 64 : NCO == 2 ? 64 : 0), BPX = 3 * TB + (NCI == 2 ? 64 : 0);
+    static_assert((APX / 4) % 64 == 16 || (APX / 4) % 64 == 48, "dz pixel stride");
+    static_assert((BPX / 4) % 64 == 16 || (BPX / 4) % 64 == 48, "x pixel stride");
+    constexpr int ASTAGE = 16 * APX, BSLOT = 18 * BPX;         // bytes per dz stage / per halo ring slot
     constexpr int RINGB = 2 * ASTAGE;                          // byte offset of the halo ring
+    constexpr int AQ = 8 * NCO, BQ = 8 * NCI;                  // channel quads per pixel
+    constexpr int AI = 16 * AQ / 256, BI = (18 * BQ + 255) / 256;      // staging items (float4) per thread
     __shared__ __attribute__((aligned(16))) float smem[(2 * ASTAGE + 4 * BSLOT) / 4];
 
     const int gb = xcd_remap(blockIdx.x, gridDim.x);
     const int split = gb / p.tiles_mn;
     const int lb = gb - split * p.tiles_mn;
     const int tile_ci = lb % p.tiles_ci, tile_m = lb / p.tiles_ci;
-    const int m0 = tile_m * 128, ci0 = tile_ci * 32;
+    const int m0 = tile_m * (32 * NCO), ci0 = tile_ci * (32 * NCI);
     int img = 0, x0 = 0, ya = 0, yb = 0;
     const int H = p.H, W = p.W;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cw = wave / NCI, cb = wave % NCI;
 
-    // staging items (one float4 = 4 channels of one pixel each): dz row 16 px x 32 quads = 512 items -> e = t, t + 256;
-    // x halo row 18 px x 8 quads = 144 items -> threads t < 144
-    const int a_cq = t & 31, a_p = t >> 5;                     // second item: pixel a_p + 8
-    const bool a_ok = m0 + a_cq * 4 < p.Cout;
-    const int b_cq = t & 7, b_hp = t >> 3;
-    const bool b_act = t < 144;
-    const bool b_ok = b_act && ci0 + b_cq * 4 < p.Cin;
+    // staging items (one float4 = 4 channels of one pixel): dz row 16 px x AQ quads, x halo row 18 px x BQ quads
+    int a_wr[AI], b_wr[BI];
+    int a_px[AI], a_ch[AI], b_hp[BI], b_ch[BI];
+    bool b_act[BI];
+#pragma unroll
+    for (int k = 0; k < AI; ++k) {
+        const int e = t + 256 * k, cq = e % AQ, px = e / AQ;
+        a_px[k] = px;
+        a_ch[k] = m0 + cq * 4 < p.Cout ? m0 + cq * 4 : -1;
+        a_wr[k] = px * APX + cq * 8;
+    }
+#pragma unroll
+    for (int k = 0; k < BI; ++k) {
+        const int e = t + 256 * k, cq = e % BQ, hp = e / BQ;
+        b_act[k] = e < 18 * BQ;
+        b_hp[k] = hp;
+        b_ch[k] = (b_act[k] && ci0 + cq * 4 < p.Cin) ? ci0 + cq * 4 : -1;
+        b_wr[k] = hp * BPX + cq * 8;
+    }
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.dz, p.a_bytes), rsB = make_rsrc(p.x, p.b_bytes);
     const unsigned rowA = (unsigned)W * p.Cout * 4, rowB = (unsigned)W * p.Cin * 4;
-    unsigned baseA = 0, baseB = 0, voffA[2], voffB = kOOB;
+    unsigned baseA = 0, baseB = 0, voffA[AI], voffB[BI];
     auto set_strip = [&](int sid) {
         const int sx = sid % p.strips_x;
         const int cy = (sid / p.strips_x) % p.chunks_y;
@@ -267,56 +291,50 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
         baseA = (unsigned)img * H * rowA;
         baseB = (unsigned)img * H * rowB;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) voffA[k] = a_ok ? (unsigned)(((x0 + a_p + 8 * k) * p.Cout + m0 + a_cq * 4) * 4) : kOOB;
-        const int px = x0 - 1 + b_hp;
-        voffB = (b_ok && (unsigned)px < (unsigned)W) ? (unsigned)((px * p.Cin + ci0 + b_cq * 4) * 4) : kOOB;
+        for (int k = 0; k < AI; ++k) voffA[k] = a_ch[k] >= 0 ? (unsigned)(((x0 + a_px[k]) * p.Cout + a_ch[k]) * 4) : kOOB;
+#pragma unroll
+        for (int k = 0; k < BI; ++k) {
+            const int px = x0 - 1 + b_hp[k];
+            voffB[k] = (b_ch[k] >= 0 && (unsigned)px < (unsigned)W) ? (unsigned)((px * p.Cin + b_ch[k]) * 4) : kOOB;
+        }
     };
     // virtual step yy stages T(yy) = { dz row yy+1, x halo row yy+2 } and multiplies row yy
-    auto load_task = [&](int yy, float4 (&v)[3]) {
+    auto load_task = [&](int yy, float4 (&v)[AI + BI]) {
         const int ra = yy + 1, rb = yy + 2;
         const bool oka = ra >= ya && ra < yb, okb = rb >= 0 && rb < H && rb <= yb;
         const unsigned sa = (unsigned)__builtin_amdgcn_readfirstlane(oka ? (int)(baseA + (unsigned)ra * rowA) : 0);
         const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane(okb ? (int)(baseB + (unsigned)rb * rowB) : 0);
-        v[0] = buf_load4(rsA, oka ? voffA[0] : kOOB, sa);
-        v[1] = buf_load4(rsA, oka ? voffA[1] : kOOB, sa);
-        v[2] = buf_load4(rsB, okb ? voffB : kOOB, sb);
+#pragma unroll
+        for (int k = 0; k < AI; ++k) v[k] = buf_load4(rsA, oka ? voffA[k] : kOOB, sa);
+#pragma unroll
+        for (int k = 0; k < BI; ++k) v[AI + k] = buf_load4(rsB, okb ? voffB[k] : kOOB, sb);
     };
-    const int a_wr = a_p * APX + a_cq * 8, b_wr = b_hp * BPX + b_cq * 8;
-    auto put = [&](char* dst, const float4 x) {
-        uint2 ph, pm, pl;
+    // float4 (4 channels of a pixel) -> three 8-byte pieces (one per term) at dst, dst + term stride, dst + 2 term strides
+    auto put = [&](char* dst, int tstride, const float4 x) {
         unsigned h0, m0_, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
         split3<false>(x.x, h0, m0_, l0);
         split3<false>(x.y, h1, m1, l1);
         split3<false>(x.z, h2, m2, l2);
         split3<false>(x.w, h3, m3, l3);
         const unsigned sel = 0x07060302u;
-        ph = make_uint2(__builtin_amdgcn_perm(h1, h0, sel), __builtin_amdgcn_perm(h3, h2, sel));
-        pm = make_uint2(__builtin_amdgcn_perm(m1, m0_, sel), __builtin_amdgcn_perm(m3, m2, sel));
-        pl = make_uint2(__builtin_amdgcn_perm(l1, l0, sel), __builtin_amdgcn_perm(l3, l2, sel));
-        *reinterpret_cast<uint2*>(dst) = ph;
-        return make_uint4(pm.x, pm.y, pl.x, pl.y);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_amdgcn_perm(h1, h0, sel), __builtin_amdgcn_perm(h3, h2, sel));
+        *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(__builtin_amdgcn_perm(m1, m0_, sel), __builtin_amdgcn_perm(m3, m2, sel));
+        *reinterpret_cast<uint2*>(dst + 2 * tstride) = make_uint2(__builtin_amdgcn_perm(l1, l0, sel), __builtin_amdgcn_perm(l3, l2, sel));
     };
-    auto store_task = [&](int yy, const float4 (&v)[3]) {
-        char* sa = reinterpret_cast<char*>(smem) + ((yy + 1) & 1) * ASTAGE + a_wr;
+    auto store_task = [&](int yy, const float4 (&v)[AI + BI]) {
+        char* sa = reinterpret_cast<char*>(smem) + ((yy + 1) & 1) * ASTAGE;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            char* d = sa + k * 8 * APX;
-            const uint4 r = put(d, v[k]);
-            *reinterpret_cast<uint2*>(d + 256) = make_uint2(r.x, r.y);
-            *reinterpret_cast<uint2*>(d + 512) = make_uint2(r.z, r.w);
-        }
-        if (b_act) {
-            char* d = reinterpret_cast<char*>(smem) + RINGB + ((yy + 3) & 3) * BSLOT + b_wr;
-            const uint4 r = put(d, v[2]);
-            *reinterpret_cast<uint2*>(d + 64) = make_uint2(r.x, r.y);
-            *reinterpret_cast<uint2*>(d + 128) = make_uint2(r.z, r.w);
-        }
+        for (int k = 0; k < AI; ++k) put(sa + a_wr[k], TA, v[k]);
+        char* sb = reinterpret_cast<char*>(smem) + RINGB + ((yy + 3) & 3) * BSLOT;
+#pragma unroll
+        for (int k = 0; k < BI; ++k)
+            if (b_act[k]) put(sb + b_wr[k], TB, v[AI + k]);
     };
 
     // fragment addressing: lane -> 16-lane group g (n-block nb = g & 1, k-octet h = g >> 1), i = lane & 15
     const int li = lane & 15, lg = lane >> 4, nb = lg & 1, hk = lg >> 1;
-    const int a_rd = (8 * hk + (li >> 2)) * APX + (32 * wave + 16 * nb + 4 * (li & 3)) * 2;
-    const int b_rd = (8 * hk + (li >> 2)) * BPX + (16 * nb + 4 * (li & 3)) * 2;
+    const int a_rd = (8 * hk + (li >> 2)) * APX + (32 * cw + 16 * nb + 4 * (li & 3)) * 2;
+    const int b_rd = (8 * hk + (li >> 2)) * BPX + (32 * cb + 16 * nb + 4 * (li & 3)) * 2;
     const int lrow = lane & 31, half = lane >> 5;
 
     f32x16 acc[9];
@@ -334,10 +352,10 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
 #pragma unroll
             for (int d = 0; d < 3; ++d)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) dst[d][q] = lds_tr2(smem, slot + b_rd + d * BPX + q * 64, 4 * BPX);
+                for (int q = 0; q < 3; ++q) dst[d][q] = lds_tr2(smem, slot + b_rd + d * BPX + q * TB, 4 * BPX);
         };
 #pragma unroll
-        for (int q = 0; q < 3; ++q) af[q] = lds_tr2(smem, a_stage + a_rd + q * 256, 4 * APX);
+        for (int q = 0; q < 3; ++q) af[q] = lds_tr2(smem, a_stage + a_rd + q * TA, 4 * APX);
         read_b(0, bf[0]);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
         }
     };
 
-    float4 v0[3], v1[3];
+    float4 v0[AI + BI], v1[AI + BI];
     for (int rep = 0; rep < p.reps; ++rep) {
         set_strip(split * p.reps + rep);
         const int ys = ya - 3;                   // three warm-up steps fill the halo ring and the first dz row
@@ -380,10 +398,10 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
     float* out = p.slab + (long)split * p.M * p.N;
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
-        const int n = tp * p.Cin + ci0 + lrow;
+        const int n = tp * p.Cin + ci0 + cb * 32 + lrow;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = m0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m < p.M) out[(long)m * p.N + n] = acc[tp][r];
         }
     }
@@ -391,6 +409,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
 
 struct WsPlan {
     int ok, swapped, rows_per_chunk, chunks_y, strips_x, tiles_m, tiles_ci, reps, splits;
+    int sq;         // 1: 64 co x 64 ci block tile (transpose-read kernel <2, 2>), 0: 128 co x 32 ci
 };
 
 // The strip kernel needs W >= 16, the shifted operand's channels % 32 == 0 and a full 128-channel block on the other
@@ -401,7 +420,11 @@ static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
     WsPlan pl = {};
     const int force = tune(TUNE_WG_STRIP);
     if (!mfma_split() || force == 0 || w % 16 != 0 || h < 4 || h % 2 != 0) return pl;   // 16-pixel strips, rows in pairs
-    if (cout >= 128 && cout % 4 == 0 && cin % 32 == 0) {
+    // square tile: both channel counts multiples of 64 (every cfg-S / cfg-M layer) -- fewer staged elements per MFMA and no
+    // operand swap; wg_strip = 3 keeps the 128 x 32 tile of the transpose-read kernel for A/B runs
+    if (force != 1 && force != 3 && cout % 64 == 0 && cin % 64 == 0) {
+        pl.sq = 1;
+    } else if (cout >= 128 && cout % 4 == 0 && cin % 32 == 0) {
         pl.swapped = 0;
     } else if (cin >= 128 && cin % 4 == 0 && cout % 32 == 0) {
         pl.swapped = 1;
@@ -411,8 +434,8 @@ static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
     }
     pl.ok = 1;
     pl.strips_x = w / 16;
-    pl.tiles_m = cdiv(cout, 128);
-    pl.tiles_ci = cin / 32;
+    pl.tiles_m = cdiv(cout, pl.sq ? 64 : 128);
+    pl.tiles_ci = cin / (pl.sq ? 64 : 32);
     const long base = (long)pl.tiles_m * pl.tiles_ci * n * pl.strips_x;
     int rows = h;
     const int minb = tune(TUNE_WG_MINBLOCKS);
@@ -460,14 +483,14 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     // transpose-read variant by default (r03: 2.80 -> 2.69 ms over the nine layers alone, +0.8 % end to end, VALU per MFMA
     // 2.9 -> see profiles/r03_summary.json); wg_strip = 1 selects the register-transpose kernel for A/B runs
     const bool tr = tune(TUNE_WG_STRIP) != 1;
-    if (tr && tune(TUNE_WG_OCC) == 2)
-        hipLaunchKernelGGL(wgrad_strip_tr_kernel<2>, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
-    else if (tr)
-        hipLaunchKernelGGL(wgrad_strip_tr_kernel<1>, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
-    else if (tune(TUNE_WG_OCC) == 2)
-        hipLaunchKernelGGL(wgrad_strip_kernel<2>, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
-    else
-        hipLaunchKernelGGL(wgrad_strip_kernel<1>, dim3(q.tiles_mn * wp.splits), dim3(256), 0, s, q);
+    const dim3 grid(q.tiles_mn * wp.splits);
+    const int occ = tune(TUNE_WG_OCC);
+    if (wp.sq && occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 2, 2>), grid, dim3(256), 0, s, q);
+    else if (wp.sq) hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 2, 2>), grid, dim3(256), 0, s, q);
+    else if (tr && occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 4, 1>), grid, dim3(256), 0, s, q);
+    else if (tr) hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 4, 1>), grid, dim3(256), 0, s, q);
+    else if (occ == 2) hipLaunchKernelGGL(wgrad_strip_kernel<2>, grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL(wgrad_strip_kernel<1>, grid, dim3(256), 0, s, q);
     RD_LAUNCH_CHECK("wgrad_strip");
     *splits_out = wp.splits;
     *swapped_out = wp.swapped;
