@@ -55,14 +55,18 @@ size_t rd_packed_weight_bytes(int rows, int taps, int cin);
  *   wf[co][tap][ci]              B operand of the forward implicit GEMM
  *   wd[ci][tap][co] = w[co][ci][8-tap]   B operand of the data-gradient GEMM (nullable) */
 int rd_pack_conv3x3_weight(const float* w_oihw, float* wf, float* wd, int cout, int cin, rd_stream_t s);
-/* All packed operands of a network in ONE launch (split-bf16 mode).  items_dev: device array of n_items records of 8 int64:
+/* All packed operands of a network in ONE or TWO launches (split-bf16 mode).  items_dev: device array of n_items records of
+ * 10 int64:
  *   { w (device pointer, torch layout), forward-operand buffer, data-gradient-operand buffer, kind (0 = conv3x3 [Cout][Cin][3][3],
- *     1 = ConvTranspose2d [Cin][Cout][2][2]), Cout, Cin, first piece index, fp32 forward-operand flag/pointer (convT only: the
- *     buffer base again when the fp32 layout wtf is wanted, else 0) }
- * with consecutive piece ranges of rd_pack_item_pieces() pieces each; the buffers are the opaque packed buffers of
+ *     1 = ConvTranspose2d [Cin][Cout][2][2]), Cout, Cin, first piece index, fp32 forward-operand pointer (convT only: the buffer
+ *     base again when the fp32 layout wtf is wanted, else 0), first tile index, 0 }
+ * A layer whose channel counts are both multiples of 32 is packed by the TILE kernel (rd_pack_item_tiles() > 0 tiles, coalesced
+ * loads through LDS; it then owns no pieces: its `first piece index` is the running piece count), every other layer piece by
+ * piece (rd_pack_item_pieces() pieces, gathered loads; it owns no tiles).  The buffers are the opaque packed buffers of
  * rd_packed_weight_bytes().  Same results as rd_pack_conv3x3_weight / rd_pack_convt2x2_weight layer by layer. */
 long long rd_pack_item_pieces(int kind, int cout, int cin, int with_f32);
-int rd_pack_weights_fused(const void* items_dev, int n_items, long long total_pieces, rd_stream_t s);
+long long rd_pack_item_tiles(int kind, int cout, int cin);
+int rd_pack_weights_fused(const void* items_dev, int n_items, long long total_pieces, long long total_tiles, rd_stream_t s);
 /* Inference: eval-mode BatchNorm folded into the forward operand -- wf[co][tap][ci] = w[co][ci][tap] * row_scale[co] with
  * row_scale = gamma / sqrt(running_var + eps) (lib/UNet.py:45 in eval mode, reached from lib/evaluation.py:497). */
 int rd_pack_conv3x3_weight_folded(const float* w_oihw, const float* row_scale, float* wf, int cout, int cin, rd_stream_t s);

@@ -33,7 +33,8 @@ SIGNATURES = {
     "rd_last_error_string": (C.c_char_p, []),
     "rd_pack_conv3x3_weight": (I, [P, P, P, I, I, P]),
     "rd_pack_item_pieces": (LL, [I, I, I, I]),
-    "rd_pack_weights_fused": (I, [P, I, LL, P]),
+    "rd_pack_item_tiles": (LL, [I, I, I]),
+    "rd_pack_weights_fused": (I, [P, I, LL, LL, P]),
     "rd_pack_conv3x3_weight_folded": (I, [P, P, P, I, I, P]),
     "rd_pack_convt2x2_weight": (I, [P, P, P, I, I, P]),
     "rd_conv3x3_fwd": (I, [P, P, P, I, I, I, I, I, P]),

@@ -282,7 +282,7 @@ class UNet(nn.Module):
             # split-bf16 mode: every operand of the network in ONE launch into persistent buffers (device item table)
             plan = self._pack_plan()
             with torch.cuda.stream(side):
-                _lib.check(_lib.load().rd_pack_weights_fused(plan["items"].data_ptr(), plan["n"], plan["total"],
+                _lib.check(_lib.load().rd_pack_weights_fused(plan["items"].data_ptr(), plan["n"], plan["total"], plan["tiles"],
                                                              _lib.stream_ptr()), "pack_weights_fused")
                 ev = torch.cuda.Event()
                 ev.record(side)
@@ -328,7 +328,18 @@ class UNet(nn.Module):
         if plan is not None and plan["flat"] == self._flat_param.data_ptr():
             return plan
         lib, dev, d = _lib.load(), self._flat_param.device, self.depth
-        rows, buffers, begin = [], {}, 0
+        rows, buffers, begin, tbegin = [], {}, 0, 0
+
+        def count(kind, cout, cin, f32):
+            """-> (first piece, first tile) of this item; tile-packed layers own no pieces and vice versa"""
+            nonlocal begin, tbegin
+            at = (begin, tbegin)
+            tiles = lib.rd_pack_item_tiles(kind, cout, cin)
+            if tiles > 0:
+                tbegin += tiles
+            else:
+                begin += lib.rd_pack_item_pieces(kind, cout, cin, f32)
+            return at
 
         def split_ptr(buf, nrows, taps, cin):
             return buf.data_ptr() + (nrows * taps * cin * 4 + 15) // 16 * 16      # the split operand follows the fp32 layout
@@ -338,8 +349,8 @@ class UNet(nn.Module):
             cout, cin = w.shape[0], w.shape[1]
             wf, wd = ops._packed_buffer(cout, 9, cin, dev), ops._packed_buffer(cin, 9, cout, dev)
             buffers[key] = (wf, wd)
-            rows.append([w.data_ptr(), split_ptr(wf, cout, 9, cin), split_ptr(wd, cin, 9, cout), 0, cout, cin, begin, 0])
-            begin += lib.rd_pack_item_pieces(0, cout, cin, 0)
+            b0, t0 = count(0, cout, cin, 0)
+            rows.append([w.data_ptr(), split_ptr(wf, cout, 9, cin), split_ptr(wd, cin, 9, cout), 0, cout, cin, b0, 0, t0, 0])
 
         def convt(key, w):
             nonlocal begin
@@ -347,9 +358,9 @@ class UNet(nn.Module):
             wtf, wtd = ops._packed_buffer(4 * cout, 1, cin, dev), ops._packed_buffer(cin, 4, cout, dev)
             buffers[key] = (wtf, wtd)
             f32 = 1 if cin <= 128 else 0       # short-K levels may run on the exact-f32 NT kernel (fp32 operand layout)
-            rows.append([w.data_ptr(), split_ptr(wtf, 4 * cout, 1, cin), split_ptr(wtd, cin, 4, cout), 1, cout, cin, begin,
-                         wtf.data_ptr() if f32 else 0])
-            begin += lib.rd_pack_item_pieces(1, cout, cin, f32)
+            b0, t0 = count(1, cout, cin, f32)
+            rows.append([w.data_ptr(), split_ptr(wtf, 4 * cout, 1, cin), split_ptr(wtd, cin, 4, cout), 1, cout, cin, b0,
+                         wtf.data_ptr() if f32 else 0, t0, 0])
 
         if self._first_generic():
             conv("enc_first", self.encoder[0][0][0].weight)
@@ -361,7 +372,8 @@ class UNet(nn.Module):
             if i < d - 1:
                 conv(("dec_c", i), self.decoder[i][1][0].weight)
         items = torch.tensor(rows, dtype=torch.int64).to(dev)
-        plan = {"flat": self._flat_param.data_ptr(), "items": items, "n": len(rows), "total": begin, "buffers": buffers}
+        plan = {"flat": self._flat_param.data_ptr(), "items": items, "n": len(rows), "total": begin, "tiles": tbegin,
+                "buffers": buffers}
         self.__dict__["_pack_plan_cache"] = plan
         return plan
 

@@ -159,7 +159,11 @@ def test_convt2x2_adjoint_identities_at_full_size(h, c):
 
 
 CONVT_SHAPES = [(2, 4, 8, 8, 12), (1, 2, 2, 4, 4), (4, 16, 16, 128, 128), (8, 32, 32, 64, 64), (2, 8, 8, 256, 256),
-                (2, 6, 10, 8, 12), (3, 12, 48, 64, 64), (2, 24, 40, 128, 128), (1, 5, 8, 32, 64)]     # not powers of two
+                (2, 6, 10, 8, 12), (3, 12, 48, 64, 64), (2, 24, 40, 128, 128), (1, 5, 8, 32, 64),     # not powers of two
+                # r03 kernels of rd_convt.hip: convt_dgrad<2,1,4> (Cin >= 128) / <2,2,2> (Cin = 64), several column tiles, a
+                # ragged last pixel tile, Cin != Cout; convt_wgrad<4|2|1> with an ODD number of K-steps per split (the extra
+                # all-zero step), several row tiles, a ragged last split
+                (4, 32, 32, 128, 128), (2, 48, 48, 256, 128), (1, 80, 80, 64, 192), (3, 36, 48, 128, 64), (5, 30, 32, 192, 64)]
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", CONVT_SHAPES)
@@ -515,7 +519,8 @@ def test_layout_roundtrip():
 @pytest.mark.parametrize("n,h,w,cin,cout,mode,kind", [
     (2, 32, 32, 64, 128, 1, "conv"), (8, 64, 64, 64, 128, 1, "conv"), (16, 64, 64, 128, 256, 2, "conv"), (2, 16, 16, 20, 36, 1, "conv"),
     (3, 24, 40, 32, 64, 1, "conv"), (2, 48, 80, 64, 128, 2, "conv"), (4, 16, 16, 128, 128, 1, "convt"), (2, 8, 8, 256, 256, 1, "convt"),
-    (2, 6, 10, 8, 12, 1, "convt"), (2, 64, 64, 64, 1, 1, "last"), (1, 24, 40, 32, 1, 1, "last"), (2, 16, 16, 8, 1, 1, "last")])
+    (2, 6, 10, 8, 12, 1, "convt"), (4, 32, 32, 128, 128, 1, "convt"), (2, 48, 48, 256, 128, 1, "convt"), (1, 80, 80, 64, 192, 1, "convt"),
+    (2, 64, 64, 64, 1, 1, "last"), (1, 24, 40, 32, 1, 1, "last"), (2, 16, 16, 8, 1, 1, "last")])
 def test_bn_backward_statistics_from_the_data_gradient_epilogues(n, h, w, cin, cout, mode, kind):
     """rd_*_bwd_data_bnstats: the data gradient is bit-identical to the plain entry point, and the per-tile partial rows,
     summed by rd_bn_bwd_stats_finalize, equal the sums of the stand-alone reduction pass rd_bn_act_bwd_reduce over

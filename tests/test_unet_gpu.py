@@ -798,3 +798,51 @@ def test_twin_forward_does_not_reload_unchanged_parameters_nor_invalidate_other_
         odd.encoder[0][0][0].weight.mul_(2.0)    # a real change is picked up
         y3 = odd(x)
     assert not torch.equal(y3, y1)
+
+
+def test_fused_weight_packing_equals_layer_by_layer_packing():
+    """rd_pack_weights_fused (tile kernel for layers whose channel counts are multiples of 32, piece kernel for the rest)
+    writes the same split-bf16 operands, bit for bit, as rd_pack_conv3x3_weight / rd_pack_convt2x2_weight layer by layer
+    (whose own layouts the per-op tests pin against torch)."""
+    from resdepth_amd import UNet, ops
+    torch.manual_seed(6)
+    # widths 16 (piece kernel), 32, 64, 128 (tile kernel: 1, 2 and 4 tiles per side), Cin != Cout in every conv
+    model = UNet(n_input_channels=3, start_kernel=16, depth=4, bias_conv_layer=True).to(DEV).eval()
+    model._ensure_flat()
+    pk = model._packed()
+    torch.cuda.synchronize()
+
+    def split_part(buf, rows, taps, cin):
+        off = (rows * taps * cin * 4 + 15) // 16 * 16
+        return buf.view(torch.uint8).flatten()[off:]
+
+    d, n_checked = model.depth, 0
+    for i in range(1, d):
+        w = model.encoder[i][0][0].weight
+        cout, cin = w.shape[0], w.shape[1]
+        wf, wd = ops.pack_conv3x3_weight(w)
+        gf, gd = pk.get(("enc", i - 1))
+        assert torch.equal(split_part(gf, cout, 9, cin), split_part(wf, cout, 9, cin)), ("enc fwd", i)
+        assert torch.equal(split_part(gd, cin, 9, cout), split_part(wd, cin, 9, cout)), ("enc dgrad", i)
+        n_checked += 1
+    for i in range(d):
+        up = model._up_of(i)
+        cin, cout = up.weight.shape[0], up.weight.shape[1]
+        wtf, wtd = ops.pack_convt2x2_weight(up.weight)
+        gf, gd = pk.get(("dec_t", i))
+        assert torch.equal(split_part(gf, 4 * cout, 1, cin), split_part(wtf, 4 * cout, 1, cin)), ("convT fwd", i)
+        assert torch.equal(split_part(gd, cin, 4, cout), split_part(wtd, cin, 4, cout)), ("convT dgrad", i)
+        if cin <= 128:      # the fp32 forward operand of the short-K levels is written too
+            nf = 4 * cout * cin
+            assert torch.equal(gf.view(torch.uint8).flatten()[:4 * nf], wtf.view(torch.uint8).flatten()[:4 * nf]), ("convT f32", i)
+        if i < d - 1:
+            w = model.decoder[i][1][0].weight
+            cout, cin = w.shape[0], w.shape[1]
+            wf, wd = ops.pack_conv3x3_weight(w)
+            gf, gd = pk.get(("dec_c", i))
+            assert torch.equal(split_part(gf, cout, 9, cin), split_part(wf, cout, 9, cin)), ("dec fwd", i)
+            assert torch.equal(split_part(gd, cin, 9, cout), split_part(wd, cin, 9, cout)), ("dec dgrad", i)
+        n_checked += 1
+    assert n_checked >= 7
+    plan = model._pack_plan()
+    assert plan["tiles"] > 0 and plan["total"] > 0          # both packers ran
