@@ -110,12 +110,13 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
                 af[i][q] = *reinterpret_cast<const bf16x8*>(stage + (i * 32 + lrow) * RS + half * 4 + q * 8);
     };
     constexpr int GP = TM >= 2 ? 2 : 1;
+    constexpr int NB_ = TM >= 4 ? 3 : 4;
     // One K-step (16 input channels).  Pipeline per tile j: global load (step j-3) -> split + LDS write (step j-1) ->
     // fragment read (end of step j-1, after the barrier) -> MFMA (step j); LDS stage of tile j = j & 1.
     auto step = [&](int kt, float4 (&ra)[NLD], uint4 (&bcur)[3], uint4 (&bnew)[3], float* stage_next) {
         store_a(stage_next, ra);          // tile kt+1 (this stage was last read before the previous barrier)
         load_a(kt + 3, ra);
-        load_b(kt + 2, bnew);             // into the register set of tile kt-1
+        load_b(kt + NB_ - 1, bnew);        // into the register set of tile kt-1
         bf16x8 bf[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) bf[q] = __builtin_bit_cast(bf16x8, bcur[q]);
@@ -136,27 +137,27 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
 
     float* st0 = smem;
     float* st1 = smem + STAGE;
-    float4 ra0[NLD], ra1[NLD];
-    uint4 b0[3], b1[3], b2[3];
-    load_a(0, ra0);
-    load_a(1, ra1);
-    load_b(0, b0);
-    load_b(1, b1);
-    store_a(st0, ra0);
-    load_a(2, ra0);
+    // A register sets alternate with period 2; weight-fragment ring of NB sets: 3 for the 128-row tile (period 6, exits after
+    // every pair of steps: nk is even), 4 for the 64-row tile (period 4 divides nk = Cin / 16 when Cin % 64 == 0, no exit
+    // inside the body -- with exits hipcc keeps several copies of the accumulators and the 64-row tile spills, cf. convt_dgrad)
+    constexpr int NB = TM >= 4 ? 3 : 4, PER = TM >= 4 ? 6 : 4;
+    float4 ra[2][NLD];
+    uint4 bq[NB][3];
+    load_a(0, ra[0]);
+    load_a(1, ra[1]);
+#pragma unroll
+    for (int j = 0; j < NB - 1; ++j) load_b(j, bq[j]);
+    store_a(st0, ra[0]);
+    load_a(2, ra[0]);
     __syncthreads();
     read_a(st0);
-    // A register sets alternate with period 2, B sets with period 3: the pattern repeats every 6 steps (nk is even)
 #pragma unroll 1
-    for (int kt = 0; kt < p.nk; kt += 6) {
-        step(kt, ra1, b0, b2, st1);
-        step(kt + 1, ra0, b1, b0, st0);
-        if (kt + 2 >= p.nk) break;
-        step(kt + 2, ra1, b2, b1, st1);
-        step(kt + 3, ra0, b0, b2, st0);
-        if (kt + 4 >= p.nk) break;
-        step(kt + 4, ra1, b1, b0, st1);
-        step(kt + 5, ra0, b2, b1, st0);
+    for (int kt = 0; kt < p.nk; kt += PER) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (NB == 3 && u > 0 && (u & 1) == 0 && kt + u >= p.nk) break;
+            step(kt + u, ra[(u + 1) & 1], bq[u % NB], bq[(u + NB - 1) % NB], (u & 1) ? st0 : st1);
+        }
     }
     __syncthreads();
 
@@ -683,7 +684,11 @@ int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, co
     if (xb >= 4294967040.0 || (double)wsplit_bytes >= 4294967040.0) return RD_OK;
     const long G = (long)n * h;
     const long M = G * w;
-    const int tm = 4;       // 128-row tiles (a 64-row instantiation spilled under hipcc's scheduler at 168 registers)
+    // 128-row tiles; 64-row tiles (151 VGPRs, three waves per SIMD) where the 128-row grid would not fill the chip twice (the
+    // 8^2 -> 16^2 level: 0.038 -> 0.032 ms).  Everywhere else they measured +3 % alone but -0.3 % end to end (r03 notes);
+    // convt_patch = 4 forces them wherever Cin % 64 == 0
+    const long blocks128 = ((G + 128 / (w < 16 ? w : 16) - 1) / (128 / (w < 16 ? w : 16))) * (w / (w < 16 ? w : 16)) * (4L * cout / 128);
+    const int tm = (cin % 64 == 0 && (tune(TUNE_CONVT_PATCH) == 4 || blocks128 < 512)) ? 2 : 4;
     CtParams p = {};
     p.x = x; p.wsplit = wsplit; p.bias = bias; p.skip = skip; p.out = out;
     p.sk_mean = sk_mean; p.sk_invstd = sk_invstd; p.sk_gamma = sk_gamma; p.sk_beta = sk_beta; p.sk_slope = sk_slope;
@@ -704,7 +709,8 @@ int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, co
     snprintf(pcls, sizeof(pcls), "convt2x2_fwd|convt_fwd<%d>", tm);
     ProfScope ps(s, pcls, 2.0 * M * 4.0 * cout * cin,
                  4.0 * ((double)M * cin + 4.0 * cout * cin + (skip ? 2.0 : 1.0) * 4.0 * M * cout), true);
-    hipLaunchKernelGGL(convt_fwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, p);
+    if (tm == 2) hipLaunchKernelGGL(convt_fwd_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(convt_fwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, p);
     RD_LAUNCH_CHECK("convt_fwd");
     *launched = 1;
     return RD_OK;
