@@ -3,7 +3,6 @@
 set -e
 LIB="$1"; OUT="$2"; T=$(mktemp -d)
 LL=/opt/rocm/lib/llvm/bin
-$LL/llvm-objdump --offloading "$LIB" > /dev/null 2>&1 || true
 # the fat binary sits in .hip_fatbin: unbundle the gfx950 code object
 $LL/llvm-objcopy --dump-section .hip_fatbin="$T/fat.bin" "$LIB" 2>/dev/null || objcopy --dump-section .hip_fatbin="$T/fat.bin" "$LIB"
 python3 - "$T/fat.bin" "$T" <<'PY'
