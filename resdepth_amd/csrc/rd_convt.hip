@@ -401,7 +401,7 @@ int convt_dgrad_launch(NtParams p, hipStream_t s, int* launched, int* tiles_m_ou
     if (grid >= (1L << 31)) return RD_OK;
     if (tiles_m_out) *tiles_m_out = (int)tiles_m;
     char pcls[64];
-    snprintf(pcls, sizeof(pcls), "convt2x2_dgrad|convt_dgrad<%d,%d>", bm, bn);
+    snprintf(pcls, sizeof(pcls), "convt2x2_dgrad|convt_dgrad<%s>", cfg == 0 ? "4,1,4" : cfg == 1 ? "2,1,4" : "2,2,2");
     ProfScope ps(s, pcls, 2.0 * p.M * (double)p.N * p.K, 4.0 * (4.0 * p.M * Cd + (double)p.N * p.K + (double)p.M * p.N * (p.bn_part ? 2 : 1)), true);
     if (cfg == 0) hipLaunchKernelGGL((convt_dgrad_kernel<4, 1, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
     else if (cfg == 1) hipLaunchKernelGGL((convt_dgrad_kernel<2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);

@@ -478,8 +478,12 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     const double ab = 4.0 * n * h * w * (double)cout, bb = 4.0 * n * h * w * (double)cin;
     RD_REQUIRE(ab < 4294967040.0 && bb < 4294967040.0, "rd_conv3x3_bwd_weight: operand beyond the 4 GiB descriptor range");
     q.a_bytes = (unsigned)ab; q.b_bytes = (unsigned)bb;
-    ProfScope ps(s, "conv3x3_wgrad|wgrad_strip", 2.0 * cout * 9.0 * cin * (double)n * h * w, ab + bb + 4.0 * cout * 9.0 * cin,
-                 true);
+    const int occ_ = tune(TUNE_WG_OCC) == 2 ? 2 : 1;
+    char pcls[64];      // "<operation>|<kernel symbol as rocprofv3 prints it, summarize_prof.py form>"
+    if (wp.sq) snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip_tr<%d,2,2>", occ_);
+    else if (tune(TUNE_WG_STRIP) != 1) snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip_tr<%d,4,1>", occ_);
+    else snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip<%d>", occ_);
+    ProfScope ps(s, pcls, 2.0 * cout * 9.0 * cin * (double)n * h * w, ab + bb + 4.0 * cout * 9.0 * cin, true);
     // transpose-read variant by default (r03: 2.80 -> 2.69 ms over the nine layers alone, +0.8 % end to end, VALU per MFMA
     // 2.9 -> see profiles/r03_summary.json); wg_strip = 1 selects the register-transpose kernel for A/B runs
     const bool tr = tune(TUNE_WG_STRIP) != 1;
