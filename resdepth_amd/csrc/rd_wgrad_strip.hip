@@ -445,7 +445,10 @@ static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
     // every split costs one [Cout][9*Cin] slab of HBM traffic (written here, read by the reduction): with more than
     // ~2048 blocks, give each block several strips instead
     const long strips = (long)n * pl.strips_x * pl.chunks_y;
-    const int target = tune(TUNE_WG_BLOCKS);   // measured: 512 (2 resident blocks/CU, one round) beats 1024/2048
+    // measured (r03, transpose-read kernel, interleaved end to end): 256 blocks 2747.9 / 2748.5 tiles/s, 384: 2716.7 / 2728.4,
+    // 512 (the r02 optimum of the 80 KB kernel): 2715.3 / 2715.1, 768: 2712.3 / 2720.6, 128: 2499 -- half the split-K slabs to
+    // write and reduce, and one block per CU leaves room beside the main-stream kernels of the two-stream backward
+    const int target = tune(TUNE_WG_BLOCKS);
     int reps = 1;
     while (base * pl.chunks_y / (2 * reps) >= target && strips % (2 * reps) == 0) reps *= 2;
     pl.reps = reps;
