@@ -60,6 +60,8 @@ CONV_SHAPES = [  # n, h, w, cin, cout
     (2, 48, 80, 64, 128),     # W % 16 == 0, H % 8 == 0: halo kernel + strip weight gradient on a 48 x 80 image
     (1, 6, 48, 32, 128),      # strip kernel with 6 rows (even, not a multiple of 4: one chunk); H % 8 != 0: no halo kernel
     (16, 40, 96, 24, 132),    # halo kernel <128> with 5 x 6 patches per image, ragged N tile
+    (32, 8, 8, 512, 512),     # the cfg-S bottleneck: two-images-per-patch halo kernel <32> (r03), 16 x 16 blocks
+    (33, 8, 8, 64, 256),      # ... with an odd image count (the last patch holds one image) and Cin != Cout
 ]
 
 
@@ -518,7 +520,7 @@ def test_layout_roundtrip():
 
 @pytest.mark.parametrize("n,h,w,cin,cout,mode,kind", [
     (2, 32, 32, 64, 128, 1, "conv"), (8, 64, 64, 64, 128, 1, "conv"), (16, 64, 64, 128, 256, 2, "conv"), (2, 16, 16, 20, 36, 1, "conv"),
-    (3, 24, 40, 32, 64, 1, "conv"), (2, 48, 80, 64, 128, 2, "conv"), (4, 16, 16, 128, 128, 1, "convt"), (2, 8, 8, 256, 256, 1, "convt"),
+    (3, 24, 40, 32, 64, 1, "conv"), (2, 48, 80, 64, 128, 2, "conv"), (32, 8, 8, 512, 512, 1, "conv"), (33, 8, 8, 256, 64, 2, "conv"), (4, 16, 16, 128, 128, 1, "convt"), (2, 8, 8, 256, 256, 1, "convt"),
     (2, 6, 10, 8, 12, 1, "convt"), (4, 32, 32, 128, 128, 1, "convt"), (2, 48, 48, 256, 128, 1, "convt"), (1, 80, 80, 64, 192, 1, "convt"),
     (2, 64, 64, 64, 1, 1, "last"), (1, 24, 40, 32, 1, 1, "last"), (2, 16, 16, 8, 1, 1, "last")])
 def test_bn_backward_statistics_from_the_data_gradient_epilogues(n, h, w, cin, cout, mode, kind):
