@@ -183,11 +183,14 @@ def test_world2_syncbn_equals_one_process_at_the_global_batch(tmp_path, coll, se
                     assert rel_l2(o["bufs0"][k], v) <= 1e-5, (tune, r, k)
                 else:
                     assert torch.equal(o["bufs0"][k], v), (r, k)
-            # weights after two Adam steps: step 2 runs on weights that differ in their last bits, so its forward is no
-            # longer bit-identical (flip noise, see above), and zero-initialised biases consist of the two updates only
+            # weights after two Adam steps: step 2 runs on weights that differ in their last bits, so its forward is no longer
+            # bit-identical (flip noise, see above).  Adam's update is lr * m / sqrt(v): scale-free, so a gradient element at
+            # noise level moves by a sizeable fraction of lr either way -- zero-initialised tensors (biases, BN beta) consist
+            # of these two updates only (measured 5e-3), the others are dominated by their initial values
             for k, v in ref["state"].items():
                 if v.dtype.is_floating_point and "running_" not in k:
-                    assert rel_l2(o["state"][k], v) <= (1e-3 if tune else 5e-2), (tune, r, k, rel_l2(o["state"][k], v))
+                    zero_init = k.endswith(".bias")
+                    assert rel_l2(o["state"][k], v) <= (5e-2 if zero_init else 1e-4), (tune, r, k, rel_l2(o["state"][k], v))
         # the all-reduced gradients and the weights after two steps are the SAME BITS on both ranks
         for k in outs[0]["grads0"]:
             assert torch.equal(outs[0]["grads0"][k], outs[1]["grads0"][k]), k

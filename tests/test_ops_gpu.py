@@ -165,7 +165,8 @@ CONVT_SHAPES = [(2, 4, 8, 8, 12), (1, 2, 2, 4, 4), (4, 16, 16, 128, 128), (8, 32
                 # r03 kernels of rd_convt.hip: convt_dgrad<2,1,4> (Cin >= 128) / <2,2,2> (Cin = 64), several column tiles, a
                 # ragged last pixel tile, Cin != Cout; convt_wgrad<4|2|1> with an ODD number of K-steps per split (the extra
                 # all-zero step), several row tiles, a ragged last split
-                (4, 32, 32, 128, 128), (2, 48, 48, 256, 128), (1, 80, 80, 64, 192), (3, 36, 48, 128, 64), (5, 30, 32, 192, 64)]
+                (4, 32, 32, 128, 128), (2, 48, 48, 256, 128), (1, 80, 80, 64, 192), (3, 36, 48, 128, 64), (5, 30, 32, 192, 64),
+                (1, 65, 70, 64, 128), (1, 67, 68, 128, 64)]      # ragged last pixel tile of convt_dgrad (M = 4550 / 4556)
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", CONVT_SHAPES)
