@@ -190,7 +190,8 @@ def test_world2_syncbn_equals_one_process_at_the_global_batch(tmp_path, coll, se
             for k, v in ref["state"].items():
                 if v.dtype.is_floating_point and "running_" not in k:
                     zero_init = k.endswith(".bias")
-                    assert rel_l2(o["state"][k], v) <= (5e-2 if zero_init else 1e-4), (tune, r, k, rel_l2(o["state"][k], v))
+                    tol_w = 5e-2 if zero_init else (1e-4 if tune else 2e-3)     # default selection: step 1 already saw flips
+                    assert rel_l2(o["state"][k], v) <= tol_w, (tune, r, k, rel_l2(o["state"][k], v))
         # the all-reduced gradients and the weights after two steps are the SAME BITS on both ranks
         for k in outs[0]["grads0"]:
             assert torch.equal(outs[0]["grads0"][k], outs[1]["grads0"][k]), k
