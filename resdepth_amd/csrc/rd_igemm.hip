@@ -461,6 +461,14 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) bf[q] = __builtin_bit_cast(bf16x8, bcur[q]);
         const float* nstage = TAP == 8 ? stage_nxt : stage_cur;
+        // Raised wave priority over the MFMA cluster of a tap: with two blocks per CU there are two waves per SIMD, and the
+        // sibling's staging VALU / LDS instructions otherwise win issue slots between this wave's MFMAs.  r03, interleaved:
+        // nine layers alone 2.74 -> 2.65 ms, end to end 2747.7 / 2758.3 / 2751.0 -> 2817.3 / 2821.7 / 2827.1 tiles/s (+2.5 %).
+        // Priority 3 instead of 1: same.  Priority for the WHOLE kernel (set once): no gain -- it is the toggling that
+        // orders the two waves, not a priority over other kernels.  The same two lines in the weight-gradient kernels (one
+        // wave per SIMD at 256 blocks, on the second stream) take the gain away again; in the transposed-convolution and
+        // generic NT kernels they cost 1.2 % (profiles/r03_notes.md section 7).
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int g = 0; g < TM; g += GP) {
 #pragma unroll
@@ -476,6 +484,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(nstage + a_rd[i] + NEXT + q * 8);
         }
+        __builtin_amdgcn_s_setprio(0);
     };
     for (int chunk = 0; chunk < p.chunks; ++chunk) {
         const int kt = chunk * 9;
