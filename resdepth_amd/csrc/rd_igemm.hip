@@ -469,21 +469,34 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         // wave per SIMD at 256 blocks, on the second stream) take the gain away again; in the transposed-convolution and
         // generic NT kernels they cost 1.2 % (profiles/r03_notes.md section 7).
         __builtin_amdgcn_s_setprio(1);
+        // products in the order of PA6 / PB6 over ALL row blocks; every A term is re-loaded for the next tap right after its
+        // last use (term 2 after the first product, term 1 after the fourth, term 0 after the sixth), and the scheduler is
+        // pinned to that interleaving (sched_group_barrier: 0x008 = MFMA, 0x100 = LDS read) -- left alone, hipcc sinks all
+        // 3 * TM fragment reads behind the ~19th MFMA and the next tap starts with four lgkmcnt waits
+        auto rd = [&](int q) {
 #pragma unroll
-        for (int g = 0; g < TM; g += GP) {
+            for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const bf16x8*>(nstage + a_rd[i] + NEXT + q * 8);
+        };
 #pragma unroll
-            for (int t6 = 0; t6 < 5; ++t6)
+        for (int i = 0; i < TM; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], lo[i], 0, 0, 0);
+        rd(2);
 #pragma unroll
-                for (int i = g; i < g + GP; ++i)
-                    lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
+        for (int t6 = 1; t6 < 4; ++t6)
 #pragma unroll
-            for (int i = g; i < g + GP; ++i)
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][0], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
+                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
+        rd(1);
 #pragma unroll
-            for (int i = g; i < g + GP; ++i)
+        for (int i = 0; i < TM; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], lo[i], 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(nstage + a_rd[i] + NEXT + q * 8);
-        }
+        for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][0], 0, 0, 0);
+        rd(0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
         __builtin_amdgcn_s_setprio(0);
     };
     for (int chunk = 0; chunk < p.chunks; ++chunk) {
