@@ -60,6 +60,9 @@ CONV_SHAPES = [  # n, h, w, cin, cout
     (2, 48, 80, 64, 128),     # W % 16 == 0, H % 8 == 0: halo kernel + strip weight gradient on a 48 x 80 image
     (1, 6, 48, 32, 128),      # strip kernel with 6 rows (even, not a multiple of 4: one chunk); H % 8 != 0: no halo kernel
     (16, 40, 96, 24, 132),    # halo kernel <128> with 5 x 6 patches per image, ragged N tile
+    (4, 32, 32, 160, 32),     # strip weight gradient <*,4,1> with swapped operand roles (Cout < 128 <= Cin, Cin % 64 != 0)
+    (4, 32, 32, 96, 160),     # ... un-swapped with a ragged second row tile (Cout = 128 + 32)
+    (2, 16, 32, 192, 320),    # square-tile strip kernel <*,2,2>: 5 x 3 tiles, two strips per image row
     (32, 8, 8, 512, 512),     # the cfg-S bottleneck (8 x 8 images: generic 64 x 64 kernel, TN weight gradient)
     (33, 8, 8, 64, 256),      # ... with an odd image count and Cin != Cout
 ]
