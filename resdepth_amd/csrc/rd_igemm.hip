@@ -435,7 +435,6 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         a_rd[i] = (row >> 4) * HP + (row & 15) * RS + half * 4;
     }
     bf16x8 af[TM][3];
-    constexpr int GP = TM >= 2 ? 2 : 1;
 
     float* stage_cur = smem;
     float* stage_nxt = smem + STAGE;
