@@ -135,6 +135,10 @@ class UNet(nn.Module):
         self.two_stream_backward = True   # weight gradients on a second HIP stream, overlapping the dgrad/BN chain
         self.fold_eval_bn = True          # inference: eval-mode BN folded into the packed conv weights + epilogue activation
         self.fused_bn_bwd_stats = True    # BN-backward sums from the epilogues of the kernels producing the gradient operands
+        # loss.backward(retain_graph=True) on the reference keeps the saved activations for a second backward.  A custom
+        # autograd.Function cannot see that flag, and keeping 137 MB per tile alive until the loss tensor dies would surprise
+        # callers that hold on to losses -- so the activations are released by the first backward unless this is set
+        self.retain_activations = False
         self._bn_gen = 0                  # bumped by every training-mode forward (the kernels update running statistics in place)
         self._side_stream = None
 
@@ -938,10 +942,12 @@ class _UNetFunction(torch.autograd.Function):
     def backward(ctx, dout):
         model, S = ctx.model, ctx.saved
         if S is None:
-            raise RuntimeError("resdepth_amd.UNet: backward called twice (activations were released)")
+            raise RuntimeError("resdepth_amd.UNet: backward called twice (activations were released; set "
+                               "model.retain_activations = True for loss.backward(retain_graph=True))")
         with _lib.device_of(dout):
             grads, dx = model._engine_backward(S, dout, want_dx=ctx.needs_input_grad[0])
-        ctx.saved = None
+        if not model.retain_activations:
+            ctx.saved = None
         return (dx, None, *grads)
 
 
@@ -967,5 +973,6 @@ class _TwinFunction(torch.autograd.Function):
             out = [UNet._corner(p, g).clone() if p.requires_grad else None for p, g in zip(model._param_list(), grads)]
             if dx is not None:
                 dx = dx[:, :ctx.cin].contiguous()
-        ctx.saved = None
+        if not model.retain_activations:
+            ctx.saved = None
         return (dx, None, None, *out)

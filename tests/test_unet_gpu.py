@@ -846,3 +846,26 @@ def test_fused_weight_packing_equals_layer_by_layer_packing():
     assert n_checked >= 7
     plan = model._pack_plan()
     assert plan["tiles"] > 0 and plan["total"] > 0          # both packers ran
+
+
+def test_second_backward_with_retained_activations():
+    """lib/UNet.py is a plain nn.Module: `loss.backward(retain_graph=True)` may be followed by another backward through the
+    same graph.  Here the saved activations are released by the first backward (a custom Function cannot see retain_graph)
+    unless `model.retain_activations` is set; a second backward then accumulates exactly the same gradient again."""
+    from resdepth_amd import UNet, masked_l1_loss
+    torch.manual_seed(3)
+    model = UNet(n_input_channels=2, start_kernel=16, depth=2, bias_conv_layer=True).to(DEV).train()
+    b = O.synthetic_batch(2, 2, 32, seed=5)
+    loss = masked_l1_loss(model(b["input"].to(DEV)), b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="retain_activations"):
+        loss.backward()
+    for p in model.parameters():
+        p.grad = None
+    model.retain_activations = True
+    loss = masked_l1_loss(model(b["input"].to(DEV)), b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
+    loss.backward(retain_graph=True)
+    g1 = [p.grad.clone() for p in model.parameters()]
+    loss.backward()
+    for p, g in zip(model.parameters(), g1):
+        assert torch.equal(p.grad, g + g), "second backward through the retained graph differs"
