@@ -193,6 +193,9 @@ class UNet(nn.Module):
         tw._ensure_flat()
         tw.train(self.training)
         tw.two_stream_backward, tw.fold_eval_bn = self.two_stream_backward, self.fold_eval_bn
+        # data parallel: the twin's engine exchanges ITS statistics and ITS flat gradient buffer (the padding channels carry
+        # zeros on every rank); this model's gradients are then corners of already all-reduced tensors
+        tw.grad_sync, tw.sync_bn = self.grad_sync, self.sync_bn
         src = list(self.named_parameters()) + list(self.named_buffers())
         # nothing to do when the source values are the ones already loaded (eval sweeps, repeated forwards)
         key = self._twin_src_key(tw)
@@ -900,9 +903,6 @@ class UNet(nn.Module):
                 raise RuntimeError(f"resdepth_amd.UNet: input on {x.device} but parameters on {params[0].device}")
             need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
             if self._needs_twin():
-                if self.grad_sync is not None:
-                    raise NotImplementedError("resdepth_amd.UNet: data-parallel gradient hooks need channel counts that are "
-                                              "multiples of 4 (this configuration runs on the zero-padded twin)")
                 tw = self._twin_load()
                 if not need_grad:
                     out, _ = tw._engine_forward(self._pad_input(x, tw), tw.training, save=False)

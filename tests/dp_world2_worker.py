@@ -24,6 +24,9 @@ for p in (ROOT, HERE):
         sys.path.insert(0, p)
 
 CFG_S = dict(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True)
+# channel counts that are not multiples of 4: the engine runs such a model on its zero-padded twin
+CFG_ODD = dict(n_input_channels=2, start_kernel=6, depth=2, max_filter_depth=10, act_fn_decoder="lrelu")
+ARCH = {"S": CFG_S, "odd": CFG_ODD}
 
 
 def make_batch(n, step, t=256, c=3):
@@ -64,6 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--bucket-mb", type=int, default=16)
     ap.add_argument("--serial-backward", type=int, default=0)
+    ap.add_argument("--arch", default="S", choices=["S", "odd"])
     ap.add_argument("--tune", default="", help="RD_TUNE string (kernel-selection knobs), applied before the library loads")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
@@ -95,7 +99,7 @@ def main():
         from resdepth_amd import UNet, FusedAdam, masked_l1_loss, dp
         if a.mode == "train":
             torch.manual_seed(100 + a.rank)              # rank 0's seed-100 weights win through the broadcast
-            model = UNet(**CFG_S).to(dev).train()
+            model = UNet(**ARCH[a.arch]).to(dev).train()
             model.two_stream_backward = not a.serial_backward
             gs = dp.attach(model, sync_bn=bool(a.sync_bn), bucket_bytes=a.bucket_mb << 20)
             dp.broadcast_parameters(model, 0)
@@ -103,7 +107,7 @@ def main():
             losses, grads0, bufs0 = [], None, None
             n_buckets = None
             for step in range(a.steps):
-                local = dp.shard_batch(make_batch(a.batch, step, a.tile), a.rank, a.world)
+                local = dp.shard_batch(make_batch(a.batch, step, a.tile, ARCH[a.arch]["n_input_channels"]), a.rank, a.world)
                 y = model(local["input"].to(dev))
                 loss = masked_l1_loss(y, local["target"], local["loss_mask"], local["dsm_mean"], local["dsm_std"], grad_sync=gs)
                 loss.backward()
@@ -111,7 +115,7 @@ def main():
                     y0 = y.detach().cpu().clone()
                     grads0 = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
                     bufs0 = {k: v.detach().cpu().clone() for k, v in model.named_buffers()}
-                    n_buckets = len(gs._buckets)
+                    n_buckets = len(gs._buckets) if gs._buckets else 0
                 opt.step()
                 for p in model.parameters():
                     p.grad = None

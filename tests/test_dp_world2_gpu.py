@@ -127,20 +127,20 @@ class _pinned:
             _lib.tune_set(k, v)
 
 
-def _single_process(batch, steps, tile=256, tune=""):
+def _single_process(batch, steps, tile=256, tune="", arch="S"):
     """ONE process, whole batch, no data-parallel hooks: the reference semantics (lib/Trainer.py:159-222)."""
     with _pinned(tune):
-        return _single_process_(batch, steps, tile)
+        return _single_process_(batch, steps, tile, arch)
 
 
-def _single_process_(batch, steps, tile):
+def _single_process_(batch, steps, tile, arch):
     from resdepth_amd import UNet, FusedAdam, masked_l1_loss
     torch.manual_seed(100)
-    model = UNet(**W.CFG_S).to(DEV).train()
+    model = UNet(**W.ARCH[arch]).to(DEV).train()
     opt = FusedAdam(model.parameters(), lr=2e-4, weight_decay=1e-5)
     losses, grads0, bufs0 = [], None, None
     for step in range(steps):
-        b = W.make_batch(batch, step, tile)
+        b = W.make_batch(batch, step, tile, W.ARCH[arch]["n_input_channels"])
         y = model(b["input"].to(DEV))
         loss = masked_l1_loss(y, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
         loss.backward()
@@ -292,6 +292,27 @@ def test_world2_small_buckets_and_four_ranks(tmp_path):
         for k, g in ref["grads0"].items():
             e = rel_l2(o["grads0"][k], g)
             assert e <= GRAD_TOL, (r, k, e)
+
+
+@pytest.mark.parametrize("sync_bn", [1, 0])
+def test_world2_on_the_zero_padded_twin(tmp_path, sync_bn):
+    """Channel counts that are not multiples of 4 (start_kernel = 6, max_filter_depth = 10) run on the zero-padded twin; its
+    engine carries the data-parallel hooks (r02 refused this combination).  SyncBN on: == one process at the global batch;
+    off: the ranks' all-reduced gradients are the same bits and the loss is the global one."""
+    outs = run_world(tmp_path, "train", coll="staged", sync_bn=sync_bn, batch=8, tile=32, steps=1, arch="odd")
+    for k in outs[0]["grads0"]:
+        assert torch.equal(outs[0]["grads0"][k], outs[1]["grads0"][k]), k
+        assert float(outs[0]["grads0"][k].abs().max()) > 0, k
+    assert outs[0]["losses"] == outs[1]["losses"]
+    if sync_bn:
+        ref = _single_process(8, 1, tile=32, arch="odd")
+        assert abs(outs[0]["losses"][0] - ref["losses"][0]) <= 2e-6 * abs(ref["losses"][0])
+        for k, g in ref["grads0"].items():
+            e = rel_l2(outs[0]["grads0"][k], g)
+            assert e <= 1e-4, (k, e)
+        for k, v in ref["bufs0"].items():
+            if v.dtype.is_floating_point:
+                assert rel_l2(outs[0]["bufs0"][k], v) <= 1e-5, k
 
 
 def test_cfg_g_tile_shards_sum_to_the_unsharded_raster(tmp_path):
