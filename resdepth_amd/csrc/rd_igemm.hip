@@ -715,11 +715,19 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const PackItem* __restr
         float v[8];
         if (I.kind == 0) {
             const int tiles_ci = cin >> 5, co0 = (lt / tiles_ci) * 32, ci0 = (lt % tiles_ci) * 32;
+            // (a parameter is a view into the flat buffer at an arbitrary float offset -- e.g. behind a 1-element PReLU slope:
+            // 16-byte loads only when the tensor happens to be 16-byte aligned)
+            const bool al16 = ((size_t)w & 15) == 0;
             for (int e = t; e < 32 * 72; e += 256) {
                 const int row = e / 72, q = e - row * 72;
-                const float4 x = *reinterpret_cast<const float4*>(w + ((long)(co0 + row) * cin + ci0) * 9 + q * 4);
+                const float* src = w + ((long)(co0 + row) * cin + ci0) * 9 + q * 4;
                 float* d = tile + row * 289 + q * 4;
-                d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+                if (al16) {
+                    const float4 x = *reinterpret_cast<const float4*>(src);
+                    d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+                } else {
+                    d[0] = src[0]; d[1] = src[1]; d[2] = src[2]; d[3] = src[3];
+                }
             }
             __syncthreads();
             const int nkf = 9 * (cin >> 4), nkd = 9 * (cout >> 4);
@@ -737,11 +745,17 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const PackItem* __restr
             }
         } else {
             const int tiles_co = cout >> 5, ci0 = (lt / tiles_co) * 32, co0 = (lt % tiles_co) * 32;
+            const bool al16 = ((size_t)w & 15) == 0;
             for (int e = t; e < 32 * 32; e += 256) {
                 const int row = e >> 5, c = e & 31;
-                const float4 x = *reinterpret_cast<const float4*>(w + ((long)(ci0 + row) * cout + co0 + c) * 4);
+                const float* src = w + ((long)(ci0 + row) * cout + co0 + c) * 4;
                 float* d = tile + row * 33 + c;
-                d[0] = x.x; d[1056] = x.y; d[2 * 1056] = x.z; d[3 * 1056] = x.w;
+                if (al16) {
+                    const float4 x = *reinterpret_cast<const float4*>(src);
+                    d[0] = x.x; d[1056] = x.y; d[2 * 1056] = x.z; d[3 * 1056] = x.w;
+                } else {
+                    d[0] = src[0]; d[1056] = src[1]; d[2 * 1056] = src[2]; d[3 * 1056] = src[3];
+                }
             }
             __syncthreads();
             const int nkf = cin >> 4, nkd = 4 * (cout >> 4);

@@ -800,15 +800,20 @@ def test_twin_forward_does_not_reload_unchanged_parameters_nor_invalidate_other_
     assert not torch.equal(y3, y1)
 
 
-def test_fused_weight_packing_equals_layer_by_layer_packing():
+@pytest.mark.parametrize("act", ["relu", "prelu"])
+def test_fused_weight_packing_equals_layer_by_layer_packing(act):
     """rd_pack_weights_fused (tile kernel for layers whose channel counts are multiples of 32, piece kernel for the rest)
     writes the same split-bf16 operands, bit for bit, as rd_pack_conv3x3_weight / rd_pack_convt2x2_weight layer by layer
     (whose own layouts the per-op tests pin against torch)."""
     from resdepth_amd import UNet, ops
     torch.manual_seed(6)
     # widths 16 (piece kernel), 32, 64, 128 (tile kernel: 1, 2 and 4 tiles per side), Cin != Cout in every conv
-    model = UNet(n_input_channels=3, start_kernel=16, depth=4, bias_conv_layer=True).to(DEV).eval()
+    # (prelu: 1-element slope parameters put the following weight tensors at float offsets that are not multiples of 4)
+    model = UNet(n_input_channels=3, start_kernel=16, depth=4, bias_conv_layer=True, act_fn_encoder=act, act_fn_decoder=act,
+                 act_fn_bottleneck=act).to(DEV).eval()
     model._ensure_flat()
+    if act == "prelu":
+        assert any(p.data_ptr() % 16 for p in model.parameters() if p.dim() == 4)
     pk = model._packed()
     torch.cuda.synchronize()
 
