@@ -33,6 +33,7 @@ SIGNATURES = {
     "rd_last_error_string": (C.c_char_p, []),
     "rd_pack_conv3x3_weight": (I, [P, P, P, I, I, P]),
     "rd_pack_item_pieces": (LL, [I, I, I, I]),
+    "rd_set_splitk_workspace": (I, [P, SZ, P]),
     "rd_pack_item_tiles": (LL, [I, I, I]),
     "rd_pack_weights_fused": (I, [P, I, LL, LL, P]),
     "rd_pack_conv3x3_weight_folded": (I, [P, P, P, I, I, P]),
@@ -179,6 +180,26 @@ def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=torch.device("cuda", index))
             _ws[key] = buf
     return buf
+
+
+_splitk = {}
+
+
+def ensure_splitk_workspace(device, nbytes: int = (64 << 20) + (64 << 10)) -> None:
+    """Register (once per device and stream) the split-K scratch of the 8 x 8 convolution kernel for the CURRENT stream of
+    `device` (include/resdepth_hip.h: rd_set_splitk_workspace).  The engine entry points call this; direct users of the op
+    wrappers may too -- without it those layers run on the generic kernel."""
+    dev = torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(index).cuda_stream
+    key = (index, stream)
+    with _ws_lock:
+        if key in _splitk:
+            return
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=torch.device("cuda", index))
+        with torch.cuda.device(index):
+            check(load().rd_set_splitk_workspace(buf.data_ptr(), buf.numel(), stream), "set_splitk_workspace")
+        _splitk[key] = buf          # kept alive for the life of the process (the library holds the raw pointer)
 
 
 # ---- parameter generation counter (bumped by in-place updates done through raw pointers) -------

@@ -51,6 +51,7 @@ enum TuneKey {
     TUNE_EDGE_CONV,        // -1 auto | 0: never use the tile kernels of the first / last convolution (rd_edge_conv.hip)
     TUNE_ROWS_BLOCKS,      // first-stage blocks of the per-channel reductions
     TUNE_LAST_BLOCKS,      // first-stage blocks of the last-conv gradient kernels
+    TUNE_NT_SPLITK,        // -1 auto | 0: never use the split-K patch kernel for 8 x 8 images (needs rd_set_splitk_workspace)
     TUNE_COUNT
 };
 int tune(int key);
@@ -87,6 +88,9 @@ int conv_first_wgrad_seg_blocks(int n, int h, int w, int cin, int cout);
 int conv_first_seg_launch(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
                           int w, int cin, int cout, hipStream_t s);
 int conv_last_wgrad_launch(const float* s_in, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s);
+
+// split-K scratch registered for this stream (rd_set_splitk_workspace): tile tickets (all zero between launches) + slab area
+bool splitk_workspace(hipStream_t s, unsigned** tickets, int* n_tickets, float** slab, size_t* slab_bytes);
 
 inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;

@@ -355,9 +355,15 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 // stride -> the tap shift is an instruction immediate).  Activation staging (global loads, split arithmetic, LDS
 // writes) drops ~6x and there is one barrier per chunk instead of per K-step.  Weights: unchanged (pre-split fragment
 // layout straight from global memory, kt = chunk*9 + tap, three register sets).
-template <int BN, int WM, int WN, int EPI, int SKEW = 8>
+// W8 = 1: 8 x 8 images (the cfg-S bottleneck, lib/UNet.py:210: 2048 pixels x 512 channels, K = 4608).  A patch is TWO images
+// side by side -- tile row r = pixel (y = r >> 4, x = r & 7) of image 2 * tile + ((r & 15) >> 3) -- each with its own zero border
+// in LDS (halo rows of 2 x 10 pixels), so the tap offsets stay instruction immediates; only the per-lane base address and the
+// row -> pixel map of the epilogue change.  16 patches x 4 column tiles are too few blocks, so K is split as well: p.ksplit
+// blocks per tile take p.chunks_per channel chunks each, park their partial tile in a scratch slab and draw a ticket; the last
+// one adds the partials in split order and runs the epilogue (statistics, BN-backward hook) on the finished tile.
+template <int BN, int WM, int WN, int EPI, int SKEW = 8, int W8 = 0>
 __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
-    constexpr int BM = 128, PH = 8, PW = 16, HW_ = PW + 2, HROWS = (PH + 2) * HW_;   // 180 halo pixels
+    constexpr int BM = 128, PH = 8, PW = 16, HW_ = W8 ? 20 : PW + 2, HROWS = (PH + 2) * HW_;   // 180 (200) halo pixels
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(TN == 1, "one 32-column block per wave");
     constexpr int RS = 28;                            // LDS row stride in words (3 terms x 16 bf16 + 16 B pad)
@@ -371,13 +377,19 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    __shared__ int sk_last;
+    const int lb0 = xcd_remap(blockIdx.x, gridDim.x);
+    const int ksp = W8 && p.ksplit > 1 ? p.ksplit : 1;
+    const int ksplit_id = lb0 % ksp, lb = lb0 / ksp;           // the K ranges of one tile are neighbours (same XCD / L2)
+    const int cbeg = W8 ? ksplit_id * p.chunks_per : 0;
+    const int cend = W8 ? (cbeg + p.chunks_per < p.chunks ? cbeg + p.chunks_per : p.chunks) : p.chunks;
     const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
     const int n0 = tile_n * BN;
     const int H = p.H, W = p.W;
-    const int pxs = W >> 4, pys = H >> 3;             // patches per image row / column
-    const int pbx = tile_m % pxs, pby = (tile_m / pxs) % pys, img = tile_m / (pxs * pys);
+    const int pxs = W8 ? 1 : W >> 4, pys = W8 ? 1 : H >> 3;   // patches per image row / column
+    const int pbx = tile_m % pxs, pby = (tile_m / pxs) % pys, img = W8 ? 2 * tile_m : tile_m / (pxs * pys);
     const int x0 = pbx * PW, y0 = pby * PH;
+    const int n_img = p.M / (H * W);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
@@ -396,16 +408,17 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     for (int k = 0; k < NLD; ++k) {
         const int e = t + 256 * k, hr = e >> 2;
         const int hy = hr / HW_, hx = hr - hy * HW_;
-        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-        const bool ok = hr < HROWS && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        s_off[k] = ok ? (unsigned)(((((long)img * H + y) * W + x) * p.Cin + c4 * 4) * 4) : kOOB;
+        const int sub = W8 ? hx / 10 : 0;                     // W8: which of the patch's two images
+        const int y = y0 - 1 + hy, x = W8 ? hx - sub * 10 - 1 : x0 - 1 + hx;
+        const bool ok = hr < HROWS && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && img + sub < n_img;
+        s_off[k] = ok ? (unsigned)(((((long)(img + sub) * H + y) * W + x) * p.Cin + c4 * 4) * 4) : kOOB;
         s_lds[k] = hr < HROWS ? hy * HP + hx * RS + c4 * 2 : -1;
     }
     const int nb = (n0 >> 5) + wn;
     const unsigned b_off = (nb * 32 < p.N) ? (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16) : kOOB;
 
     auto load_halo = [&](int chunk, float4 (&rh)[NLD]) {
-        const bool cok = chunk < p.chunks && chunk * SK + c4 * 4 < p.Cin;
+        const bool cok = chunk < cend && chunk * SK + c4 * 4 < p.Cin;
 #pragma unroll
         for (int k = 0; k < NLD; ++k) rh[k] = buf_load4(rsA, cok ? s_off[k] : kOOB, (unsigned)(chunk * SK * 4));
     };
@@ -422,7 +435,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         }
     };
     auto load_b = [&](int kt, uint4 (&rb)[3]) {
-        const unsigned voff = kt < p.nk ? b_off : kOOB;
+        const unsigned voff = kt < cend * 9 ? b_off : kOOB;
 #pragma unroll
         for (int q = 0; q < 3; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((kt * 3 + q) * 1024));
     };
@@ -432,7 +445,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = (wm * TM + i) * 32 + lrow;            // tile row -> patch pixel (row >> 4, row & 15)
-        a_rd[i] = (row >> 4) * HP + (row & 15) * RS + half * 4;
+        a_rd[i] = (row >> 4) * HP + ((row & 15) + (W8 ? 2 * ((row & 15) >> 3) : 0)) * RS + half * 4;
     }
     bf16x8 af[TM][3];
 
@@ -440,9 +453,9 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     float* stage_nxt = smem + STAGE;
     float4 rh[NLD];
     uint4 b0[3], b1[3], b2[3];
-    load_halo(0, rh);
-    load_b(0, b0);
-    load_b(1, b1);
+    load_halo(cbeg, rh);
+    load_b(cbeg * 9, b0);
+    load_b(cbeg * 9 + 1, b1);
     store_halo(stage_cur, rh);
     __syncthreads();
 #pragma unroll
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    for (int chunk = 0; chunk < p.chunks; ++chunk) {
+    for (int chunk = cbeg; chunk < cend; ++chunk) {
         const int kt = chunk * 9;
         load_halo(chunk + 1, rh);                             // next chunk's patch: in flight during taps 0..4
         tap_step(kt + 0, std::integral_constant<int, 0>(), b0, b2);
@@ -519,6 +532,41 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = merge_hi_lo(acc[i][0][r], lo[i][r]);
+    if (ksp > 1) {
+        // All traffic through the slab is agent-scope (sc1) relaxed atomics -- coherent across the XCDs' L2s by themselves --
+        // ordered by completion: the partial stores are acknowledged (vmcnt = 0) before the block's ticket is drawn.  (The
+        // portable spelling, __threadfence() on both sides, costs a buffer_wbl2 = a write-back of the XCD's whole L2 per block.)
+        float* base = p.sk_slab + ((size_t)lb * ksp) * (size_t)(BM * BN);
+        float* mine = base + (size_t)ksplit_id * (BM * BN) + (wave * TM) * 1024 + lane;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __hip_atomic_store(mine + (i * 16 + r) * 64, acc[i][0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): every partial of this wave has reached the coherence point
+        __syncthreads();
+        if (t == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(p.sk_ticket + lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk_last = prev == (unsigned)(ksp - 1);
+            if (sk_last) __hip_atomic_store(p.sk_ticket + lb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
+        }
+        __syncthreads();
+        if (!sk_last) return;
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        for (int sp = 0; sp < ksp; ++sp) {
+            const float* part = base + (size_t)sp * (BM * BN) + (wave * TM) * 1024 + lane;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][0][r] += __hip_atomic_load(part + (i * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     const int m0 = ((img * H + y0) * W) + x0;
     const long pool_base = ((long)img * (H >> 1) + (y0 >> 1)) * (W >> 1) + (x0 >> 1);
     nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m, pool_base);
@@ -851,6 +899,40 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     if (force >= 0 && force <= 2 && !(force == 0 && p.N <= 64)) cfg = force;
     const int halo_force = tune(TUNE_NT_HALO);
     const bool halo = split && AMODE == A_CONV3 && EPI == EPI_STORE && p.W % 16 == 0 && p.H % 8 == 0 && cfg != 2 && halo_force != 0;
+    // 8 x 8 images: two-images-per-patch halo kernel with split K (needs the scratch of rd_set_splitk_workspace on this stream)
+    p.ksplit = 1;
+    p.chunks_per = p.chunks;
+    if (split && AMODE == A_CONV3 && EPI == EPI_STORE && p.W == 8 && p.H == 8 && !p.pool_out && halo_force != 0 && force < 0 &&
+        tune(TUNE_NT_SPLITK) != 0 && p.N % 64 == 0 && p.M >= 1024 && p.chunks >= 8) {
+        unsigned* tickets = nullptr;
+        float* slab = nullptr;
+        int n_tickets = 0;
+        size_t slab_bytes = 0;
+        // 128 pixels x 64 channels per block (2 x 2 waves, 164 VGPRs; the 128-column variant needs 270 with the 200-pixel halo)
+        const int tiles_m = cdiv(p.M, 128), tiles_n = p.N / 64;
+        const long tiles = (long)tiles_m * tiles_n;
+        int ks = (int)(512 / tiles);
+        if (ks > 8) ks = 8;
+        if (ks >= 2 && splitk_workspace(s, &tickets, &n_tickets, &slab, &slab_bytes)) {
+            const int per = cdiv(p.chunks, ks);
+            ks = cdiv(p.chunks, per);
+            if (ks >= 2 && tiles <= n_tickets && (size_t)tiles * ks * 128 * 64 * 4 <= slab_bytes) {
+                p.patch = 2;
+                p.tiles_n = tiles_n;
+                p.ksplit = ks;
+                p.chunks_per = per;
+                p.sk_slab = slab;
+                p.sk_ticket = tickets;
+                if (tiles_m_out) *tiles_m_out = tiles_m;
+                char pc8[64];
+                snprintf(pc8, sizeof(pc8), "%s|conv3_halo_split<64,w8>", cls);
+                ProfScope ps8(s, pc8, (double)flops, bytes, true);
+                hipLaunchKernelGGL((conv3_halo_split_kernel<64, 2, 2, EPI_STORE, 8, 1>), dim3((unsigned)(tiles * ks)), dim3(256), 0, s, p);
+                RD_LAUNCH_CHECK(cls);
+                return RD_OK;
+            }
+        }
+    }
     if (p.pool_out && !halo) {
         set_error("%s: the pooling epilogue exists in the patch (halo) kernels only", cls);
         return RD_ERR_ARG;

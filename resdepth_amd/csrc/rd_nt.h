@@ -36,7 +36,7 @@ struct NtParams {
     int Cout;  // EPI_CONVT: channels per (a,b) quadrant
     int chunks, nk, taps;
     int tiles_n;
-    int patch;  // halo kernel: tile rows are an 8x16-pixel patch (row r -> pixel m0 + (r >> 4) * W + (r & 15))
+    int patch;  // halo kernel: 1 = tile rows are an 8x16-pixel patch (row r -> pixel m0 + (r >> 4) * W + (r & 15)); 2 = two 8x8 images
     int vec;  // epilogue may use 16-byte accesses (N % 4 == 0 and, for the transposed conv, Cout % 4 == 0)
     unsigned a_bytes, b_bytes;  // extents of the A / B tensors for the buffer descriptors
     float* stats;  // EPI_STORE only, nullable: per-(tile_m) column sums / sums of squares [tiles_m][2][N] (BN statistics)
@@ -60,6 +60,12 @@ struct NtParams {
     float bn_slope;
     int bn_mode;
     float* bn_part;
+    // split-K (halo kernel on 8 x 8 images): ksplit blocks per output tile each take chunks_per 16-channel chunks, park their
+    // partial accumulators in sk_slab and draw a ticket; the LAST block to arrive adds the ksplit partials in split order
+    // (bit-reproducible whatever the arrival order) and runs the epilogue with all its fusions
+    int ksplit, chunks_per;
+    float* sk_slab;
+    unsigned* sk_ticket;
 };
 
 // transposed-convolution data gradient (rd_convt.hip); *launched = 0 when the shape is left to the generic NT kernel
@@ -83,7 +89,10 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
     // ---- epilogue.  D[i][j]: lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5).  The accumulators
     // are staged through LDS (EB 32-row blocks of one wave row-band per pass) so that HBM sees 16 B per lane and whole
     // contiguous rows per wave; bias / skip-add of the transposed convolution ride the same pass.
-    auto row_to_m = [&](int r) { return p.patch ? m0 + (r >> 4) * W + (r & 15) : m0 + r; };
+    // tile row -> pixel: plain | 8 x 16 patch of one image | two 8 x 8 images side by side (m0 = first pixel of the pair)
+    auto row_to_m = [&](int r) {
+        return p.patch == 2 ? m0 + ((r & 15) >> 3) * 64 + (r >> 4) * 8 + (r & 7) : p.patch ? m0 + (r >> 4) * W + (r & 15) : m0 + r;
+    };
     constexpr int CS = BN + 4, ROWS = EB * 32, Q = BN / 4, PPB = TM / EB;   // PPB passes per wave row-band
     static_assert(TM % EB == 0, "EB must divide TM");
     static_assert(ROWS * CS + 512 <= SMEM_WORDS, "epilogue staging (+ statistics scratch) must fit the operand buffers");

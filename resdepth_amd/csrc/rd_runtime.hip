@@ -34,6 +34,7 @@ struct TuneEntry {
 static TuneEntry g_tune[TUNE_COUNT] = {
     {"mfma_f32", 0},   {"nt_tile", -1},      {"nt_halo", -1},    {"nt_skew", 1},     {"tn_tile", -1},     {"tn_blocks", 512}, {"tn_split", -1},
     {"wg_strip", -1},  {"wg_minblocks", 768}, {"wg_blocks", 256}, {"wg_occ", 2}, {"convt_patch", -1}, {"edge_conv", -1}, {"rows_blocks", 512}, {"last_blocks", 2048},
+    {"nt_splitk", -1},
 };
 static int tune_index(const char* name, size_t len) {
     for (int i = 0; i < TUNE_COUNT; ++i)
@@ -55,6 +56,30 @@ static const int g_tune_env = [] {      // RD_TUNE="name=value,..." and the RD_M
     return 0;
 }();
 int tune(int key) { return g_tune[key].value; }
+
+// ---- split-K scratch (rd_set_splitk_workspace) --------------------------------------------------------------------
+// One registration per HIP stream: [64 KB of tile tickets, zeroed here once; the kernels leave them zero] [partial-sum slabs].
+struct SkEntry {
+    hipStream_t s;
+    char* ws;
+    size_t bytes;
+};
+static std::mutex g_sk_mu;
+static std::vector<SkEntry> g_sk;
+constexpr size_t kSkTicketBytes = 64 << 10;
+
+bool splitk_workspace(hipStream_t s, unsigned** tickets, int* n_tickets, float** slab, size_t* slab_bytes) {
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    for (const SkEntry& e : g_sk)
+        if (e.s == s) {
+            *tickets = reinterpret_cast<unsigned*>(e.ws);
+            *n_tickets = (int)(kSkTicketBytes / sizeof(unsigned));
+            *slab = reinterpret_cast<float*>(e.ws + kSkTicketBytes);
+            *slab_bytes = e.bytes - kSkTicketBytes;
+            return true;
+        }
+    return false;
+}
 
 // ---- profiler ---------------------------------------------------------------------------
 struct ProfRec {
@@ -193,3 +218,22 @@ int rd_prof_collect(rd_prof_entry* out, int max_entries) {
 }
 
 }  // extern "C"
+
+extern "C" int rd_set_splitk_workspace(void* ws, size_t bytes, rd_stream_t stream) {
+    using namespace rd;
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    for (size_t i = 0; i < g_sk.size(); ++i)
+        if (g_sk[i].s == s) {
+            g_sk.erase(g_sk.begin() + i);
+            break;
+        }
+    if (!ws) return RD_OK;                           // un-register
+    if (bytes < kSkTicketBytes + (1u << 20) || ((size_t)ws & 255)) {
+        set_error("rd_set_splitk_workspace: need a 256-byte aligned buffer of at least %zu bytes", kSkTicketBytes + (1u << 20));
+        return RD_ERR_ARG;
+    }
+    if (int e = check_hip(hipMemsetAsync(ws, 0, kSkTicketBytes, s), "rd_set_splitk_workspace")) return e;
+    g_sk.push_back({s, (char*)ws, bytes});
+    return RD_OK;
+}

@@ -501,6 +501,7 @@ class UNet(nn.Module):
     def _engine_forward_folded(self, x):
         """Eval-mode forward with no pre-BN tensor after level 0: conv -> (+shift, act[, pool]) in one kernel per block."""
         d = self.depth
+        _lib.ensure_splitk_workspace(x.device)
         pk = self._packed()
         fold = self._folded()
         blk = self.encoder[0][0]
@@ -528,6 +529,7 @@ class UNet(nn.Module):
         if not training and not save and self._can_fold():
             return self._engine_forward_folded(x), None
         d = self.depth
+        _lib.ensure_splitk_workspace(x.device)
         pk = self._packed()
         if training:
             self._bn_gen += 1
@@ -674,6 +676,7 @@ class UNet(nn.Module):
             # needed for gradient computation has been modified by an inplace operation")
             raise RuntimeError("resdepth_amd.UNet: a parameter was modified (optimizer step / load_state_dict / .data write) "
                                "between this graph's forward and its backward")
+        _lib.ensure_splitk_workspace(dout.device)
         pk = self._packed()
         training = S["training"]
         params = self._param_list()

@@ -654,3 +654,45 @@ def test_fused_sgd_mixed_momentum_state_matches_torch():
         ro.step()
     for p, r in zip(ours, ref):
         np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,cin,cout", [(32, 512, 512), (33, 128, 192), (16, 256, 64)])
+def test_split_k_patch_kernel_for_8x8_images(n, cin, cout):
+    """8 x 8 images (the cfg-S bottleneck): two images per patch, several K ranges per output tile, the last block adds the
+    partials in K order (rd_set_splitk_workspace): same result as the generic kernel up to summation order, bit-identical from
+    run to run, odd image counts, and the fused epilogues (BN forward statistics, BN-backward hook) see the finished tile."""
+    from resdepth_amd import ops, _lib
+    _lib.ensure_splitk_workspace(dev())
+    g = torch.Generator().manual_seed(n + cin)
+    x = torch.randn(n, cin, 8, 8, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    wf, wd = ops.pack_conv3x3_weight(wt.to(dev()))
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    run = lambda: ops.conv3x3_fwd_stats(nhwc(x), wf)
+    try:
+        _lib.tune_set("nt_splitk", 0)
+        z0, s0 = run()
+        _lib.tune_set("nt_splitk", -1)
+        z1, s1 = run()
+        z2, s2 = run()
+    finally:
+        _lib.tune_set("nt_splitk", -1)
+    assert torch.equal(z1, z2) and torch.equal(s1, s2)                       # run-to-run bit identity
+    close(nchw(z1), ref.float(), name="split-K patch kernel vs fp64")
+    close(nchw(z0), ref.float(), name="generic kernel vs fp64")
+    assert not torch.equal(z0, z1), "the split-K patch kernel did not engage (same bits as the generic kernel)"
+    c = z1.shape[-1]
+    zz = z1.double().reshape(-1, c)
+    np.testing.assert_allclose(s1[:c].cpu().numpy(), zz.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(s1[c:].cpu().numpy(), (zz * zz).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    # data gradient with the BN-backward hook through the same kernel
+    dz = torch.randn(n, 8, 8, cout, generator=g).to(dev())
+    zb = torch.randn(n, 8, 8, cin, generator=g).to(dev())
+    mean, invstd = (torch.randn(cin, generator=g) * 0.1).to(dev()), (torch.rand(cin, generator=g) + 0.5).to(dev())
+    gamma, beta = torch.randn(cin, generator=g).to(dev()), (torch.randn(cin, generator=g) * 0.3).to(dev())
+    gout, part = ops.conv3x3_bwd_data(dz, wd, bn=ops.BnHook(zb, mean, invstd, gamma, beta, 0.01, None, 1))
+    assert torch.equal(gout, ops.conv3x3_bwd_data(dz, wd)) and part[1] > 0
+    sums = ops.bn_bwd_stats_finalize([part], cin)
+    want = ops.bn_act_bwd_reduce(zb, mean, invstd, gamma, beta, 0.01, gout, None, None)
+    scale = want.abs().view(4, cin).amax(1, keepdim=True).expand(4, cin).reshape(-1) + 1e-30
+    assert float(((sums - want).abs() / scale).max()) <= 1e-5
