@@ -51,11 +51,12 @@ const char* rd_last_error_string(void);
  *   convT2x2 wtf: (4*Cout, 1, Cin)  wtd: (Cin, 4, Cout)
  *   conv1x1  wf: (Cout, 1, Cin)   wt: (Cin, 1, Cout) */
 size_t rd_packed_weight_bytes(int rows, int taps, int cin);
-/* Optional scratch for the split-K path of the 3x3 convolutions on 8 x 8 images (the bottleneck of cfg-S, lib/UNet.py:210:
- * few output tiles, K = 9 * 512): `ws` (256-byte aligned, >= 1.1 MB; 64 MB covers cfg-S / cfg-M) is used by every
- * rd_conv3x3_fwd* / rd_conv3x3_bwd_data* launch on `stream` from now on -- partial accumulators of the K ranges + one ticket
- * per output tile; results are bit-reproducible (partials are added in K order).  Without a registration those launches take
- * the generic kernel.  The caller keeps `ws` alive and must not use it for anything else; ws = NULL un-registers the stream. */
+/* Optional scratch for the 3x3 convolutions on 8 x 8 images (the bottleneck of cfg-S, lib/UNet.py:210: few output tiles,
+ * K = 9 * 512).  That kernel accumulates K in ranges of 128 channels; with `ws` registered (256-byte aligned, >= 1.1 MB;
+ * 64 MB covers cfg-S / cfg-M) every rd_conv3x3_fwd* / rd_conv3x3_bwd_data* launch on `stream` with a small grid runs one
+ * block per range -- partial tiles + one ticket per output tile live in `ws` -- and the last block adds the ranges in the
+ * same order.  Results are the same bits with or without a registration, at any batch size; only the block count differs.
+ * The caller keeps `ws` alive and must not use it for anything else; ws = NULL un-registers the stream. */
 int rd_set_splitk_workspace(void* ws, size_t bytes, rd_stream_t stream);
 
 /* nn.Conv2d weight [Cout][Cin][3][3] (lib/UNet.py:4-5) ->

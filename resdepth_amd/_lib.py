@@ -188,7 +188,7 @@ _splitk = {}
 def ensure_splitk_workspace(device, nbytes: int = (64 << 20) + (64 << 10)) -> None:
     """Register (once per device and stream) the split-K scratch of the 8 x 8 convolution kernel for the CURRENT stream of
     `device` (include/resdepth_hip.h: rd_set_splitk_workspace).  The engine entry points call this; direct users of the op
-    wrappers may too -- without it those layers run on the generic kernel."""
+    wrappers may too -- without it those layers run the same kernel unsplit (same bits, fewer blocks at small batches)."""
     dev = torch.device(device)
     index = dev.index if dev.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(index).cuda_stream

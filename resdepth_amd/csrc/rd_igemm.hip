@@ -358,9 +358,10 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 // W8 = 1: 8 x 8 images (the cfg-S bottleneck, lib/UNet.py:210: 2048 pixels x 512 channels, K = 4608).  A patch is TWO images
 // side by side -- tile row r = pixel (y = r >> 4, x = r & 7) of image 2 * tile + ((r & 15) >> 3) -- each with its own zero border
 // in LDS (halo rows of 2 x 10 pixels), so the tap offsets stay instruction immediates; only the per-lane base address and the
-// row -> pixel map of the epilogue change.  16 patches x 4 column tiles are too few blocks, so K is split as well: p.ksplit
-// blocks per tile take p.chunks_per channel chunks each, park their partial tile in a scratch slab and draw a ticket; the last
-// one adds the partials in split order and runs the epilogue (statistics, BN-backward hook) on the finished tile.
+// row -> pixel map of the epilogue change.  K is accumulated in ranges of eight chunks, each merged into the tile total in
+// turn.  16 patches x 8 column tiles are too few blocks, so small grids give every range its own block (p.ksplit = number of
+// ranges, p.chunks_per = 8): the blocks park their range in a scratch slab and draw a ticket, the last one adds the ranges in
+// the same order and runs the epilogue (statistics, BN-backward hook) on the finished tile -- the same bits as the unsplit form.
 template <int BN, int WM, int WN, int EPI, int SKEW = 8, int W8 = 0>
 __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     constexpr int BM = 128, PH = 8, PW = 16, HW_ = W8 ? 20 : PW + 2, HROWS = (PH + 2) * HW_;   // 180 (200) halo pixels
@@ -511,7 +512,17 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    for (int chunk = cbeg; chunk < cend; ++chunk) {
+    // W8: K is accumulated in RANGES of eight chunks (128 channels), each merged into `tot` in turn -- whether the ranges of a
+    // tile run in one block (ksplit = 1) or one per block (ksplit = number of ranges, added in the same order by the fix-up),
+    // so the result does not depend on the batch size that decides between the two
+    f32x16 tot[W8 ? TM : 1];
+#pragma unroll
+    for (int i = 0; i < (W8 ? TM : 1); ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][r] = 0.f;
+    for (int c0 = cbeg; c0 < cend; c0 += W8 ? 8 : (cend - cbeg)) {
+    const int c1 = W8 ? c0 + 8 : cend;                        // W8: always eight steps (chunks past cend load zeros)
+    for (int chunk = c0; chunk < c1; ++chunk) {
         const int kt = chunk * 9;
         load_halo(chunk + 1, rh);                             // next chunk's patch: in flight during taps 0..4
         tap_step(kt + 0, std::integral_constant<int, 0>(), b0, b2);
@@ -527,11 +538,21 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         tap_step(kt + 8, std::integral_constant<int, 8>(), b2, b1);
         float* tmp = stage_cur; stage_cur = stage_nxt; stage_nxt = tmp;
     }
+    if (W8) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tot[i][r] += merge_hi_lo(acc[i][0][r], lo[i][r]);
+                acc[i][0][r] = lo[i][r] = 0.f;
+            }
+    }
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = merge_hi_lo(acc[i][0][r], lo[i][r]);
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = W8 ? tot[i][r] : merge_hi_lo(acc[i][0][r], lo[i][r]);
     if (ksp > 1) {
         // All traffic through the slab is agent-scope (sc1) relaxed atomics -- coherent across the XCDs' L2s by themselves --
         // ordered by completion: the partial stores are acknowledged (vmcnt = 0) before the block's ticket is drawn.  (The
@@ -899,39 +920,37 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     if (force >= 0 && force <= 2 && !(force == 0 && p.N <= 64)) cfg = force;
     const int halo_force = tune(TUNE_NT_HALO);
     const bool halo = split && AMODE == A_CONV3 && EPI == EPI_STORE && p.W % 16 == 0 && p.H % 8 == 0 && cfg != 2 && halo_force != 0;
-    // 8 x 8 images: two-images-per-patch halo kernel with split K (needs the scratch of rd_set_splitk_workspace on this stream)
+    // 8 x 8 images: two-images-per-patch halo kernel; K in ranges of 8 chunks, split over blocks when the grid is small and the
+    // stream has the scratch of rd_set_splitk_workspace.  Chosen by the LAYER shape only (never by the pixel count), and the
+    // split / unsplit forms add the ranges in the same order: results do not depend on the batch size.
     p.ksplit = 1;
     p.chunks_per = p.chunks;
     if (split && AMODE == A_CONV3 && EPI == EPI_STORE && p.W == 8 && p.H == 8 && !p.pool_out && halo_force != 0 && force < 0 &&
-        tune(TUNE_NT_SPLITK) != 0 && p.N % 64 == 0 && p.M >= 1024 && p.chunks >= 8) {
+        tune(TUNE_NT_SPLITK) != 0 && p.N % 64 == 0 && p.chunks >= 8) {
+        // 128 pixels x 64 channels per block (2 x 2 waves, 172 VGPRs; the 128-column variant needs 270 with the 200-pixel halo)
+        const int tiles_m = cdiv(p.M, 128), tiles_n = p.N / 64;
+        const long tiles = (long)tiles_m * tiles_n;
+        const int ranges = cdiv(p.chunks, 8);
         unsigned* tickets = nullptr;
         float* slab = nullptr;
         int n_tickets = 0;
         size_t slab_bytes = 0;
-        // 128 pixels x 64 channels per block (2 x 2 waves, 164 VGPRs; the 128-column variant needs 270 with the 200-pixel halo)
-        const int tiles_m = cdiv(p.M, 128), tiles_n = p.N / 64;
-        const long tiles = (long)tiles_m * tiles_n;
-        int ks = (int)(512 / tiles);
-        if (ks > 8) ks = 8;
-        if (ks >= 2 && splitk_workspace(s, &tickets, &n_tickets, &slab, &slab_bytes)) {
-            const int per = cdiv(p.chunks, ks);
-            ks = cdiv(p.chunks, per);
-            if (ks >= 2 && tiles <= n_tickets && (size_t)tiles * ks * 128 * 64 * 4 <= slab_bytes) {
-                p.patch = 2;
-                p.tiles_n = tiles_n;
-                p.ksplit = ks;
-                p.chunks_per = per;
-                p.sk_slab = slab;
-                p.sk_ticket = tickets;
-                if (tiles_m_out) *tiles_m_out = tiles_m;
-                char pc8[64];
-                snprintf(pc8, sizeof(pc8), "%s|conv3_halo_split<64,w8>", cls);
-                ProfScope ps8(s, pc8, (double)flops, bytes, true);
-                hipLaunchKernelGGL((conv3_halo_split_kernel<64, 2, 2, EPI_STORE, 8, 1>), dim3((unsigned)(tiles * ks)), dim3(256), 0, s, p);
-                RD_LAUNCH_CHECK(cls);
-                return RD_OK;
-            }
+        if (ranges >= 2 && tiles * ranges <= 1024 && splitk_workspace(s, &tickets, &n_tickets, &slab, &slab_bytes) &&
+            tiles <= n_tickets && (size_t)tiles * ranges * 128 * 64 * 4 <= slab_bytes) {
+            p.ksplit = ranges;
+            p.chunks_per = 8;
+            p.sk_slab = slab;
+            p.sk_ticket = tickets;
         }
+        p.patch = 2;
+        p.tiles_n = tiles_n;
+        if (tiles_m_out) *tiles_m_out = tiles_m;
+        char pc8[64];
+        snprintf(pc8, sizeof(pc8), "%s|conv3_halo_split<64,w8>", cls);
+        ProfScope ps8(s, pc8, (double)flops, bytes, true);
+        hipLaunchKernelGGL((conv3_halo_split_kernel<64, 2, 2, EPI_STORE, 8, 1>), dim3((unsigned)(tiles * p.ksplit)), dim3(256), 0, s, p);
+        RD_LAUNCH_CHECK(cls);
+        return RD_OK;
     }
     if (p.pool_out && !halo) {
         set_error("%s: the pooling epilogue exists in the patch (halo) kernels only", cls);
