@@ -42,7 +42,7 @@ ARITHMETIC = ("fp32 storage and accumulation; MFMA-class kernels multiply exactl
               "u = 2^-24, vs 16 u / 75 u for the exact-f32 MFMA chain; tests/test_split_numerics_gpu.py); +-Inf / NaN operands "
               "propagate exactly like fp32 in the forward / data-gradient kernels (weight gradients: same set of non-finite "
               "outputs, an Inf may surface as NaN); RD_MFMA=f32 selects the exact-f32 MFMA kernels")
-MFMA_RANDOM_OPERAND_TFLOPS = 1684.0     # measured, scripts/ubench/mfma_power.hip (random bf16 operands, register-only MFMA loop)
+MFMA_RANDOM_OPERAND_TFLOPS = 1850.0     # measured, scripts/ubench/mfma_order.hip: register-only MFMA loop on split terms (hi/mid/lo) of N(0,1) floats
 MFMA_CLASSES = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "convt2x2_fwd", "convt2x2_dgrad", "convt2x2_wgrad")
 
 
@@ -466,10 +466,10 @@ def main():
                     "peak_note": ("fp32-equivalent FLOP/s; bound = dense bf16 MFMA peak (2500 TF) / 6 products per fp32 "
                                   "multiply-add of the exact 3-term split" if is_split else "f32-input MFMA peak"),
                     "frac_of_f32_mfma_peak": round(ach / PEAK_F32_TFLOPS, 4),
-                    # scripts/ubench/mfma_power.hip (profiles/r02_notes.md section 7): a register-only loop of back-to-back
-                    # v_mfma_f32_32x32x16_bf16 (pipe 100 % busy, no memory traffic) sustains 2486 TFLOP/s on constant
-                    # operands but 1684 TFLOP/s on operands with random sign / exponent / mantissa -- the power limit
-                    # (effective clock 1.62 GHz).  Against THAT ceiling / 6 products:
+                    # scripts/ubench/mfma_power.hip / mfma_order.hip (profiles/r03_notes.md section 9): a register-only loop of
+                    # back-to-back v_mfma_f32_32x32x16_bf16 (pipe 100 % busy, no memory traffic) sustains 2486 TFLOP/s on constant
+                    # operands, 1684-1724 on random bits and 1850 on what these kernels feed it (the three split terms of
+                    # N(0,1) floats) -- the power limit (effective clock 1.78 GHz).  Against THAT ceiling / 6 products:
                     "power_limited_peak": round(MFMA_RANDOM_OPERAND_TFLOPS / 6.0, 1) if is_split else None,
                     "frac_of_power_limited_peak": round(ach / (MFMA_RANDOM_OPERAND_TFLOPS / 6.0), 4) if is_split else None,
                     "traffic": traffic, "traffic_source": traffic_src, "pmc": pmc, "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
