@@ -1,0 +1,127 @@
+// A consumer of libresdepth_hip.so that is NOT PyTorch: plain HIP runtime + include/resdepth_hip.h, the way a C / C++ /
+// cgo / JNI host would bind the library.  One 3x3 convolution layer (lib/UNet.py:4-5,44) forward, data
+// gradient and weight gradient on device buffers it allocates itself, checked against direct loops in double on the host;
+// then the error contract (non-zero return + rd_last_error_string).  Test infrastructure: built and run by
+// tests/test_cabi_consumer_gpu.py.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "resdepth_hip.h"
+
+#define HIP_OK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            std::fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e_));                   \
+            return 2;                                                                         \
+        }                                                                                     \
+    } while (0)
+#define RD_OK_(call)                                                                          \
+    do {                                                                                      \
+        int e_ = (call);                                                                      \
+        if (e_ != 0) {                                                                        \
+            std::fprintf(stderr, "%s -> %d: %s\n", #call, e_, rd_last_error_string());        \
+            return 3;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+static unsigned g_seed = 12345u;
+static float rnd() {      // uniform in (-1, 1), the same on every host
+    g_seed = g_seed * 1664525u + 1013904223u;
+    return ((g_seed >> 8) & 0xffff) / 32768.0f - 1.0f;
+}
+
+template <class T>
+static T* dev_alloc(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n * sizeof(T) ? n * sizeof(T) : 4) != hipSuccess) return nullptr;
+    return static_cast<T*>(p);
+}
+
+static double max_rel(const std::vector<float>& got, const std::vector<double>& want) {
+    double scale = 0, err = 0;
+    for (double v : want) scale = std::fmax(scale, std::fabs(v));
+    for (size_t i = 0; i < want.size(); ++i) err = std::fmax(err, std::fabs(got[i] - want[i]));
+    return err / (scale + 1e-30);
+}
+
+int main() {
+    const int N = 2, H = 16, W = 24, CI = 8, CO = 12;
+    std::vector<float> x((size_t)N * H * W * CI), wt((size_t)CO * CI * 9), dz((size_t)N * H * W * CO);
+    for (float& v : x) v = rnd();
+    for (float& v : wt) v = rnd() * 0.2f;
+    for (float& v : dz) v = rnd();
+
+    // host reference in double: z[n,y,x,co] = sum_{ci,ky,kx} x[n,y+ky-1,x+kx-1,ci] w[co,ci,ky,kx]   (zero padding)
+    std::vector<double> z_ref((size_t)N * H * W * CO, 0.0), dx_ref((size_t)N * H * W * CI, 0.0), dw_ref((size_t)CO * CI * 9, 0.0);
+    for (int n = 0; n < N; ++n)
+        for (int y = 0; y < H; ++y)
+            for (int xx = 0; xx < W; ++xx)
+                for (int co = 0; co < CO; ++co) {
+                    const double g = dz[(((size_t)n * H + y) * W + xx) * CO + co];
+                    double acc = 0;
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int yy = y + ky - 1, xs = xx + kx - 1;
+                            if (yy < 0 || yy >= H || xs < 0 || xs >= W) continue;
+                            for (int ci = 0; ci < CI; ++ci) {
+                                const size_t xi = (((size_t)n * H + yy) * W + xs) * CI + ci, wi = (((size_t)co * CI + ci) * 3 + ky) * 3 + kx;
+                                acc += (double)x[xi] * wt[wi];
+                                dx_ref[xi] += g * wt[wi];
+                                dw_ref[wi] += g * x[xi];
+                            }
+                        }
+                    z_ref[(((size_t)n * H + y) * W + xx) * CO + co] = acc;
+                }
+
+    hipStream_t stream;
+    HIP_OK(hipStreamCreate(&stream));
+    float *d_x = dev_alloc<float>(x.size()), *d_w = dev_alloc<float>(wt.size()), *d_dz = dev_alloc<float>(dz.size());
+    float *d_z = dev_alloc<float>(z_ref.size()), *d_dx = dev_alloc<float>(dx_ref.size()), *d_dw = dev_alloc<float>(dw_ref.size());
+    const size_t wf_bytes = rd_packed_weight_bytes(CO, 9, CI), wd_bytes = rd_packed_weight_bytes(CI, 9, CO);
+    const size_t ws_bytes = rd_conv3x3_bwd_weight_ws_bytes(N, H, W, CI, CO);
+    char *d_wf = dev_alloc<char>(wf_bytes), *d_wd = dev_alloc<char>(wd_bytes), *d_ws = dev_alloc<char>(ws_bytes);
+    if (!d_x || !d_w || !d_dz || !d_z || !d_dx || !d_dw || !d_wf || !d_wd || !d_ws) {
+        std::fprintf(stderr, "hipMalloc failed\n");
+        return 2;
+    }
+    HIP_OK(hipMemcpyAsync(d_x, x.data(), x.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemcpyAsync(d_w, wt.data(), wt.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemcpyAsync(d_dz, dz.data(), dz.size() * 4, hipMemcpyHostToDevice, stream));
+
+    RD_OK_(rd_pack_conv3x3_weight(d_w, (float*)d_wf, (float*)d_wd, CO, CI, stream));
+    RD_OK_(rd_conv3x3_fwd(d_x, (const float*)d_wf, d_z, N, H, W, CI, CO, stream));
+    RD_OK_(rd_conv3x3_bwd_data(d_dz, (const float*)d_wd, d_dx, N, H, W, CI, CO, stream));
+    RD_OK_(rd_conv3x3_bwd_weight(d_x, d_dz, d_dw, N, H, W, CI, CO, d_ws, ws_bytes, stream));
+
+    std::vector<float> z(z_ref.size()), dx(dx_ref.size()), dw(dw_ref.size());
+    HIP_OK(hipMemcpyAsync(z.data(), d_z, z.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(dx.data(), d_dx, dx.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(dw.data(), d_dw, dw.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+
+    int bad = 0;
+    const double e_z = max_rel(z, z_ref), e_dx = max_rel(dx, dx_ref), e_dw = max_rel(dw, dw_ref);
+    std::printf("conv3x3 forward       max |err| / max |ref| = %.3g\n", e_z);
+    std::printf("conv3x3 data gradient max |err| / max |ref| = %.3g\n", e_dx);
+    std::printf("conv3x3 weight grad.  max |err| / max |ref| = %.3g\n", e_dw);
+    const double tol = 2e-6;      // fp32 results (the tolerance of tests/test_ops_gpu.py)
+    if (!(e_z <= tol) || !(e_dx <= tol) || !(e_dw <= tol)) bad = 1;
+
+    // error contract: Cin must be a multiple of 4 here -> non-zero return, message names the argument, nothing launched
+    const int rc = rd_conv3x3_fwd(d_x, (const float*)d_wf, d_z, N, H, W, 3, CO, stream);
+    const char* msg = rd_last_error_string();
+    std::printf("rd_conv3x3_fwd(cin = 3) -> %d: %s\n", rc, msg ? msg : "(null)");
+    if (rc == 0 || !msg || !std::strstr(msg, "Cin")) bad = 1;
+    HIP_OK(hipStreamSynchronize(stream));
+
+    for (void* p : {(void*)d_x, (void*)d_w, (void*)d_dz, (void*)d_z, (void*)d_dx, (void*)d_dw, (void*)d_wf, (void*)d_wd, (void*)d_ws}) (void)hipFree(p);
+    (void)hipStreamDestroy(stream);
+    std::puts(bad ? "FAILED" : "OK");
+    return bad;
+}

@@ -1,0 +1,19 @@
+"""The C-ABI without PyTorch: tests/cabi/consumer.cpp allocates device memory with the HIP runtime, calls the library through
+include/resdepth_hip.h only and checks one convolution layer (forward, data gradient, weight gradient) against loops in double
+on the host, then the error contract.  What a C / cgo / JNI host sees."""
+import subprocess
+
+import pytest
+
+from cabi_build import build_consumer
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_runtime_only_consumer_runs_one_layer_through_the_c_abi(tmp_path):
+    exe = build_consumer(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1] == "OK" and sum("max |err|" in ln for ln in lines) == 3, r.stdout
+    assert any("rd_conv3x3_fwd(cin = 3) ->" in ln and "Cin" in ln for ln in lines), r.stdout

@@ -93,3 +93,14 @@ def test_shipped_code_objects_hold_no_packed_f32_valu_and_no_spills():
     r = subprocess.run(["bash", os.path.join(root, "scripts", "check_isa.sh"), _lib.LIB_PATH], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "packed-f32 VALU 0, scratch 0" in r.stdout
+
+
+def test_c_abi_consumer_without_torch_compiles_and_links(tmp_path):
+    """tests/cabi/consumer.cpp: HIP runtime + include/resdepth_hip.h only (no PyTorch) builds against the in-tree library --
+    the header is self-contained and every entry point the consumer uses resolves.  (It runs in tests/test_cabi_consumer_gpu.py.)"""
+    import subprocess
+    from cabi_build import build_consumer
+    exe = build_consumer(tmp_path)
+    needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True).stdout
+    assert "libresdepth_hip.so" in needed and "torch" not in needed and "python" not in needed.lower()
+
