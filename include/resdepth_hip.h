@@ -316,7 +316,8 @@ typedef struct {
     double bytes;   /* summed algorithmic HBM bytes declared at launch */
 } rd_prof_entry;
 /* Diagnosis knobs (tile-shape / kernel-selection overrides used by scripts/; never needed in production).  Names:
- * mfma_f32 nt_tile nt_halo tn_tile tn_blocks tn_split wg_strip wg_minblocks wg_blocks convt_patch edge_conv rows_blocks last_blocks
+ * mfma_f32 nt_tile nt_halo nt_skew nt_splitk tn_tile tn_blocks tn_split wg_strip wg_minblocks wg_blocks wg_occ convt_patch edge_conv
+ * rows_blocks last_blocks
  * (resdepth_amd/csrc/rd_common.h: TuneKey).  Also settable at load time: RD_TUNE="name=value,..." */
 int rd_tune_set(const char* name, int value);
 int rd_tune_get(const char* name, int* value);
