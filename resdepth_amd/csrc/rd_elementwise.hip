@@ -235,16 +235,18 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* __
 
 // BN-backward statistics from the dgrad epilogues: per-tile partials [rows][4][C] (fp32) of one or two producers (the
 // un-pooled and the pooled gradient operand) -> fixed-order fp64 column sums `sums[4C]` (layout of bn_act_bwd_kernel's
-// reduction) + the fp32 parameter gradients.  One WAVE = one channel quad of one of the four sums, its 64 lanes are 64 row
-// slices (16-byte loads) combined by a fixed shuffle butterfly.  No LDS and < 32 registers on purpose: this kernel sits on
-// the critical path of the backward while the two-waves-per-SIMD weight-gradient kernel holds all of a CU's LDS and all but
-// 38 of its registers -- a kernel that needs neither still finds a slot (the LDS version took 42 us per launch under
-// overlap against 12 us alone).
-__global__ __launch_bounds__(64) void bn_bwd_stats_finalize_kernel(const float* __restrict__ pa, int ra,
-                                                                   const float* __restrict__ pb, int rb, int C,
-                                                                   double* __restrict__ sums, float* __restrict__ dgamma,
-                                                                   float* __restrict__ dbeta, float* __restrict__ dextra) {
-    const int lane = threadIdx.x, CQ = C >> 2;
+// reduction) + the fp32 parameter gradients.  One block = one channel quad of one of the four sums; its 256 threads are 256
+// row slices (16-byte loads, four rows per thread in flight), combined by a fixed shuffle butterfly per wave and 128 bytes
+// of LDS across the four waves.  This launch sits on the critical path of the backward (data gradient -> statistics -> BN
+// apply): the r02 version -- one wave per quad, two loads in flight, sized to squeeze in beside a two-waves-per-SIMD
+// weight-gradient kernel -- took 50-72 us at the 256 x 256 levels (8192 partial rows); the weight-gradient stream now runs
+// one block per CU and leaves room for a real block.
+__global__ __launch_bounds__(256) void bn_bwd_stats_finalize_kernel(const float* __restrict__ pa, int ra,
+                                                                    const float* __restrict__ pb, int rb, int C,
+                                                                    double* __restrict__ sums, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, float* __restrict__ dextra) {
+    __shared__ double wred[4][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, CQ = C >> 2;
     const int sidx = blockIdx.x / CQ, cq = blockIdx.x - sidx * CQ;
     const long col = (long)sidx * C + cq * 4, stride = 4L * C;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -252,16 +254,18 @@ __global__ __launch_bounds__(64) void bn_bwd_stats_finalize_kernel(const float* 
         const float* part = src ? pb : pa;
         const int nb = src ? rb : ra;
         if (!part) continue;
-        int b = lane;
-        for (; b + 64 < nb; b += 128) {
+        int b = t;
+        for (; b + 768 < nb; b += 1024) {
             const float4 v0 = *reinterpret_cast<const float4*>(part + (long)b * stride + col);
-            const float4 v1 = *reinterpret_cast<const float4*>(part + (long)(b + 64) * stride + col);
-            a0 += (double)v0.x + (double)v1.x;
-            a1 += (double)v0.y + (double)v1.y;
-            a2 += (double)v0.z + (double)v1.z;
-            a3 += (double)v0.w + (double)v1.w;
+            const float4 v1 = *reinterpret_cast<const float4*>(part + (long)(b + 256) * stride + col);
+            const float4 v2 = *reinterpret_cast<const float4*>(part + (long)(b + 512) * stride + col);
+            const float4 v3 = *reinterpret_cast<const float4*>(part + (long)(b + 768) * stride + col);
+            a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+            a1 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+            a2 += ((double)v0.z + (double)v1.z) + ((double)v2.z + (double)v3.z);
+            a3 += ((double)v0.w + (double)v1.w) + ((double)v2.w + (double)v3.w);
         }
-        if (b < nb) {
+        for (; b < nb; b += 256) {
             const float4 v = *reinterpret_cast<const float4*>(part + (long)b * stride + col);
             a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
         }
@@ -273,20 +277,80 @@ __global__ __launch_bounds__(64) void bn_bwd_stats_finalize_kernel(const float* 
         a2 += __shfl_xor(a2, o);
         a3 += __shfl_xor(a3, o);
     }
-    if (lane < 4) {
-        const double r = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a3;
-        const int c = cq * 4 + lane;
-        sums[col + lane] = r;
+    if (lane == 0) {
+        wred[wave][0] = a0; wred[wave][1] = a1; wred[wave][2] = a2; wred[wave][3] = a3;
+    }
+    __syncthreads();
+    if (t < 4) {
+        const double r = ((wred[0][t] + wred[1][t]) + wred[2][t]) + wred[3][t];
+        const int c = cq * 4 + t;
+        sums[col + t] = r;
         if (sidx == 0 && dbeta) dbeta[c] = (float)r;
         if (sidx == 1 && dgamma) dgamma[c] = (float)r;
         if (sidx == 2 && dextra) dextra[c] = (float)r;
     }
 }
 
+// Same, C % 4 == 0 (every layer of the network): one block = one channel quad, 512 threads = 256 row slices x (sums | sums of
+// squares), 16-byte loads, eight rows per thread in flight -- the partials of a 256 x 256 level are 4096 rows, and this launch
+// sits between the convolution and its BN / activation pass with nothing to overlap it in the forward.
+__global__ __launch_bounds__(512) void bn_reduce_finalize_quad_kernel(const float* __restrict__ partial, int nb, int C, double count,
+                                                                      float eps, float momentum, float* __restrict__ mean,
+                                                                      float* __restrict__ invstd, float* __restrict__ rmean,
+                                                                      float* __restrict__ rvar, int64_t* nbt) {
+    __shared__ double red[512][4];
+    const int t = threadIdx.x, kind = t & 1, slice = t >> 1, cq = blockIdx.x;
+    const float* base = partial + (long)kind * C + cq * 4;
+    const long stride = 2L * C;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int b = slice;
+    for (; b + 7 * 256 < nb; b += 8 * 256) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(base + (long)(b + 256 * k) * stride);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a0 += v[k].x; a1 += v[k].y; a2 += v[k].z; a3 += v[k].w;
+        }
+    }
+    for (; b < nb; b += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (long)b * stride);
+        a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+    }
+    red[t][0] = a0; red[t][1] = a1; red[t][2] = a2; red[t][3] = a3;
+    __syncthreads();
+    for (int sl = 128; sl >= 1; sl >>= 1) {           // fixed tree over the 256 slices (thread = 2 * slice + kind)
+        if (slice < sl) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[t][k] += red[t + 2 * sl][k];
+        }
+        __syncthreads();
+    }
+    if (t == 0 && blockIdx.x == 0 && nbt) *nbt += 1;
+    if (t < 4) {
+        const int c = cq * 4 + t;
+        const double su = red[0][t], sq = red[1][t];
+        const double m = su / count;
+        double var = sq / count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+        if (rvar) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    }
+}
+
 int bn_reduce_finalize(const float* partial, int nb, int c, double count, float eps, float momentum, float* mean, float* invstd,
                        float* rmean, float* rvar, int64_t* nbt, hipStream_t s) {
-    hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(c, 4)), dim3(256), 0, s, partial, nb, c, count, eps, momentum, mean,
-                       invstd, rmean, rvar, nbt);
+    if (c % 4 == 0)
+        hipLaunchKernelGGL(bn_reduce_finalize_quad_kernel, dim3(c / 4), dim3(512), 0, s, partial, nb, c, count, eps, momentum, mean,
+                           invstd, rmean, rvar, nbt);
+    else
+        hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(c, 4)), dim3(256), 0, s, partial, nb, c, count, eps, momentum, mean,
+                           invstd, rmean, rvar, nbt);
     RD_LAUNCH_CHECK("bn_reduce_finalize");
     return RD_OK;
 }
@@ -1324,7 +1388,7 @@ int rd_bn_bwd_stats_finalize(const float* part_a, int rows_a, const float* part_
                              float* dgamma, float* dbeta, float* dextra, rd_stream_t s) {
     RD_REQUIRE(part_a && rows_a > 0 && sums && c > 0 && c % 4 == 0 && (!part_b || rows_b > 0), "rd_bn_bwd_stats_finalize: bad arguments");
     ProfScope ps((hipStream_t)s, "bn_act_bwd_reduce", 0, 16.0 * c * ((double)rows_a + (part_b ? rows_b : 0)));
-    hipLaunchKernelGGL(bn_bwd_stats_finalize_kernel, dim3(c), dim3(64), 0, (hipStream_t)s, part_a, rows_a, part_b,
+    hipLaunchKernelGGL(bn_bwd_stats_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)s, part_a, rows_a, part_b,
                        part_b ? rows_b : 0, c, sums, dgamma, dbeta, dextra);
     RD_LAUNCH_CHECK("bn_bwd_stats_finalize");
     return RD_OK;
