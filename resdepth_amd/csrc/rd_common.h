@@ -85,8 +85,24 @@ int conv_last_wgrad_blocks(int n, int h, int w, int c);
 // first convolution, segment kernels: tiles / blocks = 0 when the shape stays on the generic kernel
 int conv_first_seg_tiles(int n, int h, int w, int cin, int cout);
 int conv_first_wgrad_seg_blocks(int n, int h, int w, int cin, int cout);
+// weight gradient with dz computed on the fly: the arguments of rd_bn_act_bwd_apply for the first block (pooled form)
+struct FirstBnBwd {
+    const float* z;
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    const float* slope_dev;
+    float slope;
+    const float* g_full;
+    const float* g_pool;
+    const unsigned char* idx;
+    const double* sums;
+    double count;
+    int training;
+};
 int conv_first_seg_launch(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
-                          int w, int cin, int cout, hipStream_t s);
+                          int w, int cin, int cout, hipStream_t s, const FirstBnBwd* bn = nullptr);
 int conv_last_wgrad_launch(const float* s_in, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s);
 
 // split-K scratch registered for this stream (rd_set_splitk_workspace): tile tickets (all zero between launches) + slab area

@@ -387,10 +387,13 @@ __global__ __launch_bounds__(256, 4) void conv_first_fwd_seg_kernel(const float*
     }
 }
 
-template <int CIN, int CQ>
+// FUSED: there is no dz tensor.  The first block's BN + activation + pool backward (bn_act_bwd_kernel<true, true> in
+// rd_elementwise.hip, the same expressions in the same order) is evaluated on the operands as they are loaded: dz of level 0 has
+// this kernel as its only reader, so its 537 MB (cfg-S) are neither written nor read back.
+template <int CIN, int CQ, bool FUSED>
 __global__ __launch_bounds__(256, 2) void conv_first_wgrad_seg_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                    float* __restrict__ partial, int N, int H, int W, int tiles_x,
-                                                                   int tiles_y, int ntiles) {
+                                                                   int tiles_y, int ntiles, FirstBnBwd bn) {
     constexpr int Cout = CQ * 4, SLOTS = 256 / CQ, NSEG = (ET_H * ET_W / 8) / SLOTS, NT = 9 * CIN;
     extern __shared__ __attribute__((aligned(16))) float fsm[];       // halo planes, then the reduction scratch [9][256][4]
     float* X = fsm;
@@ -401,6 +404,25 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_seg_kernel(const floa
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int k = 0; k < 4; ++k) wg[j][k] = 0.f;
+    float sc[4] = {0, 0, 0, 0}, sh[4] = {0, 0, 0, 0}, mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0}, k1[4] = {0, 0, 0, 0}, k2[4] = {0, 0, 0, 0};
+    float slope = 0.f;
+    if (FUSED) {
+        slope = bn.slope_dev ? bn.slope_dev[0] : bn.slope;
+        const float4 m4 = *reinterpret_cast<const float4*>(bn.mean + cq * 4), i4 = *reinterpret_cast<const float4*>(bn.invstd + cq * 4);
+        const float4 g4 = *reinterpret_cast<const float4*>(bn.gamma + cq * 4), b4 = *reinterpret_cast<const float4*>(bn.beta + cq * 4);
+        mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+        is[0] = i4.x; is[1] = i4.y; is[2] = i4.z; is[3] = i4.w;
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc[q] = is[q] * gg[q];
+            sh[q] = bb[q] - mu[q] * sc[q];
+            if (bn.training) {
+                k1[q] = (float)(bn.sums[cq * 4 + q] / bn.count);
+                k2[q] = (float)(bn.sums[Cout + cq * 4 + q] / bn.count);
+            }
+        }
+    }
     for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
         const int y0 = ty * ET_H, x0 = tx * ET_W;
@@ -413,11 +435,59 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_seg_kernel(const floa
             const int py = seg >> 2, c0 = (seg & 3) * 8;
             const int gy = y0 + py;
             float4 d[8];
+            if (!FUSED) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {          // eight 16-byte loads of dz in flight
-                const int gx = x0 + c0 + i;
-                d[i] = (gy < H && gx < W) ? *reinterpret_cast<const float4*>(dz + (((long)n * H + gy) * W + gx) * Cout + cq * 4)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = 0; i < 8; ++i) {          // eight 16-byte loads of dz in flight
+                    const int gx = x0 + c0 + i;
+                    d[i] = (gy < H && gx < W) ? *reinterpret_cast<const float4*>(dz + (((long)n * H + gy) * W + gx) * Cout + cq * 4)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+                // H, W even (pooled level): the segment's eight pixels are four window halves of pooled row gy / 2
+                const bool rowok = gy < H;
+                float4 gpv[4];
+                uchar4 piv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gx = x0 + c0 + 2 * j;
+                    const bool ok = rowok && gx < W && bn.g_pool;
+                    const long pp = (((long)n * (H >> 1) + (gy >> 1)) * (W >> 1) + (gx >> 1)) * Cout + cq * 4;
+                    gpv[j] = ok ? *reinterpret_cast<const float4*>(bn.g_pool + pp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    piv[j] = ok ? *reinterpret_cast<const uchar4*>(bn.idx + pp) : make_uchar4(255, 255, 255, 255);
+                }
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {    // four pixels at a time: z and the skip gradient in flight together
+                    float4 zv[4], gv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = hlf * 4 + u, gx = x0 + c0 + i;
+                        const bool ok = rowok && gx < W;
+                        const long o = (((long)n * H + gy) * W + gx) * Cout + cq * 4;
+                        zv[u] = ok ? *reinterpret_cast<const float4*>(bn.z + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        gv[u] = (ok && bn.g_full) ? *reinterpret_cast<const float4*>(bn.g_full + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = hlf * 4 + u, gx = x0 + c0 + i;
+                        const int k = ((gy & 1) << 1) | (i & 1);                  // position of this pixel in its 2x2 window
+                        const float4 gp4 = gpv[i >> 1];
+                        const uchar4 pi4 = piv[i >> 1];
+                        const float xz[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w}, gf[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+                        const float gpq[4] = {gp4.x, gp4.y, gp4.z, gp4.w};
+                        const int piq[4] = {pi4.x, pi4.y, pi4.z, pi4.w};
+                        float o4[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float y = fmaf(xz[q], sc[q], sh[q]);
+                            float g = gf[q];
+                            if (piq[q] == k) g += gpq[q];
+                            const float gm = g * (y > 0.f ? 1.f : slope);
+                            const float xh = (xz[q] - mu[q]) * is[q];
+                            o4[q] = bn.training ? sc[q] * (gm - k1[q] - xh * k2[q]) : sc[q] * gm;
+                        }
+                        d[i] = (rowok && gx < W) ? make_float4(o4[0], o4[1], o4[2], o4[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
             }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
@@ -473,18 +543,30 @@ int conv_first_wgrad_seg_blocks(int n, int h, int w, int cin, int cout) {
 
 template <int CIN>
 static int launch_first_seg(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
-                            int w, int cout, hipStream_t s) {
+                            int w, int cout, hipStream_t s, const FirstBnBwd* bn) {
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H), nt = n * tx * ty;
     if (!wgrad) {
         if (cout == 64) hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 16>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
         else if (cout == 32) hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 8>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
         else hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 32>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
+    } else if (bn) {
+        if constexpr (CIN > 3) {      // 144 accumulators + the fused operands do not fit 256 registers
+            set_error("conv_first_wgrad (fused BN backward): Cin <= 3 only");
+            return RD_ERR_ARG;
+        } else {
+        const int nb = nt < 1024 ? nt : 1024;
+        const size_t smem = (size_t)(CIN * FH_PLANE + 9 * 256 * 4) * sizeof(float);
+        if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 16, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
+        else if (cout == 32) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 8, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
+        else hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 32, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
+        }
     } else {
         const int nb = nt < 1024 ? nt : 1024;
         const size_t smem = (size_t)(CIN * FH_PLANE + 9 * 256 * 4) * sizeof(float);
-        if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 16>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt);
-        else if (cout == 32) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 8>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt);
-        else hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 32>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt);
+        const FirstBnBwd none = {};
+        if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 16, false>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, none);
+        else if (cout == 32) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 8, false>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, none);
+        else hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 32, false>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, none);
     }
     RD_LAUNCH_CHECK("conv_first_seg");
     return RD_OK;
@@ -492,12 +574,12 @@ static int launch_first_seg(bool wgrad, const float* x, const float* wt, float* 
 
 // forward (partial = per-tile BN statistics [tiles][2][Cout], nullable) / weight gradient (partial = [blocks][9*Cin][Cout])
 int conv_first_seg_launch(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
-                          int w, int cin, int cout, hipStream_t s) {
+                          int w, int cin, int cout, hipStream_t s, const FirstBnBwd* bn) {
     switch (cin) {
-        case 1: return launch_first_seg<1>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s);
-        case 2: return launch_first_seg<2>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s);
-        case 3: return launch_first_seg<3>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s);
-        default: return launch_first_seg<4>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s);
+        case 1: return launch_first_seg<1>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s, bn);
+        case 2: return launch_first_seg<2>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s, bn);
+        case 3: return launch_first_seg<3>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s, bn);
+        default: return launch_first_seg<4>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s, bn);
     }
 }
 

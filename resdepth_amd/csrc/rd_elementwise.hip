@@ -1536,6 +1536,37 @@ size_t rd_conv3x3_first_bwd_weight_ws_bytes(int n, int h, int w, int cin, int co
     return (size_t)grid * 9 * cin * cout * sizeof(float);
 }
 
+int rd_conv3x3_first_bwd_weight_bn_available(int n, int h, int w, int cin, int cout) {
+    return conv_first_wgrad_seg_blocks(n, h, w, cin, cout) != 0 && cin <= 3 && h % 2 == 0 && w % 2 == 0;
+}
+
+int rd_conv3x3_first_bwd_weight_bn(const float* x, const float* z, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, float slope, const float* slope_dev, const float* g_full, const float* g_pool,
+                                   const uint8_t* idx, const double* sums, double count, int training, float* dw, int n, int h,
+                                   int w, int cin, int cout, void* ws, size_t ws_bytes, rd_stream_t s) {
+    RD_REQUIRE(x && z && mean && invstd && gamma && beta && sums && dw, "rd_conv3x3_first_bwd_weight_bn: null pointer");
+    RD_REQUIRE(g_full || g_pool, "rd_conv3x3_first_bwd_weight_bn: no gradient source");
+    RD_REQUIRE(!g_pool || idx, "rd_conv3x3_first_bwd_weight_bn: g_pool needs idx");
+    RD_REQUIRE(count > 0, "rd_conv3x3_first_bwd_weight_bn: count must be positive");
+    RD_REQUIRE(rd_conv3x3_first_bwd_weight_bn_available(n, h, w, cin, cout),
+               "rd_conv3x3_first_bwd_weight_bn: shape not handled (Cin <= 3, Cout in {32, 64, 128}, H and W even; got %d -> %d, %dx%d)",
+               cin, cout, h, w);
+    const int grid = conv_first_wgrad_seg_blocks(n, h, w, cin, cout);
+    const size_t need = (size_t)grid * 9 * cin * cout * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        set_error("rd_conv3x3_first_bwd_weight_bn: workspace too small (%zu < %zu)", ws_bytes, need);
+        return RD_ERR_WS;
+    }
+    ProfScope ps((hipStream_t)s, "conv_first_wgrad", 2.0 * n * h * w * cout * 9.0 * cin,
+                 4.0 * n * h * w * ((double)cin + cout * (1.0 + (g_full ? 1.0 : 0.0) + (g_pool ? 0.3 : 0.0))));
+    const FirstBnBwd bn = {z, mean, invstd, gamma, beta, slope_dev, slope, g_full, g_pool, idx, sums, count, training};
+    if (int e = conv_first_seg_launch(true, x, nullptr, nullptr, nullptr, (float*)ws, n, h, w, cin, cout, (hipStream_t)s, &bn)) return e;
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 16)), dim3(256), 0, (hipStream_t)s, (const float*)ws, dw,
+                       grid, cin, cout);
+    RD_LAUNCH_CHECK("conv_first_wgrad");
+    return RD_OK;
+}
+
 int rd_conv3x3_first_bwd_weight(const float* x, const float* dz, float* dw, int n, int h, int w, int cin, int cout,
                                 void* ws, size_t ws_bytes, rd_stream_t s) {
     RD_REQUIRE(x && dz && dw, "rd_conv3x3_first_bwd_weight: null pointer");

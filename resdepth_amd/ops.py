@@ -188,6 +188,28 @@ def conv3x3_first_fwd_bn(x_nchw, w, running_mean, running_var, num_batches_track
     return z, mean, invstd
 
 
+def conv3x3_first_bwd_weight_bn_available(x_nchw, cout) -> bool:
+    n, cin, h, wd_ = x_nchw.shape
+    return bool(load().rd_conv3x3_first_bwd_weight_bn_available(n, h, wd_, cin, int(cout)))
+
+
+def conv3x3_first_bwd_weight_bn(x_nchw, z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx, sums, count, training=True,
+                                slope_dev=None, out=None, ws_slot=0):
+    """Weight gradient of the first convolution with dz = bn_act_bwd_apply(z, ..., g_full, g_pool, idx, sums, count, training)
+    evaluated on the fly (include/resdepth_hip.h: rd_conv3x3_first_bwd_weight_bn): no dz tensor."""
+    n, cin, h, wd_ = x_nchw.shape
+    cout = z.shape[3]
+    if out is None:
+        out = torch.empty(cout, cin, 3, 3, device=z.device, dtype=torch.float32)
+    nb = load().rd_conv3x3_first_bwd_weight_ws_bytes(n, h, wd_, cin, cout)
+    ws = workspace(nb, z.device, ws_slot)
+    check(load().rd_conv3x3_first_bwd_weight_bn(ptr(x_nchw), ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
+                                                float(slope), ptr(slope_dev), ptr(g_full), ptr(g_pool), ptr(idx), ptr(sums),
+                                                float(count), 1 if training else 0, ptr(out), n, h, wd_, cin, cout, ws.data_ptr(),
+                                                ws.numel(), stream_ptr()), "conv3x3_first_bwd_weight_bn")
+    return out
+
+
 def conv3x3_first_bwd_weight(x_nchw, dz, out=None, ws_slot=0):
     n, cin, h, wd_ = x_nchw.shape
     cout = dz.shape[3]

@@ -135,6 +135,7 @@ class UNet(nn.Module):
         self.two_stream_backward = True   # weight gradients on a second HIP stream, overlapping the dgrad/BN chain
         self.fold_eval_bn = True          # inference: eval-mode BN folded into the packed conv weights + epilogue activation
         self.fused_bn_bwd_stats = True    # BN-backward sums from the epilogues of the kernels producing the gradient operands
+        self.fused_first_wgrad = True     # level 0: BN / activation / pool backward evaluated inside the first conv's weight gradient
         # loss.backward(retain_graph=True) on the reference keeps the saved activations for a second backward.  A custom
         # autograd.Function cannot see that flag, and keeping 137 MB per tile alive until the loss tensor dies would surprise
         # callers that hold on to losses -- so the activations are released by the first backward unless this is set
@@ -753,7 +754,10 @@ class UNet(nn.Module):
             out, part = fn(*args, bn=bn)
             return out, (part if part[1] > 0 else None)
 
-        def bn_backward(rec, block, act_name, g_full, g_pool, idx, extra_bias=None, pre=()):
+        def bn_backward(rec, block, act_name, g_full, g_pool, idx, extra_bias=None, pre=(), fuse_into=None):
+            """-> dz of the block.  fuse_into (level 0 only): a weight-gradient op that evaluates dz itself from the arguments
+            of the apply pass (ops.conv3x3_first_bwd_weight_bn) -- the statistics are reduced here, dz is never written and
+            None is returned."""
             c = rec["z"].shape[-1]
             bn, cbias = self._norm_of(block)
             act = self._act_of(block, act_name)
@@ -800,11 +804,13 @@ class UNet(nn.Module):
                 self.grad_sync.allreduce_sums(sums)
                 gv(bn.weight).copy_(local[c:2 * c])
                 gv(bn.bias).copy_(local[:c])
-                dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
-                                          g_pool, idx, sums, rec["count"], training, slope_dev=sdev)
-            else:
-                dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
-                                          g_pool, idx, sums, rec["count"], training, slope_dev=sdev)
+            if fuse_into is not None:
+                done(bn.weight, bn.bias, prelu_w, extra_bias)
+                fuse_into(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full, g_pool, idx, sums, rec["count"],
+                          training, sdev)
+                return None
+            dz = ops.bn_act_bwd_apply(rec["z"], rec["mean"], rec["invstd"], bn.weight, bn.bias, slope, g_full,
+                                      g_pool, idx, sums, rec["count"], training, slope_dev=sdev)
             done(bn.weight, bn.bias, prelu_w, extra_bias)
             return dz
 
@@ -863,9 +869,28 @@ class UNet(nn.Module):
             # ConvTranspose2d whose output was added to this skip (decoder level d-1-i)
             j = d - 1 - i
             up = self._up_of(j)
+            fuse = None
+            if (i == 0 and self.fused_first_wgrad and self.do_BN and not want_dx and not self._first_generic()
+                    and ops.conv3x3_first_bwd_weight_bn_available(S["x"], blk[0].weight.shape[0])):
+                # level 0: dz has one reader, the first convolution's weight gradient -- which evaluates it itself.  On the MAIN
+                # stream, where the apply pass it replaces ran: behind the side stream's queue of strip kernels it lengthens the
+                # tail of the step (interleaved: -0.4 % there, +1.1 % here, against the two-kernel route)
+                def fuse(z_, mean_, invstd_, gamma_, beta_, slope_, gf_, gp_, idx_, sums_, count_, training_, sdev_, w_=blk[0].weight):
+                    ops.conv3x3_first_bwd_weight_bn(S["x"], z_, mean_, invstd_, gamma_, beta_, slope_, gf_, gp_, idx_, sums_, count_,
+                                                    training=training_, slope_dev=sdev_, out=gv(w_))
+                    if side is None:
+                        done(w_)
+                        return
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    with torch.cuda.stream(side):      # bucket launches are ordered on the side stream
+                        side.wait_event(ev)
+                        done(w_)
             dz = bn_backward(e, blk, self.act_fn_encoder, skipgrad[i], gp, e["idx"], extra_bias=up.bias,
-                             pre=(skipstat[i], gpstat))
+                             pre=(skipstat[i], gpstat), fuse_into=fuse)
             skipgrad[i] = skipstat[i] = None
+            if dz is None:
+                continue
             if i > 0:
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][i - 1]["p"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
                 gp, gpstat = with_stats(ops.conv3x3_bwd_data, dz, pk.get(("enc", i - 1))[1],

@@ -722,3 +722,34 @@ def test_8x8_patch_kernel_does_not_depend_on_the_batch_size():
     side.synchronize()
     assert torch.equal(small, big[:3])
     close(nchw(big[:8]), F.conv2d(x[:8].double(), wt.double(), None, 1, 1).float(), name="8x8 patch kernel vs fp64")
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,slope,training", [(2, 64, 64, 3, 64, 0.0, True), (3, 32, 96, 1, 32, 0.01, True),
+                                                           (1, 48, 34, 2, 128, 0.01, False), (2, 18, 30, 3, 64, 0.0, True)])
+def test_first_conv_weight_gradient_with_the_bn_backward_evaluated_on_the_fly(n, h, w, cin, cout, slope, training):
+    """rd_conv3x3_first_bwd_weight_bn == rd_conv3x3_first_bwd_weight(x, rd_bn_act_bwd_apply(...)): the first block's dz (BN +
+    activation + un-pool + skip add, lib/UNet.py:44-47,159-161 differentiated) has the weight gradient as its only reader and
+    is evaluated inside it; tiles that are not multiples of 16 x 32, PReLU slope on the device, eval-mode form."""
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(h * 7 + cout)
+    x = torch.randn(n, cin, h, w, generator=g).to(dev())
+    z = torch.randn(n, h, w, cout, generator=g).to(dev())
+    g_full = torch.randn(n, h, w, cout, generator=g).to(dev())
+    g_pool = torch.randn(n, h // 2, w // 2, cout, generator=g).to(dev())
+    idx = torch.randint(0, 4, (n, h // 2, w // 2, cout), generator=g, dtype=torch.uint8).to(dev())
+    mean, invstd = (torch.randn(cout, generator=g) * 0.2).to(dev()), (torch.rand(cout, generator=g) + 0.5).to(dev())
+    gamma, beta = torch.randn(cout, generator=g).to(dev()), (torch.randn(cout, generator=g) * 0.3).to(dev())
+    sums = ops.bn_act_bwd_reduce(z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx)
+    count = n * h * w
+    assert ops.conv3x3_first_bwd_weight_bn_available(x, cout)
+    for sdev in (None, torch.full((1,), 0.2, device=dev())):
+        for gf, gp, ix in ((g_full, g_pool, idx), (None, g_pool, idx)):
+            dz = ops.bn_act_bwd_apply(z, mean, invstd, gamma, beta, slope, gf, gp, ix, sums, count, training, slope_dev=sdev)
+            want = ops.conv3x3_first_bwd_weight(x, dz)
+            got = ops.conv3x3_first_bwd_weight_bn(x, z, mean, invstd, gamma, beta, slope, gf, gp, ix, sums, count, training,
+                                                  slope_dev=sdev)
+            scale = float(want.abs().max())
+            assert float((got - want).abs().max()) <= 2e-6 * scale, (float((got - want).abs().max()), scale)
+    with pytest.raises(RuntimeError, match="shape not handled"):
+        ops.conv3x3_first_bwd_weight_bn(torch.randn(1, 4, 16, 32, device=dev()), z[:1, :16, :32].contiguous(), mean, invstd, gamma,
+                                        beta, slope, None, g_pool[:1, :8, :16].contiguous(), idx[:1, :8, :16].contiguous(), sums, 512)

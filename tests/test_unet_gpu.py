@@ -874,3 +874,45 @@ def test_second_backward_with_retained_activations():
     loss.backward()
     for p, g in zip(model.parameters(), g1):
         assert torch.equal(p.grad, g + g), "second backward through the retained graph differs"
+
+
+@pytest.mark.parametrize("act,two_stream", [("relu", True), ("lrelu", False), ("prelu", True)])
+def test_first_weight_gradient_without_a_dz_tensor_equals_the_two_kernel_route(act, two_stream):
+    """model.fused_first_wgrad (default): level 0's BN / activation / pool backward runs inside the first convolution's
+    weight-gradient kernel (its dz has no other reader).  Every gradient of the model as with the separate apply pass +
+    weight gradient; d loss / d x asked for -> the separate route (dz is needed twice then)."""
+    from resdepth_amd import UNet, masked_l1_loss
+    torch.manual_seed(31)
+    model = UNet(n_input_channels=3, start_kernel=32, depth=3, act_fn_encoder=act, act_fn_decoder=act, act_fn_bottleneck=act).to(DEV)
+    model.two_stream_backward = two_stream
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(4, 3, 64, 96, generator=g).to(DEV)
+    t = torch.randn(4, 1, 64, 96, generator=g).to(DEV)
+    mask = (torch.rand(4, 1, 64, 96, generator=g) > 0.2).to(DEV)
+    mean, std = torch.zeros(4, device=DEV), torch.ones(4, device=DEV)
+    outs = []
+    for fused in (True, False):
+        model.load_state_dict(sd)
+        model.fused_first_wgrad = fused
+        model.train()
+        model.zero_grad(set_to_none=True)
+        masked_l1_loss(model(x), t, mask, mean, std).backward()
+        torch.cuda.synchronize()
+        outs.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    for k in outs[0]:
+        if k == "encoder.0.0.0.weight":
+            scale = float(outs[1][k].abs().max())
+            assert float((outs[0][k] - outs[1][k]).abs().max()) <= 2e-6 * scale, k
+        else:
+            assert torch.equal(outs[0][k], outs[1][k]), k
+    # input gradient requested: both settings take the separate route and agree bit for bit
+    grads = []
+    for fused in (True, False):
+        model.load_state_dict(sd)
+        model.fused_first_wgrad = fused
+        model.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_(True)
+        masked_l1_loss(model(xin), t, mask, mean, std).backward()
+        grads.append((xin.grad.clone(), model.encoder[0][0][0].weight.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
