@@ -141,6 +141,27 @@ int rd_conv3x3_last_fwd(const float* s_in, const float* w_oihw, const float* bia
                         float* out, int n, int h, int w, int c, rd_stream_t s);
 int rd_conv3x3_last_bwd_data(const float* dout, const float* w_oihw, float* ds, int n, int h, int w, int c,
                              rd_stream_t s);
+/* ---- the tail: last up-convolution composed with the last convolution (lib/UNet.py:21,218-227) ----
+ * The last decoder level is ConvTranspose2d(Cin -> C0, k2 s2) + skip add, followed directly by the 3x3 convolution C0 -> 1.
+ * Both are linear, so the backward of the up-convolution does not need the C0-channel gradient g = conv_last^T(dout) at full
+ * resolution (the largest gradient tensor of the network) as an operand:
+ *   M[ci][ab][tap] = sum_co Wt[ci][co][a][b] wl[co][tap]                    (Cin x 4 x 9)
+ *   V[ci][d]       = sum of M over the (ab, tap) with (a, b) - off(tap) = d   (Cin x 16, d in [-1, 2]^2, off = (tap/3-1, tap%3-1))
+ *   d loss / d input[p][ci] = sum_d dout[2p + d] V[ci][d]                     (rd_convt_last_bwd_data)
+ * rd_tail_compose writes M and V (tiny; once per step).  rd_convt_last_bwd_data(hc, wc = the COARSE grid) == rd_convt2x2_bwd_data
+ * applied to rd_conv3x3_last_bwd_data(dout) up to fp32 rounding; bn_z != NULL: the BN-backward statistics hook of
+ * rd_convt2x2_bwd_data_bnstats (mode 1), part / rows_out as there.  Cin in {32, 64, 128, 256} (rd_tail_available). */
+int rd_tail_available(int cin, int c0);
+int rd_tail_compose(const float* wt_iohw, const float* w_last, float* M, float* V, int cin, int c0, rd_stream_t s);
+int rd_convt_last_bwd_data(const float* dout, const float* V, float* dprev, int n, int hc, int wc, int cin, const float* bn_z,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                           const float* slope_dev, float* part, size_t part_floats, int* rows_out, rd_stream_t s);
+/* Weight gradient of the last up-convolution from dout: C16[ci][d] = sum_p x[p][ci] dout[2p + d] (16 correlations per input
+ * channel, one pass over the up-convolution's INPUT x [N, hc, wc, Cin]), then dWt[ci][co][a][b] = sum_tap w_last[co][tap]
+ * C16[ci][(a,b) - off(tap)]  == rd_convt2x2_bwd_weight(x, rd_conv3x3_last_bwd_data(dout)) up to fp32 rounding. */
+size_t rd_convt_last_bwd_weight_ws_bytes(int n, int hc, int wc, int cin);
+int rd_convt_last_bwd_weight(const float* x, const float* dout, const float* w_last, float* dwt_iohw, int n, int hc, int wc, int cin,
+                             int c0, void* ws, size_t ws_bytes, rd_stream_t s);
 size_t rd_conv3x3_last_bwd_weight_ws_bytes(int n, int h, int w, int c);
 /* dw[1][C][3][3], dbias[1] (nullable) */
 int rd_conv3x3_last_bwd_weight(const float* s_in, const float* dout, float* dw_oihw, float* dbias, int n, int h, int w,

@@ -82,6 +82,15 @@ int conv_last_dgrad_bn_launch(const float* dout, const float* wt, float* ds, int
                               const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                               const float* slope_dev, float* part, hipStream_t s, int* rows);
 int conv_last_wgrad_blocks(int n, int h, int w, int c);
+// tail of the network (last up-convolution composed with the last convolution, rd_edge_conv.hip)
+int tail_compose_launch(const float* wt, const float* wl, float* M, float* V, int cin, int c0, hipStream_t s);
+bool tail_shape_ok(int cin);
+int tail_corr_blocks(int n, int hc, int wc);
+int convt_last_wgrad_launch(const float* x, const float* dout, const float* wl, float* dwt, double* partial, double* c16, int n,
+                            int hc, int wc, int cin, int c0, hipStream_t s);
+int convt_last_dgrad_launch(const float* dout, const float* V, float* dprev, int n, int hc, int wc, int cin, const float* bn_z,
+                            const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                            const float* slope_dev, float* part, hipStream_t s, int* rows);
 // first convolution, segment kernels: tiles / blocks = 0 when the shape stays on the generic kernel
 int conv_first_seg_tiles(int n, int h, int w, int cin, int cout);
 int conv_first_wgrad_seg_blocks(int n, int h, int w, int cin, int cout);

@@ -18,7 +18,8 @@
 
 namespace rd {
 
-// TUNE_EDGE_CONV: -1 all kernels of this file, else a bit mask (1 last fwd, 2 last dgrad, 4 last wgrad, 8 first fwd, 16 first wgrad)
+// TUNE_EDGE_CONV: -1 all kernels of this file, else a bit mask (1 last fwd, 2 last dgrad, 4 last wgrad, 8 first fwd, 16 first wgrad,
+// 32 the composed tail kernels)
 static bool edge_on(int bit) {
     const int v = tune(TUNE_EDGE_CONV);
     return v < 0 || (v & bit);
@@ -207,6 +208,219 @@ __global__ __launch_bounds__(256) void conv_last_dgrad_tile_kernel(const float* 
             for (int sl = 0; sl < PPI; ++sl) sum += red[(sl * CQ + (c >> 2)) * 16 + sidx * 4 + (c & 3)];
             bn.part[((long)tl * 4 + sidx) * C + c] = sum;
         }
+    }
+}
+
+// ---- the tail of the network: last up-convolution (ConvTranspose2d k2 s2, Cin -> C0, lib/UNet.py:21,218-225) followed by the
+// last convolution (C0 -> 1, 3x3, lib/UNet.py:227).  Both are linear, so the gradient w.r.t. the up-convolution's INPUT is a
+// 16-tap stride-2 stencil on the 1-channel output gradient:
+//   g[q][co]     = sum_tap dout[q - off(tap)] wl[co][tap]                       (last conv, data gradient; off = (tap/3-1, tap%3-1))
+//   dprev[p][ci] = sum_{a,b,co} g[2p + (a,b)][co] Wt[ci][co][a][b]              (up-convolution, data gradient)
+//                = sum_{d in 4x4} dout[2p + d] V[ci][d],   d = (a,b) - off(tap) in [-1, 2]^2,
+//   M[ci][ab][tap] = sum_co Wt[ci][co][a][b] wl[co][tap],   V[ci][d] = sum over the (ab, tap) with (a,b) - off(tap) = d of M.
+// The C0-channel gradient g at full resolution (537 MB in cfg-S) is then not an operand of this layer at all.
+// tail_compose_kernel: one block per ci; M [Cin][4][9] and V [Cin][16] (fp64 accumulation, fp32 results).
+__global__ __launch_bounds__(64) void tail_compose_kernel(const float* __restrict__ wt, const float* __restrict__ wl,
+                                                          float* __restrict__ M, float* __restrict__ V, int Cin, int C0) {
+    __shared__ float m[36];
+    const int ci = blockIdx.x, t = threadIdx.x;
+    if (t < 36) {
+        const int ab = t / 9, tap = t - ab * 9;
+        double acc = 0.0;
+        for (int co = 0; co < C0; ++co) acc += (double)wt[((long)ci * C0 + co) * 4 + ab] * (double)wl[co * 9 + tap];
+        m[t] = (float)acc;
+        M[(long)ci * 36 + t] = (float)acc;
+    }
+    __syncthreads();
+    if (t < 16) {
+        const int dy = t / 4 - 1, dx = t % 4 - 1;
+        double acc = 0.0;
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                const int oy = a - dy, ox = b - dx;          // off(tap) = (a, b) - d
+                if (oy < -1 || oy > 1 || ox < -1 || ox > 1) continue;
+                acc += (double)m[(a * 2 + b) * 9 + (oy + 1) * 3 + (ox + 1)];
+            }
+        V[(long)ci * 16 + t] = (float)acc;
+    }
+}
+
+constexpr int TL_W = 2 * ET_W + 3, TL_H = 2 * ET_H + 3;     // dout region of a 16 x 32 coarse tile: rows 2 y0 - 1 .. 2 y0 + 2 ET_H + 1
+
+// dprev [N][Hc][Wc][C] = stencil above; BN: + the BN-backward statistics of the block whose activation gradient this is
+// (its z at the coarse resolution), per-tile partial rows like conv_last_dgrad_tile_kernel
+template <bool BN>
+__global__ __launch_bounds__(256) void convt_last_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ V,
+                                                               float* __restrict__ dprev, int N, int Hc, int Wc, int C, int CQ,
+                                                               int tiles_x, int tiles_y, BnHook bn) {
+    __shared__ float D[TL_H * TL_W];
+    __shared__ float red[BN ? 256 * 16 : 1];
+    const int t = threadIdx.x, q = t % CQ, slot = t / CQ, PPI = 256 / CQ;
+    const int tl = blockIdx.x;
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+    const int y0 = ty * ET_H, x0 = tx * ET_W, H = 2 * Hc, W = 2 * Wc;
+    float v[16][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int d = 0; d < 16; ++d) v[d][k] = V[(long)(q * 4 + k) * 16 + d];
+    float sc[4], sh[4], mu[4], is[4], bacc[16], slope = 0.f;
+    if (BN) {
+        slope = bn.slope_dev ? bn.slope_dev[0] : bn.slope;
+        const float4 m4 = *reinterpret_cast<const float4*>(bn.mean + q * 4), i4 = *reinterpret_cast<const float4*>(bn.invstd + q * 4);
+        const float4 g4 = *reinterpret_cast<const float4*>(bn.gamma + q * 4), b4 = *reinterpret_cast<const float4*>(bn.beta + q * 4);
+        const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w};
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mu[k] = mm[k];
+            is[k] = ii[k];
+            sc[k] = ii[k] * gg[k];
+            sh[k] = bb[k] - mm[k] * sc[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bacc[k] = 0.f;
+    }
+    for (int e = t; e < TL_H * TL_W; e += 256) {
+        const int hy = e / TL_W, hx = e - hy * TL_W;
+        const int gy = 2 * y0 - 1 + hy, gx = 2 * x0 - 1 + hx;
+        D[e] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? dout[((long)n * H + gy) * W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int e = slot; e < ET_H * ET_W; e += PPI) {
+        const int py = e / ET_W, px = e - py * ET_W;
+        const int gy = y0 + py, gx = x0 + px;
+        if (gy >= Hc || gx >= Wc) continue;
+        const long o = (((long)n * Hc + gy) * Wc + gx) * C + q * 4;
+        float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (BN) z4 = *reinterpret_cast<const float4*>(bn.z + o);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const float dv = D[(2 * py + d / 4) * TL_W + 2 * px + d % 4];       // dout[2p + (d/4 - 1, d%4 - 1)]
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(dv, v[d][k], acc[k]);
+        }
+        *reinterpret_cast<float4*>(dprev + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (BN) {
+            const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float y = fmaf(zz[k], sc[k], sh[k]);
+                const float gm = acc[k] * (y > 0.f ? 1.f : slope);
+                const float xh = (zz[k] - mu[k]) * is[k];
+                bacc[k] += gm;
+                bacc[4 + k] = fmaf(gm, xh, bacc[4 + k]);
+                bacc[8 + k] += acc[k];
+                if (!(y > 0.f)) bacc[12 + k] = fmaf(acc[k], y, bacc[12 + k]);
+            }
+        }
+    }
+    if (BN) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) red[t * 16 + k] = bacc[k];
+        __syncthreads();
+        for (int o = t; o < 4 * C; o += 256) {
+            const int sidx = o / C, c = o - sidx * C;
+            float sum = 0.f;
+            for (int sl = 0; sl < PPI; ++sl) sum += red[(sl * CQ + (c >> 2)) * 16 + sidx * 4 + (c & 3)];
+            bn.part[((long)tl * 4 + sidx) * C + c] = sum;
+        }
+    }
+}
+
+// Weight gradient of the last up-convolution, same composition:
+//   dWt[ci][co][a][b] = sum_p x[p][ci] g[2p + (a,b)][co] = sum_tap wl[co][tap] C16[ci][(a,b) - off(tap)],
+//   C16[ci][d] = sum_p x[p][ci] dout[2p + d]                        (16 correlations per input channel)
+// tail_corr_kernel: persistent blocks over 16 x 32 coarse tiles, per block one partial row [16][C] of doubles.
+__global__ __launch_bounds__(256) void tail_corr_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                        double* __restrict__ partial, int N, int Hc, int Wc, int C, int CQ,
+                                                        int tiles_x, int tiles_y, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float tsm[];     // D[TL_H * TL_W] (padded to 2368), then the reduction scratch
+    float* D = tsm;
+    float* red = tsm + 2368;                       // [PPI][16][C] floats = 16384
+    const int t = threadIdx.x, q = t % CQ, slot = t / CQ, PPI = 256 / CQ;
+    const int H = 2 * Hc, W = 2 * Wc;
+    float acc[16][4];
+#pragma unroll
+    for (int d = 0; d < 16; ++d)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[d][k] = 0.f;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+        const int y0 = ty * ET_H, x0 = tx * ET_W;
+        __syncthreads();
+        for (int e = t; e < TL_H * TL_W; e += 256) {
+            const int hy = e / TL_W, hx = e - hy * TL_W;
+            const int gy = 2 * y0 - 1 + hy, gx = 2 * x0 - 1 + hx;
+            D[e] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? dout[((long)n * H + gy) * W + gx] : 0.f;
+        }
+        __syncthreads();
+        constexpr int UN = 4;
+        for (int e0 = 0; e0 < ET_H * ET_W; e0 += PPI * UN) {
+            float4 x4[UN];
+            int py[UN], px[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int e = e0 + u * PPI + slot;
+                py[u] = e / ET_W;
+                px[u] = e - py[u] * ET_W;
+                const bool ok = y0 + py[u] < Hc && x0 + px[u] < Wc;
+                x4[u] = ok ? *reinterpret_cast<const float4*>(x + (((long)n * Hc + y0 + py[u]) * Wc + x0 + px[u]) * C + q * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const float xv[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const float dv = D[(2 * py[u] + d / 4) * TL_W + 2 * px[u] + d % 4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[d][k] = fmaf(xv[k], dv, acc[d][k]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 16; ++d)
+        *reinterpret_cast<float4*>(red + ((slot * 16 + d) * C) + q * 4) = make_float4(acc[d][0], acc[d][1], acc[d][2], acc[d][3]);
+    __syncthreads();
+    double* out = partial + (long)blockIdx.x * (16 * C);
+    for (int e = t; e < 16 * C; e += 256) {
+        double sum = 0.0;
+        for (int sl = 0; sl < PPI; ++sl) sum += (double)red[sl * 16 * C + e];
+        out[e] = sum;
+    }
+}
+
+// one block per input channel: C16[ci][d] = sum_b partial[b][d * C + ci] (fixed order), then
+// dWt[ci][co][ab] = sum_tap wl[co][tap] C16[ci][(a,b) - off(tap)]; c16 (nullable) receives the correlations
+__global__ __launch_bounds__(256) void tail_wgrad_finish_kernel(const double* __restrict__ partial, int nb, const float* __restrict__ wl,
+                                                                float* __restrict__ dwt, double* __restrict__ c16, int C, int C0) {
+    __shared__ double red[256];
+    __shared__ double cs[16];
+    const int ci = blockIdx.x, t = threadIdx.x, d = t & 15, slice = t >> 4;
+    double acc = 0.0;
+    for (int b = slice; b < nb; b += 16) acc += partial[(long)b * 16 * C + d * C + ci];
+    red[t] = acc;
+    __syncthreads();
+    if (t < 16) {
+        double sum = 0.0;
+        for (int sl = 0; sl < 16; ++sl) sum += red[sl * 16 + t];
+        cs[t] = sum;
+        if (c16) c16[(long)ci * 16 + t] = sum;
+    }
+    __syncthreads();
+    for (int e = t; e < C0 * 4; e += 256) {
+        const int co = e >> 2, ab = e & 3, a = ab >> 1, b = ab & 1;
+        double sum = 0.0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = a - (tap / 3 - 1), dx = b - (tap % 3 - 1);      // d = (a, b) - off(tap), each in [-1, 2]
+            sum += (double)wl[co * 9 + tap] * cs[(dy + 1) * 4 + dx + 1];
+        }
+        dwt[((long)ci * C0 + co) * 4 + ab] = (float)sum;
     }
 }
 
@@ -623,6 +837,50 @@ int conv_last_dgrad_bn_launch(const float* dout, const float* wt, float* ds, int
                        ty, bn);
     RD_LAUNCH_CHECK("conv_last_dgrad");
     *rows = n * tx * ty;
+    return RD_OK;
+}
+
+int tail_compose_launch(const float* wt, const float* wl, float* M, float* V, int cin, int c0, hipStream_t s) {
+    hipLaunchKernelGGL(tail_compose_kernel, dim3(cin), dim3(64), 0, s, wt, wl, M, V, cin, c0);
+    RD_LAUNCH_CHECK("tail_compose");
+    return RD_OK;
+}
+
+// 256 / (Cin / 4) pixel slots; knob edge_conv bit 32 switches the composed tail kernels off
+bool tail_shape_ok(int cin) { return (cin == 32 || cin == 64 || cin == 128 || cin == 256) && edge_on(32); }
+
+// coarse grid hc x wc; *rows = statistics rows written (0 without a hook)
+int convt_last_dgrad_launch(const float* dout, const float* V, float* dprev, int n, int hc, int wc, int cin, const float* bn_z,
+                            const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                            const float* slope_dev, float* part, hipStream_t s, int* rows) {
+    const int tx = cdiv(wc, ET_W), ty = cdiv(hc, ET_H);
+    *rows = 0;
+    if (bn_z) {
+        const BnHook bn = {bn_z, mean, invstd, gamma, beta, slope_dev, slope, part};
+        hipLaunchKernelGGL(convt_last_dgrad_kernel<true>, dim3(n * tx * ty), dim3(256), 0, s, dout, V, dprev, n, hc, wc, cin, cin / 4,
+                           tx, ty, bn);
+        *rows = n * tx * ty;
+    } else {
+        const BnHook none = {};
+        hipLaunchKernelGGL(convt_last_dgrad_kernel<false>, dim3(n * tx * ty), dim3(256), 0, s, dout, V, dprev, n, hc, wc, cin, cin / 4,
+                           tx, ty, none);
+    }
+    RD_LAUNCH_CHECK("convt_last_dgrad");
+    return RD_OK;
+}
+
+int tail_corr_blocks(int n, int hc, int wc) {
+    const long nt = (long)n * cdiv(wc, ET_W) * cdiv(hc, ET_H);
+    return (int)(nt < 512 ? nt : 512);
+}
+
+int convt_last_wgrad_launch(const float* x, const float* dout, const float* wl, float* dwt, double* partial, double* c16, int n,
+                            int hc, int wc, int cin, int c0, hipStream_t s) {
+    const int tx = cdiv(wc, ET_W), ty = cdiv(hc, ET_H), nb = tail_corr_blocks(n, hc, wc);
+    const size_t smem = (2368 + 16384) * sizeof(float);
+    hipLaunchKernelGGL(tail_corr_kernel, dim3(nb), dim3(256), smem, s, x, dout, partial, n, hc, wc, cin, cin / 4, tx, ty, n * tx * ty);
+    hipLaunchKernelGGL(tail_wgrad_finish_kernel, dim3(cin), dim3(256), 0, s, (const double*)partial, nb, wl, dwt, c16, cin, c0);
+    RD_LAUNCH_CHECK("convt_last_wgrad");
     return RD_OK;
 }
 

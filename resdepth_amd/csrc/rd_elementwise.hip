@@ -1655,6 +1655,51 @@ int rd_conv3x3_last_bwd_data_bnstats(const float* dout, const float* wt, float* 
     return rd_conv3x3_last_bwd_data(dout, wt, ds, n, h, w, c, s);
 }
 
+int rd_tail_available(int cin, int c0) { return tail_shape_ok(cin) && c0 > 0 && c0 <= 1024 ? 1 : 0; }
+
+int rd_tail_compose(const float* wt_iohw, const float* wl, float* M, float* V, int cin, int c0, rd_stream_t s) {
+    RD_REQUIRE(wt_iohw && wl && M && V && cin > 0 && c0 > 0, "rd_tail_compose: bad arguments");
+    return tail_compose_launch(wt_iohw, wl, M, V, cin, c0, (hipStream_t)s);
+}
+
+int rd_convt_last_bwd_data(const float* dout, const float* V, float* dprev, int n, int hc, int wc, int cin, const float* bn_z,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                           const float* slope_dev, float* part, size_t part_floats, int* rows_out, rd_stream_t s) {
+    RD_REQUIRE(dout && V && dprev && n > 0 && hc > 0 && wc > 0, "rd_convt_last_bwd_data: bad arguments");
+    RD_REQUIRE(tail_shape_ok(cin), "rd_convt_last_bwd_data: Cin must be 32, 64, 128 or 256 (got %d)", cin);
+    RD_REQUIRE(!bn_z || (mean && invstd && gamma && beta && part && rows_out &&
+                         part_floats >= rd_bn_bwd_part_floats((long long)n * hc * wc, cin)),
+               "rd_convt_last_bwd_data: statistics hook arguments");
+    int rows = 0;
+    ProfScope ps((hipStream_t)s, "convt2x2_dgrad|convt_last_dgrad", 2.0 * n * hc * wc * 16.0 * cin,
+                 4.0 * n * hc * wc * (double)(cin * (bn_z ? 2 : 1) + 4));
+    if (int e = convt_last_dgrad_launch(dout, V, dprev, n, hc, wc, cin, bn_z, mean, invstd, gamma, beta, slope, slope_dev, part,
+                                        (hipStream_t)s, &rows))
+        return e;
+    if (rows_out) *rows_out = rows;
+    return RD_OK;
+}
+
+size_t rd_convt_last_bwd_weight_ws_bytes(int n, int hc, int wc, int cin) {
+    return ((size_t)tail_corr_blocks(n, hc, wc) + 1) * 16 * (size_t)cin * sizeof(double);      // block partials + C16
+}
+
+int rd_convt_last_bwd_weight(const float* x, const float* dout, const float* w_last, float* dwt_iohw, int n, int hc, int wc, int cin,
+                             int c0, void* ws, size_t ws_bytes, rd_stream_t s) {
+    RD_REQUIRE(x && dout && w_last && dwt_iohw && n > 0 && hc > 0 && wc > 0 && c0 > 0, "rd_convt_last_bwd_weight: bad arguments");
+    RD_REQUIRE(tail_shape_ok(cin), "rd_convt_last_bwd_weight: Cin must be 32, 64, 128 or 256 (got %d)", cin);
+    const size_t need = rd_convt_last_bwd_weight_ws_bytes(n, hc, wc, cin);
+    if (!ws || ws_bytes < need) {
+        set_error("rd_convt_last_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
+        return RD_ERR_WS;
+    }
+    const int nb = tail_corr_blocks(n, hc, wc);
+    double* partial = (double*)ws;
+    double* c16 = partial + (size_t)nb * 16 * cin;
+    ProfScope ps((hipStream_t)s, "convt2x2_wgrad|convt_last_wgrad", 2.0 * n * hc * wc * 16.0 * cin, 4.0 * n * hc * wc * (double)(cin + 4));
+    return convt_last_wgrad_launch(x, dout, w_last, dwt_iohw, partial, c16, n, hc, wc, cin, c0, (hipStream_t)s);
+}
+
 size_t rd_conv3x3_last_bwd_weight_ws_bytes(int n, int h, int w, int c) {
     if (const int nb = conv_last_wgrad_blocks(n, h, w, c)) return (size_t)nb * (9 * c + 1) * sizeof(double);
     RowPlan pl;

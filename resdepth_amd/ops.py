@@ -245,6 +245,51 @@ def conv3x3_last_bwd_data(dout, w, c, bn=None):
     return ds, (part, rows.value)
 
 
+# ---- the tail: last up-convolution composed with the last convolution (include/resdepth_hip.h) ------------------------------
+def tail_available(cin, c0) -> bool:
+    return bool(load().rd_tail_available(int(cin), int(c0)))
+
+
+def tail_compose(wt_iohw, w_last):
+    """-> (M [Cin, 4, 9], V [Cin, 16]): the last up-convolution's weight [Cin, C0, 2, 2] contracted with the last
+    convolution's [1, C0, 3, 3] over C0."""
+    cin, c0 = wt_iohw.shape[0], wt_iohw.shape[1]
+    m = torch.empty(cin, 4, 9, device=wt_iohw.device, dtype=torch.float32)
+    v = torch.empty(cin, 16, device=wt_iohw.device, dtype=torch.float32)
+    check(load().rd_tail_compose(ptr(wt_iohw.detach()), ptr(w_last.detach()), ptr(m), ptr(v), cin, c0, stream_ptr()), "tail_compose")
+    return m, v
+
+
+def convt_last_bwd_data(dout, v, bn=None):
+    """Gradient w.r.t. the INPUT of the last up-convolution straight from the network's output gradient dout [N, 1, H, W]
+    (16-tap stride-2 stencil V): == convt2x2_bwd_data(conv3x3_last_bwd_data(dout)) without the full-resolution tensor.
+    bn: BnHook of the block that produced that input -> (dprev, (partial rows, count))."""
+    n, _, h, w = dout.shape
+    cin = v.shape[0]
+    dprev = torch.empty(n, h // 2, w // 2, cin, device=dout.device, dtype=torch.float32)
+    if bn is None:
+        check(load().rd_convt_last_bwd_data(ptr(dout), ptr(v), ptr(dprev), n, h // 2, w // 2, cin, None, None, None, None, None, 0.0,
+                                            None, None, 0, None, stream_ptr()), "convt_last_bwd_data")
+        return dprev
+    part, rows = _bn_part(n * (h // 2) * (w // 2), cin, dout.device), ctypes.c_int(0)
+    check(load().rd_convt_last_bwd_data(ptr(dout), ptr(v), ptr(dprev), n, h // 2, w // 2, cin, *bn.args(), ptr(part), part.numel(),
+                                        ctypes.byref(rows), stream_ptr()), "convt_last_bwd_data")
+    return dprev, (part, rows.value)
+
+
+def convt_last_bwd_weight(x, dout, w_last, out=None, ws_slot=0):
+    """Weight gradient [Cin, C0, 2, 2] of the last up-convolution from its input x [N, h, w, Cin] and the network's output
+    gradient dout [N, 1, 2h, 2w]: == convt2x2_bwd_weight(x, conv3x3_last_bwd_data(dout))."""
+    n, hc, wc, cin = x.shape
+    c0 = w_last.shape[1]
+    if out is None:
+        out = torch.empty(cin, c0, 2, 2, device=x.device, dtype=torch.float32)
+    ws = workspace(load().rd_convt_last_bwd_weight_ws_bytes(n, hc, wc, cin), x.device, ws_slot)
+    check(load().rd_convt_last_bwd_weight(ptr(x), ptr(dout), ptr(w_last.detach()), ptr(out), n, hc, wc, cin, c0, ws.data_ptr(),
+                                          ws.numel(), stream_ptr()), "convt_last_bwd_weight")
+    return out
+
+
 def conv3x3_last_bwd_weight(s, dout, dw=None, dbias=None, want_bias=True, ws_slot=0):
     n, h, wd_, c = s.shape
     if dw is None:

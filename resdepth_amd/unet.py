@@ -18,6 +18,7 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import os
 import torch
 import torch.nn as nn
 
@@ -135,6 +136,7 @@ class UNet(nn.Module):
         self.two_stream_backward = True   # weight gradients on a second HIP stream, overlapping the dgrad/BN chain
         self.fold_eval_bn = True          # inference: eval-mode BN folded into the packed conv weights + epilogue activation
         self.fused_bn_bwd_stats = True    # BN-backward sums from the epilogues of the kernels producing the gradient operands
+        self.composed_tail = os.environ.get("RD_EXP_NOTAIL") != "1"        # last up-convolution's gradients straight from dout (ops.tail_*)
         self.fused_first_wgrad = True     # level 0: BN / activation / pool backward evaluated inside the first conv's weight gradient
         # loss.backward(retain_graph=True) on the reference keeps the saved activations for a second backward.  A custom
         # autograd.Function cannot see that flag, and keeping 137 MB per tile alive until the loss tensor dies would surprise
@@ -845,9 +847,16 @@ class UNet(nn.Module):
                 wgrad(ops.conv1x1_bwd_weight, (dt,), src["a"], dt, gv(up.weight), ready=(up.weight,))
                 dprev, dstat = ops.conv1x1_bwd_data(dt, pk.get(("dec_t", i))[1]), None
             else:
-                wgrad(ops.convt2x2_bwd_weight, (g,), src["a"], g, gv(up.weight), ready=(up.weight,))
                 sblk, sact = (self.decoder[i - 1][1], self.act_fn_decoder) if i > 0 else (self.bottleneck, self.act_fn_bottleneck)
-                dprev, dstat = with_stats(ops.convt2x2_bwd_data, g, pk.get(("dec_t", i))[1], bn=hook(src, sblk, sact))
+                if i == d - 1 and self.composed_tail and ops.tail_available(up.weight.shape[0], up.weight.shape[1]):
+                    # the last up-convolution feeds the last convolution directly (lib/UNet.py:218-227): its two gradients are
+                    # stencils / correlations on the 1-channel dout, the C0-channel gradient g is not an operand (ops.tail_*)
+                    _, tail_v = ops.tail_compose(up.weight, ll.weight)
+                    wgrad(ops.convt_last_bwd_weight, (dout, tail_v), src["a"], dout, ll.weight, gv(up.weight), ready=(up.weight,))
+                    dprev, dstat = with_stats(ops.convt_last_bwd_data, dout, tail_v, bn=hook(src, sblk, sact))
+                else:
+                    wgrad(ops.convt2x2_bwd_weight, (g,), src["a"], g, gv(up.weight), ready=(up.weight,))
+                    dprev, dstat = with_stats(ops.convt2x2_bwd_data, g, pk.get(("dec_t", i))[1], bn=hook(src, sblk, sact))
             skipgrad[d - 1 - i], skipstat[d - 1 - i] = g, st       # gradient wrt the encoder skip a_{d-1-i} (SkipConnection is an ADD)
             if i > 0:
                 blk = self.decoder[i - 1][1]

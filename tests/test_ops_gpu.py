@@ -753,3 +753,53 @@ def test_first_conv_weight_gradient_with_the_bn_backward_evaluated_on_the_fly(n,
     with pytest.raises(RuntimeError, match="shape not handled"):
         ops.conv3x3_first_bwd_weight_bn(torch.randn(1, 4, 16, 32, device=dev()), z[:1, :16, :32].contiguous(), mean, invstd, gamma,
                                         beta, slope, None, g_pool[:1, :8, :16].contiguous(), idx[:1, :8, :16].contiguous(), sums, 512)
+
+
+@pytest.mark.parametrize("n,h,w,cin,c0", [(2, 64, 64, 128, 64), (3, 32, 96, 64, 32), (1, 36, 20, 32, 16), (2, 16, 16, 256, 64)])
+def test_tail_data_gradient_of_the_last_up_convolution_from_the_output_gradient(n, h, w, cin, c0):
+    """rd_tail_compose + rd_convt_last_bwd_data: the last up-convolution's input gradient as a 16-tap stride-2 stencil on dout
+    == ConvTranspose2d's data gradient of the last convolution's data gradient (lib/UNet.py:21,218-227 differentiated), and
+    the same BN-backward statistics as the hook of the two-kernel route; coarse grids that are not multiples of 16 x 32."""
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(h + cin)
+    dout = torch.randn(n, 1, h, w, generator=g)
+    wt = torch.randn(cin, c0, 2, 2, generator=g) / (cin ** 0.5)
+    wl = torch.randn(1, c0, 3, 3, generator=g) / 3
+    # torch: g = conv_last^T(dout) [N, C0, H, W]; dprev = conv2d(g, wt as [Cin, C0, 2, 2], stride 2) = the convT's data gradient
+    g4 = F.conv_transpose2d(dout.double(), wl.double(), padding=1)
+    want = F.conv2d(g4, wt.double(), stride=2)
+    m, v = ops.tail_compose(wt.to(dev()), wl.to(dev()))
+    m_ref = torch.einsum("ioab,ot->iabt", wt.double(), wl.double()[0].reshape(c0, 9)).reshape(cin, 4, 9)
+    close(m.cpu(), m_ref.float(), name="M")
+    assert ops.tail_available(cin, c0)
+    got = ops.convt_last_bwd_data(dout.to(dev()), v)
+    close(nchw(got), want.float(), name="composed data gradient")
+    # the statistics hook against the two-kernel route's
+    zb = torch.randn(n, h // 2, w // 2, cin, generator=g).to(dev())
+    mean, invstd = (torch.randn(cin, generator=g) * 0.1).to(dev()), (torch.rand(cin, generator=g) + 0.5).to(dev())
+    gamma, beta = torch.randn(cin, generator=g).to(dev()), (torch.randn(cin, generator=g) * 0.3).to(dev())
+    hook = ops.BnHook(zb, mean, invstd, gamma, beta, 0.01, None, 1)
+    got2, part = ops.convt_last_bwd_data(dout.to(dev()), v, bn=hook)
+    assert torch.equal(got2, got) and part[1] > 0
+    sums = ops.bn_bwd_stats_finalize([part], cin)
+    want_sums = ops.bn_act_bwd_reduce(zb, mean, invstd, gamma, beta, 0.01, got, None, None)
+    scale = want_sums.abs().view(4, cin).amax(1, keepdim=True).expand(4, cin).reshape(-1) + 1e-30
+    assert float(((sums - want_sums).abs() / scale).max()) <= 1e-5
+
+
+@pytest.mark.parametrize("n,h,w,cin,c0", [(2, 64, 64, 128, 64), (3, 32, 96, 64, 32), (1, 36, 20, 32, 16), (2, 16, 16, 256, 64)])
+def test_tail_weight_gradient_of_the_last_up_convolution_from_the_output_gradient(n, h, w, cin, c0):
+    """rd_convt_last_bwd_weight: 16 correlations of the up-convolution's input with dout per input channel, contracted with the
+    last convolution's weight == ConvTranspose2d's weight gradient against the last convolution's data gradient."""
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(h + cin + 1)
+    dout = torch.randn(n, 1, h, w, generator=g)
+    x = torch.randn(n, cin, h // 2, w // 2, generator=g)
+    wl = torch.randn(1, c0, 3, 3, generator=g) / 3
+    g4 = F.conv_transpose2d(dout.double(), wl.double(), padding=1)                  # [N, C0, H, W]
+    wt = torch.zeros(cin, c0, 2, 2, dtype=torch.float64, requires_grad=True)
+    (F.conv_transpose2d(x.double(), wt, stride=2) * g4).sum().backward()
+    got = ops.convt_last_bwd_weight(nhwc(x), dout.to(dev()), wl.to(dev()))
+    close(got.cpu(), wt.grad.float(), name="composed weight gradient")
+    want2 = ops.convt2x2_bwd_weight(nhwc(x), ops.conv3x3_last_bwd_data(dout.to(dev()), wl.to(dev()), c0))
+    close(got.cpu(), want2.cpu(), name="vs the two-kernel route")
