@@ -126,14 +126,16 @@ int rd_conv3x3_first_bwd_weight(const float* x_nchw, const float* dz, float* dw_
 /* The same weight gradient with dz = rd_bn_act_bwd_apply(z, ..., g_full, g_pool, idx, sums, count, training) of the first
  * block (lib/UNet.py:44-47,159-161 differentiated) evaluated on the fly: this kernel is dz's only reader, so the largest
  * gradient tensor of the network (64 channels at full resolution) is never written.  Arguments as rd_bn_act_bwd_apply (pooled
- * form) + rd_conv3x3_first_bwd_weight; same workspace size.  Cin <= 3, Cout in {32, 64, 128}, H and W even
+ * form) + rd_conv3x3_first_bwd_weight; same workspace size.  dout / w_last (with g_full = NULL): the full-resolution gradient
+ * operand is rd_conv3x3_last_bwd_data(dout, w_last) -- the skip gradient of level 0, lib/UNet.py:218-227 -- evaluated per
+ * element from the 1-channel dout instead of being read.  Cin <= 3, Cout in {32, 64, 128}, H and W even
  * (rd_conv3x3_first_bwd_weight_bn_available). */
 int rd_conv3x3_first_bwd_weight_bn_available(int n, int h, int w, int cin, int cout);
 int rd_conv3x3_first_bwd_weight_bn(const float* x_nchw, const float* z, const float* mean, const float* invstd, const float* gamma,
                                    const float* beta, float slope, const float* slope_dev, const float* g_full,
                                    const float* g_pool, const uint8_t* idx, const double* sums, double count, int training,
-                                   float* dw_oihw, int n, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,
-                                   rd_stream_t s);
+                                   const float* dout, const float* w_last, float* dw_oihw, int n, int h, int w, int cin, int cout,
+                                   void* ws, size_t ws_bytes, rd_stream_t s);
 
 /* ---- last conv C -> 1 (+bias) with the outer residual add fused (lib/UNet.py:184,227-244)
  * out[N,1,H,W] = conv(s[N,H,W,C], w[1][C][3][3]) + bias[0] + x0, x0 = x_nchw[:,0] (both nullable) */

@@ -109,6 +109,11 @@ struct FirstBnBwd {
     const double* sums;
     double count;
     int training;
+    // g_full == NULL and these set: the full-resolution gradient operand is the last convolution's data gradient of the
+    // network's output gradient (lib/UNet.py:227: skip ADD + conv C0 -> 1), evaluated from dout [N][H][W] and w_last [C0][9]
+    // per element -- g[q][c] = sum_tap dout[q - off(tap)] w_last[c][tap] -- instead of being read
+    const float* dout;
+    const float* w_last;
 };
 int conv_first_seg_launch(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
                           int w, int cin, int cout, hipStream_t s, const FirstBnBwd* bn = nullptr);

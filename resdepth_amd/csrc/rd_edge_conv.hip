@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_last_dgrad_tile_kernel(const float* 
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] = fmaf(d, wr[tap][k], acc[k]);
         }
-        *reinterpret_cast<float4*>(ds + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (ds) *reinterpret_cast<float4*>(ds + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);   // NULL: statistics only
         if (BN) {
             const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
 #pragma unroll
@@ -612,7 +612,12 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_seg_kernel(const floa
     extern __shared__ __attribute__((aligned(16))) float fsm[];       // halo planes, then the reduction scratch [9][256][4]
     float* X = fsm;
     float* red = fsm + CIN * FH_PLANE;
+    float* Dl = red + 9 * 256 * 4;            // FUSED with bn.dout: dout tile + halo [EH_NP] (padded to 640), then w_last [9][Cout]
+    float* Wl = Dl + 640;
     const int t = threadIdx.x, cq = t % CQ, slot = t / CQ;
+    const bool lazy_g = FUSED && bn.dout != nullptr;
+    if (lazy_g)
+        for (int e = t; e < 9 * Cout; e += 256) Wl[e] = bn.w_last[(e % Cout) * 9 + e / Cout];
     float wg[NT][4];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -642,6 +647,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_seg_kernel(const floa
         const int y0 = ty * ET_H, x0 = tx * ET_W;
         __syncthreads();
         load_x_halo<CIN>(X, x, n, y0, x0, H, W, t);
+        if (lazy_g) load_dout_tile(Dl, bn.dout, n, y0, x0, H, W, t);
         __syncthreads();
 #pragma unroll 1
         for (int sg = 0; sg < NSEG; ++sg) {
@@ -679,6 +685,27 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_seg_kernel(const floa
                         const long o = (((long)n * H + gy) * W + gx) * Cout + cq * 4;
                         zv[u] = ok ? *reinterpret_cast<const float4*>(bn.z + o) : make_float4(0.f, 0.f, 0.f, 0.f);
                         gv[u] = (ok && bn.g_full) ? *reinterpret_cast<const float4*>(bn.g_full + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    if (lazy_g) {                      // g[q][c] = sum_tap dout[q - off(tap)] w_last[c][tap] (conv_last_dgrad_tile_kernel)
+                        float ga[4][4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) ga[u][k] = 0.f;
+#pragma unroll
+                        for (int tap = 0; tap < 9; ++tap) {
+                            const float4 w4 = *reinterpret_cast<const float4*>(Wl + tap * Cout + cq * 4);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float dv = Dl[(py + 2 - tap / 3) * EH_W + c0 + hlf * 4 + u + 2 - tap % 3];
+                                ga[u][0] = fmaf(dv, w4.x, ga[u][0]);
+                                ga[u][1] = fmaf(dv, w4.y, ga[u][1]);
+                                ga[u][2] = fmaf(dv, w4.z, ga[u][2]);
+                                ga[u][3] = fmaf(dv, w4.w, ga[u][3]);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) gv[u] = make_float4(ga[u][0], ga[u][1], ga[u][2], ga[u][3]);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -769,7 +796,7 @@ static int launch_first_seg(bool wgrad, const float* x, const float* wt, float* 
             return RD_ERR_ARG;
         } else {
         const int nb = nt < 1024 ? nt : 1024;
-        const size_t smem = (size_t)(CIN * FH_PLANE + 9 * 256 * 4) * sizeof(float);
+        const size_t smem = (size_t)(CIN * FH_PLANE + 9 * 256 * 4 + 640 + 9 * cout) * sizeof(float);
         if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 16, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
         else if (cout == 32) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 8, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
         else hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 32, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);

@@ -1542,10 +1542,12 @@ int rd_conv3x3_first_bwd_weight_bn_available(int n, int h, int w, int cin, int c
 
 int rd_conv3x3_first_bwd_weight_bn(const float* x, const float* z, const float* mean, const float* invstd, const float* gamma,
                                    const float* beta, float slope, const float* slope_dev, const float* g_full, const float* g_pool,
-                                   const uint8_t* idx, const double* sums, double count, int training, float* dw, int n, int h,
-                                   int w, int cin, int cout, void* ws, size_t ws_bytes, rd_stream_t s) {
+                                   const uint8_t* idx, const double* sums, double count, int training, const float* dout,
+                                   const float* w_last, float* dw, int n, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,
+                                   rd_stream_t s) {
     RD_REQUIRE(x && z && mean && invstd && gamma && beta && sums && dw, "rd_conv3x3_first_bwd_weight_bn: null pointer");
-    RD_REQUIRE(g_full || g_pool, "rd_conv3x3_first_bwd_weight_bn: no gradient source");
+    RD_REQUIRE(g_full || g_pool || dout, "rd_conv3x3_first_bwd_weight_bn: no gradient source");
+    RD_REQUIRE(!dout || (w_last && !g_full), "rd_conv3x3_first_bwd_weight_bn: dout needs w_last and excludes g_full");
     RD_REQUIRE(!g_pool || idx, "rd_conv3x3_first_bwd_weight_bn: g_pool needs idx");
     RD_REQUIRE(count > 0, "rd_conv3x3_first_bwd_weight_bn: count must be positive");
     RD_REQUIRE(rd_conv3x3_first_bwd_weight_bn_available(n, h, w, cin, cout),
@@ -1559,7 +1561,7 @@ int rd_conv3x3_first_bwd_weight_bn(const float* x, const float* z, const float* 
     }
     ProfScope ps((hipStream_t)s, "conv_first_wgrad", 2.0 * n * h * w * cout * 9.0 * cin,
                  4.0 * n * h * w * ((double)cin + cout * (1.0 + (g_full ? 1.0 : 0.0) + (g_pool ? 0.3 : 0.0))));
-    const FirstBnBwd bn = {z, mean, invstd, gamma, beta, slope_dev, slope, g_full, g_pool, idx, sums, count, training};
+    const FirstBnBwd bn = {z, mean, invstd, gamma, beta, slope_dev, slope, g_full, g_pool, idx, sums, count, training, dout, w_last};
     if (int e = conv_first_seg_launch(true, x, nullptr, nullptr, nullptr, (float*)ws, n, h, w, cin, cout, (hipStream_t)s, &bn)) return e;
     hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 16)), dim3(256), 0, (hipStream_t)s, (const float*)ws, dw,
                        grid, cin, cout);
@@ -1640,7 +1642,7 @@ int rd_conv3x3_last_bwd_data_bnstats(const float* dout, const float* wt, float* 
                                      const float* bn_z, const float* mean, const float* invstd, const float* gamma,
                                      const float* beta, float slope, const float* slope_dev, float* part, size_t part_floats,
                                      int* rows_out, rd_stream_t s) {
-    RD_REQUIRE(dout && wt && ds && bn_z && mean && invstd && gamma && beta && part && rows_out,
+    RD_REQUIRE(dout && wt && bn_z && mean && invstd && gamma && beta && part && rows_out,
                "rd_conv3x3_last_bwd_data_bnstats: null pointer");
     RD_REQUIRE(part_floats >= rd_bn_bwd_part_floats((long long)n * h * w, c),
                "rd_conv3x3_last_bwd_data_bnstats: statistics buffer too small");
@@ -1652,6 +1654,7 @@ int rd_conv3x3_last_bwd_data_bnstats(const float* dout, const float* wt, float* 
         if (*rows_out) return RD_OK;
     }
     // channel counts without a tile kernel: plain data gradient, the caller runs the stand-alone reduction
+    RD_REQUIRE(ds, "rd_conv3x3_last_bwd_data_bnstats: ds = NULL (statistics only) needs C in {16, 32, 64} (got %d)", c);
     return rd_conv3x3_last_bwd_data(dout, wt, ds, n, h, w, c, s);
 }
 

@@ -193,10 +193,25 @@ def conv3x3_first_bwd_weight_bn_available(x_nchw, cout) -> bool:
     return bool(load().rd_conv3x3_first_bwd_weight_bn_available(n, h, wd_, cin, int(cout)))
 
 
+class LastConvGrad:
+    """The full-resolution gradient operand g = conv3x3_last_bwd_data(dout, w_last) that is NOT materialised: consumers evaluate
+    it from the network's 1-channel output gradient (conv3x3_first_bwd_weight_bn), or call .tensor() to build it after all."""
+
+    def __init__(self, dout, w_last, c):
+        self.dout, self.w_last, self.c = dout, w_last, c
+
+    def tensor(self):
+        return conv3x3_last_bwd_data(self.dout, self.w_last, self.c)
+
+
 def conv3x3_first_bwd_weight_bn(x_nchw, z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx, sums, count, training=True,
                                 slope_dev=None, out=None, ws_slot=0):
     """Weight gradient of the first convolution with dz = bn_act_bwd_apply(z, ..., g_full, g_pool, idx, sums, count, training)
-    evaluated on the fly (include/resdepth_hip.h: rd_conv3x3_first_bwd_weight_bn): no dz tensor."""
+    evaluated on the fly (include/resdepth_hip.h: rd_conv3x3_first_bwd_weight_bn): no dz tensor.  g_full may be a LastConvGrad:
+    then that operand is evaluated from dout too."""
+    dout = w_last = None
+    if isinstance(g_full, LastConvGrad):
+        dout, w_last, g_full = g_full.dout, g_full.w_last.detach(), None
     n, cin, h, wd_ = x_nchw.shape
     cout = z.shape[3]
     if out is None:
@@ -205,8 +220,8 @@ def conv3x3_first_bwd_weight_bn(x_nchw, z, mean, invstd, gamma, beta, slope, g_f
     ws = workspace(nb, z.device, ws_slot)
     check(load().rd_conv3x3_first_bwd_weight_bn(ptr(x_nchw), ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
                                                 float(slope), ptr(slope_dev), ptr(g_full), ptr(g_pool), ptr(idx), ptr(sums),
-                                                float(count), 1 if training else 0, ptr(out), n, h, wd_, cin, cout, ws.data_ptr(),
-                                                ws.numel(), stream_ptr()), "conv3x3_first_bwd_weight_bn")
+                                                float(count), 1 if training else 0, ptr(dout), ptr(w_last), ptr(out), n, h, wd_, cin,
+                                                cout, ws.data_ptr(), ws.numel(), stream_ptr()), "conv3x3_first_bwd_weight_bn")
     return out
 
 
@@ -231,9 +246,11 @@ def conv3x3_last_fwd(s, w, bias, x_nchw):
     return out
 
 
-def conv3x3_last_bwd_data(dout, w, c, bn=None):
+def conv3x3_last_bwd_data(dout, w, c, bn=None, write=True):
+    """write=False (with bn): only the BN-backward statistics of the hook -> (None, (partial rows, count)); the gradient tensor
+    itself is left to consumers that evaluate it from dout (LastConvGrad)."""
     n, _, h, wd_ = dout.shape
-    ds = torch.empty(n, h, wd_, c, device=dout.device, dtype=torch.float32)
+    ds = torch.empty(n, h, wd_, c, device=dout.device, dtype=torch.float32) if write else None
     if bn is None:
         check(load().rd_conv3x3_last_bwd_data(ptr(dout), ptr(w.detach()), ptr(ds), n, h, wd_, c, stream_ptr()),
               "conv3x3_last_bwd_data")

@@ -18,7 +18,6 @@ from __future__ import annotations
 
 from typing import List, Optional
 
-import os
 import torch
 import torch.nn as nn
 
@@ -136,7 +135,7 @@ class UNet(nn.Module):
         self.two_stream_backward = True   # weight gradients on a second HIP stream, overlapping the dgrad/BN chain
         self.fold_eval_bn = True          # inference: eval-mode BN folded into the packed conv weights + epilogue activation
         self.fused_bn_bwd_stats = True    # BN-backward sums from the epilogues of the kernels producing the gradient operands
-        self.composed_tail = os.environ.get("RD_EXP_NOTAIL") != "1"        # last up-convolution's gradients straight from dout (ops.tail_*)
+        self.composed_tail = True         # last up-convolution's gradients straight from the 1-channel dout (ops.tail_*)
         self.fused_first_wgrad = True     # level 0: BN / activation / pool backward evaluated inside the first conv's weight gradient
         # loss.backward(retain_graph=True) on the reference keeps the saved activations for a second backward.  A custom
         # autograd.Function cannot see that flag, and keeping 137 MB per tile alive until the loss tensor dies would surprise
@@ -769,6 +768,8 @@ class UNet(nn.Module):
             operands = (g_full is not None) + (g_pool is not None)
             pre = [q for q in pre if q is not None]
             pre = pre if len(pre) == operands else None
+            if isinstance(g_full, ops.LastConvGrad) and (fuse_into is None or not pre):
+                g_full = g_full.tensor()         # a consumer that needs the tensor after all
 
             dextra = gv(extra_bias) if extra_bias is not None else None     # ConvTranspose2d bias (skip add): by-product
 
@@ -836,7 +837,20 @@ class UNet(nn.Module):
         # every data-gradient kernel below also emits the BN-backward sums of the block that consumes its output
         # (`hook`): the skip gradient of encoder level j (full part), the pooled gradient (pooled part), the decoder /
         # bottleneck block behind a transposed convolution
-        g, st = with_stats(ops.conv3x3_last_bwd_data, dout, ll.weight, c0, bn=hook(S["enc"][0], self.encoder[0][0], self.act_fn_encoder))
+        hook0 = hook(S["enc"][0], self.encoder[0][0], self.act_fn_encoder)
+        up_last = self._up_of(d - 1)
+        tail = (self.composed_tail and self.up_mode == "transpose" and ops.tail_available(up_last.weight.shape[0], up_last.weight.shape[1]))
+        fuse_first = (self.fused_first_wgrad and self.do_BN and not want_dx and not self._first_generic()
+                      and ops.conv3x3_first_bwd_weight_bn_available(S["x"], c0))
+        if tail and fuse_first and hook0 is not None and c0 in (16, 32, 64):
+            # g = conv_last^T(dout), C0 channels at full resolution, has three readers -- the last up-convolution's two gradients
+            # and level 0's BN backward -- and all three evaluate what they need from the 1-channel dout: only the statistics of
+            # the hook leave this launch, the tensor is never written
+            _, st = ops.conv3x3_last_bwd_data(dout, ll.weight, c0, bn=hook0, write=False)
+            st = st if st[1] > 0 else None
+            g = ops.LastConvGrad(dout, ll.weight, c0)
+        else:
+            g, st = with_stats(ops.conv3x3_last_bwd_data, dout, ll.weight, c0, bn=hook0)
         skipgrad, skipstat = [None] * d, [None] * d
         gp = gpstat = None
         for i in reversed(range(d)):
@@ -848,13 +862,14 @@ class UNet(nn.Module):
                 dprev, dstat = ops.conv1x1_bwd_data(dt, pk.get(("dec_t", i))[1]), None
             else:
                 sblk, sact = (self.decoder[i - 1][1], self.act_fn_decoder) if i > 0 else (self.bottleneck, self.act_fn_bottleneck)
-                if i == d - 1 and self.composed_tail and ops.tail_available(up.weight.shape[0], up.weight.shape[1]):
+                if i == d - 1 and tail:
                     # the last up-convolution feeds the last convolution directly (lib/UNet.py:218-227): its two gradients are
                     # stencils / correlations on the 1-channel dout, the C0-channel gradient g is not an operand (ops.tail_*)
                     _, tail_v = ops.tail_compose(up.weight, ll.weight)
                     wgrad(ops.convt_last_bwd_weight, (dout, tail_v), src["a"], dout, ll.weight, gv(up.weight), ready=(up.weight,))
                     dprev, dstat = with_stats(ops.convt_last_bwd_data, dout, tail_v, bn=hook(src, sblk, sact))
                 else:
+                    assert not isinstance(g, ops.LastConvGrad)
                     wgrad(ops.convt2x2_bwd_weight, (g,), src["a"], g, gv(up.weight), ready=(up.weight,))
                     dprev, dstat = with_stats(ops.convt2x2_bwd_data, g, pk.get(("dec_t", i))[1], bn=hook(src, sblk, sact))
             skipgrad[d - 1 - i], skipstat[d - 1 - i] = g, st       # gradient wrt the encoder skip a_{d-1-i} (SkipConnection is an ADD)
@@ -879,8 +894,7 @@ class UNet(nn.Module):
             j = d - 1 - i
             up = self._up_of(j)
             fuse = None
-            if (i == 0 and self.fused_first_wgrad and self.do_BN and not want_dx and not self._first_generic()
-                    and ops.conv3x3_first_bwd_weight_bn_available(S["x"], blk[0].weight.shape[0])):
+            if i == 0 and fuse_first:
                 # level 0: dz has one reader, the first convolution's weight gradient -- which evaluates it itself.  On the MAIN
                 # stream, where the apply pass it replaces ran: behind the side stream's queue of strip kernels it lengthens the
                 # tail of the step (interleaved: -0.4 % there, +1.1 % here, against the two-kernel route)

@@ -750,6 +750,23 @@ def test_first_conv_weight_gradient_with_the_bn_backward_evaluated_on_the_fly(n,
                                                   slope_dev=sdev)
             scale = float(want.abs().max())
             assert float((got - want).abs().max()) <= 2e-6 * scale, (float((got - want).abs().max()), scale)
+    # the full-resolution operand as the last convolution's data gradient of a 1-channel dout, evaluated inside (LastConvGrad)
+    if cout <= 64:
+        dout = torch.randn(n, 1, h, w, generator=g).to(dev())
+        wl = (torch.randn(1, cout, 3, 3, generator=g) / 3).to(dev())
+        gl = ops.conv3x3_last_bwd_data(dout, wl, cout)
+        sums_l = ops.bn_act_bwd_reduce(z, mean, invstd, gamma, beta, slope, gl, g_pool, idx)
+        dz = ops.bn_act_bwd_apply(z, mean, invstd, gamma, beta, slope, gl, g_pool, idx, sums_l, count, training)
+        want = ops.conv3x3_first_bwd_weight(x, dz)
+        got = ops.conv3x3_first_bwd_weight_bn(x, z, mean, invstd, gamma, beta, slope, ops.LastConvGrad(dout, wl, cout), g_pool, idx,
+                                              sums_l, count, training)
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 2e-6 * scale, (float((got - want).abs().max()), scale)
+        # ... and the statistics-only form of the producer: same partial rows, no tensor
+        hook = ops.BnHook(z, mean, invstd, gamma, beta, slope, None, 1)
+        ds1, part1 = ops.conv3x3_last_bwd_data(dout, wl, cout, bn=hook)
+        ds0, part0 = ops.conv3x3_last_bwd_data(dout, wl, cout, bn=hook, write=False)
+        assert ds0 is None and part0[1] == part1[1] > 0 and torch.equal(part0[0][:part0[1] * 4 * cout], part1[0][:part1[1] * 4 * cout])
     with pytest.raises(RuntimeError, match="shape not handled"):
         ops.conv3x3_first_bwd_weight_bn(torch.randn(1, 4, 16, 32, device=dev()), z[:1, :16, :32].contiguous(), mean, invstd, gamma,
                                         beta, slope, None, g_pool[:1, :8, :16].contiguous(), idx[:1, :8, :16].contiguous(), sums, 512)
