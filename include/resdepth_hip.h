@@ -150,11 +150,13 @@ int rd_conv3x3_last_bwd_data(const float* dout, const float* w_oihw, float* ds, 
  *   M[ci][ab][tap] = sum_co Wt[ci][co][a][b] wl[co][tap]                    (Cin x 4 x 9)
  *   V[ci][d]       = sum of M over the (ab, tap) with (a, b) - off(tap) = d   (Cin x 16, d in [-1, 2]^2, off = (tap/3-1, tap%3-1))
  *   d loss / d input[p][ci] = sum_d dout[2p + d] V[ci][d]                     (rd_convt_last_bwd_data)
- * rd_tail_compose writes M and V (tiny; once per step).  rd_convt_last_bwd_data(hc, wc = the COARSE grid) == rd_convt2x2_bwd_data
+ * rd_tail_compose writes M and V (tiny; once per step), and on request VT [16][Cin] = V transposed (the weight of a 1x1
+ * convolution Cin -> 16) and B9[tap] = sum_co w_last[co][tap] bias_t[co] (bias_t nullable) for the forward below.  rd_convt_last_bwd_data(hc, wc = the COARSE grid) == rd_convt2x2_bwd_data
  * applied to rd_conv3x3_last_bwd_data(dout) up to fp32 rounding; bn_z != NULL: the BN-backward statistics hook of
  * rd_convt2x2_bwd_data_bnstats (mode 1), part / rows_out as there.  Cin in {32, 64, 128, 256} (rd_tail_available). */
 int rd_tail_available(int cin, int c0);
-int rd_tail_compose(const float* wt_iohw, const float* w_last, float* M, float* V, int cin, int c0, rd_stream_t s);
+int rd_tail_compose(const float* wt_iohw, const float* bias_t, const float* w_last, float* M, float* V, float* VT, float* B9, int cin,
+                    int c0, rd_stream_t s);
 int rd_convt_last_bwd_data(const float* dout, const float* V, float* dprev, int n, int hc, int wc, int cin, const float* bn_z,
                            const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                            const float* slope_dev, float* part, size_t part_floats, int* rows_out, rd_stream_t s);
@@ -162,8 +164,26 @@ int rd_convt_last_bwd_data(const float* dout, const float* V, float* dprev, int 
  * channel, one pass over the up-convolution's INPUT x [N, hc, wc, Cin]), then dWt[ci][co][a][b] = sum_tap w_last[co][tap]
  * C16[ci][(a,b) - off(tap)]  == rd_convt2x2_bwd_weight(x, rd_conv3x3_last_bwd_data(dout)) up to fp32 rounding. */
 size_t rd_convt_last_bwd_weight_ws_bytes(int n, int hc, int wc, int cin);
-int rd_convt_last_bwd_weight(const float* x, const float* dout, const float* w_last, float* dwt_iohw, int n, int hc, int wc, int cin,
-                             int c0, void* ws, size_t ws_bytes, rd_stream_t s);
+int rd_convt_last_bwd_weight(const float* x, const float* dout, const float* w_last, float* dwt_iohw, double* c16_out /* [Cin][16],
+                             nullable */, int n, int hc, int wc, int cin, int c0, void* ws, size_t ws_bytes, rd_stream_t s);
+/* FORWARD of the tail without its input tensor.  s = up-convolution(x_coarse) + bias_t + act(BN(z)) is what the reference feeds
+ * the last convolution (lib/UNet.py:218-227); here
+ *   out[q] = conv_last(act(BN(z)))[q] + sum_{p': d = q - 2p' in [-1,2]^2} T[p'][d] + sum_{tap: q + off(tap) inside} B9[tap] + bias
+ *            (+ x[:, 0], the outer residual)
+ * with T [N, H/2, W/2, 16] = rd_conv1x1_fwd(x_coarse, VT): z (level 0's pre-BN tensor, which exists anyway) is read once with BN
+ * + activation applied on load, the up-convolution's 64-channel full-resolution output is neither written nor read.
+ * rd_conv3x3_last_bwd_weight_tail: the last convolution's weight / bias gradient in the same terms -- the act(BN(z)) part from
+ * z and dout, the up-convolution part from the correlations C16 of rd_convt_last_bwd_weight, the bias part from dout alone.
+ * C in {16, 32, 64}; == rd_conv3x3_last_fwd / rd_conv3x3_last_bwd_weight on the materialised s up to fp32 rounding. */
+int rd_conv3x3_last_fwd_tail(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             float slope, const float* slope_dev, const float* t16, const float* b9, const float* w_last,
+                             const float* bias, const float* x_nchw, int x_channels, float* out, int n, int h, int w, int c,
+                             rd_stream_t s);
+size_t rd_conv3x3_last_bwd_weight_tail_ws_bytes(int n, int h, int w, int c);
+int rd_conv3x3_last_bwd_weight_tail(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                    float slope, const float* slope_dev, const float* dout, const double* c16, const float* wt_iohw,
+                                    const float* bias_t, float* dw, float* dbias, int n, int h, int w, int cin, int c, void* ws,
+                                    size_t ws_bytes, rd_stream_t s);
 size_t rd_conv3x3_last_bwd_weight_ws_bytes(int n, int h, int w, int c);
 /* dw[1][C][3][3], dbias[1] (nullable) */
 int rd_conv3x3_last_bwd_weight(const float* s_in, const float* dout, float* dw_oihw, float* dbias, int n, int h, int w,

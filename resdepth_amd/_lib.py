@@ -52,9 +52,12 @@ SIGNATURES = {
     "rd_conv3x3_first_fwd_bn": (I, [P, P, P, D, F, F, P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_conv3x3_first_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_tail_available": (I, [I, I]),
-    "rd_tail_compose": (I, [P, P, P, P, I, I, P]),
+    "rd_tail_compose": (I, [P, P, P, P, P, P, P, I, I, P]),
+    "rd_conv3x3_last_fwd_tail": (I, [P, P, P, P, P, F, P, P, P, P, P, P, I, P, I, I, I, I, P]),
+    "rd_conv3x3_last_bwd_weight_tail_ws_bytes": (SZ, [I, I, I, I]),
+    "rd_conv3x3_last_bwd_weight_tail": (I, [P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_convt_last_bwd_weight_ws_bytes": (SZ, [I, I, I, I]),
-    "rd_convt_last_bwd_weight": (I, [P, P, P, P, I, I, I, I, I, P, SZ, P]),
+    "rd_convt_last_bwd_weight": (I, [P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_convt_last_bwd_data": (I, [P, P, P, I, I, I, I, P, P, P, P, P, F, P, P, SZ, P, P]),
     "rd_conv3x3_first_bwd_weight_bn_available": (I, [I, I, I, I, I]),
     "rd_conv3x3_first_bwd_weight_bn": (I, [P, P, P, P, P, P, F, P, P, P, P, P, D, I, P, P, P, I, I, I, I, I, P, SZ, P]),

@@ -83,7 +83,24 @@ int conv_last_dgrad_bn_launch(const float* dout, const float* wt, float* ds, int
                               const float* slope_dev, float* part, hipStream_t s, int* rows);
 int conv_last_wgrad_blocks(int n, int h, int w, int c);
 // tail of the network (last up-convolution composed with the last convolution, rd_edge_conv.hip)
-int tail_compose_launch(const float* wt, const float* wl, float* M, float* V, int cin, int c0, hipStream_t s);
+// level 0's activation act(BN(z)) as an operand that is recomputed from z where it is used (the descriptor the transposed
+// convolution's lazy skip takes); `t16` / `b9`: the up-convolution's contribution through the composed stencil (see TailSkip use)
+struct TailSkip {
+    const float* z;
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    const float* slope_dev;
+    float slope;
+};
+int tail_compose_launch(const float* wt, const float* bt, const float* wl, float* M, float* V, float* VT, float* B9, int cin, int c0,
+                        hipStream_t s);
+int conv_last_fwd_tail_launch(const TailSkip& sk, const float* t16, const float* b9, const float* wt, const float* bias,
+                              const float* x_nchw, int xc, float* out, int n, int h, int w, int c, hipStream_t s);
+int conv_last_wgrad_tail_launch(const TailSkip& sk, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s);
+int tail_wl_finish_launch(const double* partial, int nb, const double* c16, const float* wt, const float* bt, float* dw, float* dbias,
+                          int cin, int c0, hipStream_t s);
 bool tail_shape_ok(int cin);
 int tail_corr_blocks(int n, int hc, int wc);
 int convt_last_wgrad_launch(const float* x, const float* dout, const float* wl, float* dwt, double* partial, double* c16, int n,

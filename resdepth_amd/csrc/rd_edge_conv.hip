@@ -109,6 +109,113 @@ __global__ __launch_bounds__(256) void conv_last_fwd_dpp_kernel(const float* __r
     }
 }
 
+// The same convolution when its input s = up-convolution(x_coarse) + bias_t + act(BN(z)) is NOT a tensor (tail of the network):
+//   out[q] = conv_last(act(BN(z)))[q]                                   -- z read here, BN + activation applied on load
+//          + sum over the <= 4 coarse pixels p' with d = q - 2p' in [-1, 2]^2 of T[p'][d]     -- T = x_coarse . V (1x1 conv, 16 ch)
+//          + sum over the taps whose pixel q + off(tap) lies inside the image of B9[tap]       -- the up-convolution's bias
+//          + bias + x[:, 0]
+template <int LP>
+__global__ __launch_bounds__(256) void conv_last_fwd_tail_kernel(TailSkip sk, const float* __restrict__ t16, const float* __restrict__ b9,
+                                                                 const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 const float* __restrict__ x_nchw, int xc, float* __restrict__ out,
+                                                                 int N, int H, int W, int tiles_x, int tiles_y) {
+    constexpr int C = LP * 8, PPI = 256 / LP;
+    __shared__ float V[EH_NP * EVS];
+    const int t = threadIdx.x, q = t % LP, slot = t / LP;
+    const int tl = blockIdx.x;
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+    const int y0 = ty * ET_H, x0 = tx * ET_W;
+    float wr[9][8];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wr[tap][k] = w[(q * 8 + k) * 9 + tap];
+    float sc[8], sh[8];
+    const float slope = sk.slope_dev ? sk.slope_dev[0] : sk.slope;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = q * 8 + k;
+        sc[k] = sk.invstd[c] * sk.gamma[c];
+        sh[k] = sk.beta[c] - sk.mean[c] * sc[k];
+    }
+    constexpr int UN = 2;
+    for (int p0 = 0; p0 < EH_NP; p0 += PPI * UN) {
+        float4 v[UN][2];
+        int hp[UN];
+        bool in[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            hp[u] = p0 + u * PPI + slot;
+            const int hy = hp[u] / EH_W, hx = hp[u] - hy * EH_W;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            v[u][0] = v[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            in[u] = hp[u] < EH_NP && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            if (in[u]) {
+                const float* src = sk.z + (((long)n * H + gy) * W + gx) * C + q * 8;
+                v[u][0] = *reinterpret_cast<const float4*>(src);
+                v[u][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float sv[8] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w, v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {          // zero padding applies to the ACTIVATION: pixels outside stay 0
+                const float y = fmaf(sv[k], sc[k], sh[k]);
+                sv[k] = in[u] ? (y > 0.f ? y : y * slope) : 0.f;
+            }
+            float pt[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                float a = sv[0] * wr[tap][0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) a = fmaf(sv[k], wr[tap][k], a);
+                pt[tap] = lane_group_sum<LP>(a);
+            }
+            if (q == 0 && hp[u] < EH_NP) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) V[hp[u] * EVS + tap] = pt[tap];
+            }
+        }
+    }
+    __syncthreads();
+    const float b0 = bias ? bias[0] : 0.f;
+    const int Hc = H >> 1, Wc = W >> 1;
+    float bq[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) bq[tap] = b9[tap];
+    for (int e = t; e < ET_H * ET_W; e += 256) {
+        const int py = e / ET_W, px = e - py * ET_W;
+        const int gy = y0 + py, gx = x0 + px;
+        if (gy >= H || gx >= W) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) acc += V[((py + tap / 3) * EH_W + px + tap % 3) * EVS + tap];
+        // up-convolution part: q even -> (p', d) = (q/2, 0), (q/2 - 1, 2); q odd -> ((q-1)/2, 1), ((q+1)/2, -1)
+        float up = 0.f;
+#pragma unroll
+        for (int jy = 0; jy < 2; ++jy) {
+            const int cy = (gy >> 1) + ((gy & 1) ? jy : -jy), dy = (gy & 1) ? (jy ? -1 : 1) : (jy ? 2 : 0);
+            if ((unsigned)cy >= (unsigned)Hc) continue;
+#pragma unroll
+            for (int jx = 0; jx < 2; ++jx) {
+                const int cx = (gx >> 1) + ((gx & 1) ? jx : -jx), dx = (gx & 1) ? (jx ? -1 : 1) : (jx ? 2 : 0);
+                if ((unsigned)cx >= (unsigned)Wc) continue;
+                up += t16[(((long)n * Hc + cy) * Wc + cx) * 16 + (dy + 1) * 4 + dx + 1];
+            }
+        }
+        float bsum = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ry = gy + tap / 3 - 1, rx = gx + tap % 3 - 1;
+            if ((unsigned)ry < (unsigned)H && (unsigned)rx < (unsigned)W) bsum += bq[tap];
+        }
+        acc = ((acc + up) + bsum) + b0;
+        if (x_nchw) acc = x_nchw[(((long)n * xc) * H + gy) * W + gx] + acc;
+        out[((long)n * H + gy) * W + gx] = acc;
+    }
+}
+
 // dout tile (+ one-pixel halo, zero outside the image) -> LDS; D[hy][hx] = dout[y0 - 1 + hy][x0 - 1 + hx]
 __device__ __forceinline__ void load_dout_tile(float* D, const float* __restrict__ dout, int n, int y0, int x0, int H, int W,
                                                int t) {
@@ -220,10 +327,20 @@ __global__ __launch_bounds__(256) void conv_last_dgrad_tile_kernel(const float* 
 //   M[ci][ab][tap] = sum_co Wt[ci][co][a][b] wl[co][tap],   V[ci][d] = sum over the (ab, tap) with (a,b) - off(tap) = d of M.
 // The C0-channel gradient g at full resolution (537 MB in cfg-S) is then not an operand of this layer at all.
 // tail_compose_kernel: one block per ci; M [Cin][4][9] and V [Cin][16] (fp64 accumulation, fp32 results).
-__global__ __launch_bounds__(64) void tail_compose_kernel(const float* __restrict__ wt, const float* __restrict__ wl,
-                                                          float* __restrict__ M, float* __restrict__ V, int Cin, int C0) {
+// VT [16][Cin] (nullable): V transposed = the weight of a 1x1 convolution Cin -> 16 (forward use); B9 [9] (nullable):
+// B9[tap] = sum_co wl[co][tap] bt[co], the up-convolution's bias seen through the last convolution.
+__global__ __launch_bounds__(64) void tail_compose_kernel(const float* __restrict__ wt, const float* __restrict__ bt,
+                                                          const float* __restrict__ wl, float* __restrict__ M, float* __restrict__ V,
+                                                          float* __restrict__ VT, float* __restrict__ B9, int Cin, int C0) {
     __shared__ float m[36];
     const int ci = blockIdx.x, t = threadIdx.x;
+    if (ci == 0 && B9 && t >= 48 && t < 57) {
+        const int tap = t - 48;
+        double acc = 0.0;
+        if (bt)
+            for (int co = 0; co < C0; ++co) acc += (double)wl[co * 9 + tap] * (double)bt[co];
+        B9[tap] = (float)acc;
+    }
     if (t < 36) {
         const int ab = t / 9, tap = t - ab * 9;
         double acc = 0.0;
@@ -242,6 +359,7 @@ __global__ __launch_bounds__(64) void tail_compose_kernel(const float* __restric
                 acc += (double)m[(a * 2 + b) * 9 + (oy + 1) * 3 + (ox + 1)];
             }
         V[(long)ci * 16 + t] = (float)acc;
+        if (VT) VT[(long)t * Cin + ci] = (float)acc;
     }
 }
 
@@ -493,6 +611,138 @@ __global__ __launch_bounds__(256) void conv_last_wgrad_tile_kernel(const float* 
         out[9 * C] = sum;
     }
 }
+
+// The same when the convolution's input is not a tensor (tail of the network): the act(BN(z)) part of it is recomputed from z on
+// load; per block one partial row [9][C] + [9] (doubles): the second part = S[tap] = sum_{q inside} dout[q - off(tap)], which
+// multiplies the up-convolution's bias (and S[4] = sum dout is the last convolution's bias gradient).  The up-convolution part
+// of the input enters through the correlations C16 (tail_wl_finish_kernel).
+__global__ __launch_bounds__(256) void conv_last_wgrad_tail_kernel(TailSkip sk, const float* __restrict__ dout,
+                                                                   double* __restrict__ partial, int N, int H, int W, int C,
+                                                                   int CQ, int tiles_x, int tiles_y, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float esm[];     // D[EH_NP] (padded to 640), then the reduction scratch
+    float* D = esm;
+    float* red = esm + 640;                        // [PPI][9][C] floats
+    const int t = threadIdx.x, q = t % CQ, slot = t / CQ, PPI = 256 / CQ;
+    float acc[9][4];
+    float accs[9];
+    float sc[4], sh[4];
+    const float slope = sk.slope_dev ? sk.slope_dev[0] : sk.slope;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = q * 4 + k;
+        sc[k] = sk.invstd[c] * sk.gamma[c];
+        sh[k] = sk.beta[c] - sk.mean[c] * sc[k];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) accs[tap] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[tap][k] = 0.f;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+        const int y0 = ty * ET_H, x0 = tx * ET_W;
+        __syncthreads();
+        load_dout_tile(D, dout, n, y0, x0, H, W, t);
+        __syncthreads();
+        constexpr int UN = 4;
+        for (int e0 = 0; e0 < ET_H * ET_W; e0 += PPI * UN) {
+            float4 s4[UN];
+            int py[UN], px[UN];
+            bool ok[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int e = e0 + u * PPI + slot;
+                py[u] = e / ET_W;
+                px[u] = e - py[u] * ET_W;
+                ok[u] = y0 + py[u] < H && x0 + px[u] < W;
+                s4[u] = ok[u] ? *reinterpret_cast<const float4*>(sk.z + (((long)n * H + y0 + py[u]) * W + x0 + px[u]) * C + q * 4)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                float sv[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float y = fmaf(sv[k], sc[k], sh[k]);
+                    sv[k] = ok[u] ? (y > 0.f ? y : y * slope) : 0.f;
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float d = D[(py[u] + 2 - tap / 3) * EH_W + px[u] + 2 - tap % 3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[tap][k] = fmaf(sv[k], d, acc[tap][k]);
+                    if (q == 0 && ok[u]) accs[tap] += d;
+                }
+            }
+        }
+    }
+    // one block-level reduction over the PPI pixel slots (fixed order)
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+        *reinterpret_cast<float4*>(red + ((slot * 9 + tap) * C) + q * 4) = make_float4(acc[tap][0], acc[tap][1], acc[tap][2], acc[tap][3]);
+    __syncthreads();
+    double* out = partial + (long)blockIdx.x * (9 * C + 9);
+    for (int e = t; e < 9 * C; e += 256) {
+        double sum = 0.0;
+        for (int sl = 0; sl < PPI; ++sl) sum += (double)red[sl * 9 * C + e];
+        out[e] = sum;
+    }
+    __syncthreads();
+    if (q == 0) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) red[slot * 9 + tap] = accs[tap];
+    }
+    __syncthreads();
+    if (t < 9) {
+        double sum = 0.0;
+        for (int sl = 0; sl < PPI; ++sl) sum += (double)red[sl * 9 + t];
+        out[9 * C + t] = sum;
+    }
+}
+
+// dw[co][tap] = sum_b partial[b][tap * C0 + co]                                              (act(BN(z)) part)
+//             + sum_ci sum_ab Wt[ci][co][ab] C16[ci][(a,b) - off(tap)]                        (up-convolution part)
+//             + bt[co] S[tap]                                                                 (its bias);   dbias = S[4]
+// one block per output channel co, fixed orders
+__global__ __launch_bounds__(256) void tail_wl_finish_kernel(const double* __restrict__ partial, int nb, const double* __restrict__ c16,
+                                                             const float* __restrict__ wt, const float* __restrict__ bt,
+                                                             float* __restrict__ dw, float* __restrict__ dbias, int Cin, int C0) {
+    __shared__ double red[256];
+    __shared__ double tot[18];
+    const int co = blockIdx.x, t = threadIdx.x;
+    const int row = 9 * C0 + 9;
+    // columns tap * C0 + co (9) and 9 * C0 + tap (9): 18 columns x 14 row slices
+    const int col = t % 18, slice = t / 18;
+    double acc = 0.0;
+    if (slice < 14) {
+        const int e = col < 9 ? col * C0 + co : 9 * C0 + (col - 9);
+        for (int b = slice; b < nb; b += 14) acc += partial[(long)b * row + e];
+    }
+    red[t] = acc;
+    __syncthreads();
+    if (t < 18) {
+        double sum = 0.0;
+        for (int sl = 0; sl < 14; ++sl) sum += red[sl * 18 + t];
+        tot[t] = sum;
+    }
+    __syncthreads();
+    if (t < 9) {
+        const int tap = t;
+        double up = 0.0;
+        for (int ci = 0; ci < Cin; ++ci)
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {
+                const int dy = (ab >> 1) - (tap / 3 - 1), dx = (ab & 1) - (tap % 3 - 1);
+                up += (double)wt[((long)ci * C0 + co) * 4 + ab] * c16[(long)ci * 16 + (dy + 1) * 4 + dx + 1];
+            }
+        const double bias_part = bt ? (double)bt[co] * tot[9 + tap] : 0.0;
+        dw[co * 9 + tap] = (float)((tot[tap] + up) + bias_part);
+        if (co == 0 && tap == 4 && dbias) dbias[0] = (float)tot[9 + 4];
+    }
+}
+
 
 // ---- first convolution (NCHW input with 1..6 channels -> NHWC, Cout = 32 / 64 / 128) ---------------------------------------
 // Tile = 16 x 32 output pixels; the input halo (18 x 34 per channel plane, row pitch 36 floats = 16-byte aligned rows) sits in
@@ -840,6 +1090,34 @@ int conv_last_fwd_launch(const float* s_in, const float* wt, const float* bias, 
     return RD_OK;
 }
 
+int conv_last_fwd_tail_launch(const TailSkip& sk, const float* t16, const float* b9, const float* wt, const float* bias,
+                              const float* x_nchw, int xc, float* out, int n, int h, int w, int c, hipStream_t s) {
+    const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
+    const dim3 grid(n * tx * ty);
+    if (c == 64) hipLaunchKernelGGL(conv_last_fwd_tail_kernel<8>, grid, dim3(256), 0, s, sk, t16, b9, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    else if (c == 32) hipLaunchKernelGGL(conv_last_fwd_tail_kernel<4>, grid, dim3(256), 0, s, sk, t16, b9, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    else hipLaunchKernelGGL(conv_last_fwd_tail_kernel<2>, grid, dim3(256), 0, s, sk, t16, b9, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    RD_LAUNCH_CHECK("conv_last_fwd_tail");
+    return RD_OK;
+}
+
+int conv_last_wgrad_tail_launch(const TailSkip& sk, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s) {
+    const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
+    const long nt = (long)n * tx * ty;
+    const int nb = (int)(nt < 1024 ? nt : 1024);
+    const size_t smem = (640 + (size_t)(256 / (c / 4)) * 9 * c) * sizeof(float);
+    hipLaunchKernelGGL(conv_last_wgrad_tail_kernel, dim3(nb), dim3(256), smem, s, sk, dout, partial, n, h, w, c, c / 4, tx, ty, (int)nt);
+    RD_LAUNCH_CHECK("conv_last_wgrad_tail");
+    return RD_OK;
+}
+
+int tail_wl_finish_launch(const double* partial, int nb, const double* c16, const float* wt, const float* bt, float* dw, float* dbias,
+                          int cin, int c0, hipStream_t s) {
+    hipLaunchKernelGGL(tail_wl_finish_kernel, dim3(c0), dim3(256), 0, s, partial, nb, c16, wt, bt, dw, dbias, cin, c0);
+    RD_LAUNCH_CHECK("tail_wl_finish");
+    return RD_OK;
+}
+
 int conv_last_dgrad_launch(const float* dout, const float* wt, float* ds, int n, int h, int w, int c, hipStream_t s, int* launched) {
     *launched = 0;
     if (!edge_shape_ok(c) || !edge_on(2)) return RD_OK;
@@ -867,8 +1145,9 @@ int conv_last_dgrad_bn_launch(const float* dout, const float* wt, float* ds, int
     return RD_OK;
 }
 
-int tail_compose_launch(const float* wt, const float* wl, float* M, float* V, int cin, int c0, hipStream_t s) {
-    hipLaunchKernelGGL(tail_compose_kernel, dim3(cin), dim3(64), 0, s, wt, wl, M, V, cin, c0);
+int tail_compose_launch(const float* wt, const float* bt, const float* wl, float* M, float* V, float* VT, float* B9, int cin, int c0,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(tail_compose_kernel, dim3(cin), dim3(64), 0, s, wt, bt, wl, M, V, VT, B9, cin, c0);
     RD_LAUNCH_CHECK("tail_compose");
     return RD_OK;
 }

@@ -1660,9 +1660,46 @@ int rd_conv3x3_last_bwd_data_bnstats(const float* dout, const float* wt, float* 
 
 int rd_tail_available(int cin, int c0) { return tail_shape_ok(cin) && c0 > 0 && c0 <= 1024 ? 1 : 0; }
 
-int rd_tail_compose(const float* wt_iohw, const float* wl, float* M, float* V, int cin, int c0, rd_stream_t s) {
+int rd_tail_compose(const float* wt_iohw, const float* bias_t, const float* wl, float* M, float* V, float* VT, float* B9, int cin,
+                    int c0, rd_stream_t s) {
     RD_REQUIRE(wt_iohw && wl && M && V && cin > 0 && c0 > 0, "rd_tail_compose: bad arguments");
-    return tail_compose_launch(wt_iohw, wl, M, V, cin, c0, (hipStream_t)s);
+    return tail_compose_launch(wt_iohw, bias_t, wl, M, V, VT, B9, cin, c0, (hipStream_t)s);
+}
+
+int rd_conv3x3_last_fwd_tail(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             float slope, const float* slope_dev, const float* t16, const float* b9, const float* w_last,
+                             const float* bias, const float* x_nchw, int x_channels, float* out, int n, int h, int w, int c,
+                             rd_stream_t s) {
+    RD_REQUIRE(z && mean && invstd && gamma && beta && t16 && b9 && w_last && out, "rd_conv3x3_last_fwd_tail: null pointer");
+    RD_REQUIRE((c == 16 || c == 32 || c == 64) && h % 2 == 0 && w % 2 == 0,
+               "rd_conv3x3_last_fwd_tail: C in {16, 32, 64}, H and W even (got %d, %dx%d)", c, h, w);
+    const TailSkip sk = {z, mean, invstd, gamma, beta, slope_dev, slope};
+    ProfScope ps((hipStream_t)s, "conv_last_fwd", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(c + 2 + 4));
+    return conv_last_fwd_tail_launch(sk, t16, b9, w_last, bias, x_nchw, x_channels, out, n, h, w, c, (hipStream_t)s);
+}
+
+size_t rd_conv3x3_last_bwd_weight_tail_ws_bytes(int n, int h, int w, int c) {
+    const long nt = (long)n * cdiv(w, 32) * cdiv(h, 16);
+    return (size_t)(nt < 1024 ? nt : 1024) * (9 * (size_t)c + 9) * sizeof(double);
+}
+
+int rd_conv3x3_last_bwd_weight_tail(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                    float slope, const float* slope_dev, const float* dout, const double* c16, const float* wt_iohw,
+                                    const float* bias_t, float* dw, float* dbias, int n, int h, int w, int cin, int c, void* ws,
+                                    size_t ws_bytes, rd_stream_t s) {
+    RD_REQUIRE(z && mean && invstd && gamma && beta && dout && c16 && wt_iohw && dw, "rd_conv3x3_last_bwd_weight_tail: null pointer");
+    RD_REQUIRE((c == 16 || c == 32 || c == 64) && cin > 0, "rd_conv3x3_last_bwd_weight_tail: C in {16, 32, 64} (got %d)", c);
+    const size_t need = rd_conv3x3_last_bwd_weight_tail_ws_bytes(n, h, w, c);
+    if (!ws || ws_bytes < need) {
+        set_error("rd_conv3x3_last_bwd_weight_tail: workspace too small (%zu < %zu)", ws_bytes, need);
+        return RD_ERR_WS;
+    }
+    const TailSkip sk = {z, mean, invstd, gamma, beta, slope_dev, slope};
+    const long nt = (long)n * cdiv(w, 32) * cdiv(h, 16);
+    const int nb = (int)(nt < 1024 ? nt : 1024);
+    ProfScope ps((hipStream_t)s, "conv_last_wgrad", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(c + 1));
+    if (int e = conv_last_wgrad_tail_launch(sk, dout, (double*)ws, n, h, w, c, (hipStream_t)s)) return e;
+    return tail_wl_finish_launch((const double*)ws, nb, c16, wt_iohw, bias_t, dw, dbias, cin, c, (hipStream_t)s);
 }
 
 int rd_convt_last_bwd_data(const float* dout, const float* V, float* dprev, int n, int hc, int wc, int cin, const float* bn_z,
@@ -1687,8 +1724,8 @@ size_t rd_convt_last_bwd_weight_ws_bytes(int n, int hc, int wc, int cin) {
     return ((size_t)tail_corr_blocks(n, hc, wc) + 1) * 16 * (size_t)cin * sizeof(double);      // block partials + C16
 }
 
-int rd_convt_last_bwd_weight(const float* x, const float* dout, const float* w_last, float* dwt_iohw, int n, int hc, int wc, int cin,
-                             int c0, void* ws, size_t ws_bytes, rd_stream_t s) {
+int rd_convt_last_bwd_weight(const float* x, const float* dout, const float* w_last, float* dwt_iohw, double* c16_out, int n, int hc,
+                             int wc, int cin, int c0, void* ws, size_t ws_bytes, rd_stream_t s) {
     RD_REQUIRE(x && dout && w_last && dwt_iohw && n > 0 && hc > 0 && wc > 0 && c0 > 0, "rd_convt_last_bwd_weight: bad arguments");
     RD_REQUIRE(tail_shape_ok(cin), "rd_convt_last_bwd_weight: Cin must be 32, 64, 128 or 256 (got %d)", cin);
     const size_t need = rd_convt_last_bwd_weight_ws_bytes(n, hc, wc, cin);
@@ -1698,7 +1735,7 @@ int rd_convt_last_bwd_weight(const float* x, const float* dout, const float* w_l
     }
     const int nb = tail_corr_blocks(n, hc, wc);
     double* partial = (double*)ws;
-    double* c16 = partial + (size_t)nb * 16 * cin;
+    double* c16 = c16_out ? c16_out : partial + (size_t)nb * 16 * cin;
     ProfScope ps((hipStream_t)s, "convt2x2_wgrad|convt_last_wgrad", 2.0 * n * hc * wc * 16.0 * cin, 4.0 * n * hc * wc * (double)(cin + 4));
     return convt_last_wgrad_launch(x, dout, w_last, dwt_iohw, partial, c16, n, hc, wc, cin, c0, (hipStream_t)s);
 }

@@ -267,14 +267,52 @@ def tail_available(cin, c0) -> bool:
     return bool(load().rd_tail_available(int(cin), int(c0)))
 
 
-def tail_compose(wt_iohw, w_last):
+def tail_compose(wt_iohw, w_last, bias_t=None, forward=False):
     """-> (M [Cin, 4, 9], V [Cin, 16]): the last up-convolution's weight [Cin, C0, 2, 2] contracted with the last
-    convolution's [1, C0, 3, 3] over C0."""
+    convolution's [1, C0, 3, 3] over C0.  forward=True: also VT [16, Cin, 1, 1] (V transposed, a 1x1 convolution weight) and
+    B9 [9] (the up-convolution's bias seen through the last convolution)."""
     cin, c0 = wt_iohw.shape[0], wt_iohw.shape[1]
     m = torch.empty(cin, 4, 9, device=wt_iohw.device, dtype=torch.float32)
     v = torch.empty(cin, 16, device=wt_iohw.device, dtype=torch.float32)
-    check(load().rd_tail_compose(ptr(wt_iohw.detach()), ptr(w_last.detach()), ptr(m), ptr(v), cin, c0, stream_ptr()), "tail_compose")
-    return m, v
+    vt = torch.empty(16, cin, 1, 1, device=wt_iohw.device, dtype=torch.float32) if forward else None
+    b9 = torch.empty(9, device=wt_iohw.device, dtype=torch.float32) if forward else None
+    check(load().rd_tail_compose(ptr(wt_iohw.detach()), ptr(bias_t.detach() if bias_t is not None else None), ptr(w_last.detach()),
+                                 ptr(m), ptr(v), ptr(vt), ptr(b9), cin, c0, stream_ptr()), "tail_compose")
+    return (m, v, vt, b9) if forward else (m, v)
+
+
+def conv3x3_last_fwd_tail(skip, t16, b9, w_last, bias, x_nchw):
+    """Last convolution on s = up-convolution + act(BN(z)) without s (include/resdepth_hip.h: rd_conv3x3_last_fwd_tail).  skip:
+    level 0's lazy-skip descriptor {z, mean, invstd, gamma, beta, slope, slope_dev}; t16 = conv1x1_fwd(x_coarse, VT)."""
+    z = skip["z"]
+    n, h, wd_, c = z.shape
+    out = torch.empty(n, 1, h, wd_, device=z.device, dtype=torch.float32)
+    xc = x_nchw.shape[1] if x_nchw is not None else 0
+    beta = skip["beta"]
+    check(load().rd_conv3x3_last_fwd_tail(ptr(z), ptr(skip["mean"]), ptr(skip["invstd"]), ptr(skip["gamma"].detach()),
+                                          ptr(beta.detach()), float(skip["slope"]), ptr(skip["slope_dev"]), ptr(t16), ptr(b9),
+                                          ptr(w_last.detach()), ptr(bias.detach() if bias is not None else None), ptr(x_nchw), xc,
+                                          ptr(out), n, h, wd_, c, stream_ptr()), "conv3x3_last_fwd_tail")
+    return out
+
+
+def conv3x3_last_bwd_weight_tail(skip, dout, c16, wt_iohw, bias_t, dw=None, dbias=None, want_bias=True, ws_slot=0):
+    """Weight / bias gradient of the last convolution whose input was never a tensor (conv3x3_last_fwd_tail): from z + dout,
+    the correlations c16 of convt_last_bwd_weight and the up-convolution's weight / bias."""
+    z = skip["z"]
+    n, h, wd_, c = z.shape
+    cin = wt_iohw.shape[0]
+    if dw is None:
+        dw = torch.empty(1, c, 3, 3, device=z.device, dtype=torch.float32)
+    if dbias is None and want_bias:
+        dbias = torch.empty(1, device=z.device, dtype=torch.float32)
+    ws = workspace(load().rd_conv3x3_last_bwd_weight_tail_ws_bytes(n, h, wd_, c), z.device, ws_slot)
+    check(load().rd_conv3x3_last_bwd_weight_tail(ptr(z), ptr(skip["mean"]), ptr(skip["invstd"]), ptr(skip["gamma"].detach()),
+                                                 ptr(skip["beta"].detach()), float(skip["slope"]), ptr(skip["slope_dev"]), ptr(dout),
+                                                 ptr(c16), ptr(wt_iohw.detach()), ptr(bias_t.detach() if bias_t is not None else None),
+                                                 ptr(dw), ptr(dbias), n, h, wd_, cin, c, ws.data_ptr(), ws.numel(), stream_ptr()),
+          "conv3x3_last_bwd_weight_tail")
+    return dw, dbias
 
 
 def convt_last_bwd_data(dout, v, bn=None):
@@ -294,16 +332,17 @@ def convt_last_bwd_data(dout, v, bn=None):
     return dprev, (part, rows.value)
 
 
-def convt_last_bwd_weight(x, dout, w_last, out=None, ws_slot=0):
+def convt_last_bwd_weight(x, dout, w_last, out=None, c16=None, ws_slot=0):
     """Weight gradient [Cin, C0, 2, 2] of the last up-convolution from its input x [N, h, w, Cin] and the network's output
-    gradient dout [N, 1, 2h, 2w]: == convt2x2_bwd_weight(x, conv3x3_last_bwd_data(dout))."""
+    gradient dout [N, 1, 2h, 2w]: == convt2x2_bwd_weight(x, conv3x3_last_bwd_data(dout)).  c16 (optional [Cin, 16] float64
+    tensor): receives the correlations sum_p x[p][ci] dout[2p + d] (conv3x3_last_bwd_weight_tail takes them)."""
     n, hc, wc, cin = x.shape
     c0 = w_last.shape[1]
     if out is None:
         out = torch.empty(cin, c0, 2, 2, device=x.device, dtype=torch.float32)
     ws = workspace(load().rd_convt_last_bwd_weight_ws_bytes(n, hc, wc, cin), x.device, ws_slot)
-    check(load().rd_convt_last_bwd_weight(ptr(x), ptr(dout), ptr(w_last.detach()), ptr(out), n, hc, wc, cin, c0, ws.data_ptr(),
-                                          ws.numel(), stream_ptr()), "convt_last_bwd_weight")
+    check(load().rd_convt_last_bwd_weight(ptr(x), ptr(dout), ptr(w_last.detach()), ptr(out), ptr(c16), n, hc, wc, cin, c0,
+                                          ws.data_ptr(), ws.numel(), stream_ptr()), "convt_last_bwd_weight")
     return out
 
 

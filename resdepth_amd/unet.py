@@ -392,6 +392,19 @@ class UNet(nn.Module):
         up = self.decoder[i][0] if i < self.depth - 1 else self.decoder[i]
         return up[1] if self.up_mode == "bilinear" else up
 
+    def _tail_forward(self, cur, up, skip):
+        """The last up-convolution when the last convolution follows it directly (lib/UNet.py:218-227) and the skip is level 0's
+        lazy descriptor: its 64-channel full-resolution output is not built -- T = cur . V (a 1x1 convolution to 16 channels at
+        the coarse resolution) and B9 are all the last convolution needs of it (ops.conv3x3_last_fwd_tail).  -> None when this
+        shape / mode keeps the two-kernel route, else {skip, t16, b9, v}."""
+        ll = self.last_layer
+        if not (self.composed_tail and self.up_mode == "transpose" and isinstance(skip, dict) and ll.weight.shape[1] in (16, 32, 64)
+                and cur.shape[1] * 2 == skip["z"].shape[1] and ops.tail_available(up.weight.shape[0], up.weight.shape[1])):
+            return None
+        _, v, vt, b9 = ops.tail_compose(up.weight, ll.weight, up.bias, forward=True)
+        t16 = ops.conv1x1_fwd(cur, ops.pack_conv1x1_weight(vt)[0])
+        return {"skip": skip, "t16": t16, "b9": b9, "v": v}
+
     def _up_forward(self, cur, packed, up, skip):
         if self.up_mode == "bilinear":
             return ops.upsample2x_add_fwd(ops.conv1x1_fwd(cur, packed[0]), up.bias, skip)
@@ -518,13 +531,20 @@ class UNet(nn.Module):
             a, cur = self._conv_act(cur, fold[i - 1], True)
             skips.append(a)
         cur, _ = self._conv_act(cur, fold[d - 1], False)
+        tail = None
         for i in range(d):
+            if i == d - 1:
+                tail = self._tail_forward(cur, self._up_of(i), skips[0])
+                if tail is not None:
+                    break
             s = self._up_forward(cur, pk.get(("dec_t", i)), self._up_of(i), skips[d - 1 - i])
             skips[d - 1 - i] = None
             cur = self._conv_act(s, fold[d + i], False)[0] if i < d - 1 else s
         x_res = x if self.do_outer_skip else None
         if self.do_outer_skip and self.do_outer_skip_BN:
             x_res, _ = self._outer_bn_forward(x, False)
+        if tail is not None:
+            return ops.conv3x3_last_fwd_tail(tail["skip"], tail["t16"], tail["b9"], self.last_layer.weight, self.last_layer.bias, x_res)
         return ops.conv3x3_last_fwd(cur, self.last_layer.weight, self.last_layer.bias, x_res)
 
     def _engine_forward(self, x, training: bool, save: bool, keep_skips: bool = False):
@@ -592,7 +612,14 @@ class UNet(nn.Module):
         if save:
             S["bott"] = {"z": zb, "mean": mean, "invstd": invstd, "count": count, "a": ab}
         cur = ab
+        tail = None
         for i in range(d):
+            if i == d - 1:
+                tail = self._tail_forward(cur, self._up_of(i), skips[0])
+                if tail is not None:
+                    if save:
+                        S["dec"].append({"s": None, "tail": tail})
+                    break
             s = self._up_forward(cur, pk.get(("dec_t", i)), self._up_of(i), skips[d - 1 - i])
             skips[d - 1 - i] = None          # the skip tensor is not needed by the backward pass
             rec = {"s": s}
@@ -613,7 +640,10 @@ class UNet(nn.Module):
             x_res, obn = self._outer_bn_forward(x, training)          # BatchNorm2d(1) on channel 0 (lib/UNet.py:230-237)
             if save:
                 S["outer_bn"] = obn
-        out = ops.conv3x3_last_fwd(cur, self.last_layer.weight, self.last_layer.bias, x_res)
+        if tail is not None:
+            out = ops.conv3x3_last_fwd_tail(tail["skip"], tail["t16"], tail["b9"], self.last_layer.weight, self.last_layer.bias, x_res)
+        else:
+            out = ops.conv3x3_last_fwd(cur, self.last_layer.weight, self.last_layer.bias, x_res)
         return out, S
 
     def _outer_bn_forward(self, x, training):
@@ -821,9 +851,11 @@ class UNet(nn.Module):
         c0 = self.filter_depths[0]
         # head (lib/UNet.py:227-244): the outer residual add passes dout straight through to x (not needed)
         ll = self.last_layer
-        wgrad(lambda *a, **k: ops.conv3x3_last_bwd_weight(*a, want_bias=ll.bias is not None, **k), (dout,),
-              S["dec"][d - 1]["s"], dout, gv(ll.weight), gv(ll.bias) if ll.bias is not None else None,
-              ready=(ll.weight, ll.bias))
+        fwd_tail = S["dec"][d - 1].get("tail")      # the forward never built the last convolution's input (_tail_forward)
+        if fwd_tail is None:
+            wgrad(lambda *a, **k: ops.conv3x3_last_bwd_weight(*a, want_bias=ll.bias is not None, **k), (dout,),
+                  S["dec"][d - 1]["s"], dout, gv(ll.weight), gv(ll.bias) if ll.bias is not None else None,
+                  ready=(ll.weight, ll.bias))
         if "outer_bn" in S:
             # BatchNorm2d(1) on the outer skip: only its affine parameters need gradients (x is an input)
             ob = S["outer_bn"]
@@ -839,7 +871,8 @@ class UNet(nn.Module):
         # bottleneck block behind a transposed convolution
         hook0 = hook(S["enc"][0], self.encoder[0][0], self.act_fn_encoder)
         up_last = self._up_of(d - 1)
-        tail = (self.composed_tail and self.up_mode == "transpose" and ops.tail_available(up_last.weight.shape[0], up_last.weight.shape[1]))
+        tail = fwd_tail is not None or (self.composed_tail and self.up_mode == "transpose"
+                                        and ops.tail_available(up_last.weight.shape[0], up_last.weight.shape[1]))
         fuse_first = (self.fused_first_wgrad and self.do_BN and not want_dx and not self._first_generic()
                       and ops.conv3x3_first_bwd_weight_bn_available(S["x"], c0))
         if tail and fuse_first and hook0 is not None and c0 in (16, 32, 64):
@@ -865,8 +898,19 @@ class UNet(nn.Module):
                 if i == d - 1 and tail:
                     # the last up-convolution feeds the last convolution directly (lib/UNet.py:218-227): its two gradients are
                     # stencils / correlations on the 1-channel dout, the C0-channel gradient g is not an operand (ops.tail_*)
-                    _, tail_v = ops.tail_compose(up.weight, ll.weight)
-                    wgrad(ops.convt_last_bwd_weight, (dout, tail_v), src["a"], dout, ll.weight, gv(up.weight), ready=(up.weight,))
+                    if fwd_tail is not None:
+                        tail_v = fwd_tail["v"]
+                        c16 = torch.empty(up.weight.shape[0], 16, device=dout.device, dtype=torch.float64)
+                        wgrad(lambda *a, **k: ops.convt_last_bwd_weight(*a, c16=c16, **k), (dout, tail_v, c16), src["a"], dout,
+                              ll.weight, gv(up.weight), ready=(up.weight,))
+                        # ... and the last convolution's own weight gradient, whose input s was never a tensor: z of level 0 +
+                        # dout, the correlations c16 just computed, the up-convolution's weight and bias
+                        wgrad(lambda *a, **k: ops.conv3x3_last_bwd_weight_tail(*a, want_bias=ll.bias is not None, **k), (dout,),
+                              fwd_tail["skip"], dout, c16, up.weight, up.bias, gv(ll.weight),
+                              gv(ll.bias) if ll.bias is not None else None, ready=(ll.weight, ll.bias))
+                    else:
+                        _, tail_v = ops.tail_compose(up.weight, ll.weight)
+                        wgrad(ops.convt_last_bwd_weight, (dout, tail_v), src["a"], dout, ll.weight, gv(up.weight), ready=(up.weight,))
                     dprev, dstat = with_stats(ops.convt_last_bwd_data, dout, tail_v, bn=hook(src, sblk, sact))
                 else:
                     assert not isinstance(g, ops.LastConvGrad)

@@ -820,3 +820,49 @@ def test_tail_weight_gradient_of_the_last_up_convolution_from_the_output_gradien
     close(got.cpu(), wt.grad.float(), name="composed weight gradient")
     want2 = ops.convt2x2_bwd_weight(nhwc(x), ops.conv3x3_last_bwd_data(dout.to(dev()), wl.to(dev()), c0))
     close(got.cpu(), want2.cpu(), name="vs the two-kernel route")
+
+
+@pytest.mark.parametrize("n,h,w,cin,c0,slope,res", [(2, 64, 64, 128, 64, 0.0, True), (3, 32, 96, 64, 32, 0.01, False),
+                                                    (1, 36, 20, 32, 16, 0.01, True)])
+def test_tail_forward_and_last_weight_gradient_without_the_up_convolution_output(n, h, w, cin, c0, slope, res):
+    """rd_conv3x3_last_fwd_tail / rd_conv3x3_last_bwd_weight_tail: the last convolution applied to
+    s = ConvTranspose2d(x_coarse) + act(BN(z)) (lib/UNet.py:218-227) without s ever being a tensor -- forward from z (BN +
+    activation on load), T = x_coarse . V and the bias stencil; its weight / bias gradient from z, dout and the correlations C16.
+    Against torch in fp64 on the materialised s, borders included."""
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(h * 3 + cin)
+    xc = torch.randn(n, cin, h // 2, w // 2, generator=g)
+    z = torch.randn(n, c0, h, w, generator=g)
+    wt = torch.randn(cin, c0, 2, 2, generator=g) / (cin ** 0.5)
+    bt = torch.randn(c0, generator=g) * 0.2
+    wl = torch.randn(1, c0, 3, 3, generator=g) / 3
+    bl = torch.randn(1, generator=g)
+    xin = torch.randn(n, 3, h, w, generator=g)
+    mean, invstd = torch.randn(c0, generator=g) * 0.2, torch.rand(c0, generator=g) + 0.5
+    gamma, beta = torch.randn(c0, generator=g), torch.randn(c0, generator=g) * 0.3
+    # reference in fp64
+    y = (z.double() - mean.double().view(1, -1, 1, 1)) * (invstd.double() * gamma.double()).view(1, -1, 1, 1) + beta.double().view(1, -1, 1, 1)
+    a0 = torch.where(y > 0, y, y * slope)
+    s = F.conv_transpose2d(xc.double(), wt.double(), bt.double(), stride=2) + a0
+    wl64 = wl.double().requires_grad_(True)
+    bl64 = bl.double().requires_grad_(True)
+    out_ref = F.conv2d(s, wl64, bl64, padding=1) + (xin.double()[:, 0:1] if res else 0)
+    dout = torch.randn(n, 1, h, w, generator=g)
+    (out_ref * dout.double()).sum().backward()
+    # HIP
+    D = dev()
+    skip = {"z": nhwc(z), "mean": mean.to(D), "invstd": invstd.to(D), "gamma": gamma.to(D), "beta": beta.to(D), "slope": slope, "slope_dev": None}
+    m, v, vt, b9 = ops.tail_compose(wt.to(D), wl.to(D), bt.to(D), forward=True)
+    assert torch.equal(vt.view(16, cin).t().contiguous(), v)
+    t16 = ops.conv1x1_fwd(nhwc(xc), ops.pack_conv1x1_weight(vt)[0])
+    out = ops.conv3x3_last_fwd_tail(skip, t16, b9, wl.to(D), bl.to(D), xin.to(D) if res else None)
+    close(out.cpu(), out_ref.detach().float(), tol=3e-6, name="tail forward")
+    c16 = torch.empty(cin, 16, dtype=torch.float64, device=D)
+    ops.convt_last_bwd_weight(nhwc(xc), dout.to(D), wl.to(D), c16=c16)
+    dw, db = ops.conv3x3_last_bwd_weight_tail(skip, dout.to(D), c16, wt.to(D), bt.to(D))
+    close(dw.cpu(), wl64.grad.float(), tol=3e-6, name="tail last-conv weight gradient")
+    assert abs(float(db) - float(bl64.grad)) <= 1e-5 * max(1.0, abs(float(bl64.grad)))
+    # without an up-convolution bias
+    out_nb = ops.conv3x3_last_fwd_tail(skip, t16, ops.tail_compose(wt.to(D), wl.to(D), None, forward=True)[3], wl.to(D), None, None)
+    s_nb = F.conv_transpose2d(xc.double(), wt.double(), None, stride=2) + a0
+    close(out_nb.cpu(), F.conv2d(s_nb, wl.double(), None, padding=1).float(), tol=3e-6, name="tail forward, no biases")
