@@ -179,6 +179,16 @@ int rd_conv3x3_last_fwd_tail(const float* z, const float* mean, const float* inv
                              float slope, const float* slope_dev, const float* t16, const float* b9, const float* w_last,
                              const float* bias, const float* x_nchw, int x_channels, float* out, int n, int h, int w, int c,
                              rd_stream_t s);
+/* The head of the backward in one pass over z: the partial sums of rd_conv3x3_last_bwd_weight_tail (wpartial:
+ * rd_conv3x3_last_bwd_tail_blocks() rows of 9*C + 9 doubles, finished by rd_tail_wl_finish once C16 is there) AND the BN-backward
+ * statistics of level 0 that rd_conv3x3_last_bwd_data_bnstats emits (part / rows_out as there; the data gradient itself is
+ * evaluated per element and not stored). */
+int rd_conv3x3_last_bwd_tail_blocks(int n, int h, int w);
+int rd_conv3x3_last_bwd_tail_fused(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                   float slope, const float* slope_dev, const float* dout, const float* w_last, double* wpartial,
+                                   float* part, size_t part_floats, int* rows_out, int n, int h, int w, int c, rd_stream_t s);
+int rd_tail_wl_finish(const double* wpartial, int nb, const double* c16, const float* wt_iohw, const float* bias_t, float* dw,
+                      float* dbias, int cin, int c, rd_stream_t s);
 size_t rd_conv3x3_last_bwd_weight_tail_ws_bytes(int n, int h, int w, int c);
 int rd_conv3x3_last_bwd_weight_tail(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                     float slope, const float* slope_dev, const float* dout, const double* c16, const float* wt_iohw,

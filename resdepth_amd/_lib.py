@@ -54,6 +54,9 @@ SIGNATURES = {
     "rd_tail_available": (I, [I, I]),
     "rd_tail_compose": (I, [P, P, P, P, P, P, P, I, I, P]),
     "rd_conv3x3_last_fwd_tail": (I, [P, P, P, P, P, F, P, P, P, P, P, P, I, P, I, I, I, I, P]),
+    "rd_conv3x3_last_bwd_tail_blocks": (I, [I, I, I]),
+    "rd_conv3x3_last_bwd_tail_fused": (I, [P, P, P, P, P, F, P, P, P, P, P, SZ, P, I, I, I, I, P]),
+    "rd_tail_wl_finish": (I, [P, I, P, P, P, P, P, I, I, P]),
     "rd_conv3x3_last_bwd_weight_tail_ws_bytes": (SZ, [I, I, I, I]),
     "rd_conv3x3_last_bwd_weight_tail": (I, [P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_convt_last_bwd_weight_ws_bytes": (SZ, [I, I, I, I]),

@@ -99,6 +99,9 @@ int tail_compose_launch(const float* wt, const float* bt, const float* wl, float
 int conv_last_fwd_tail_launch(const TailSkip& sk, const float* t16, const float* b9, const float* wt, const float* bias,
                               const float* x_nchw, int xc, float* out, int n, int h, int w, int c, hipStream_t s);
 int conv_last_wgrad_tail_launch(const TailSkip& sk, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s);
+int conv_last_tail_blocks(int n, int h, int w);
+int conv_last_bwd_tail_fused_launch(const TailSkip& sk, const float* dout, const float* wl, double* wpartial, float* bn_part, int n,
+                                    int h, int w, int c, hipStream_t s);
 int tail_wl_finish_launch(const double* partial, int nb, const double* c16, const float* wt, const float* bt, float* dw, float* dbias,
                           int cin, int c0, hipStream_t s);
 bool tail_shape_ok(int cin);

@@ -702,6 +702,126 @@ __global__ __launch_bounds__(256) void conv_last_wgrad_tail_kernel(TailSkip sk, 
     }
 }
 
+// Head of the backward in ONE pass over level 0's z (tail of the network): the partial sums of conv_last_wgrad_tail_kernel AND the
+// BN-backward statistics of level 0 that conv_last_dgrad_tile_kernel<true> emits (g = conv_last^T(dout) evaluated per element, never
+// stored) -- both need exactly z and the dout tile.  Persistent blocks; per block one row [9][C] + [9] of doubles (wpartial) and
+// one row [4][C] of floats (bn_part, the layout bn_bwd_stats_finalize_kernel takes).
+__global__ __launch_bounds__(256) void conv_last_bwd_tail_fused_kernel(TailSkip sk, const float* __restrict__ dout,
+                                                                       const float* __restrict__ w, double* __restrict__ wpartial,
+                                                                       float* __restrict__ bn_part, int N, int H, int W, int C, int CQ,
+                                                                       int tiles_x, int tiles_y, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float esm[];     // D[EH_NP] (padded to 640), then the reduction scratch
+    float* D = esm;
+    float* red = esm + 640;                        // [PPI][9][C] floats (>= 256 * 16)
+    const int t = threadIdx.x, q = t % CQ, slot = t / CQ, PPI = 256 / CQ;
+    float acc[9][4], wr[9][4], accs[9], bacc[16];
+    float sc[4], sh[4], mu[4], is[4];
+    const float slope = sk.slope_dev ? sk.slope_dev[0] : sk.slope;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = q * 4 + k;
+        mu[k] = sk.mean[c];
+        is[k] = sk.invstd[c];
+        sc[k] = is[k] * sk.gamma[c];
+        sh[k] = sk.beta[c] - mu[k] * sc[k];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        accs[tap] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[tap][k] = 0.f;
+            wr[tap][k] = w[(q * 4 + k) * 9 + tap];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bacc[k] = 0.f;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+        const int y0 = ty * ET_H, x0 = tx * ET_W;
+        __syncthreads();
+        load_dout_tile(D, dout, n, y0, x0, H, W, t);
+        __syncthreads();
+        constexpr int UN = 4;
+        for (int e0 = 0; e0 < ET_H * ET_W; e0 += PPI * UN) {
+            float4 z4[UN];
+            int py[UN], px[UN];
+            bool ok[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int e = e0 + u * PPI + slot;
+                py[u] = e / ET_W;
+                px[u] = e - py[u] * ET_W;
+                ok[u] = y0 + py[u] < H && x0 + px[u] < W;
+                z4[u] = ok[u] ? *reinterpret_cast<const float4*>(sk.z + (((long)n * H + y0 + py[u]) * W + x0 + px[u]) * C + q * 4)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (!ok[u]) continue;
+                const float zz[4] = {z4[u].x, z4[u].y, z4[u].z, z4[u].w};
+                float yv[4], av[4], g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    yv[k] = fmaf(zz[k], sc[k], sh[k]);
+                    av[k] = yv[k] > 0.f ? yv[k] : yv[k] * slope;
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float d = D[(py[u] + 2 - tap / 3) * EH_W + px[u] + 2 - tap % 3];      // dout[q - off(tap)]
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        acc[tap][k] = fmaf(av[k], d, acc[tap][k]);
+                        g[k] = fmaf(d, wr[tap][k], g[k]);
+                    }
+                    if (q == 0) accs[tap] += d;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float gm = g[k] * (yv[k] > 0.f ? 1.f : slope);
+                    const float xh = (zz[k] - mu[k]) * is[k];
+                    bacc[k] += gm;
+                    bacc[4 + k] = fmaf(gm, xh, bacc[4 + k]);
+                    bacc[8 + k] += g[k];
+                    if (!(yv[k] > 0.f)) bacc[12 + k] = fmaf(g[k], yv[k], bacc[12 + k]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+        *reinterpret_cast<float4*>(red + ((slot * 9 + tap) * C) + q * 4) = make_float4(acc[tap][0], acc[tap][1], acc[tap][2], acc[tap][3]);
+    __syncthreads();
+    double* out = wpartial + (long)blockIdx.x * (9 * C + 9);
+    for (int e = t; e < 9 * C; e += 256) {
+        double sum = 0.0;
+        for (int sl = 0; sl < PPI; ++sl) sum += (double)red[sl * 9 * C + e];
+        out[e] = sum;
+    }
+    __syncthreads();
+    if (q == 0) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) red[slot * 9 + tap] = accs[tap];
+    }
+    __syncthreads();
+    if (t < 9) {
+        double sum = 0.0;
+        for (int sl = 0; sl < PPI; ++sl) sum += (double)red[sl * 9 + t];
+        out[9 * C + t] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) red[t * 16 + k] = bacc[k];
+    __syncthreads();
+    for (int o = t; o < 4 * C; o += 256) {
+        const int sidx = o / C, c = o - sidx * C;
+        float sum = 0.f;
+        for (int sl = 0; sl < PPI; ++sl) sum += red[(sl * CQ + (c >> 2)) * 16 + sidx * 4 + (c & 3)];
+        bn_part[((long)blockIdx.x * 4 + sidx) * C + c] = sum;
+    }
+}
+
 // dw[co][tap] = sum_b partial[b][tap * C0 + co]                                              (act(BN(z)) part)
 //             + sum_ci sum_ab Wt[ci][co][ab] C16[ci][(a,b) - off(tap)]                        (up-convolution part)
 //             + bt[co] S[tap]                                                                 (its bias);   dbias = S[4]
@@ -1108,6 +1228,21 @@ int conv_last_wgrad_tail_launch(const TailSkip& sk, const float* dout, double* p
     const size_t smem = (640 + (size_t)(256 / (c / 4)) * 9 * c) * sizeof(float);
     hipLaunchKernelGGL(conv_last_wgrad_tail_kernel, dim3(nb), dim3(256), smem, s, sk, dout, partial, n, h, w, c, c / 4, tx, ty, (int)nt);
     RD_LAUNCH_CHECK("conv_last_wgrad_tail");
+    return RD_OK;
+}
+
+int conv_last_tail_blocks(int n, int h, int w) {
+    const long nt = (long)n * cdiv(w, ET_W) * cdiv(h, ET_H);
+    return (int)(nt < 1024 ? nt : 1024);
+}
+
+int conv_last_bwd_tail_fused_launch(const TailSkip& sk, const float* dout, const float* wl, double* wpartial, float* bn_part, int n,
+                                    int h, int w, int c, hipStream_t s) {
+    const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H), nb = conv_last_tail_blocks(n, h, w);
+    const size_t smem = (640 + (size_t)(256 / (c / 4)) * 9 * c) * sizeof(float);
+    hipLaunchKernelGGL(conv_last_bwd_tail_fused_kernel, dim3(nb), dim3(256), smem, s, sk, dout, wl, wpartial, bn_part, n, h, w, c, c / 4,
+                       tx, ty, n * tx * ty);
+    RD_LAUNCH_CHECK("conv_last_bwd_tail_fused");
     return RD_OK;
 }
 

@@ -1678,6 +1678,30 @@ int rd_conv3x3_last_fwd_tail(const float* z, const float* mean, const float* inv
     return conv_last_fwd_tail_launch(sk, t16, b9, w_last, bias, x_nchw, x_channels, out, n, h, w, c, (hipStream_t)s);
 }
 
+int rd_conv3x3_last_bwd_tail_blocks(int n, int h, int w) { return conv_last_tail_blocks(n, h, w); }
+
+int rd_conv3x3_last_bwd_tail_fused(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                   float slope, const float* slope_dev, const float* dout, const float* w_last, double* wpartial,
+                                   float* part, size_t part_floats, int* rows_out, int n, int h, int w, int c, rd_stream_t s) {
+    RD_REQUIRE(z && mean && invstd && gamma && beta && dout && w_last && wpartial && part && rows_out,
+               "rd_conv3x3_last_bwd_tail_fused: null pointer");
+    RD_REQUIRE(c == 16 || c == 32 || c == 64, "rd_conv3x3_last_bwd_tail_fused: C in {16, 32, 64} (got %d)", c);
+    const int nb = conv_last_tail_blocks(n, h, w);
+    RD_REQUIRE(part_floats >= (size_t)nb * 4 * c, "rd_conv3x3_last_bwd_tail_fused: statistics buffer too small");
+    const TailSkip sk = {z, mean, invstd, gamma, beta, slope_dev, slope};
+    ProfScope ps((hipStream_t)s, "conv_last_dgrad", 2.0 * n * h * w * 18.0 * c, 4.0 * n * h * w * (double)(c + 1));
+    if (int e = conv_last_bwd_tail_fused_launch(sk, dout, w_last, wpartial, part, n, h, w, c, (hipStream_t)s)) return e;
+    *rows_out = nb;
+    return RD_OK;
+}
+
+int rd_tail_wl_finish(const double* wpartial, int nb, const double* c16, const float* wt_iohw, const float* bias_t, float* dw,
+                      float* dbias, int cin, int c, rd_stream_t s) {
+    RD_REQUIRE(wpartial && nb > 0 && c16 && wt_iohw && dw && cin > 0 && c > 0, "rd_tail_wl_finish: bad arguments");
+    ProfScope ps((hipStream_t)s, "conv_last_wgrad", 0, 8.0 * nb * (9.0 * c + 9));
+    return tail_wl_finish_launch(wpartial, nb, c16, wt_iohw, bias_t, dw, dbias, cin, c, (hipStream_t)s);
+}
+
 size_t rd_conv3x3_last_bwd_weight_tail_ws_bytes(int n, int h, int w, int c) {
     const long nt = (long)n * cdiv(w, 32) * cdiv(h, 16);
     return (size_t)(nt < 1024 ? nt : 1024) * (9 * (size_t)c + 9) * sizeof(double);

@@ -296,6 +296,34 @@ def conv3x3_last_fwd_tail(skip, t16, b9, w_last, bias, x_nchw):
     return out
 
 
+def conv3x3_last_bwd_tail_fused(skip, dout, w_last):
+    """One pass over level 0's z at the head of the backward: -> (wpartial, (BN-backward partial rows, count)) -- the partial
+    sums of the last convolution's weight gradient (tail_wl_finish completes them) and the statistics of the level-0 hook."""
+    z = skip["z"]
+    n, h, wd_, c = z.shape
+    nb = load().rd_conv3x3_last_bwd_tail_blocks(n, h, wd_)
+    wpartial = torch.empty(nb, 9 * c + 9, device=z.device, dtype=torch.float64)
+    part, rows = torch.empty(nb * 4 * c, device=z.device, dtype=torch.float32), ctypes.c_int(0)
+    check(load().rd_conv3x3_last_bwd_tail_fused(ptr(z), ptr(skip["mean"]), ptr(skip["invstd"]), ptr(skip["gamma"].detach()),
+                                                ptr(skip["beta"].detach()), float(skip["slope"]), ptr(skip["slope_dev"]), ptr(dout),
+                                                ptr(w_last.detach()), ptr(wpartial), ptr(part), part.numel(), ctypes.byref(rows),
+                                                n, h, wd_, c, stream_ptr()), "conv3x3_last_bwd_tail_fused")
+    return wpartial, (part, rows.value)
+
+
+def tail_wl_finish(wpartial, c16, wt_iohw, bias_t, dw=None, dbias=None, want_bias=True, ws_slot=0):
+    """Completes conv3x3_last_bwd_tail_fused's weight-gradient partials with the up-convolution part (c16) and its bias."""
+    c = (wpartial.shape[1] - 9) // 9
+    if dw is None:
+        dw = torch.empty(1, c, 3, 3, device=wpartial.device, dtype=torch.float32)
+    if dbias is None and want_bias:
+        dbias = torch.empty(1, device=wpartial.device, dtype=torch.float32)
+    check(load().rd_tail_wl_finish(ptr(wpartial), wpartial.shape[0], ptr(c16), ptr(wt_iohw.detach()),
+                                   ptr(bias_t.detach() if bias_t is not None else None), ptr(dw), ptr(dbias), wt_iohw.shape[0], c,
+                                   stream_ptr()), "tail_wl_finish")
+    return dw, dbias
+
+
 def conv3x3_last_bwd_weight_tail(skip, dout, c16, wt_iohw, bias_t, dw=None, dbias=None, want_bias=True, ws_slot=0):
     """Weight / bias gradient of the last convolution whose input was never a tensor (conv3x3_last_fwd_tail): from z + dout,
     the correlations c16 of convt_last_bwd_weight and the up-convolution's weight / bias."""

@@ -879,10 +879,17 @@ class UNet(nn.Module):
             # g = conv_last^T(dout), C0 channels at full resolution, has three readers -- the last up-convolution's two gradients
             # and level 0's BN backward -- and all three evaluate what they need from the 1-channel dout: only the statistics of
             # the hook leave this launch, the tensor is never written
-            _, st = ops.conv3x3_last_bwd_data(dout, ll.weight, c0, bn=hook0, write=False)
+            wpart = None
+            if fwd_tail is not None:
+                # ... and with the forward tail the last convolution's weight gradient needs the same two operands (z of level
+                # 0, the dout tile): one pass gives its partial sums and the hook's statistics
+                wpart, st = ops.conv3x3_last_bwd_tail_fused(fwd_tail["skip"], dout, ll.weight)
+            else:
+                _, st = ops.conv3x3_last_bwd_data(dout, ll.weight, c0, bn=hook0, write=False)
             st = st if st[1] > 0 else None
             g = ops.LastConvGrad(dout, ll.weight, c0)
         else:
+            wpart = None
             g, st = with_stats(ops.conv3x3_last_bwd_data, dout, ll.weight, c0, bn=hook0)
         skipgrad, skipstat = [None] * d, [None] * d
         gp = gpstat = None
@@ -905,9 +912,14 @@ class UNet(nn.Module):
                               ll.weight, gv(up.weight), ready=(up.weight,))
                         # ... and the last convolution's own weight gradient, whose input s was never a tensor: z of level 0 +
                         # dout, the correlations c16 just computed, the up-convolution's weight and bias
-                        wgrad(lambda *a, **k: ops.conv3x3_last_bwd_weight_tail(*a, want_bias=ll.bias is not None, **k), (dout,),
-                              fwd_tail["skip"], dout, c16, up.weight, up.bias, gv(ll.weight),
-                              gv(ll.bias) if ll.bias is not None else None, ready=(ll.weight, ll.bias))
+                        if wpart is not None:      # its pass over z already ran with the statistics hook (head of the backward)
+                            wgrad(lambda *a, **k: ops.tail_wl_finish(*a, want_bias=ll.bias is not None, **k), (wpart,), wpart, c16,
+                                  up.weight, up.bias, gv(ll.weight), gv(ll.bias) if ll.bias is not None else None,
+                                  ready=(ll.weight, ll.bias))
+                        else:
+                            wgrad(lambda *a, **k: ops.conv3x3_last_bwd_weight_tail(*a, want_bias=ll.bias is not None, **k), (dout,),
+                                  fwd_tail["skip"], dout, c16, up.weight, up.bias, gv(ll.weight),
+                                  gv(ll.bias) if ll.bias is not None else None, ready=(ll.weight, ll.bias))
                     else:
                         _, tail_v = ops.tail_compose(up.weight, ll.weight)
                         wgrad(ops.convt_last_bwd_weight, (dout, tail_v), src["a"], dout, ll.weight, gv(up.weight), ready=(up.weight,))

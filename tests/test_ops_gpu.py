@@ -862,6 +862,16 @@ def test_tail_forward_and_last_weight_gradient_without_the_up_convolution_output
     dw, db = ops.conv3x3_last_bwd_weight_tail(skip, dout.to(D), c16, wt.to(D), bt.to(D))
     close(dw.cpu(), wl64.grad.float(), tol=3e-6, name="tail last-conv weight gradient")
     assert abs(float(db) - float(bl64.grad)) <= 1e-5 * max(1.0, abs(float(bl64.grad)))
+    # the fused head of the backward: same weight gradient through tail_wl_finish, same statistics as the data-gradient hook
+    wpart, stat = ops.conv3x3_last_bwd_tail_fused(skip, dout.to(D), wl.to(D))
+    dw2, db2 = ops.tail_wl_finish(wpart, c16, wt.to(D), bt.to(D))
+    close(dw2.cpu(), wl64.grad.float(), tol=3e-6, name="fused head: last-conv weight gradient")
+    assert abs(float(db2) - float(bl64.grad)) <= 1e-5 * max(1.0, abs(float(bl64.grad)))
+    hook = ops.BnHook(skip["z"], skip["mean"], skip["invstd"], skip["gamma"], skip["beta"], slope, None, 1)
+    _, stat_ref = ops.conv3x3_last_bwd_data(dout.to(D), wl.to(D), c0, bn=hook)
+    s_a, s_b = ops.bn_bwd_stats_finalize([stat], c0), ops.bn_bwd_stats_finalize([stat_ref], c0)
+    scale = s_b.abs().view(4, c0).amax(1, keepdim=True).expand(4, c0).reshape(-1) + 1e-30
+    assert float(((s_a - s_b).abs() / scale).max()) <= 1e-5
     # without an up-convolution bias
     out_nb = ops.conv3x3_last_fwd_tail(skip, t16, ops.tail_compose(wt.to(D), wl.to(D), None, forward=True)[3], wl.to(D), None, None)
     s_nb = F.conv_transpose2d(xc.double(), wt.double(), None, stride=2) + a0
