@@ -848,15 +848,26 @@ __global__ __launch_bounds__(256) void tail_wl_finish_kernel(const double* __res
         tot[t] = sum;
     }
     __syncthreads();
+    // up-convolution part: 9 taps x 28 slices of the input channels (fixed order), combined through LDS
+    {
+        const int tap = t % 9, sl = t / 9;          // 252 threads
+        double up = 0.0;
+        if (sl < 28) {
+            for (int ci = sl; ci < Cin; ci += 28)
+#pragma unroll
+                for (int ab = 0; ab < 4; ++ab) {
+                    const int dy = (ab >> 1) - (tap / 3 - 1), dx = (ab & 1) - (tap % 3 - 1);
+                    up += (double)wt[((long)ci * C0 + co) * 4 + ab] * c16[(long)ci * 16 + (dy + 1) * 4 + dx + 1];
+                }
+        }
+        __syncthreads();
+        red[t] = up;
+        __syncthreads();
+    }
     if (t < 9) {
         const int tap = t;
         double up = 0.0;
-        for (int ci = 0; ci < Cin; ++ci)
-#pragma unroll
-            for (int ab = 0; ab < 4; ++ab) {
-                const int dy = (ab >> 1) - (tap / 3 - 1), dx = (ab & 1) - (tap % 3 - 1);
-                up += (double)wt[((long)ci * C0 + co) * 4 + ab] * c16[(long)ci * 16 + (dy + 1) * 4 + dx + 1];
-            }
+        for (int sl = 0; sl < 28; ++sl) up += red[sl * 9 + tap];
         const double bias_part = bt ? (double)bt[co] * tot[9 + tap] : 0.0;
         dw[co * 9 + tap] = (float)((tot[tap] + up) + bias_part);
         if (co == 0 && tap == 4 && dbias) dbias[0] = (float)tot[9 + 4];
