@@ -166,6 +166,14 @@ int rd_convt_last_bwd_data(const float* dout, const float* V, float* dprev, int 
 size_t rd_convt_last_bwd_weight_ws_bytes(int n, int hc, int wc, int cin);
 int rd_convt_last_bwd_weight(const float* x, const float* dout, const float* w_last, float* dwt_iohw, double* c16_out /* [Cin][16],
                              nullable */, int n, int hc, int wc, int cin, int c0, void* ws, size_t ws_bytes, rd_stream_t s);
+/* The same with x = act(BN(z)) evaluated on load (x = z, the pre-BN tensor of the block that feeds the up-convolution): that
+ * block's activation need not be a tensor either.  rd_tail_t16: T [pixels][16] = act(BN(z)) . V on the exact-f32 matrix pipe
+ * (mean = NULL: z is the activation itself) -- the 1x1 convolution of the forward below without a packed operand. */
+int rd_convt_last_bwd_weight_bn(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                float slope, const float* slope_dev, const float* dout, const float* w_last, float* dwt_iohw,
+                                double* c16_out, int n, int hc, int wc, int cin, int c0, void* ws, size_t ws_bytes, rd_stream_t s);
+int rd_tail_t16(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                const float* slope_dev, const float* V, float* t16, long long pixels, int cin, rd_stream_t s);
 /* FORWARD of the tail without its input tensor.  s = up-convolution(x_coarse) + bias_t + act(BN(z)) is what the reference feeds
  * the last convolution (lib/UNet.py:218-227); here
  *   out[q] = conv_last(act(BN(z)))[q] + sum_{p': d = q - 2p' in [-1,2]^2} T[p'][d] + sum_{tap: q + off(tap) inside} B9[tap] + bias

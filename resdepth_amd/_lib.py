@@ -61,6 +61,8 @@ SIGNATURES = {
     "rd_conv3x3_last_bwd_weight_tail": (I, [P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_convt_last_bwd_weight_ws_bytes": (SZ, [I, I, I, I]),
     "rd_convt_last_bwd_weight": (I, [P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
+    "rd_convt_last_bwd_weight_bn": (I, [P, P, P, P, P, F, P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
+    "rd_tail_t16": (I, [P, P, P, P, P, F, P, P, P, LL, I, P]),
     "rd_convt_last_bwd_data": (I, [P, P, P, I, I, I, I, P, P, P, P, P, F, P, P, SZ, P, P]),
     "rd_conv3x3_first_bwd_weight_bn_available": (I, [I, I, I, I, I]),
     "rd_conv3x3_first_bwd_weight_bn": (I, [P, P, P, P, P, P, F, P, P, P, P, P, D, I, P, P, P, I, I, I, I, I, P, SZ, P]),

@@ -99,6 +99,9 @@ int tail_compose_launch(const float* wt, const float* bt, const float* wl, float
 int conv_last_fwd_tail_launch(const TailSkip& sk, const float* t16, const float* b9, const float* wt, const float* bias,
                               const float* x_nchw, int xc, float* out, int n, int h, int w, int c, hipStream_t s);
 int conv_last_wgrad_tail_launch(const TailSkip& sk, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s);
+int tail_t16_launch(const TailSkip& sk, const float* V, float* t16, long pixels, int cin, hipStream_t s);
+int convt_last_wgrad_launch(const float* x, const TailSkip& sk, const float* dout, const float* wl, float* dwt, double* partial,
+                            double* c16, int n, int hc, int wc, int cin, int c0, hipStream_t s);
 int conv_last_tail_blocks(int n, int h, int w);
 int conv_last_bwd_tail_fused_launch(const TailSkip& sk, const float* dout, const float* wl, double* wpartial, float* bn_part, int n,
                                     int h, int w, int c, hipStream_t s);
@@ -106,8 +109,7 @@ int tail_wl_finish_launch(const double* partial, int nb, const double* c16, cons
                           int cin, int c0, hipStream_t s);
 bool tail_shape_ok(int cin);
 int tail_corr_blocks(int n, int hc, int wc);
-int convt_last_wgrad_launch(const float* x, const float* dout, const float* wl, float* dwt, double* partial, double* c16, int n,
-                            int hc, int wc, int cin, int c0, hipStream_t s);
+
 int convt_last_dgrad_launch(const float* dout, const float* V, float* dprev, int n, int hc, int wc, int cin, const float* bn_z,
                             const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                             const float* slope_dev, float* part, hipStream_t s, int* rows);

@@ -363,6 +363,53 @@ __global__ __launch_bounds__(64) void tail_compose_kernel(const float* __restric
     }
 }
 
+// T[p][d] = sum_ci a[p][ci] V[ci][d], a = act(BN(z)) evaluated on load (identity when sk.mean == NULL: z IS the activation):
+// the up-convolution's input contracted with the 16 stencil columns, on the exact-f32 matrix pipe.  One wave = 16 pixels per
+// iteration: lane (m = l % 16, j = l / 16) loads the CPL = Cin / 4 contiguous channels [j CPL, (j + 1) CPL) of pixel m (16-byte
+// loads) and feeds v_mfma_f32_16x16x4_f32 number i with A[m][j] = a[m][j CPL + i], B[j][n] = V[j CPL + i][n] -- any partition
+// of the channels into groups of four is a valid K order.  HBM-bound: reads the tensor once, writes 64 bytes per pixel.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int CPL>
+__global__ __launch_bounds__(256) void tail_t16_kernel(TailSkip sk, const float* __restrict__ V, float* __restrict__ t16, long P) {
+    constexpr int C = CPL * 4;
+    __shared__ float scs[C], shs[C];
+    const int t = threadIdx.x, lane = t & 63, m = lane & 15, j = lane >> 4;
+    const bool ident = sk.mean == nullptr;
+    for (int c = t; c < C; c += 256) {
+        const float scv = ident ? 1.f : sk.invstd[c] * sk.gamma[c];
+        scs[c] = scv;
+        shs[c] = ident ? 0.f : sk.beta[c] - sk.mean[c] * scv;
+    }
+    const float slope = ident ? 1.f : (sk.slope_dev ? sk.slope_dev[0] : sk.slope);
+    float bv[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) bv[i] = V[(long)(j * CPL + i) * 16 + m];        // B[k = j][n = m] of MFMA i
+    __syncthreads();
+    const long ntile = (P + 15) / 16, wave0 = (long)blockIdx.x * 4 + (t >> 6), nwave = (long)gridDim.x * 4;
+    for (long tile = wave0; tile < ntile; tile += nwave) {
+        const long pix = tile * 16 + m;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        float a[CPL];
+#pragma unroll
+        for (int g = 0; g < CPL / 4; ++g) {
+            const float4 z4 = pix < P ? *reinterpret_cast<const float4*>(sk.z + pix * C + j * CPL + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[g * 4 + 0] = z4.x; a[g * 4 + 1] = z4.y; a[g * 4 + 2] = z4.z; a[g * 4 + 3] = z4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const float y = fmaf(a[i], scs[j * CPL + i], shs[j * CPL + i]);
+            const float av = pix < P ? (y > 0.f ? y : y * slope) : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[i], acc, 0, 0, 0);
+        }
+        // C[row = 4 (l / 16) + r][col = l % 16]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long op = tile * 16 + 4 * j + r;
+            if (op < P) t16[op * 16 + m] = acc[r];
+        }
+    }
+}
+
 constexpr int TL_W = 2 * ET_W + 3, TL_H = 2 * ET_H + 3;     // dout region of a 16 x 32 coarse tile: rows 2 y0 - 1 .. 2 y0 + 2 ET_H + 1
 
 // dprev [N][Hc][Wc][C] = stencil above; BN: + the BN-backward statistics of the block whose activation gradient this is
@@ -451,7 +498,8 @@ __global__ __launch_bounds__(256) void convt_last_dgrad_kernel(const float* __re
 //   dWt[ci][co][a][b] = sum_p x[p][ci] g[2p + (a,b)][co] = sum_tap wl[co][tap] C16[ci][(a,b) - off(tap)],
 //   C16[ci][d] = sum_p x[p][ci] dout[2p + d]                        (16 correlations per input channel)
 // tail_corr_kernel: persistent blocks over 16 x 32 coarse tiles, per block one partial row [16][C] of doubles.
-__global__ __launch_bounds__(256) void tail_corr_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+// sk.mean != NULL: x = act(BN(sk.z)) evaluated on load (x itself unused)
+__global__ __launch_bounds__(256) void tail_corr_kernel(const float* __restrict__ x, TailSkip sk, const float* __restrict__ dout,
                                                         double* __restrict__ partial, int N, int Hc, int Wc, int C, int CQ,
                                                         int tiles_x, int tiles_y, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float tsm[];     // D[TL_H * TL_W] (padded to 2368), then the reduction scratch
@@ -459,6 +507,18 @@ __global__ __launch_bounds__(256) void tail_corr_kernel(const float* __restrict_
     float* red = tsm + 2368;                       // [PPI][16][C] floats = 16384
     const int t = threadIdx.x, q = t % CQ, slot = t / CQ, PPI = 256 / CQ;
     const int H = 2 * Hc, W = 2 * Wc;
+    const bool lazy = sk.mean != nullptr;
+    const float* src = lazy ? sk.z : x;
+    float scq[4] = {1.f, 1.f, 1.f, 1.f}, shq[4] = {0.f, 0.f, 0.f, 0.f}, slope = 1.f;
+    if (lazy) {
+        slope = sk.slope_dev ? sk.slope_dev[0] : sk.slope;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = q * 4 + k;
+            scq[k] = sk.invstd[c] * sk.gamma[c];
+            shq[k] = sk.beta[c] - sk.mean[c] * scq[k];
+        }
+    }
     float acc[16][4];
 #pragma unroll
     for (int d = 0; d < 16; ++d)
@@ -484,8 +544,16 @@ __global__ __launch_bounds__(256) void tail_corr_kernel(const float* __restrict_
                 py[u] = e / ET_W;
                 px[u] = e - py[u] * ET_W;
                 const bool ok = y0 + py[u] < Hc && x0 + px[u] < Wc;
-                x4[u] = ok ? *reinterpret_cast<const float4*>(x + (((long)n * Hc + y0 + py[u]) * Wc + x0 + px[u]) * C + q * 4)
+                x4[u] = ok ? *reinterpret_cast<const float4*>(src + (((long)n * Hc + y0 + py[u]) * Wc + x0 + px[u]) * C + q * 4)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lazy) {
+                    float* xe = reinterpret_cast<float*>(&x4[u]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float y = fmaf(xe[k], scq[k], shq[k]);
+                        xe[k] = ok ? (y > 0.f ? y : y * slope) : 0.f;
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
@@ -1326,11 +1394,24 @@ int tail_corr_blocks(int n, int hc, int wc) {
     return (int)(nt < 512 ? nt : 512);
 }
 
-int convt_last_wgrad_launch(const float* x, const float* dout, const float* wl, float* dwt, double* partial, double* c16, int n,
-                            int hc, int wc, int cin, int c0, hipStream_t s) {
+int tail_t16_launch(const TailSkip& sk, const float* V, float* t16, long pixels, int cin, hipStream_t s) {
+    const long ntile = (pixels + 15) / 16;
+    const int grid = (int)(ntile / 4 < 2048 ? (ntile + 3) / 4 : 2048);
+    switch (cin) {
+        case 32: hipLaunchKernelGGL(tail_t16_kernel<8>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
+        case 64: hipLaunchKernelGGL(tail_t16_kernel<16>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
+        case 128: hipLaunchKernelGGL(tail_t16_kernel<32>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
+        default: hipLaunchKernelGGL(tail_t16_kernel<64>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
+    }
+    RD_LAUNCH_CHECK("tail_t16");
+    return RD_OK;
+}
+
+int convt_last_wgrad_launch(const float* x, const TailSkip& sk, const float* dout, const float* wl, float* dwt, double* partial,
+                            double* c16, int n, int hc, int wc, int cin, int c0, hipStream_t s) {
     const int tx = cdiv(wc, ET_W), ty = cdiv(hc, ET_H), nb = tail_corr_blocks(n, hc, wc);
     const size_t smem = (2368 + 16384) * sizeof(float);
-    hipLaunchKernelGGL(tail_corr_kernel, dim3(nb), dim3(256), smem, s, x, dout, partial, n, hc, wc, cin, cin / 4, tx, ty, n * tx * ty);
+    hipLaunchKernelGGL(tail_corr_kernel, dim3(nb), dim3(256), smem, s, x, sk, dout, partial, n, hc, wc, cin, cin / 4, tx, ty, n * tx * ty);
     hipLaunchKernelGGL(tail_wgrad_finish_kernel, dim3(cin), dim3(256), 0, s, (const double*)partial, nb, wl, dwt, c16, cin, c0);
     RD_LAUNCH_CHECK("convt_last_wgrad");
     return RD_OK;

@@ -1748,9 +1748,27 @@ size_t rd_convt_last_bwd_weight_ws_bytes(int n, int hc, int wc, int cin) {
     return ((size_t)tail_corr_blocks(n, hc, wc) + 1) * 16 * (size_t)cin * sizeof(double);      // block partials + C16
 }
 
+int rd_tail_t16(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                const float* slope_dev, const float* V, float* t16, long long pixels, int cin, rd_stream_t s) {
+    RD_REQUIRE(z && V && t16 && pixels > 0, "rd_tail_t16: bad arguments");
+    RD_REQUIRE(!mean || (invstd && gamma && beta), "rd_tail_t16: incomplete BN descriptor");
+    RD_REQUIRE(tail_shape_ok(cin), "rd_tail_t16: Cin must be 32, 64, 128 or 256 (got %d)", cin);
+    const TailSkip sk = {z, mean, invstd, gamma, beta, slope_dev, slope};
+    ProfScope ps((hipStream_t)s, "conv1x1_fwd|tail_t16", 2.0 * pixels * cin * 16.0, 4.0 * pixels * (double)(cin + 16));
+    return tail_t16_launch(sk, V, t16, (long)pixels, cin, (hipStream_t)s);
+}
+
 int rd_convt_last_bwd_weight(const float* x, const float* dout, const float* w_last, float* dwt_iohw, double* c16_out, int n, int hc,
                              int wc, int cin, int c0, void* ws, size_t ws_bytes, rd_stream_t s) {
+    return rd_convt_last_bwd_weight_bn(x, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, dout, w_last, dwt_iohw, c16_out, n, hc, wc,
+                                       cin, c0, ws, ws_bytes, s);
+}
+
+int rd_convt_last_bwd_weight_bn(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                float slope, const float* slope_dev, const float* dout, const float* w_last, float* dwt_iohw,
+                                double* c16_out, int n, int hc, int wc, int cin, int c0, void* ws, size_t ws_bytes, rd_stream_t s) {
     RD_REQUIRE(x && dout && w_last && dwt_iohw && n > 0 && hc > 0 && wc > 0 && c0 > 0, "rd_convt_last_bwd_weight: bad arguments");
+    RD_REQUIRE(!mean || (invstd && gamma && beta), "rd_convt_last_bwd_weight_bn: incomplete BN descriptor");
     RD_REQUIRE(tail_shape_ok(cin), "rd_convt_last_bwd_weight: Cin must be 32, 64, 128 or 256 (got %d)", cin);
     const size_t need = rd_convt_last_bwd_weight_ws_bytes(n, hc, wc, cin);
     if (!ws || ws_bytes < need) {
@@ -1761,7 +1779,8 @@ int rd_convt_last_bwd_weight(const float* x, const float* dout, const float* w_l
     double* partial = (double*)ws;
     double* c16 = c16_out ? c16_out : partial + (size_t)nb * 16 * cin;
     ProfScope ps((hipStream_t)s, "convt2x2_wgrad|convt_last_wgrad", 2.0 * n * hc * wc * 16.0 * cin, 4.0 * n * hc * wc * (double)(cin + 4));
-    return convt_last_wgrad_launch(x, dout, w_last, dwt_iohw, partial, c16, n, hc, wc, cin, c0, (hipStream_t)s);
+    const TailSkip sk = {x, mean, invstd, gamma, beta, slope_dev, slope};
+    return convt_last_wgrad_launch(x, sk, dout, w_last, dwt_iohw, partial, c16, n, hc, wc, cin, c0, (hipStream_t)s);
 }
 
 size_t rd_conv3x3_last_bwd_weight_ws_bytes(int n, int h, int w, int c) {

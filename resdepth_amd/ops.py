@@ -360,17 +360,36 @@ def convt_last_bwd_data(dout, v, bn=None):
     return dprev, (part, rows.value)
 
 
+def _desc_args(d):
+    """(z, mean, invstd, gamma, beta, slope, slope_dev) pointers of a lazy activation descriptor (UNet._bn_forward)"""
+    return (ptr(d["z"]), ptr(d["mean"]), ptr(d["invstd"]), ptr(d["gamma"].detach()), ptr(d["beta"].detach()), float(d["slope"]),
+            ptr(d["slope_dev"]))
+
+
+def tail_t16(x, v):
+    """T [N, h, w, 16] = x . V for the forward tail (conv3x3_last_fwd_tail).  x: the up-convolution's input [N, h, w, Cin], or the
+    lazy descriptor {z, mean, invstd, gamma, beta, slope, slope_dev} of the block that produces it (BN + activation on load)."""
+    z = x["z"] if isinstance(x, dict) else x
+    n, h, w, cin = z.shape
+    t16 = torch.empty(n, h, w, 16, device=z.device, dtype=torch.float32)
+    args = _desc_args(x) if isinstance(x, dict) else (ptr(_f32(z, "x")), None, None, None, None, 1.0, None)
+    check(load().rd_tail_t16(*args, ptr(v), ptr(t16), n * h * w, cin, stream_ptr()), "tail_t16")
+    return t16
+
+
 def convt_last_bwd_weight(x, dout, w_last, out=None, c16=None, ws_slot=0):
     """Weight gradient [Cin, C0, 2, 2] of the last up-convolution from its input x [N, h, w, Cin] and the network's output
     gradient dout [N, 1, 2h, 2w]: == convt2x2_bwd_weight(x, conv3x3_last_bwd_data(dout)).  c16 (optional [Cin, 16] float64
     tensor): receives the correlations sum_p x[p][ci] dout[2p + d] (conv3x3_last_bwd_weight_tail takes them)."""
-    n, hc, wc, cin = x.shape
+    z = x["z"] if isinstance(x, dict) else x            # dict: lazy descriptor of the producing block (see tail_t16)
+    n, hc, wc, cin = z.shape
     c0 = w_last.shape[1]
     if out is None:
-        out = torch.empty(cin, c0, 2, 2, device=x.device, dtype=torch.float32)
-    ws = workspace(load().rd_convt_last_bwd_weight_ws_bytes(n, hc, wc, cin), x.device, ws_slot)
-    check(load().rd_convt_last_bwd_weight(ptr(x), ptr(dout), ptr(w_last.detach()), ptr(out), ptr(c16), n, hc, wc, cin, c0,
-                                          ws.data_ptr(), ws.numel(), stream_ptr()), "convt_last_bwd_weight")
+        out = torch.empty(cin, c0, 2, 2, device=z.device, dtype=torch.float32)
+    ws = workspace(load().rd_convt_last_bwd_weight_ws_bytes(n, hc, wc, cin), z.device, ws_slot)
+    args = _desc_args(x) if isinstance(x, dict) else (ptr(z), None, None, None, None, 1.0, None)
+    check(load().rd_convt_last_bwd_weight_bn(*args, ptr(dout), ptr(w_last.detach()), ptr(out), ptr(c16), n, hc, wc, cin, c0,
+                                             ws.data_ptr(), ws.numel(), stream_ptr()), "convt_last_bwd_weight")
     return out
 
 

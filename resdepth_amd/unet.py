@@ -397,13 +397,18 @@ class UNet(nn.Module):
         lazy descriptor: its 64-channel full-resolution output is not built -- T = cur . V (a 1x1 convolution to 16 channels at
         the coarse resolution) and B9 are all the last convolution needs of it (ops.conv3x3_last_fwd_tail).  -> None when this
         shape / mode keeps the two-kernel route, else {skip, t16, b9, v}."""
-        ll = self.last_layer
-        if not (self.composed_tail and self.up_mode == "transpose" and isinstance(skip, dict) and ll.weight.shape[1] in (16, 32, 64)
-                and cur.shape[1] * 2 == skip["z"].shape[1] and ops.tail_available(up.weight.shape[0], up.weight.shape[1])):
+        if not (isinstance(skip, dict) and self._tail_expected(True)):
             return None
-        _, v, vt, b9 = ops.tail_compose(up.weight, ll.weight, up.bias, forward=True)
-        t16 = ops.conv1x1_fwd(cur, ops.pack_conv1x1_weight(vt)[0])
-        return {"skip": skip, "t16": t16, "b9": b9, "v": v}
+        _, v, _, b9 = ops.tail_compose(up.weight, self.last_layer.weight, up.bias, forward=True)
+        # cur: the up-convolution's input, or the lazy descriptor of the block that produces it (BN + activation on load)
+        return {"skip": skip, "t16": ops.tail_t16(cur, v), "b9": b9, "v": v}
+
+    def _tail_expected(self, lazy_skip: bool) -> bool:
+        """Will the forward take the composed tail (then the block feeding the last up-convolution need not write its
+        activation: `_bn_forward(want_a=False)` hands a descriptor on)?"""
+        up, ll = self._up_of(self.depth - 1), self.last_layer
+        return bool(self.composed_tail and self.up_mode == "transpose" and lazy_skip and ll.weight.shape[1] in (16, 32, 64)
+                    and ops.tail_available(up.weight.shape[0], up.weight.shape[1]))
 
     def _up_forward(self, cur, packed, up, skip):
         if self.up_mode == "bilinear":
@@ -450,6 +455,9 @@ class UNet(nn.Module):
         if bn is None:
             # do_BN=False: activation(conv + bias) == the fused BN-apply kernel with mean 0, invstd 1, gamma 1, beta = bias
             mean, invstd = self._const(c, 0.0, z.device), self._const(c, 1.0, z.device)
+            if not pool and not want_a:
+                return ({"z": z, "mean": mean, "invstd": invstd, "gamma": invstd, "beta": bias, "slope": slope, "slope_dev": sdev},
+                        None, None, mean, invstd, 1)
             a, p, idx, *zp = ops.bn_act_pool_fwd(z, mean, invstd, invstd, bias, slope, pool, sdev, want_a=want_a,
                                                  want_zpool=want_zpool)
             if a is None:
@@ -469,6 +477,9 @@ class UNet(nn.Module):
         else:
             mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, eps=bn.eps)
             count = z.numel() // c
+        if not pool and not want_a:          # nothing to compute: the consumers evaluate act(BN(z)) on load (the composed tail)
+            a = {"z": z, "mean": mean, "invstd": invstd, "gamma": bn.weight, "beta": bn.bias, "slope": slope, "slope_dev": sdev}
+            return (a, None, None, mean, invstd, count)
         a, p, idx, *zp = ops.bn_act_pool_fwd(z, mean, invstd, bn.weight, bn.bias, slope, pool, sdev, want_a=want_a,
                                              want_zpool=want_zpool)
         if a is None:
@@ -607,8 +618,11 @@ class UNet(nn.Module):
             cur = p
         bn, cbias = self._norm_of(self.bottleneck)
         zb, sums, st = conv_stats(cur, pk.get("bott")[0], bn)
+        # the block feeding the LAST up-convolution need not write its activation when the composed tail runs (its two readers
+        # evaluate act(BN(z)) on load): the bottleneck for depth 1, decoder block d - 2 otherwise
+        lazy_last = self._tail_expected(self.up_mode == "transpose" and not keep_skips)
         ab, _, _, mean, invstd, count = self._bn_forward(zb, bn, self._act_of(self.bottleneck, self.act_fn_bottleneck),
-                                                         False, training, sums, cbias, stats=st)
+                                                         False, training, sums, cbias, stats=st, want_a=not (lazy_last and d == 1))
         if save:
             S["bott"] = {"z": zb, "mean": mean, "invstd": invstd, "count": count, "a": ab}
         cur = ab
@@ -620,6 +634,7 @@ class UNet(nn.Module):
                     if save:
                         S["dec"].append({"s": None, "tail": tail})
                     break
+                assert not isinstance(cur, dict), "a lazy activation reached the two-kernel tail"
             s = self._up_forward(cur, pk.get(("dec_t", i)), self._up_of(i), skips[d - 1 - i])
             skips[d - 1 - i] = None          # the skip tensor is not needed by the backward pass
             rec = {"s": s}
@@ -628,7 +643,8 @@ class UNet(nn.Module):
                 bn, cbias = self._norm_of(blk)
                 zd, sums, st = conv_stats(s, pk.get(("dec_c", i))[0], bn)
                 ad, _, _, mean, invstd, count = self._bn_forward(zd, bn, self._act_of(blk, self.act_fn_decoder), False,
-                                                                 training, sums, cbias, stats=st)
+                                                                 training, sums, cbias, stats=st,
+                                                                 want_a=not (lazy_last and i == d - 2))
                 rec.update(z=zd, mean=mean, invstd=invstd, count=count, a=ad)
                 cur = ad
             else:

@@ -855,7 +855,21 @@ def test_tail_forward_and_last_weight_gradient_without_the_up_convolution_output
     m, v, vt, b9 = ops.tail_compose(wt.to(D), wl.to(D), bt.to(D), forward=True)
     assert torch.equal(vt.view(16, cin).t().contiguous(), v)
     t16 = ops.conv1x1_fwd(nhwc(xc), ops.pack_conv1x1_weight(vt)[0])
-    out = ops.conv3x3_last_fwd_tail(skip, t16, b9, wl.to(D), bl.to(D), xin.to(D) if res else None)
+    t16b = ops.tail_t16(nhwc(xc), v)                          # the dedicated kernel (exact-f32 matrix pipe), same contraction
+    close(t16b.cpu(), torch.einsum("nchw,cd->nhwd", xc.double(), v.cpu().double()).float(), tol=3e-6, name="T = x . V")
+    assert float((t16 - t16b).abs().max()) <= 3e-6 * float(t16b.abs().max())
+    # ... and from the pre-BN tensor of the producing block, BN + activation on load (forward and the correlations)
+    zc = torch.randn(n, cin, h // 2, w // 2, generator=g)
+    mc, ic = torch.randn(cin, generator=g) * 0.2, torch.rand(cin, generator=g) + 0.5
+    gc, bc = torch.randn(cin, generator=g), torch.randn(cin, generator=g) * 0.3
+    yc = (zc.double() - mc.double().view(1, -1, 1, 1)) * (ic.double() * gc.double()).view(1, -1, 1, 1) + bc.double().view(1, -1, 1, 1)
+    ac = torch.where(yc > 0, yc, yc * slope).float()
+    desc = {"z": nhwc(zc), "mean": mc.to(D), "invstd": ic.to(D), "gamma": gc.to(D), "beta": bc.to(D), "slope": slope, "slope_dev": None}
+    close(ops.tail_t16(desc, v).cpu(), ops.tail_t16(nhwc(ac), v).cpu(), tol=3e-6, name="T from the pre-BN tensor")
+    dprobe = torch.randn(n, 1, h, w, generator=g).to(D)
+    close(ops.convt_last_bwd_weight(desc, dprobe, wl.to(D)).cpu(), ops.convt_last_bwd_weight(nhwc(ac), dprobe, wl.to(D)).cpu(),
+          tol=3e-6, name="correlations from the pre-BN tensor")
+    out = ops.conv3x3_last_fwd_tail(skip, t16b, b9, wl.to(D), bl.to(D), xin.to(D) if res else None)
     close(out.cpu(), out_ref.detach().float(), tol=3e-6, name="tail forward")
     c16 = torch.empty(cin, 16, dtype=torch.float64, device=D)
     ops.convt_last_bwd_weight(nhwc(xc), dout.to(D), wl.to(D), c16=c16)
