@@ -153,7 +153,7 @@ int rd_conv3x3_last_bwd_data(const float* dout, const float* w_oihw, float* ds, 
  * rd_tail_compose writes M and V (tiny; once per step), and on request VT [16][Cin] = V transposed (the weight of a 1x1
  * convolution Cin -> 16) and B9[tap] = sum_co w_last[co][tap] bias_t[co] (bias_t nullable) for the forward below.  rd_convt_last_bwd_data(hc, wc = the COARSE grid) == rd_convt2x2_bwd_data
  * applied to rd_conv3x3_last_bwd_data(dout) up to fp32 rounding; bn_z != NULL: the BN-backward statistics hook of
- * rd_convt2x2_bwd_data_bnstats (mode 1), part / rows_out as there.  Cin in {32, 64, 128, 256} (rd_tail_available). */
+ * rd_convt2x2_bwd_data_bnstats (mode 1), part / rows_out as there.  Cin in {16, 32, 64, 128, 256} (rd_tail_available). */
 int rd_tail_available(int cin, int c0);
 int rd_tail_compose(const float* wt_iohw, const float* bias_t, const float* w_last, float* M, float* V, float* VT, float* B9, int cin,
                     int c0, rd_stream_t s);

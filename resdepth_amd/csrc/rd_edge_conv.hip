@@ -1367,7 +1367,7 @@ int tail_compose_launch(const float* wt, const float* bt, const float* wl, float
 }
 
 // 256 / (Cin / 4) pixel slots; knob edge_conv bit 32 switches the composed tail kernels off
-bool tail_shape_ok(int cin) { return (cin == 32 || cin == 64 || cin == 128 || cin == 256) && edge_on(32); }
+bool tail_shape_ok(int cin) { return (cin == 16 || cin == 32 || cin == 64 || cin == 128 || cin == 256) && edge_on(32); }
 
 // coarse grid hc x wc; *rows = statistics rows written (0 without a hook)
 int convt_last_dgrad_launch(const float* dout, const float* V, float* dprev, int n, int hc, int wc, int cin, const float* bn_z,
@@ -1398,6 +1398,7 @@ int tail_t16_launch(const TailSkip& sk, const float* V, float* t16, long pixels,
     const long ntile = (pixels + 15) / 16;
     const int grid = (int)(ntile / 4 < 2048 ? (ntile + 3) / 4 : 2048);
     switch (cin) {
+        case 16: hipLaunchKernelGGL(tail_t16_kernel<4>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
         case 32: hipLaunchKernelGGL(tail_t16_kernel<8>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
         case 64: hipLaunchKernelGGL(tail_t16_kernel<16>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
         case 128: hipLaunchKernelGGL(tail_t16_kernel<32>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;

@@ -1730,7 +1730,7 @@ int rd_convt_last_bwd_data(const float* dout, const float* V, float* dprev, int 
                            const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                            const float* slope_dev, float* part, size_t part_floats, int* rows_out, rd_stream_t s) {
     RD_REQUIRE(dout && V && dprev && n > 0 && hc > 0 && wc > 0, "rd_convt_last_bwd_data: bad arguments");
-    RD_REQUIRE(tail_shape_ok(cin), "rd_convt_last_bwd_data: Cin must be 32, 64, 128 or 256 (got %d)", cin);
+    RD_REQUIRE(tail_shape_ok(cin), "rd_convt_last_bwd_data: Cin must be 16, 32, 64, 128 or 256 (got %d)", cin);
     RD_REQUIRE(!bn_z || (mean && invstd && gamma && beta && part && rows_out &&
                          part_floats >= rd_bn_bwd_part_floats((long long)n * hc * wc, cin)),
                "rd_convt_last_bwd_data: statistics hook arguments");
@@ -1752,7 +1752,7 @@ int rd_tail_t16(const float* z, const float* mean, const float* invstd, const fl
                 const float* slope_dev, const float* V, float* t16, long long pixels, int cin, rd_stream_t s) {
     RD_REQUIRE(z && V && t16 && pixels > 0, "rd_tail_t16: bad arguments");
     RD_REQUIRE(!mean || (invstd && gamma && beta), "rd_tail_t16: incomplete BN descriptor");
-    RD_REQUIRE(tail_shape_ok(cin), "rd_tail_t16: Cin must be 32, 64, 128 or 256 (got %d)", cin);
+    RD_REQUIRE(tail_shape_ok(cin), "rd_tail_t16: Cin must be 16, 32, 64, 128 or 256 (got %d)", cin);
     const TailSkip sk = {z, mean, invstd, gamma, beta, slope_dev, slope};
     ProfScope ps((hipStream_t)s, "conv1x1_fwd|tail_t16", 2.0 * pixels * cin * 16.0, 4.0 * pixels * (double)(cin + 16));
     return tail_t16_launch(sk, V, t16, (long)pixels, cin, (hipStream_t)s);
@@ -1769,7 +1769,7 @@ int rd_convt_last_bwd_weight_bn(const float* x, const float* mean, const float* 
                                 double* c16_out, int n, int hc, int wc, int cin, int c0, void* ws, size_t ws_bytes, rd_stream_t s) {
     RD_REQUIRE(x && dout && w_last && dwt_iohw && n > 0 && hc > 0 && wc > 0 && c0 > 0, "rd_convt_last_bwd_weight: bad arguments");
     RD_REQUIRE(!mean || (invstd && gamma && beta), "rd_convt_last_bwd_weight_bn: incomplete BN descriptor");
-    RD_REQUIRE(tail_shape_ok(cin), "rd_convt_last_bwd_weight: Cin must be 32, 64, 128 or 256 (got %d)", cin);
+    RD_REQUIRE(tail_shape_ok(cin), "rd_convt_last_bwd_weight: Cin must be 16, 32, 64, 128 or 256 (got %d)", cin);
     const size_t need = rd_convt_last_bwd_weight_ws_bytes(n, hc, wc, cin);
     if (!ws || ws_bytes < need) {
         set_error("rd_convt_last_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);

@@ -772,7 +772,7 @@ def test_first_conv_weight_gradient_with_the_bn_backward_evaluated_on_the_fly(n,
                                         beta, slope, None, g_pool[:1, :8, :16].contiguous(), idx[:1, :8, :16].contiguous(), sums, 512)
 
 
-@pytest.mark.parametrize("n,h,w,cin,c0", [(2, 64, 64, 128, 64), (3, 32, 96, 64, 32), (1, 36, 20, 32, 16), (2, 16, 16, 256, 64)])
+@pytest.mark.parametrize("n,h,w,cin,c0", [(2, 64, 64, 128, 64), (3, 32, 96, 64, 32), (1, 36, 20, 32, 16), (2, 16, 16, 256, 64), (2, 32, 32, 16, 16)])
 def test_tail_data_gradient_of_the_last_up_convolution_from_the_output_gradient(n, h, w, cin, c0):
     """rd_tail_compose + rd_convt_last_bwd_data: the last up-convolution's input gradient as a 16-tap stride-2 stencil on dout
     == ConvTranspose2d's data gradient of the last convolution's data gradient (lib/UNet.py:21,218-227 differentiated), and
@@ -804,7 +804,7 @@ def test_tail_data_gradient_of_the_last_up_convolution_from_the_output_gradient(
     assert float(((sums - want_sums).abs() / scale).max()) <= 1e-5
 
 
-@pytest.mark.parametrize("n,h,w,cin,c0", [(2, 64, 64, 128, 64), (3, 32, 96, 64, 32), (1, 36, 20, 32, 16), (2, 16, 16, 256, 64)])
+@pytest.mark.parametrize("n,h,w,cin,c0", [(2, 64, 64, 128, 64), (3, 32, 96, 64, 32), (1, 36, 20, 32, 16), (2, 16, 16, 256, 64), (2, 32, 32, 16, 16)])
 def test_tail_weight_gradient_of_the_last_up_convolution_from_the_output_gradient(n, h, w, cin, c0):
     """rd_convt_last_bwd_weight: 16 correlations of the up-convolution's input with dout per input channel, contracted with the
     last convolution's weight == ConvTranspose2d's weight gradient against the last convolution's data gradient."""
@@ -823,7 +823,7 @@ def test_tail_weight_gradient_of_the_last_up_convolution_from_the_output_gradien
 
 
 @pytest.mark.parametrize("n,h,w,cin,c0,slope,res", [(2, 64, 64, 128, 64, 0.0, True), (3, 32, 96, 64, 32, 0.01, False),
-                                                    (1, 36, 20, 32, 16, 0.01, True)])
+                                                    (1, 36, 20, 32, 16, 0.01, True), (2, 32, 32, 16, 16, 0.0, True)])
 def test_tail_forward_and_last_weight_gradient_without_the_up_convolution_output(n, h, w, cin, c0, slope, res):
     """rd_conv3x3_last_fwd_tail / rd_conv3x3_last_bwd_weight_tail: the last convolution applied to
     s = ConvTranspose2d(x_coarse) + act(BN(z)) (lib/UNet.py:218-227) without s ever being a tensor -- forward from z (BN +

@@ -916,3 +916,50 @@ def test_first_weight_gradient_without_a_dz_tensor_equals_the_two_kernel_route(a
         masked_l1_loss(model(xin), t, mask, mean, std).backward()
         grads.append((xin.grad.clone(), model.encoder[0][0][0].weight.grad.clone()))
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
+@pytest.mark.parametrize("n,t,kw", [
+    (2, 32, dict(n_input_channels=3, start_kernel=16, depth=1)),                                  # depth 1: the bottleneck feeds the tail
+    (2, 32, dict(n_input_channels=1, start_kernel=32, depth=2, do_BN=False, bias_conv_layer=True)),
+    (3, 32, dict(n_input_channels=2, start_kernel=16, depth=2, act_fn_encoder="prelu", act_fn_decoder="prelu",
+                 act_fn_bottleneck="prelu", outer_skip=False)),
+    (2, 64, dict(n_input_channels=3, start_kernel=32, depth=3, act_fn_decoder="lrelu", outer_skip_BN=True, bias_conv_layer=True)),
+])
+def test_composed_tail_variants_against_oracle(n, t, kw):
+    """The composed tail (no up-convolution output, no gradient w.r.t. it, no dz of the first block, no activation
+    of the block before the last up-convolution) in the constructor variants that change its operands: depth 1, no BatchNorm
+    (bias + activation descriptors), PReLU slopes on the device, no outer residual, BatchNorm on the residual.  Forward, loss,
+    every gradient (under the HIP path's discrete decisions) and the BN buffers against the fp64 oracle; eval forward too."""
+    from resdepth_amd import UNet, masked_l1_loss
+    spec = O.Spec(**{"depth": 8, **kw})
+    torch.manual_seed(8)
+    model = UNet(**kw)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    b = O.synthetic_batch(n, kw["n_input_channels"], t, seed=41)
+    model = model.to(DEV).train()
+    assert model._tail_expected(True), "this configuration does not take the composed tail"
+    yp = model(b["input"].to(DEV))
+    loss = masked_l1_loss(yp, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
+    loss.backward()
+    sd1 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    yo, lo, go, work = _oracle_fp64_under_hip_decisions(model, sd0, spec, b["input"], b["target"], b["loss_mask"],
+                                                        b["dsm_mean"], b["dsm_std"], yp)
+    assert float((yp.detach().cpu().double() - yo).abs().max()) <= 1e-4
+    assert abs(float(loss) - lo) <= 1e-5 * abs(lo)
+    for (k, p), gr in zip(model.named_parameters(), go):
+        assert tuple(p.grad.shape) == tuple(gr.shape) and rel_l2(p.grad, gr) <= 1e-3, (k, rel_l2(p.grad, gr))
+    work = {k: (v.detach().float() if v.is_floating_point() else v) for k, v in work.items()}
+    for k, v in sd1.items():
+        if "running" in k:
+            np.testing.assert_allclose(v.numpy(), work[k].detach().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    model.eval()
+    with torch.no_grad():
+        ye = model(b["input"].to(DEV))
+    assert float((ye.cpu() - O.forward(work, b["input"], spec, training=False).detach()).abs().max()) <= 1e-4
+    # the two-kernel route (composed_tail off) agrees to fp32 rounding
+    model.train()
+    model.load_state_dict(sd0)
+    model.composed_tail = False
+    model.zero_grad(set_to_none=True)
+    y2 = model(b["input"].to(DEV))
+    assert float((y2 - yp).abs().max()) <= 2e-5
