@@ -293,10 +293,18 @@ class UNet(nn.Module):
             with torch.cuda.stream(side):
                 _lib.check(_lib.load().rd_pack_weights_fused(plan["items"].data_ptr(), plan["n"], plan["total"], plan["tiles"],
                                                              _lib.stream_ptr()), "pack_weights_fused")
+                if self._tail_expected(True):
+                    up_l = self._up_of(d - 1)
+                    _, v_, _, b9_ = ops.tail_compose(up_l.weight, self.last_layer.weight, up_l.bias, forward=True)
+                    v_.record_stream(main)
+                    b9_.record_stream(main)
+                    pk.items["tail"] = (v_, b9_)
                 ev = torch.cuda.Event()
                 ev.record(side)
             for k, tensors in plan["buffers"].items():
                 pk.items[k], pk.events[k] = tensors, ev
+            if "tail" in pk.items:
+                pk.events["tail"] = ev
             self._pack_cache, self._pack_key = pk, key
             return pk
 
@@ -399,7 +407,13 @@ class UNet(nn.Module):
         shape / mode keeps the two-kernel route, else {skip, t16, b9, v}."""
         if not (isinstance(skip, dict) and self._tail_expected(True)):
             return None
-        _, v, _, b9 = ops.tail_compose(up.weight, self.last_layer.weight, up.bias, forward=True)
+        # V and B9 depend on the weights only: composed with the weight pack on the second stream (UNet._packed), off the
+        # forward's serial chain
+        pk = self._pack_cache
+        if pk is not None and "tail" in pk.items and self._pack_key == self._current_pack_key():
+            v, b9 = pk.get("tail")
+        else:
+            _, v, _, b9 = ops.tail_compose(up.weight, self.last_layer.weight, up.bias, forward=True)
         # cur: the up-convolution's input, or the lazy descriptor of the block that produces it (BN + activation on load)
         return {"skip": skip, "t16": ops.tail_t16(cur, v), "b9": b9, "v": v}
 
