@@ -1735,7 +1735,7 @@ int rd_convt_last_bwd_data(const float* dout, const float* V, float* dprev, int 
                          part_floats >= rd_bn_bwd_part_floats((long long)n * hc * wc, cin)),
                "rd_convt_last_bwd_data: statistics hook arguments");
     int rows = 0;
-    ProfScope ps((hipStream_t)s, "convt2x2_dgrad|convt_last_dgrad", 2.0 * n * hc * wc * 16.0 * cin,
+    ProfScope ps((hipStream_t)s, "convt_last_dgrad", 2.0 * n * hc * wc * 16.0 * cin,
                  4.0 * n * hc * wc * (double)(cin * (bn_z ? 2 : 1) + 4));
     if (int e = convt_last_dgrad_launch(dout, V, dprev, n, hc, wc, cin, bn_z, mean, invstd, gamma, beta, slope, slope_dev, part,
                                         (hipStream_t)s, &rows))
@@ -1754,7 +1754,7 @@ int rd_tail_t16(const float* z, const float* mean, const float* invstd, const fl
     RD_REQUIRE(!mean || (invstd && gamma && beta), "rd_tail_t16: incomplete BN descriptor");
     RD_REQUIRE(tail_shape_ok(cin), "rd_tail_t16: Cin must be 16, 32, 64, 128 or 256 (got %d)", cin);
     const TailSkip sk = {z, mean, invstd, gamma, beta, slope_dev, slope};
-    ProfScope ps((hipStream_t)s, "conv1x1_fwd|tail_t16", 2.0 * pixels * cin * 16.0, 4.0 * pixels * (double)(cin + 16));
+    ProfScope ps((hipStream_t)s, "tail_t16", 2.0 * pixels * cin * 16.0, 4.0 * pixels * (double)(cin + 16));
     return tail_t16_launch(sk, V, t16, (long)pixels, cin, (hipStream_t)s);
 }
 
@@ -1778,7 +1778,7 @@ int rd_convt_last_bwd_weight_bn(const float* x, const float* mean, const float* 
     const int nb = tail_corr_blocks(n, hc, wc);
     double* partial = (double*)ws;
     double* c16 = c16_out ? c16_out : partial + (size_t)nb * 16 * cin;
-    ProfScope ps((hipStream_t)s, "convt2x2_wgrad|convt_last_wgrad", 2.0 * n * hc * wc * 16.0 * cin, 4.0 * n * hc * wc * (double)(cin + 4));
+    ProfScope ps((hipStream_t)s, "convt_last_wgrad", 2.0 * n * hc * wc * 16.0 * cin, 4.0 * n * hc * wc * (double)(cin + 4));
     const TailSkip sk = {x, mean, invstd, gamma, beta, slope_dev, slope};
     return convt_last_wgrad_launch(x, sk, dout, w_last, dwt_iohw, partial, c16, n, hc, wc, cin, c0, (hipStream_t)s);
 }
