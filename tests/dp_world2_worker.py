@@ -74,11 +74,14 @@ def main():
     if a.tune:
         os.environ["RD_TUNE"] = a.tune
 
+    import datetime
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(a.port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")        # the box's hostname may not resolve: pairs connect over loopback
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
+    # a rendezvous that does not complete fails in two minutes (the launcher then retries once on a fresh port)
+    dist.init_process_group("gloo", rank=a.rank, world_size=a.world, timeout=datetime.timedelta(seconds=120))
     try:
         if a.coll == "staged":
             import host_staged_collectives

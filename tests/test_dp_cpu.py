@@ -62,6 +62,7 @@ def test_shard_batch():
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")        # the container hostname may not resolve
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(2)
@@ -178,6 +179,7 @@ class _SyncBN(torch.autograd.Function):
 def _worker4(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")        # the container hostname may not resolve
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(1)

@@ -60,7 +60,19 @@ def rel_l2(a, b):
 
 
 def run_world(tmp_path, mode, world=2, timeout=600, **kw):
-    """Launch `world` worker processes on cuda:0; -> list of their saved outputs (raises with the workers' stderr)."""
+    """Launch `world` worker processes on cuda:0; -> list of their saved outputs (raises with the workers' stderr).  A failed
+    RENDEZVOUS (port taken between the probe and the bind, a connection refused while a rank was still starting) is retried
+    once on a fresh port; a failure inside the run is not."""
+    try:
+        return _run_world_once(tmp_path, mode, world, timeout, **kw)
+    except RuntimeError as e:
+        msg = str(e)
+        if not any(k in msg for k in ("init_process_group", "Connection", "connect", "Address already in use", "TIMEOUT")):
+            raise
+    return _run_world_once(tmp_path, mode, world, timeout, **kw)
+
+
+def _run_world_once(tmp_path, mode, world, timeout, **kw):
     port = _free_port()
     outs = [str(tmp_path / f"{mode}_{kw.get('coll', 'staged')}_{kw.get('sync_bn', 0)}_r{r}.pt") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
