@@ -1,6 +1,7 @@
 // A consumer of libresdepth_hip.so that is NOT PyTorch: plain HIP runtime + include/resdepth_hip.h, the way a C / C++ /
 // cgo / JNI host would bind the library.  One 3x3 convolution layer (lib/UNet.py:4-5,44) forward, data
-// gradient and weight gradient on device buffers it allocates itself, checked against direct loops in double on the host;
+// gradient and weight gradient on device buffers it allocates itself, then the block behind it (training-mode BatchNorm
+// statistics from the convolution's epilogue, BN + LeakyReLU + max-pool), checked against direct loops in double on the host;
 // then the error contract (non-zero return + rd_last_error_string).  Test infrastructure: built and run by
 // tests/test_cabi_consumer_gpu.py.
 #include <hip/hip_runtime.h>
@@ -112,6 +113,60 @@ int main() {
     std::printf("conv3x3 weight grad.  max |err| / max |ref| = %.3g\n", e_dw);
     const double tol = 2e-6;      // fp32 results (the tolerance of tests/test_ops_gpu.py)
     if (!(e_z <= tol) || !(e_dx <= tol) || !(e_dw <= tol)) bad = 1;
+
+    // ---- the block behind the convolution: training-mode BatchNorm statistics from the convolution's epilogue, BN apply +
+    // LeakyReLU + 2x2 max-pool (lib/UNet.py:44-47,161), against the host in double
+    {
+        float *d_mean = dev_alloc<float>(CO), *d_invstd = dev_alloc<float>(CO), *d_gamma = dev_alloc<float>(CO), *d_beta = dev_alloc<float>(CO);
+        float *d_p = dev_alloc<float>((size_t)N * (H / 2) * (W / 2) * CO), *d_z2 = dev_alloc<float>(z_ref.size());
+        unsigned char* d_idx = dev_alloc<unsigned char>((size_t)N * (H / 2) * (W / 2) * CO);
+        const size_t sws = rd_conv3x3_fwd_stats_ws_bytes(N, H, W, CI, CO);
+        char* d_sws = dev_alloc<char>(sws);
+        std::vector<float> gamma(CO), beta(CO);
+        for (int c = 0; c < CO; ++c) { gamma[c] = 1.0f + 0.5f * rnd(); beta[c] = 0.3f * rnd(); }
+        HIP_OK(hipMemcpyAsync(d_gamma, gamma.data(), CO * 4, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemcpyAsync(d_beta, beta.data(), CO * 4, hipMemcpyHostToDevice, stream));
+        const float eps = 1e-5f, slope = 0.01f;
+        RD_OK_(rd_conv3x3_fwd_bn(d_x, (const float*)d_wf, d_z2, (double)N * H * W, eps, 0.1f, d_mean, d_invstd, nullptr, nullptr, nullptr,
+                                 N, H, W, CI, CO, d_sws, sws, stream));
+        RD_OK_(rd_bn_act_pool_fwd(d_z2, d_mean, d_invstd, d_gamma, d_beta, slope, nullptr, nullptr, d_p, d_idx, nullptr, N, H, W, CO, stream));
+        std::vector<float> mean(CO), invstd(CO), pooled((size_t)N * (H / 2) * (W / 2) * CO);
+        HIP_OK(hipMemcpyAsync(mean.data(), d_mean, CO * 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(invstd.data(), d_invstd, CO * 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(pooled.data(), d_p, pooled.size() * 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        const double cnt = (double)N * H * W;
+        double e_stat = 0, e_pool = 0, pscale = 0;
+        std::vector<double> mu(CO), is(CO);
+        for (int c = 0; c < CO; ++c) {
+            double s1 = 0, s2 = 0;
+            for (size_t p = 0; p < (size_t)N * H * W; ++p) { const double v = z_ref[p * CO + c]; s1 += v; s2 += v * v; }
+            mu[c] = s1 / cnt;
+            is[c] = 1.0 / std::sqrt(s2 / cnt - mu[c] * mu[c] + (double)eps);
+            e_stat = std::fmax(e_stat, std::fabs(mean[c] - mu[c]) * is[c]);
+            e_stat = std::fmax(e_stat, std::fabs(invstd[c] / is[c] - 1.0));
+        }
+        for (int n = 0; n < N; ++n)
+            for (int y = 0; y < H / 2; ++y)
+                for (int xx = 0; xx < W / 2; ++xx)
+                    for (int c = 0; c < CO; ++c) {
+                        double best = -1e300;
+                        for (int k = 0; k < 4; ++k) {
+                            const size_t q = (((size_t)n * H + 2 * y + (k >> 1)) * W + 2 * xx + (k & 1)) * CO + c;
+                            double a = (z_ref[q] - mu[c]) * is[c] * gamma[c] + beta[c];
+                            a = a > 0 ? a : a * slope;
+                            best = std::fmax(best, a);
+                        }
+                        const double got = pooled[(((size_t)n * (H / 2) + y) * (W / 2) + xx) * CO + c];
+                        e_pool = std::fmax(e_pool, std::fabs(got - best));
+                        pscale = std::fmax(pscale, std::fabs(best));
+                    }
+        std::printf("BatchNorm statistics   max relative deviation = %.3g\n", e_stat);
+        std::printf("BN + act + max-pool    max |err| / max |ref| = %.3g\n", e_pool / pscale);
+        if (!(e_stat <= 1e-5) || !(e_pool / pscale <= 1e-5)) bad = 1;
+        for (void* p : {(void*)d_mean, (void*)d_invstd, (void*)d_gamma, (void*)d_beta, (void*)d_p, (void*)d_z2, (void*)d_idx, (void*)d_sws})
+            (void)hipFree(p);
+    }
 
     // error contract: Cin must be a multiple of 4 here -> non-zero return, message names the argument, nothing launched
     const int rc = rd_conv3x3_fwd(d_x, (const float*)d_wf, d_z, N, H, W, 3, CO, stream);
