@@ -963,3 +963,40 @@ def test_composed_tail_variants_against_oracle(n, t, kw):
     model.zero_grad(set_to_none=True)
     y2 = model(b["input"].to(DEV))
     assert float((y2 - yp).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("flags", [dict(fused_bn_bwd_stats=False), dict(composed_tail=False), dict(fused_first_wgrad=False, composed_tail=False),
+                                   dict(fused_bn_bwd_stats=False, two_stream_backward=False), dict(fold_eval_bn=False)])
+def test_engine_routes_agree(flags):
+    """Every switchable route of the engine (statistics hooks vs the stand-alone reduction, composed tail vs the two-kernel
+    tail, fused vs separate level-0 backward, one stream vs two, folded vs unfolded eval BN) computes the same function: the
+    training forward and every gradient agree with the default configuration to fp32 rounding, the eval forward too."""
+    from resdepth_amd import UNet, masked_l1_loss
+    kw = dict(n_input_channels=3, start_kernel=32, depth=3, bias_conv_layer=True, act_fn_decoder="lrelu")
+    torch.manual_seed(12)
+    model = UNet(**kw).to(DEV)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    b = O.synthetic_batch(4, 3, 64, seed=51)
+    x = b["input"].to(DEV)
+
+    def run(m):
+        m.load_state_dict(sd)
+        m.train()
+        m.zero_grad(set_to_none=True)
+        y = m(x)
+        masked_l1_loss(y, b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"]).backward()
+        g = {k: p.grad.clone() for k, p in m.named_parameters()}
+        m.eval()
+        with torch.no_grad():
+            ye = m(x)
+        return y.detach().clone(), g, ye.clone()
+
+    y0, g0, e0 = run(model)
+    assert model._tail_expected(True)
+    for k, v in flags.items():
+        assert hasattr(model, k), k
+        setattr(model, k, v)
+    y1, g1, e1 = run(model)
+    assert float((y1 - y0).abs().max()) <= 2e-5 and float((e1 - e0).abs().max()) <= 2e-5
+    for k in g0:
+        assert rel_l2(g1[k], g0[k]) <= 2e-5, (k, rel_l2(g1[k], g0[k]))
