@@ -890,3 +890,39 @@ def test_tail_forward_and_last_weight_gradient_without_the_up_convolution_output
     out_nb = ops.conv3x3_last_fwd_tail(skip, t16, ops.tail_compose(wt.to(D), wl.to(D), None, forward=True)[3], wl.to(D), None, None)
     s_nb = F.conv_transpose2d(xc.double(), wt.double(), None, stride=2) + a0
     close(out_nb.cpu(), F.conv2d(s_nb, wl.double(), None, padding=1).float(), tol=3e-6, name="tail forward, no biases")
+
+
+def test_tail_ops_on_random_shapes_against_the_two_kernel_route():
+    """Seeded random coarse grids (1 x 1 up to 40 x 50, odd sizes, one image up to five) and every supported channel pair: the
+    composed data gradient, weight gradient and forward of the tail against the kernels they replace."""
+    from resdepth_amd import ops
+    rng = np.random.RandomState(7)
+    D = dev()
+    for case in range(8):
+        n, hc, wc = int(rng.randint(1, 6)), int(rng.randint(1, 41)), int(rng.randint(1, 51))
+        cin, c0 = int(rng.choice([16, 32, 64, 128, 256])), int(rng.choice([16, 32, 64]))
+        g = torch.Generator().manual_seed(100 + case)
+        h, w = 2 * hc, 2 * wc
+        xc = torch.randn(n, hc, wc, cin, generator=g).to(D)
+        dout = torch.randn(n, 1, h, w, generator=g).to(D)
+        wt = (torch.randn(cin, c0, 2, 2, generator=g) / cin ** 0.5).to(D)
+        bt = (torch.randn(c0, generator=g) * 0.2).to(D)
+        wl = (torch.randn(1, c0, 3, 3, generator=g) / 3).to(D)
+        tag = (case, n, hc, wc, cin, c0)
+        # backward: g = conv_last^T(dout) materialised, then the transposed convolution's two gradients
+        g4 = ops.conv3x3_last_bwd_data(dout, wl, c0)
+        _, wtd = ops.pack_convt2x2_weight(wt)
+        _, v, _, b9 = ops.tail_compose(wt, wl, bt, forward=True)
+        want, got = ops.convt2x2_bwd_data(g4, wtd), ops.convt_last_bwd_data(dout, v)
+        assert float((got - want).abs().max()) <= 3e-6 * float(want.abs().max() + 1e-30), ("dgrad",) + tag
+        want, got = ops.convt2x2_bwd_weight(xc, g4), ops.convt_last_bwd_weight(xc, dout, wl)
+        assert float((got - want).abs().max()) <= 3e-6 * float(want.abs().max() + 1e-30), ("wgrad",) + tag
+        # forward: s = up-convolution + identity skip of a random z (mean 0, invstd 1, gamma 1, beta 0, slope 1), last convolution
+        z = torch.randn(n, h, w, c0, generator=g).to(D)
+        one, zero = torch.ones(c0, device=D), torch.zeros(c0, device=D)
+        skip = {"z": z, "mean": zero, "invstd": one, "gamma": one, "beta": zero, "slope": 1.0, "slope_dev": None}
+        wtf, _ = ops.pack_convt2x2_weight(wt)
+        s = ops.convt2x2_fwd(xc, wtf, bt, z)
+        want = ops.conv3x3_last_fwd(s, wl, None, None)
+        got = ops.conv3x3_last_fwd_tail(skip, ops.tail_t16(xc, v), b9, wl, None, None)
+        assert float((got - want).abs().max()) <= 5e-6 * float(want.abs().max() + 1e-30), ("forward",) + tag
