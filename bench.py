@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        # no launcher: bench.py starts its N ranks itself (self_launch)
 
 Workload = BASELINE.json configs[1] (cfg-S): config_ResDepth-stereo, 3-channel 256x256 tiles, depth-5 U-Net,
 batch 32 per GPU (weak scaling: 8 GPUs = global batch 256), fp32, synthetic tiles already resident in HBM,
@@ -21,7 +22,14 @@ import os
 import sys
 import time
 
-import torch
+# RCCL on these hosts: the kernel driver supports only dmabuf IPC handles; with the legacy IPC mode RCCL's intra-node
+# peer-to-peer set-up (and any sharing of device tensors between processes) fails with `hipIpcGetMemHandle: invalid
+# argument`.  The HSA runtime reads the variable when it initialises, i.e. at the first HIP call of the process -- so it is
+# set here, before torch is imported, and handed to the ranks self_launch() starts.  The image exports it already; the
+# default only matters for environments built by hand (a bare `env -i python bench.py --gpus 8`).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -57,14 +65,15 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(warm=2, timed=5):
-    """the oracle's train step (same module graph / loss / Adam as the reference; the oracle is
-    the CPU restatement pinned on the reference, oracle/unet_oracle.py) on this box's host cores -- cfg-0 (1-ch, batch 4)
-    and cfg-S (3-ch) at batch 8, 2 warm-up + 5 timed steps each, median.  A bounded sample (~15 s of CPU work)."""
+def cpu_baseline(warm=1, timed=3, batch=32):
+    """BASELINE.md section 4 / SURVEY 8d: the oracle's train step (same module graph / loss / Adam as the reference; the
+    oracle is the CPU restatement pinned on the reference, oracle/unet_oracle.py) on this box's host cores -- cfg-S (3-ch)
+    at the GPU leg's batch 32, 1 warm-up + 3 timed steps, median (about 20 s of CPU work), and cfg-0 (1-ch, batch 4,
+    BASELINE configs[0]) beside it."""
     from oracle import unet_oracle as O
     host = os.cpu_count() or 1
 
-    def run(c, batch, warm=warm, timed=timed):
+    def run(c, batch, warm, timed):
         spec = O.Spec(n_input_channels=c, start_kernel=64, depth=5, bias_conv_layer=True)
         sd = O.init_state_dict(spec, 0)
         b = O.synthetic_batch(batch, c, 256, seed=1234)
@@ -87,18 +96,19 @@ def cpu_baseline(warm=2, timed=5):
     for th in (8, 16, 32, 64):
         if th <= host:
             torch.set_num_threads(th)
-            sweep[th] = run(3, 8, warm=1, timed=2)["tiles_per_s"]
+            sweep[th] = run(3, 8, 1, 2)["tiles_per_s"]
     threads = max(sweep, key=sweep.get) if sweep else min(16, host)
     torch.set_num_threads(threads)
 
-    s8 = run(3, 8)
-    c0 = run(1, 4)
-    return {"value": s8["tiles_per_s"], "unit": "tiles/s", "cores": threads, "kind": "port",
+    big = run(3, batch, warm, timed)
+    c0 = run(1, 4, 2, 5)
+    return {"value": big["tiles_per_s"], "unit": "tiles/s", "cores": threads, "kind": "port",
             "host_cores": host, "threads": threads, "cpu_model": _cpu_model(),
-            "cfg_S": s8, "cfg_0": c0, "thread_sweep_tiles_per_s": {str(k): v for k, v in sweep.items()},
+            "cfg_S": big, "cfg_0": c0, "thread_sweep_tiles_per_s_at_batch_8": {str(k): v for k, v in sweep.items()},
             "sample": f"{warm} warm-up + {timed} timed train steps (fwd+loss+bwd+Adam), median: cfg-S 3-ch 256x256 depth-5 at batch "
-                      f"{s8['batch']} ({s8['step_s_median'] * 1e3:.0f} ms/step) and cfg-0 1-ch at batch {c0['batch']} "
-                      f"({c0['step_s_median'] * 1e3:.0f} ms/step); torch-CPU oracle, {threads} threads of {host} hardware threads"}
+                      f"{big['batch']} -- the GPU leg's batch -- ({big['step_s_median'] * 1e3:.0f} ms/step), and cfg-0 1-ch at batch "
+                      f"{c0['batch']} ({c0['step_s_median'] * 1e3:.0f} ms/step); torch-CPU oracle, {threads} threads of {host} "
+                      f"hardware threads (thread count swept in this run at batch 8)"}
 
 
 def infer_main(args, world, rank, dev):
@@ -131,15 +141,20 @@ def infer_main(args, world, rank, dev):
     for _ in range(max(1, args.warmup)):
         predict_linear_blend(loader, model)
     torch.cuda.synchronize()
-    if not args.no_prof:
-        _lib.prof_reset(); _lib.prof_enable(2)
+    if use_dist:
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = predict_linear_blend(loader, model)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kern = []
-    if not args.no_prof:
+    if not args.no_prof:        # one more sweep, instrumented with HIP events per kernel class (never part of `value`)
+        _lib.prof_reset(); _lib.prof_enable(2)
+        predict_linear_blend(loader, model, reduce_to_rank0=False)
+        torch.cuda.synchronize()
         _lib.prof_enable(False); kern = _lib.prof_collect()
     dist_info = None
     if use_dist:
@@ -160,9 +175,10 @@ def infer_main(args, world, rank, dev):
                                    f"eval-mode BN, batch {args.batch}", "parallelism": f"tiles sharded over {world} GPU(s)"},
             "e2e": {"tflops": round(tiles_s / world * fwd_flop / 1e12, 2),
                     "frac_f32_peak": round(tiles_s / world * fwd_flop / 1e12 / PEAK_F32_TFLOPS, 4)},
+            "roofline": build_roofline(kern, 1, PMC_SUMMARIES["G"], "HIP events, one instrumented sweep right after the timed "
+                                       "sweeps (this rank's shard of the tiles)", per="sweep"),
             "raster_checksum": float(out.sum()), "dist": dist_info,
-            "kernels": [{"name": k["name"], "ms_per_sweep": round(k["ms"] / args.steps, 3)} for k in
-                        sorted(kern, key=lambda e: -e["ms"])[:8]]}), flush=True)
+            "kernels": kernel_rows(kern, 1, per="sweep")}), flush=True)
     if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -239,6 +255,81 @@ class TrainBench:
         return dt, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
 
+# committed rocprofv3 PMC summaries (scripts/profile.sh + scripts/summarize_prof.py) per workload, newest first: the source
+# of `roofline.traffic` / `roofline.pmc` -- counters are never collected by bench.py itself
+PMC_SUMMARIES = {"S": ("r04_summary.json", "r03_summary.json", "r02_summary.json", "r01_summary.json"),
+                 "M": ("r04_cfgM_summary.json",), "G": ("r04_cfgG_summary.json",)}
+
+
+def kernel_rows(kern, prof_steps, per="step"):
+    """rd_prof_collect() records -> the `kernels` list of the JSON line (per step / per sweep)."""
+    rows = []
+    for k in sorted(kern, key=lambda e: -e["ms"]):
+        if k["launches"] == 0:
+            continue
+        op, _, sym = k["name"].partition("|")
+        e = {"name": op, f"launches_per_{per}": k["launches"] / prof_steps, f"ms_per_{per}": round(k["ms"] / prof_steps, 4)}
+        if sym:
+            e["kernel"] = sym
+        if k["flops"] > 0:
+            e["tflops"] = round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2)
+        if k["bytes"] > 0:
+            e["alg_gbs"] = round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1)
+            if op not in MFMA_CLASSES:              # HBM-class kernel: fraction of the 8 TB/s spec on ALGORITHMIC bytes
+                e["hbm_frac"] = round(e["alg_gbs"] / PEAK_HBM_GBS, 3)
+        rows.append(e)
+    return rows
+
+
+def build_roofline(kern, prof_steps, summaries, measured, per="step"):
+    """`roofline` of the dominant KERNEL (= one kernel symbol as rocprofv3 reports it; e.g. the conv3x3 forward and
+    data-gradient launches are the same conv3_halo_split instantiation): algorithmic FLOP per launch / average launch
+    duration from the HIP events of rd_prof_*, against the pipe that bounds it."""
+    by_sym = {}
+    for k in kern:
+        op, _, sym = k["name"].partition("|")
+        if op in MFMA_CLASSES and k["launches"] > 0:
+            g = by_sym.setdefault(sym or op, {"ms": 0.0, "flops": 0.0, "launches": 0, "ops": set()})
+            g["ms"] += k["ms"]; g["flops"] += k["flops"]; g["launches"] += k["launches"]; g["ops"].add(op)
+    if not by_sym:
+        return None
+    sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
+    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    traffic, traffic_src, pmc = None, None, None
+    for name in summaries:
+        # HBM bytes per launch are NOT measured by this process: they come from the committed rocprofv3 PMC passes
+        # of this same command (scripts/profile.sh + scripts/summarize_prof.py; FETCH_SIZE doubled per the guide)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f)["kernels"][sym]
+            traffic = rec["hbm_bytes_per_launch"]
+            # same passes: MFMA pipe busy fraction IN CYCLES and the effective clock (power-limited DVFS) -- the
+            # product of the two, relative to 2.4 GHz, is what `frac` sees
+            pmc = {"mfma_pipe_busy": rec.get("mfma_pipe_util"), "effective_clock_ghz": rec.get("clock_ghz_under_pmc"),
+                   "l2_hit_rate": rec.get("l2_hit_rate"), "source": f"profiles/{name}"}
+            traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, not this run)"
+            break
+        except Exception:       # noqa: BLE001
+            continue
+    is_split = any(tag in sym for tag in ("split", "strip", "convt_"))
+    peak = PEAK_SPLIT_TFLOPS if is_split else PEAK_F32_TFLOPS
+    return {"kernel": sym, "ops": sorted(dom["ops"]), "bound": "mfma", "achieved": round(ach, 2),
+            "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "peak_note": ("fp32-equivalent FLOP/s; bound = dense bf16 MFMA peak (2500 TF) / 6 products per fp32 "
+                          "multiply-add of the exact 3-term split" if is_split else "f32-input MFMA peak"),
+            "frac_of_f32_mfma_peak": round(ach / PEAK_F32_TFLOPS, 4),
+            # scripts/ubench/mfma_power.hip / mfma_order.hip (profiles/r03_notes.md section 9): a register-only loop of
+            # back-to-back v_mfma_f32_32x32x16_bf16 (pipe 100 % busy, no memory traffic) sustains 2486 TFLOP/s on constant
+            # operands, 1684-1724 on random bits and 1850 on what these kernels feed it (the three split terms of
+            # N(0,1) floats) -- the power limit (effective clock 1.78 GHz).  Against THAT ceiling / 6 products:
+            "power_limited_peak": round(MFMA_RANDOM_OPERAND_TFLOPS / 6.0, 1) if is_split else None,
+            "frac_of_power_limited_peak": round(ach / (MFMA_RANDOM_OPERAND_TFLOPS / 6.0), 4) if is_split else None,
+            "traffic": traffic, "traffic_source": traffic_src, "pmc": pmc, "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+            "alg_flop_per_launch": dom["flops"] / dom["launches"],
+            f"launches_per_{per}": dom["launches"] / prof_steps,
+            "measured": measured}
+
+
 def _median(v):
     v = sorted(v)
     return v[len(v) // 2] if v else None
@@ -294,14 +385,67 @@ def secondary_measurements(args, dev, tb):
     except Exception as e:      # noqa: BLE001
         out["cfg_M"] = {"error": repr(e)[:200]}
     try:
-        ts, nt = infer_sweep(dev, 4096, 32, 2)
+        ts, nt = infer_sweep(dev, 8192, 32, 2)
         out["cfg_G"] = {"tiles_per_s": round(ts, 1), "tiles": nt, "tflops": round(ts * 19.80e9 / 1e12, 1),
-                        "workload": "cfg-G on one GPU: 4096x4096 raster, 256x256 tiles at stride 128, eval-mode BN, batch 32, "
-                                    "forward + linear blend, 2 timed sweeps"}
+                        "workload": "cfg-G on one GPU (SURVEY 8d size): 8192x8192 raster, 3969 tiles of 256x256 at stride 128, "
+                                    "eval-mode BN folded, batch 32, forward + linear blend, 2 timed sweeps"}
     except Exception as e:      # noqa: BLE001
         out["cfg_G"] = {"error": repr(e)[:200]}
     torch.cuda.empty_cache()
     return out
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without torch.distributed.run: start the N ranks (one process per GPU, LOCAL_RANK = GPU
+    index, rendezvous on 127.0.0.1 at a free port) with the same arguments and wait for them.  Rank 0 prints the JSON
+    line on the inherited stdout; the return code is 0 only if every rank exited 0 (a failing rank takes the others down,
+    by PID, so a dead rank cannot leave the rest waiting in a collective)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RD_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc, alive = 0, set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()
+        if alive:
+            time.sleep(0.05)
+    return rc
+
+
+def rendezvous_only(args, world, rank):
+    """--rendezvous-only: the launcher path without the workload -- every rank joins the process group (`--backend gloo`
+    in the GPU-less build container, nccl = RCCL on the GPU box), all-reduces its rank number and rank 0 prints what it
+    saw.  tests/test_host_cpu.py runs `bench.py --gpus 2 --rendezvous-only --backend gloo` with no launcher."""
+    import torch.distributed as dist
+    backend = args.backend or "nccl"
+    if os.environ.get("RD_BENCH_TEST_FAIL_RANK") == str(rank):      # test hook: a rank that dies before the rendezvous
+        sys.exit(3)
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend)
+    t = torch.tensor([float(rank)], device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"rendezvous": "ok", "backend": dist.get_backend(), "world_size_reported": dist.get_world_size(),
+                          "n_gpus": world, "rank_sum": float(t), "self_launched": bool(os.environ.get("RD_BENCH_SELF_LAUNCHED")),
+                          "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
@@ -329,7 +473,10 @@ def main():
     ap.add_argument("--infer", action="store_true",
                     help="measure the tiled full-raster inference sweep instead (BASELINE configs[4], cfg-G: 3-ch tiles of "
                          "256x256 at stride 128 over a synthetic --raster x --raster DSM, eval-mode BN, linear blend)")
-    ap.add_argument("--raster", type=int, default=4096)
+    ap.add_argument("--raster", type=int, default=8192, help="--infer: side of the synthetic raster (SURVEY 8d: 8192 -> 3969 tiles)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, join the process group, all-reduce one number, print what rank 0 saw and exit")
+    ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; gloo for --rendezvous-only on CPU)")
     ap.add_argument("--no-fold", action="store_true", help="--infer: keep eval-mode BN as separate kernels (A/B of the folded path)")
     ap.add_argument("--prof-all", action="store_true", help="(kept for scripts) same as the default full breakdown")
     ap.add_argument("--force-dist", action="store_true",
@@ -339,10 +486,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
-              f"(WORLD_SIZE={world})", file=sys.stderr)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's plain `python3 bench.py --gpus N ...`: no launcher set the rank environment, so this process becomes
+        # the launcher (one rank per GPU over RCCL, exactly what torch.distributed.run --nproc-per-node N would start)
+        if not args.rendezvous_only and torch.cuda.device_count() < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible", file=sys.stderr)
+            sys.exit(2)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} under a launcher that started {world} rank(s) (WORLD_SIZE={world}): "
+              f"start it with --nproc-per-node {args.gpus}, or with no launcher at all", file=sys.stderr)
         sys.exit(2)
+    if args.rendezvous_only:
+        return rendezvous_only(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -415,68 +571,10 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         tiles_s = n * world * args.steps / dt
-        kernels = []
-        for k in sorted(kern, key=lambda e: -e["ms"]):
-            if k["launches"] == 0:
-                continue
-            op, _, sym = k["name"].partition("|")
-            e = {"name": op, "launches_per_step": k["launches"] / prof_steps,
-                 "ms_per_step": round(k["ms"] / prof_steps, 4)}
-            if sym:
-                e["kernel"] = sym
-            if k["flops"] > 0:
-                e["tflops"] = round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2)
-            if k["bytes"] > 0:
-                e["alg_gbs"] = round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1)
-                if op not in MFMA_CLASSES:              # HBM-class kernel: fraction of the 8 TB/s spec on ALGORITHMIC bytes
-                    e["hbm_frac"] = round(e["alg_gbs"] / PEAK_HBM_GBS, 3)
-            kernels.append(e)
-        # roofline of the dominant KERNEL (= one kernel symbol as rocprofv3 reports it; e.g. the conv3x3 forward
-        # and data-gradient launches are the same igemm_nt instantiation)
-        roof = None
-        by_sym = {}
-        for k in kern:
-            op, _, sym = k["name"].partition("|")
-            if op in MFMA_CLASSES and k["launches"] > 0:
-                g = by_sym.setdefault(sym or op, {"ms": 0.0, "flops": 0.0, "launches": 0, "ops": set()})
-                g["ms"] += k["ms"]; g["flops"] += k["flops"]; g["launches"] += k["launches"]; g["ops"].add(op)
-        if by_sym:
-            sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
-            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            traffic, traffic_src, pmc = None, None, None
-            for name in ("r03_summary.json", "r02_summary.json", "r01_summary.json"):
-                # HBM bytes per launch are NOT measured by this process: they come from the committed rocprofv3 PMC passes
-                # of this same command (scripts/profile.sh + scripts/summarize_prof.py; FETCH_SIZE doubled per the guide)
-                try:
-                    with open(os.path.join(ROOT, "profiles", name)) as f:
-                        rec = json.load(f)["kernels"][sym]
-                    traffic = rec["hbm_bytes_per_launch"]
-                    # same passes: MFMA pipe busy fraction IN CYCLES and the effective clock (power-limited DVFS) -- the
-                    # product of the two, relative to 2.4 GHz, is what `frac` sees
-                    pmc = {"mfma_pipe_busy": rec.get("mfma_pipe_util"), "effective_clock_ghz": rec.get("clock_ghz_under_pmc"),
-                           "l2_hit_rate": rec.get("l2_hit_rate"), "source": f"profiles/{name}"}
-                    traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, not this run)"
-                    break
-                except Exception:       # noqa: BLE001
-                    continue
-            is_split = any(tag in sym for tag in ("split", "strip", "convt_"))
-            peak = PEAK_SPLIT_TFLOPS if is_split else PEAK_F32_TFLOPS
-            roof = {"kernel": sym, "ops": sorted(dom["ops"]), "bound": "mfma", "achieved": round(ach, 2),
-                    "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "peak_note": ("fp32-equivalent FLOP/s; bound = dense bf16 MFMA peak (2500 TF) / 6 products per fp32 "
-                                  "multiply-add of the exact 3-term split" if is_split else "f32-input MFMA peak"),
-                    "frac_of_f32_mfma_peak": round(ach / PEAK_F32_TFLOPS, 4),
-                    # scripts/ubench/mfma_power.hip / mfma_order.hip (profiles/r03_notes.md section 9): a register-only loop of
-                    # back-to-back v_mfma_f32_32x32x16_bf16 (pipe 100 % busy, no memory traffic) sustains 2486 TFLOP/s on constant
-                    # operands, 1684-1724 on random bits and 1850 on what these kernels feed it (the three split terms of
-                    # N(0,1) floats) -- the power limit (effective clock 1.78 GHz).  Against THAT ceiling / 6 products:
-                    "power_limited_peak": round(MFMA_RANDOM_OPERAND_TFLOPS / 6.0, 1) if is_split else None,
-                    "frac_of_power_limited_peak": round(ach / (MFMA_RANDOM_OPERAND_TFLOPS / 6.0), 4) if is_split else None,
-                    "traffic": traffic, "traffic_source": traffic_src, "pmc": pmc, "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                    "alg_flop_per_launch": dom["flops"] / dom["launches"],
-                    "launches_per_step": dom["launches"] / prof_steps,
-                    "measured": f"HIP events, serialized pass of {prof_steps} steps right after the timed region "
-                                "(timed region itself: un-instrumented, wgrad kernels overlapped on a 2nd stream)"}
+        kernels = kernel_rows(kern, prof_steps)
+        roof = build_roofline(kern, prof_steps, PMC_SUMMARIES[args.workload],
+                              f"HIP events, serialized pass of {prof_steps} steps right after the timed region "
+                              "(timed region itself: un-instrumented, wgrad kernels overlapped on a 2nd stream)")
         per_gpu = tiles_s / world
         out = {
             "metric": "DSM tiles/sec fwd+bwd (256x256, 3-ch, depth-5 U-Net)" if args.workload == "S" else

@@ -14,8 +14,10 @@
  *  - activations are NHWC fp32 ("pixel-major, channel-contiguous"): index
  *    ((n*H + y)*W + x)*C + c.  Only the network input (NCHW, few channels) and the
  *    1-channel output / target / mask keep the reference's NCHW layout;
- *  - H and W are powers of two (the reference validates tile_size = 2^k >= 2^(depth+2),
- *    lib/validate_arguments.py:143-171);
+ *  - H and W are arbitrary positive sizes at the op level (the patch / strip kernels take W % 16 == 0 and H % 8 == 0,
+ *    every other shape runs the generic kernels); a depth-d network needs H and W to be multiples of 2^d.  The reference
+ *    itself only ever feeds square tiles of 2^k >= 2^(depth+2) pixels (lib/validate_arguments.py:143-171), which is the
+ *    rule resdepth_amd.validate_tile_size restates for callers;
  *  - all work is enqueued on `stream` (a hipStream_t); nothing synchronises;
  *  - return 0 on success, non-zero on error; rd_last_error_string() (thread-local)
  *    describes the last failure of the calling thread;
@@ -56,7 +58,10 @@ size_t rd_packed_weight_bytes(int rows, int taps, int cin);
  * 64 MB covers cfg-S / cfg-M) every rd_conv3x3_fwd* / rd_conv3x3_bwd_data* launch on `stream` with a small grid runs one
  * block per range -- partial tiles + one ticket per output tile live in `ws` -- and the last block adds the ranges in the
  * same order.  Results are the same bits with or without a registration, at any batch size; only the block count differs.
- * The caller keeps `ws` alive and must not use it for anything else; ws = NULL un-registers the stream. */
+ * A registration belongs to (the device that is current at the call, stream) -- a stream handle alone does not name a device
+ * (the null stream is handle 0 on all of them) -- and `ws` must be memory of that device (RD_ERR_ARG otherwise); launches look
+ * the scratch up under (their current device, their stream).  32 MB + 64 KB is the most any launch uses.
+ * The caller keeps `ws` alive and must not use it for anything else; ws = NULL un-registers (current device, stream). */
 int rd_set_splitk_workspace(void* ws, size_t bytes, rd_stream_t stream);
 
 /* nn.Conv2d weight [Cout][Cin][3][3] (lib/UNet.py:4-5) ->

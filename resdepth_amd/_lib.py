@@ -198,18 +198,25 @@ def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
 
 
 _splitk = {}
+# the most a launch uses: tiles * ranges <= 1024 partial tiles of 128 x 64 floats (csrc/rd_igemm.hip launch_nt) + 64 KB of tickets
+SPLITK_BYTES = (32 << 20) + (64 << 10)
+SPLITK_MAX_STREAMS = 8          # per device; further streams run the same kernel unsplit (same bits, fewer blocks)
 
 
-def ensure_splitk_workspace(device, nbytes: int = (64 << 20) + (64 << 10)) -> None:
+def ensure_splitk_workspace(device, nbytes: int = SPLITK_BYTES) -> None:
     """Register (once per device and stream) the split-K scratch of the 8 x 8 convolution kernel for the CURRENT stream of
-    `device` (include/resdepth_hip.h: rd_set_splitk_workspace).  The engine entry points call this; direct users of the op
-    wrappers may too -- without it those layers run the same kernel unsplit (same bits, fewer blocks at small batches)."""
+    `device` (include/resdepth_hip.h: rd_set_splitk_workspace; the library keys it by (device, stream) too).  The engine
+    entry points call this; direct users of the op wrappers may too -- without it those layers run the same kernel unsplit
+    (same bits, fewer blocks at small batches).  At most SPLITK_MAX_STREAMS streams per device get a buffer, so a server
+    running requests on many short-lived streams does not grow device memory by one scratch per stream handle."""
     dev = torch.device(device)
     index = dev.index if dev.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(index).cuda_stream
     key = (index, stream)
     with _ws_lock:
         if key in _splitk:
+            return
+        if sum(1 for k in _splitk if k[0] == index) >= SPLITK_MAX_STREAMS:
             return
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=torch.device("cuda", index))
         with torch.cuda.device(index):

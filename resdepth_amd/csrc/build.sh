@@ -18,6 +18,9 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 #      0.3-0.6 % end to end (r03 interleaved A/B, profiles/r03_notes.md).
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -fno-slp-vectorize -Wall -Wno-unused-result $RD_EXTRA_FLAGS"
 FLAGS="$BASE -mllvm -amdgpu-mfma-vgpr-form"
+# RD_CLEAN=1 (what __graft_entry__.build() sets): drop every object first, so "does it build" compiles all seven translation
+# units from source instead of re-linking whatever obj/ holds
+[ -n "$RD_CLEAN" ] && rm -rf "$OBJ"
 mkdir -p "$OBJ"
 pids=()
 for f in rd_runtime rd_igemm rd_convt rd_wgrad_strip rd_elementwise rd_edge_conv rd_stats; do

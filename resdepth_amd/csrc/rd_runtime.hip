@@ -58,8 +58,11 @@ static const int g_tune_env = [] {      // RD_TUNE="name=value,..." and the RD_M
 int tune(int key) { return g_tune[key].value; }
 
 // ---- split-K scratch (rd_set_splitk_workspace) --------------------------------------------------------------------
-// One registration per HIP stream: [64 KB of tile tickets, zeroed here once; the kernels leave them zero] [partial-sum slabs].
+// One registration per (device, HIP stream): [64 KB of tile tickets, zeroed here once; the kernels leave them zero]
+// [partial-sum slabs].  The device is part of the key because a stream HANDLE does not name a device: the null stream (torch's
+// default stream) is handle 0 on every device of a process.
 struct SkEntry {
+    int dev;
     hipStream_t s;
     char* ws;
     size_t bytes;
@@ -69,9 +72,11 @@ static std::vector<SkEntry> g_sk;
 constexpr size_t kSkTicketBytes = 64 << 10;
 
 bool splitk_workspace(hipStream_t s, unsigned** tickets, int* n_tickets, float** slab, size_t* slab_bytes) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;      // the launch that follows goes to the current device
     std::lock_guard<std::mutex> lk(g_sk_mu);
     for (const SkEntry& e : g_sk)
-        if (e.s == s) {
+        if (e.dev == dev && e.s == s) {
             *tickets = reinterpret_cast<unsigned*>(e.ws);
             *n_tickets = (int)(kSkTicketBytes / sizeof(unsigned));
             *slab = reinterpret_cast<float*>(e.ws + kSkTicketBytes);
@@ -222,18 +227,30 @@ int rd_prof_collect(rd_prof_entry* out, int max_entries) {
 extern "C" int rd_set_splitk_workspace(void* ws, size_t bytes, rd_stream_t stream) {
     using namespace rd;
     hipStream_t s = (hipStream_t)stream;
+    int dev = -1;
+    if (int e = check_hip(hipGetDevice(&dev), "rd_set_splitk_workspace")) return e;
+    if (ws) {
+        if (bytes < kSkTicketBytes + (1u << 20) || ((size_t)ws & 255)) {
+            set_error("rd_set_splitk_workspace: need a 256-byte aligned buffer of at least %zu bytes", kSkTicketBytes + (1u << 20));
+            return RD_ERR_ARG;
+        }
+        // the scratch has to live on the device the launches of (current device, stream) go to: tickets and slabs are
+        // accessed with agent-scope atomics, which another device's memory does not honour
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, ws) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != dev) {
+            (void)hipGetLastError();
+            set_error("rd_set_splitk_workspace: ws is not device memory of the current device %d", dev);
+            return RD_ERR_ARG;
+        }
+    }
     std::lock_guard<std::mutex> lk(g_sk_mu);
     for (size_t i = 0; i < g_sk.size(); ++i)
-        if (g_sk[i].s == s) {
+        if (g_sk[i].dev == dev && g_sk[i].s == s) {
             g_sk.erase(g_sk.begin() + i);
             break;
         }
     if (!ws) return RD_OK;                           // un-register
-    if (bytes < kSkTicketBytes + (1u << 20) || ((size_t)ws & 255)) {
-        set_error("rd_set_splitk_workspace: need a 256-byte aligned buffer of at least %zu bytes", kSkTicketBytes + (1u << 20));
-        return RD_ERR_ARG;
-    }
     if (int e = check_hip(hipMemsetAsync(ws, 0, kSkTicketBytes, s), "rd_set_splitk_workspace")) return e;
-    g_sk.push_back({s, (char*)ws, bytes});
+    g_sk.push_back({dev, s, (char*)ws, bytes});
     return RD_OK;
 }

@@ -104,3 +104,41 @@ def test_c_abi_consumer_without_torch_compiles_and_links(tmp_path):
     needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True).stdout
     assert "libresdepth_hip.so" in needed and "torch" not in needed and "python" not in needed.lower()
 
+
+
+def _run_bench(args, env=None, timeout=240):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)                      # the driver's plain `python3 bench.py --gpus N`: no launcher environment
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e,
+                          timeout=timeout)
+
+
+def test_bench_gpus_n_starts_its_own_ranks_without_a_launcher():
+    """`python3 bench.py --gpus N` (the driver's command form) must not need torch.distributed.run.  Here: two
+    ranks on CPU (gloo stands in for RCCL in the GPU-less container) rendezvous, all-reduce, and rank 0 prints ONE line."""
+    import json
+    r = _run_bench(["--gpus", "2", "--rendezvous-only", "--backend", "gloo"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["rendezvous"] == "ok" and rec["world_size_reported"] == 2 and rec["rank_sum"] == 1.0
+    assert rec["self_launched"] is True
+    assert rec["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"       # the RCCL precondition of these hosts travels to the ranks
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    r = _run_bench(["--gpus", "2", "--rendezvous-only", "--backend", "gloo"], env={"RD_BENCH_TEST_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    assert "rank 1 exited with 3" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_under_a_launcher_of_the_wrong_size_is_refused():
+    r = _run_bench(["--gpus", "4", "--rendezvous-only", "--backend", "gloo"],
+                   env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29655"})
+    assert r.returncode == 2 and "--nproc-per-node 4" in r.stderr
