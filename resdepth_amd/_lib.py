@@ -244,6 +244,17 @@ def param_generation(flat_ptr: int):
     return (_param_gen.get(flat_ptr, 0), _global_gen)
 
 
+def generations(ptrs):
+    """Raw-pointer generations of several tensors (a model's parameters): what a per-tensor optimizer step or any other
+    `.data` writer that calls bump_param_generation(p.data_ptr()) leaves behind.  Does not include the global counter."""
+    g = _param_gen
+    return tuple(g.get(q, 0) for q in ptrs)
+
+
+def global_generation() -> int:
+    return _global_gen
+
+
 # ---- diagnosis knobs ----------------------------------------------------------------------------
 def tune_set(name: str, value: int):
     check(load().rd_tune_set(name.encode(), int(value)), "tune_set")

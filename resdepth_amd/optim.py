@@ -135,8 +135,10 @@ class FusedAdam(torch.optim.Optimizer):
                 ops.adam_step(p.data.view(-1) if p.data.is_contiguous() else p.data, g.view(-1),
                               st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1), b1, b2, eps, wd, step_size,
                               bc2_sqrt, self.grad_scale)
-            # `.data` writes do not bump Parameter._version: tell every packed-weight cache explicitly
-            _lib.bump_param_generation(None)
+            # `.data` writes do not bump Parameter._version: tell the packed-weight caches of the models that own these
+            # tensors (UNet._current_pack_key reads the generation of every parameter pointer) -- and only those
+            for p in active:
+                _lib.bump_param_generation(p.data_ptr())
 
     def _ensure_state_per_tensor(self, params):
         for p in params:
@@ -238,7 +240,7 @@ class FusedSGD(torch.optim.Optimizer):
             g = p.grad.contiguous()
             ops.sgd_step(p.data.view(-1) if p.data.is_contiguous() else p.data, g.view(-1), buf, lr, wd, mom, damp, nest,
                          first, self.grad_scale)
-        _lib.bump_param_generation(None)
+            _lib.bump_param_generation(p.data_ptr())
 
 
 def get_optimizer(cfg, model, logger=None):

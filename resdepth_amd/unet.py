@@ -213,9 +213,17 @@ class UNet(nn.Module):
 
     def _twin_src_key(self, tw):
         """Identity of this model's parameter / buffer values as the twin last saw them: autograd versions + the raw-pointer
-        generation (optimizers that write through .data bump the global one)."""
-        return (tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers())),
-                _lib.param_generation(0), id(tw))
+        generations of every tensor (optimizers and other writers that go through `.data` / raw pointers, which autograd's
+        counters do not see, bump the generation of the pointers they wrote: _lib.bump_param_generation) + the global one
+        (broadcast).  A writer that does neither -- `p.data.clamp_()` -- has to call `invalidate_twin()`."""
+        ts = list(self.parameters()) + list(self.buffers())
+        ptrs = [t.data_ptr() for t in ts]
+        return (tuple(zip(ptrs, (t._version for t in ts))), _lib.generations(ptrs), _lib.global_generation(), id(tw))
+
+    def invalidate_twin(self):
+        """Force the next forward to re-load the zero-padded twin from this model's parameters (after a `.data` write that
+        neither bumps an autograd version nor calls _lib.bump_param_generation)."""
+        self.__dict__.pop("_twin_key", None)
 
     def _twin_store_buffers(self, tw):
         """Running statistics / num_batches_tracked updated by a training-mode forward of the twin -> this model."""
@@ -335,8 +343,15 @@ class UNet(nn.Module):
         """Identity of the parameter values the packed operands were built from: flat buffer, its raw-pointer generation
         (FusedAdam / broadcast write through `.data`), the autograd versions, and the arithmetic mode (the split-bf16 and the
         exact-f32 kernels read different layouts of the packed buffers; only the active one is written)."""
-        return (self._flat_param.data_ptr(), _lib.param_generation(self._flat_param.data_ptr()),
-                tuple(p._version for p in self._param_list()), _lib.tune_get("mfma_f32"))
+        return (self._own_param_key(), _lib.global_generation(), _lib.tune_get("mfma_f32"))
+
+    def _own_param_key(self):
+        """The part of the pack key that only THIS model's parameters move: flat buffer, autograd versions, and the raw-pointer
+        generations of its tensors (the flat FusedAdam / FusedSGD step bumps the flat buffer's = the first parameter's, the
+        per-tensor fallback every tensor's).  The backward's "parameters changed since the forward" guard compares this part:
+        another model's optimizer step, a broadcast or a change of the arithmetic mode only cause a re-pack."""
+        params = self._param_list()
+        return (self._flat_param.data_ptr(), _lib.generations([p.data_ptr() for p in params]), tuple(p._version for p in params))
 
     def _pack_plan(self):
         """Persistent packed-operand buffers of every conv3x3 / ConvTranspose2d layer + the device-resident item table of
@@ -732,7 +747,7 @@ class UNet(nn.Module):
         encoder levels d-1..0 -- i.e. from the END of the flat buffer towards its start, which is what the
         data-parallel bucketing in resdepth_amd.dp relies on for overlap."""
         d = self.depth
-        if S.get("pack_key") is not None and self._current_pack_key() != S["pack_key"]:
+        if S.get("pack_key") is not None and self._own_param_key() != S["pack_key"][0]:
             # the packed operands live in persistent buffers that a later forward re-packs in place: the data gradients
             # of THIS graph would silently use the new weights.  torch raises in the same situation ("one of the variables
             # needed for gradient computation has been modified by an inplace operation")

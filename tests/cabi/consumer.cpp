@@ -2,6 +2,7 @@
 // cgo / JNI host would bind the library.  One 3x3 convolution layer (lib/UNet.py:4-5,44) forward, data
 // gradient and weight gradient on device buffers it allocates itself, then the block behind it (training-mode BatchNorm
 // statistics from the convolution's epilogue, BN + LeakyReLU + max-pool), checked against direct loops in double on the host;
+// the optional split-K scratch of the 8 x 8 convolution (register for (device, stream) / run / un-register: same bits each way);
 // then the error contract (non-zero return + rd_last_error_string).  Test infrastructure: built and run by
 // tests/test_cabi_consumer_gpu.py.
 #include <hip/hip_runtime.h>
@@ -166,6 +167,60 @@ int main() {
         if (!(e_stat <= 1e-5) || !(e_pool / pscale <= 1e-5)) bad = 1;
         for (void* p : {(void*)d_mean, (void*)d_invstd, (void*)d_gamma, (void*)d_beta, (void*)d_p, (void*)d_z2, (void*)d_idx, (void*)d_sws})
             (void)hipFree(p);
+    }
+
+    // ---- rd_set_splitk_workspace: the 3x3 convolution on 8 x 8 images (the bottleneck shape, lib/UNet.py:78-93) without a
+    // registration, with one for (current device, stream), and after un-registering: the header promises the same bits
+    {
+        const int n8 = 4, h8 = 8, ci8 = 512, co8 = 64;
+        std::vector<float> x8((size_t)n8 * h8 * h8 * ci8), w8((size_t)co8 * ci8 * 9);
+        for (float& v : x8) v = rnd();
+        for (float& v : w8) v = rnd() * 0.05f;
+        std::vector<double> ref((size_t)n8 * h8 * h8 * co8, 0.0);
+        for (int n = 0; n < n8; ++n)
+            for (int y = 0; y < h8; ++y)
+                for (int xx = 0; xx < h8; ++xx)
+                    for (int co = 0; co < co8; ++co) {
+                        double acc = 0;
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const int yy = y + ky - 1, xs = xx + kx - 1;
+                                if (yy < 0 || yy >= h8 || xs < 0 || xs >= h8) continue;
+                                const float* xp = &x8[(((size_t)n * h8 + yy) * h8 + xs) * ci8];
+                                for (int ci = 0; ci < ci8; ++ci) acc += (double)xp[ci] * w8[(((size_t)co * ci8 + ci) * 3 + ky) * 3 + kx];
+                            }
+                        ref[(((size_t)n * h8 + y) * h8 + xx) * co8 + co] = acc;
+                    }
+        float *d_x8 = dev_alloc<float>(x8.size()), *d_w8 = dev_alloc<float>(w8.size()), *d_z8 = dev_alloc<float>(ref.size());
+        const size_t pk = rd_packed_weight_bytes(co8, 9, ci8), sk_bytes = (32u << 20) + (64u << 10);
+        char *d_pk = dev_alloc<char>(pk), *d_sk = dev_alloc<char>(sk_bytes);
+        if (!d_x8 || !d_w8 || !d_z8 || !d_pk || !d_sk) return 2;
+        HIP_OK(hipMemcpyAsync(d_x8, x8.data(), x8.size() * 4, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemcpyAsync(d_w8, w8.data(), w8.size() * 4, hipMemcpyHostToDevice, stream));
+        RD_OK_(rd_pack_conv3x3_weight(d_w8, (float*)d_pk, nullptr, co8, ci8, stream));
+        std::vector<float> z[3] = {std::vector<float>(ref.size()), std::vector<float>(ref.size()), std::vector<float>(ref.size())};
+        for (int pass = 0; pass < 3; ++pass) {
+            if (pass == 1) RD_OK_(rd_set_splitk_workspace(d_sk, sk_bytes, stream));      // register
+            if (pass == 2) RD_OK_(rd_set_splitk_workspace(nullptr, 0, stream));           // un-register
+            HIP_OK(hipMemsetAsync(d_z8, 0xff, ref.size() * 4, stream));
+            RD_OK_(rd_conv3x3_fwd(d_x8, (const float*)d_pk, d_z8, n8, h8, h8, ci8, co8, stream));
+            HIP_OK(hipMemcpyAsync(z[pass].data(), d_z8, ref.size() * 4, hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+        }
+        const double e8 = max_rel(z[1], ref);
+        const bool same = !std::memcmp(z[0].data(), z[1].data(), ref.size() * 4) && !std::memcmp(z[1].data(), z[2].data(), ref.size() * 4);
+        std::printf("split-K scratch: 8 x 8 convolution unregistered / registered / un-registered: %s, deviation from the host %.3g\n",
+                    same ? "same bits" : "DIFFERENT BITS", e8);
+        if (!same || !(e8 <= tol)) bad = 1;
+        // the scratch must be device memory of the current device, 256-byte aligned and large enough
+        std::vector<char> host_buf(sk_bytes);
+        const int r_host = rd_set_splitk_workspace(host_buf.data(), sk_bytes, stream);
+        const int r_align = rd_set_splitk_workspace(d_sk + 4, sk_bytes - 4, stream);
+        const int r_small = rd_set_splitk_workspace(d_sk, 4096, stream);
+        std::printf("split-K scratch: host pointer -> %d, misaligned -> %d, too small -> %d (%s)\n", r_host, r_align, r_small,
+                    rd_last_error_string());
+        if (r_host != RD_ERR_ARG || r_align != RD_ERR_ARG || r_small != RD_ERR_ARG) bad = 1;
+        for (void* p : {(void*)d_x8, (void*)d_w8, (void*)d_z8, (void*)d_pk, (void*)d_sk}) (void)hipFree(p);
     }
 
     // error contract: Cin must be a multiple of 4 here -> non-zero return, message names the argument, nothing launched

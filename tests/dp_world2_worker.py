@@ -9,6 +9,9 @@ modes:
             two-stream backward, FusedAdam, K steps; rank != 0 starts from DIFFERENT weights and adopts rank 0's through
             dp.broadcast_parameters.  Writes losses, step-0 gradients (after the all-reduce), final parameters + buffers.
   infer  -- cfg-G: predict_linear_blend over this rank's tile shard, rasters summed on rank 0 (torch.distributed.reduce)
+  trainer -- resdepth_amd.Trainer (lib/Trainer.py surface) under data parallelism: every rank its own loader shard and its own
+            output directory, ReduceLROnPlateau driven by the (global) validation loss, four epochs; --ragged 1 / 2 gives
+            rank 1 a shard with one more batch / a smaller last batch, which the constructor must refuse on EVERY rank
 """
 import argparse
 import os
@@ -51,6 +54,59 @@ def make_infer_model(dev):
     return model.to(dev).eval()
 
 
+TRAINER = dict(per_rank_batch=2, train_batches=3, val_batches=2, lr=1e-3, epochs=4)
+
+
+def trainer_datasets(rank, tile, c, ragged=0):
+    """This rank's shard of the training / validation samples (disjoint seeds per rank)."""
+    from resdepth_amd import SyntheticDsmOrthoDataset
+    T = TRAINER
+    n_train = T["per_rank_batch"] * T["train_batches"]
+    if rank == 1 and ragged == 1:
+        n_train += T["per_rank_batch"]           # one more batch than rank 0: the per-step collectives would deadlock
+    if rank == 1 and ragged == 2:
+        n_train -= 1                             # same number of batches, smaller last batch: biased SyncBN statistics
+    return (SyntheticDsmOrthoDataset(n_train, c, tile, seed=10 + rank),
+            SyntheticDsmOrthoDataset(T["per_rank_batch"] * T["val_batches"], c, tile, seed=20 + rank))
+
+
+def run_trainer(a, dev):
+    import types
+    from torch.utils.data import DataLoader
+    from resdepth_amd import UNet, FusedAdam, Trainer, dp
+    T = TRAINER
+    kw = ARCH[a.arch]
+    torch.manual_seed(100 + a.rank)                  # rank 0's weights win through the broadcast
+    model = UNet(**kw).to(dev)
+    dp.attach(model, sync_bn=bool(a.sync_bn), bucket_bytes=a.bucket_mb << 20)
+    dp.broadcast_parameters(model, 0)
+    opt = FusedAdam(model.parameters(), lr=T["lr"], weight_decay=1e-5)
+    # threshold 0.9 (relative): an epoch counts as an improvement only below 0.1 x the best validation loss, i.e. never after
+    # the first one -- with patience 0 the rate halves after each of the epochs 1, 2 and 3, on every rank or on none
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=0, threshold=0.9)
+    ds_train, ds_val = trainer_datasets(a.rank, a.tile, kw["n_input_channels"], a.ragged)
+    out_dir = os.path.join(os.path.dirname(a.out), f"trainer_out_r{a.rank}")
+    args = types.SimpleNamespace(
+        model=model, optimizer=opt, scheduler=sched, criterion=torch.nn.L1Loss(reduction="mean"),
+        trainloader=DataLoader(ds_train, batch_size=T["per_rank_batch"], shuffle=False),
+        valloader=DataLoader(ds_val, batch_size=T["per_rank_batch"], shuffle=False), n_epochs=T["epochs"], evaluate_rate=1,
+        save_model_rate=2, freq_average_train_loss=2, save_dir=out_dir, log_file=os.path.join(out_dir, "training.log"),
+        checkpoint_dir=os.path.join(out_dir, "checkpoints"), tboard_log_dir=os.path.join(out_dir, "tb"), pretrained_path=None)
+    try:
+        tr = Trainer(args)
+    except RuntimeError as e:
+        torch.save({"error": str(e)}, a.out)
+        return
+    tr.train()
+    torch.cuda.synchronize()
+    files = sorted(os.path.relpath(os.path.join(d, f), out_dir) for d, _, fs in os.walk(out_dir) for f in fs) \
+        if os.path.isdir(out_dir) else []
+    torch.save({"lr": opt.param_groups[0]["lr"], "best_loss": tr.best_loss, "index_best_loss": tr.index_best_loss,
+                "is_main": tr.is_main, "files": files, "out_dir": out_dir, "num_bad_epochs": sched.num_bad_epochs,
+                "adam_steps": float(next(iter(opt.state.values()))["step"]) if opt.state else None,
+                "state": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}, a.out)
+
+
 INFER_RASTER = dict(rows=640, cols=900, areas=[((0, 559), (0, 383)), ((300, 899), (200, 639))])
 
 
@@ -69,6 +125,7 @@ def main():
     ap.add_argument("--serial-backward", type=int, default=0)
     ap.add_argument("--arch", default="S", choices=["S", "odd"])
     ap.add_argument("--tune", default="", help="RD_TUNE string (kernel-selection knobs), applied before the library loads")
+    ap.add_argument("--ragged", type=int, default=0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     if a.tune:
@@ -134,6 +191,8 @@ def main():
                                       areas=INFER_RASTER["areas"], shard=(a.rank, a.world))
             out = predict_linear_blend(DataLoader(ds, batch_size=5, shuffle=False), model)      # reduce_to_rank0 default
             torch.save({"raster": torch.from_numpy(out.copy()), "n_tiles": len(ds)}, a.out)
+        elif a.mode == "trainer":
+            run_trainer(a, dev)
         else:
             raise SystemExit(f"unknown mode {a.mode}")
     finally:

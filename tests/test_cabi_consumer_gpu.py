@@ -17,3 +17,6 @@ def test_hip_runtime_only_consumer_runs_one_layer_through_the_c_abi(tmp_path):
     lines = r.stdout.strip().splitlines()
     assert lines[-1] == "OK" and sum("max |err|" in ln for ln in lines) == 4 and any("BatchNorm statistics" in ln for ln in lines), r.stdout
     assert any("rd_conv3x3_fwd(cin = 3) ->" in ln and "Cin" in ln for ln in lines), r.stdout
+    # rd_set_splitk_workspace: register for (device, stream) / run / un-register, and its argument checks
+    assert any("split-K scratch" in ln and "same bits" in ln for ln in lines), r.stdout
+    assert any("host pointer -> 1, misaligned -> 1, too small -> 1" in ln for ln in lines), r.stdout

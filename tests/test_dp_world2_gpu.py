@@ -349,3 +349,65 @@ def test_cfg_g_tile_shards_sum_to_the_unsharded_raster(tmp_path):
     got = outs[0]["raster"].numpy()
     assert np.abs(got - full).max() <= 1e-9, np.abs(got - full).max()
     assert np.abs(outs[1]["raster"].numpy() - b).max() <= 1e-9       # a non-destination rank keeps its own partial raster
+
+
+@pytest.mark.parametrize("sync_bn", [1, 0])
+def test_world2_trainer_shell_under_data_parallelism(tmp_path, sync_bn):
+    """resdepth_amd.Trainer (lib/Trainer.py:14-58,113-157,255-318) at world size 2: rank 0 alone writes the log and the
+    checkpoints; the validation loss that drives ReduceLROnPlateau (lib/Trainer.py:296-300) is the GLOBAL masked L1
+    (sum over both shards / valid pixels of both shards, lib/Trainer.py:98), so both ranks see the same number, step the
+    scheduler identically and end with bit-identical weights."""
+    from resdepth_amd import UNet, masked_l1_loss
+    T = W.TRAINER
+    tile = 64
+    r0, r1 = run_world(tmp_path, "trainer", coll="staged", sync_bn=sync_bn, tile=tile, bucket_mb=4)
+    assert "error" not in r0 and "error" not in r1, (r0.get("error"), r1.get("error"))
+    assert r0["is_main"] and not r1["is_main"]
+    # rank-0-only I/O: best + last + the periodic checkpoint
+    # (save_model_rate 2: the periodic checkpoint needs (epoch + 1) % 2 == 0 and epoch > evaluate_rate, lib/Trainer.py:302-306:
+    # of the four epochs only the last one qualifies)
+    assert [f for f in r0["files"] if f.startswith("checkpoints")] == [
+        "checkpoints/Model_after_4_epochs.pth", "checkpoints/Model_best.pth", "checkpoints/Model_last.pth"], r0["files"]
+    assert "training.log" in r0["files"]
+    assert r1["files"] == [], r1["files"]
+    # the scheduler: epoch 0 sets the best loss, epochs 1-3 are "no improvement" under threshold 0.9 -> lr halves three times
+    for r in (r0, r1):
+        assert abs(r["lr"] - T["lr"] * 0.125) < 1e-15, r["lr"]
+        assert r["adam_steps"] == T["epochs"] * T["train_batches"]
+    assert r0["best_loss"] == r1["best_loss"] and r0["index_best_loss"] == r1["index_best_loss"]
+    for k, v in r0["state"].items():
+        if "running" in k or "num_batches" in k:
+            if sync_bn:                      # SyncBN: global statistics -> identical buffers; local BN: per-rank buffers
+                assert torch.equal(v, r1["state"][k]), k
+        else:
+            assert torch.equal(v, r1["state"][k]), k          # same bits on every rank
+    # the logged validation loss of the last epoch == global masked L1 of the final weights over BOTH shards, batch by batch
+    last = torch.load(os.path.join(r0["out_dir"], "checkpoints", "Model_last.pth"), weights_only=False)
+    assert set(last) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss_train", "loss_val", "scheduler_state_dict"}
+    assert last["epoch"] == T["epochs"] - 1
+    if sync_bn:
+        from torch.utils.data import DataLoader
+        model = UNet(**W.CFG_S)
+        model.load_state_dict(last["model_state_dict"])
+        model = model.to(DEV).eval()
+        vals = [DataLoader(W.trainer_datasets(r, tile, 3)[1], batch_size=T["per_rank_batch"], shuffle=False) for r in range(2)]
+        per_batch = []
+        with torch.no_grad():
+            for b0, b1 in zip(*vals):
+                cat = {k: torch.cat([b0[k], b1[k]]) for k in ("input", "target", "loss_mask", "dsm_mean", "dsm_std")}
+                y = model(cat["input"].to(DEV))
+                per_batch.append(float(masked_l1_loss(y, cat["target"], cat["loss_mask"], cat["dsm_mean"], cat["dsm_std"])))
+        want = sum(per_batch) / len(per_batch)
+        assert abs(last["loss_val"] - want) <= 2e-5 * abs(want), (last["loss_val"], want)
+    log = open(os.path.join(r0["out_dir"], "training.log")).read()
+    assert log.count("val:\tEpoch:") == T["epochs"] and "Training finished!" in log
+
+
+@pytest.mark.parametrize("ragged,what", [(1, "len(train loader)"), (2, "size of the last (ragged) train batch")])
+def test_world2_trainer_refuses_unequal_shards_on_every_rank(tmp_path, ragged, what):
+    """A rank with one more batch would leave the others waiting in a collective; a smaller last batch would bias the SyncBN
+    statistics (the count is not exchanged).  Trainer.__init__ compares loader lengths / batch sizes across ranks and raises on
+    ALL of them (resdepth_amd/trainer.py, dp.check_equal_across_ranks)."""
+    r0, r1 = run_world(tmp_path, "trainer", coll="staged", sync_bn=1, tile=64, ragged=ragged)
+    for r in (r0, r1):
+        assert "error" in r and what in r["error"] and "differs across ranks" in r["error"], r.get("error")

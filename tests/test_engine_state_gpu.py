@@ -1,0 +1,131 @@
+"""Host-side engine state (-m gpu): the caches that sit between nn.Parameters and the kernels -- packed GEMM operands, the
+zero-padded twin, saved activations -- must follow every way a caller can change a parameter, and only those."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _batch(n, c, t, seed=0):
+    from resdepth_amd import synthetic_batch
+    return synthetic_batch(n, c, t, seed=seed)
+
+
+def _loss(model, b):
+    from resdepth_amd import masked_l1_loss
+    return masked_l1_loss(model(b["input"].to(DEV)), b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
+
+
+def test_two_models_interleaved_another_models_step_does_not_trip_the_backward_guard():
+    """forward A, forward B, backward B, step B, backward A: A's parameters did not change, so A's backward must
+    run -- also when B's optimizer takes the per-tensor path (one gradient missing), which used to bump a GLOBAL generation
+    that A's guard read.  A's gradients equal the ones of an undisturbed forward / backward, bit for bit."""
+    from resdepth_amd import UNet, FusedAdam
+    kw = dict(n_input_channels=3, start_kernel=16, depth=3, bias_conv_layer=True)
+    torch.manual_seed(0)
+    A = UNet(**kw).to(DEV).train()
+    torch.manual_seed(1)
+    B = UNet(**kw).to(DEV).train()
+    optB = FusedAdam(B.parameters(), lr=1e-3)
+    b = _batch(4, 3, 64)
+    bufs = [v.clone() for v in A.buffers()]
+    la = _loss(A, b)
+    la.backward()
+    want = [p.grad.clone() for p in A.parameters()]
+    for p in A.parameters():
+        p.grad = None
+    for v, o in zip(A.buffers(), bufs):
+        v.copy_(o)
+    la = _loss(A, b)
+    lb = _loss(B, b)
+    lb.backward()
+    next(iter(B.parameters())).grad = None          # FusedAdam: a parameter without gradient -> per-tensor path
+    optB.step()
+    la.backward()                                    # must not raise
+    for p, w in zip(A.parameters(), want):
+        assert torch.equal(p.grad, w)
+
+
+@pytest.mark.parametrize("how", ["flat_step", "per_tensor_step", "inplace_op"])
+def test_backward_guard_still_sees_this_models_own_parameter_changes(how):
+    from resdepth_amd import UNet, FusedAdam
+    torch.manual_seed(0)
+    A = UNet(n_input_channels=3, start_kernel=16, depth=3, bias_conv_layer=True).to(DEV).train()
+    opt = FusedAdam(A.parameters(), lr=1e-3)
+    b = _batch(4, 3, 64)
+    _loss(A, b).backward()                           # gradients for the optimizer step below
+    la = _loss(A, b)
+    if how == "flat_step":
+        opt.step()
+    elif how == "per_tensor_step":
+        list(A.parameters())[3].grad = None
+        opt.step()
+    else:
+        with torch.no_grad():
+            A.last_layer.weight.mul_(1.5)
+    with pytest.raises(RuntimeError, match="a parameter was modified"):
+        la.backward()
+
+
+def test_twin_follows_optimizer_steps_and_explicit_invalidation():
+    """A model that runs on its zero-padded twin (start_kernel = 6) re-loads the twin only when its parameters changed.  The
+    change detectors: autograd versions, the raw-pointer generations the optimizers bump, and invalidate_twin() for `.data`
+    writes nothing else can see."""
+    from resdepth_amd import UNet, FusedAdam
+    kw = dict(n_input_channels=2, start_kernel=6, depth=2, max_filter_depth=10)
+    torch.manual_seed(0)
+    m = UNet(**kw).to(DEV)
+    assert m._needs_twin()
+    b = _batch(2, 2, 32)
+
+    def fresh_eval(sd):
+        f = UNet(**kw)
+        f.load_state_dict(sd)
+        f = f.to(DEV).eval()
+        with torch.no_grad():
+            return f(b["input"].to(DEV))
+
+    opt = FusedAdam(m.parameters(), lr=1e-2)
+    for _ in range(2):
+        m.train()
+        _loss(m, b).backward()
+        opt.step()                                   # writes through raw pointers (per tensor: the gradients are twin corners)
+        for p in m.parameters():
+            p.grad = None
+        m.eval()
+        with torch.no_grad():
+            y = m(b["input"].to(DEV))
+        assert torch.equal(y, fresh_eval({k: v.detach().cpu() for k, v in m.state_dict().items()}))
+    with torch.no_grad():
+        y0 = m(b["input"].to(DEV))
+        m.last_layer.weight.data.mul_(2.0)           # invisible to autograd versions and to the generation counters
+        m.invalidate_twin()
+        y1 = m(b["input"].to(DEV))
+    assert not torch.equal(y0, y1)
+    assert torch.equal(y1, fresh_eval({k: v.detach().cpu() for k, v in m.state_dict().items()}))
+
+
+def test_second_backward_with_retained_activations_on_the_composed_tail_route():
+    """loss.backward(retain_graph=True) twice (the reference's torch modules allow it; here `retain_activations` has to be set,
+    INTEGRATION.md): both backwards give the same gradients, on the default route (composed tail, level-0 BN backward inside the
+    first convolution's weight gradient) whose saved state holds live references to parameters."""
+    from resdepth_amd import UNet
+    torch.manual_seed(0)
+    m = UNet(n_input_channels=3, start_kernel=16, depth=3, bias_conv_layer=True).to(DEV).train()
+    assert m.composed_tail and m.fused_first_wgrad
+    m.retain_activations = True
+    b = _batch(4, 3, 64)
+    loss = _loss(m, b)
+    loss.backward(retain_graph=True)
+    g1 = [p.grad.clone() for p in m.parameters()]
+    for p in m.parameters():
+        p.grad = None
+    loss.backward()
+    for p, g in zip(m.parameters(), g1):
+        assert torch.equal(p.grad, g)
+    m.retain_activations = False
+    loss = _loss(m, b)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError):
+        loss.backward()
