@@ -8,9 +8,9 @@
 import collections, csv, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof")
-DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "prof")      # PROF_DIR of scripts/profile.sh
+DST = os.environ.get("PROF_DST") or os.path.join(ROOT, "profiles")     # PROF_DST: summarise on the GPU box into gpurun_out/
 
 
 def sym(name):

@@ -564,6 +564,7 @@ def _hip_decisions(model, x_dev, spec):
     if model._needs_twin():
         eng = model._twin_load()
         xin = model._pad_input(x_dev, eng)
+    eng._ensure_flat()                       # what UNet.forward does before it enters the engine
     with torch.no_grad():
         bufs = [(v, v.clone()) for v in eng.buffers()]
         _, S = eng._engine_forward(xin.detach(), True, save=True, keep_skips=True)
