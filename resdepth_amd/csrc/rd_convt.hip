@@ -36,6 +36,7 @@ struct CtParams {
     int PW, logPW, TR;       // patch = TR rows x PW columns, TR * PW = 32 * TM
     int tiles_x, ngroups, nk;
     unsigned x_bytes, w_bytes;
+    int direct;              // register-direct epilogue (r04) instead of the LDS-staged one (tune nt_epi = 0)
 };
 
 __device__ __forceinline__ float ct_act(float y, float slope) { return y > 0.f ? y : y * slope; }
@@ -161,6 +162,63 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
     }
     __syncthreads();
 
+    if (p.direct) {
+        // ---- register-direct epilogue (r04; cf. nt_epilogue_direct in rd_nt.h): no LDS round trip, no barriers.  A lane holds
+        // ONE output column (32-column block `wave` of the tile's 128 contiguous floats per pixel) of sixteen tile rows per
+        // 32 x 32 block -- so one bias value and one (scale, shift) pair per lane instead of four; lanes 0-31 of a load / store
+        // cover 128 contiguous bytes of one output pixel, lanes 32-63 the pixel four input columns on.  The pixel part of the
+        // address is wave-uniform (SGPR offset of a buffer access), the lane part one offset computed once.  All skip loads of
+        // the tile are issued before the first use.
+        const int col0d = cg * 128;
+        const int ab0d = col0d / p.Cout, co0d = col0d - ab0d * p.Cout;
+        const long obased = (((long)(2 * g0 + (ab0d >> 1)) * (2 * W)) + 2 * x0 + (ab0d & 1)) * p.Cout + co0d;
+        const int ystr = __builtin_amdgcn_readfirstlane(4 * W * p.Cout * 4), xstr = __builtin_amdgcn_readfirstlane(2 * p.Cout * 4);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        int cod = co0d + wv * 32 + lrow;
+        if (cod >= p.Cout) cod -= p.Cout;                   // Cout = 64: columns 64..127 are the b = 1 pixel
+        const float bias1 = p.bias ? p.bias[cod] : 0.f;
+        // skip value = act(sc * s + sh): the lazy act(BN(z)) recomputation; a materialised skip is the identity case
+        // (sc, sh, slope) = (1, 0, 1), no skip at all loads zeros (out-of-extent offset) -- one code path, no per-element selects
+        float sc1 = 1.f, sh1 = 0.f, slope1 = 1.f;
+        if (p.sk_mean) {
+            sc1 = p.sk_invstd[cod] * p.sk_gamma[cod];
+            sh1 = p.sk_beta[cod] - p.sk_mean[cod] * sc1;
+            slope1 = p.sk_slope_dev ? p.sk_slope_dev[0] : p.sk_slope;
+        }
+        const unsigned lane_off_s = p.skip ? lane_off : kOOB;
+        const unsigned span = (unsigned)(p.TR * (4 * W * p.Cout * 4));
+        const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.out + obased, span), rsS = make_rsrc(p.skip ? p.skip + obased : p.out + obased, span);
+        const unsigned lane_off = (unsigned)(4 * half * xstr + (wv * 32 + lrow) * 4);
+        const int rows_left = __builtin_amdgcn_readfirstlane(p.G - g0);         // patch rows inside the stacked image rows
+        auto soffd = [&](int i, int r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2);                      // + 4 * half in the lane offset
+            return (unsigned)((row >> logPW) * ystr + (row & pwm) * xstr);
+        };
+        auto rowok = [&](int i, int r) { return ((i * 32 + (r & 3) + 8 * (r >> 2)) >> logPW) < rows_left; };
+        // FULL: every patch row of the tile exists (all tiles but the last row band of a ragged grid) -- no per-row select
+        auto emit = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+            auto voff = [&](int i, int r) { return FULL || rowok(i, r) ? lane_off : kOOB; };
+            auto voff_s = [&](int i, int r) { return FULL || rowok(i, r) ? lane_off_s : kOOB; };
+            float skv[TM][16];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    skv[i][r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsS, voff_s(i, r), soffd(i, r), 0));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = merge_hi_lo(acc[i][r], lo[i][r]) + bias1;
+                    const float s1 = ct_act(fmaf(skv[i][r], sc1, sh1), slope1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(s1 + v), rsO, voff(i, r), soffd(i, r), 0);
+                }
+        };
+        if (rows_left >= p.TR) emit(std::true_type());
+        else emit(std::false_type());
+        return;
+    }
     // ---- epilogue: 32-row passes through LDS; tile row r = (gy, px) owns 128 contiguous floats of the output
     const int col0 = cg * 128;
     const int ab0 = col0 / p.Cout, co0 = col0 - ab0 * p.Cout;
@@ -400,6 +458,7 @@ int convt_dgrad_launch(NtParams p, hipStream_t s, int* launched, int* tiles_m_ou
     const long grid = tiles_m * p.tiles_n;
     if (grid >= (1L << 31)) return RD_OK;
     if (tiles_m_out) *tiles_m_out = (int)tiles_m;
+    p.direct = tune(TUNE_NT_EPI) != 0 && p.M % bm == 0 && p.N % 32 == 0 && !p.shift && !p.pool_out;     // rd_nt.h: nt_epilogue_direct
     char pcls[64];
     snprintf(pcls, sizeof(pcls), "convt2x2_dgrad|convt_dgrad<%s>", cfg == 0 ? "4,1,4" : cfg == 1 ? "2,1,4" : "2,2,2");
     ProfScope ps(s, pcls, 2.0 * p.M * (double)p.N * p.K, 4.0 * (4.0 * p.M * Cd + (double)p.N * p.K + (double)p.M * p.N * (p.bn_part ? 2 : 1)), true);
@@ -709,6 +768,7 @@ int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, co
     snprintf(pcls, sizeof(pcls), "convt2x2_fwd|convt_fwd<%d>", tm);
     ProfScope ps(s, pcls, 2.0 * M * 4.0 * cout * cin,
                  4.0 * ((double)M * cin + 4.0 * cout * cin + (skip ? 2.0 : 1.0) * 4.0 * M * cout), true);
+    p.direct = tune(TUNE_NT_EPI) != 0;
     if (tm == 2) hipLaunchKernelGGL(convt_fwd_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(convt_fwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, p);
     RD_LAUNCH_CHECK("convt_fwd");

@@ -66,6 +66,9 @@ struct NtParams {
     int ksplit, chunks_per;
     float* sk_slab;
     unsigned* sk_ticket;
+    // training-mode EPI_STORE (no shift / pooling epilogue), N % 32 == 0, patch kernels or plain row tiles with M a multiple
+    // of the tile height: the register-direct epilogue (nt_epilogue_direct) instead of the LDS-staged one
+    int direct;
 };
 
 // transposed-convolution data gradient (rd_convt.hip); *launched = 0 when the shape is left to the generic NT kernel
@@ -76,12 +79,203 @@ __device__ __forceinline__ float nt_act_grad(float y, float slope) { return y > 
 
 __device__ __forceinline__ float skip_act(float y, float slope) { return y > 0.f ? y : y * slope; }
 
+// ---- register-direct epilogue of the patch (halo) kernels in training (r04).  The LDS-staged epilogue below costs the 3 x 3
+// convolutions 6 % with the BatchNorm statistics and 4 % with the BN-backward hook on top of the plain store, which is
+// itself ~1000 VALU instructions per wave and eight barriers (scripts/epilogue_cost.py: enc1 forward 0.383 -> 0.449 ms with
+// statistics) -- VALU work that a sibling wave's MFMAs on the same SIMD wait behind.  Here nothing goes through LDS:
+//  * C: a lane holds column n = lane & 31 of sixteen rows per 32 x 32 block; lanes 0-31 of a store instruction cover 128
+//    contiguous bytes (one cache line) of one pixel, lanes 32-63 the same columns four pixels on.  The row part of the
+//    address is wave-uniform (scalar registers), the lane part one 32-bit offset computed once: no address VALU per element;
+//  * BatchNorm statistics (forward): column sums straight from the accumulator registers (64 adds + 64 FMAs per 32-column
+//    block), halves combined by one cross-lane exchange -- replaces 4 passes of scalar LDS reads with per-row bounds checks;
+//  * BN-backward hook (data gradient): z is loaded in the accumulator layout (all loads issued before the C stores), the
+//    sums stay in registers, one cross-lane exchange.
+// Summation order differs from the staged epilogue's (still fixed: deterministic); rows of a patch are always inside the
+// image, only the second image of a two-image patch (patch == 2) can be absent.
+template <int BM, int BN, int WM, int WN, int SMEM_WORDS>
+__device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem, const NtParams& p,
+                                                   int m0, int n0, int tile_m) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 31, half = lane >> 5;
+    const int N = p.N;
+    const bool two = p.patch == 2;
+    const bool img2_ok = !two || m0 + 64 < p.M;
+    // pixel offset (from m0) of accumulator element r of row block i: wave-uniform part; the lane adds 4 * half pixels.
+    //   8 x 16 patch:            (tile row >> 4) * W + (tile row & 15)           two 8 x 8 images: ((row & 15) >> 3) * 64 + (row >> 4) * 8 + (row & 7)
+    // with tile row = 32 (wm TM + i) + (r & 3) + 8 (r >> 2) + 4 half, i.e. patch row 2 (wm TM + i) + (r >> 3), bit 3 of the column = (r >> 2) & 1
+    // plain row tiles (patch == 0, every row inside M: the host only asks for this epilogue then) are the W = 16 case of the formula
+    const int SA = two ? 8 : p.patch ? p.W : 16, SB = two ? 64 : 8;   // pixels per patch row / per column-bit-3
+    const int rowN = __builtin_amdgcn_readfirstlane(N * 4);
+    const int pu0 = __builtin_amdgcn_readfirstlane(2 * wm * TM * SA);
+    auto pix_u = [&](int i, int r) { return pu0 + (2 * i + (r >> 3)) * SA + (r & 3) + ((r >> 2) & 1) * SB; };
+    const int ncol0 = n0 + wn * TN * 32;                        // first column of this wave (N % 32 == 0: a block is in or out)
+    // buffer addressing: descriptor base = first pixel of the tile (wave-uniform), scalar offset = the element's pixel row
+    // (wave-uniform, SGPR), lane offset = (4 * half pixels, column) computed once; an absent second image / column block gets
+    // the out-of-extent offset, which the hardware drops (stores) or answers with zeros (loads).  A tile spans fewer than
+    // 8 * W + 16 pixels: its byte extent stays far below 2^32
+    const unsigned span = (unsigned)((two ? 128 : p.patch ? 7 * p.W + 16 : BM) * N * 4);
+    const unsigned lane_off = (unsigned)(((4 * half) * N + ncol0 + lrow) * 4);
+    unsigned vo1[TN], vo2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        vo1[j] = ncol0 + j * 32 < N ? lane_off + j * 128 : kOOB;
+        vo2[j] = img2_ok ? vo1[j] : kOOB;                       // elements of the second image of a two-image patch
+    }
+    auto soff = [&](int i, int r) { return (unsigned)(pix_u(i, r) * rowN); };
+    const __amdgpu_buffer_rsrc_t rsC = make_rsrc(p.C + (long)m0 * N, span);
+    const bool bn_on = p.bn_part != nullptr;
+    const bool st_on = p.stats != nullptr;
+
+    // ---- BN-backward hook: request z first (accumulator layout), its latency hides behind the C stores
+    float zr[TM][TN][16];
+    if (bn_on) {
+        const __amdgpu_buffer_rsrc_t rsZ = make_rsrc(p.bn_z + (long)m0 * N, span);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    zr[i][j][r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsZ, ((r >> 2) & 1) ? vo2[j] : vo1[j], soff(i, r), 0));
+    }
+    // ---- C
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[i][j][r]), rsC, ((r >> 2) & 1) ? vo2[j] : vo1[j], soff(i, r), 0);
+    // ---- forward BatchNorm statistics: per-(tile_m) column sums / sums of squares [tiles_m][2][N]
+    if (st_on) {
+        float* red = smem;                                      // WM > 1: [wm][2][BN]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float ss = 0.f, qq = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = (img2_ok || !((r >> 2) & 1)) ? acc[i][j][r] : 0.f;
+                    ss += v;
+                    qq = fmaf(v, v, qq);
+                }
+            ss += __shfl_xor(ss, 32);
+            qq += __shfl_xor(qq, 32);
+            const int col = wn * TN * 32 + j * 32 + lrow;        // column inside the block tile
+            if (WM == 1) {
+                if (half == 0 && n0 + col < N) {
+                    float* out = p.stats + (long)tile_m * 2 * N + n0 + col;
+                    out[0] = ss;
+                    out[N] = qq;
+                }
+            } else if (half == 0) {
+                red[(wm * 2 + 0) * BN + col] = ss;
+                red[(wm * 2 + 1) * BN + col] = qq;
+            }
+        }
+        if (WM > 1) {
+            static_assert(WM * 2 * BN <= SMEM_WORDS, "statistics scratch must fit the operand buffers");
+            __syncthreads();
+            if (t < BN && n0 + t < N) {
+                float ss = 0.f, qq = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WM; ++w2) {
+                    ss += red[(w2 * 2 + 0) * BN + t];
+                    qq += red[(w2 * 2 + 1) * BN + t];
+                }
+                float* out = p.stats + (long)tile_m * 2 * N + n0 + t;
+                out[0] = ss;
+                out[N] = qq;
+            }
+        }
+    }
+    // ---- BN-backward statistics [tile_m][4][N]: g' = g act'(y), g' xhat, g (mode 1), g y [y <= 0]
+    if (bn_on) {
+        const float bslope = p.bn_slope_dev ? p.bn_slope_dev[0] : p.bn_slope;
+        const bool mode1 = p.bn_mode == 1;
+        float* red = smem;                                      // WM > 1: [wm][4][BN]
+        if (WM > 1 && st_on) __syncthreads();                   // (never both in one launch; keeps the scratch uses apart)
+        // 10 VALU per element: y, y > 0, g * slope, select, xhat as one FMA, three accumulations, and the fourth sum (the
+        // learnable slope's gradient: select + FMA; part of the entry points' contract whatever the activation)
+        {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * TN * 32 + j * 32 + lrow;
+                const int n = n0 + col;
+                float sc = 0.f, sh = 0.f, is = 0.f, nmi = 0.f;
+                if (n < N) {
+                    const float mu = p.bn_mean[n];
+                    is = p.bn_invstd[n];
+                    sc = is * p.bn_gamma[n];
+                    sh = p.bn_beta[n] - mu * sc;
+                    nmi = -mu * is;
+                }
+                float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool ok = img2_ok || !((r >> 2) & 1);
+                        const float g = ok ? acc[i][j][r] : 0.f, z = zr[i][j][r];
+                        const float y = fmaf(z, sc, sh);
+                        const float gm = y > 0.f ? g : g * bslope;
+                        const float xh = fmaf(z, is, nmi);
+                        b0 += gm;
+                        b1 = fmaf(gm, xh, b1);
+                        b2 += g;
+                        if (!(y > 0.f)) b3 = fmaf(g, y, b3);
+                    }
+                if (!mode1) b2 = 0.f;
+                b0 += __shfl_xor(b0, 32);
+                b1 += __shfl_xor(b1, 32);
+                b2 += __shfl_xor(b2, 32);
+                b3 += __shfl_xor(b3, 32);
+                if (WM == 1) {
+                    if (half == 0 && n < N) {
+                        float* out = p.bn_part + (long)tile_m * 4 * N + n;
+                        out[0] = b0;
+                        out[N] = b1;
+                        out[2 * N] = b2;
+                        out[3 * N] = b3;
+                    }
+                } else if (half == 0) {
+                    red[(wm * 4 + 0) * BN + col] = b0;
+                    red[(wm * 4 + 1) * BN + col] = b1;
+                    red[(wm * 4 + 2) * BN + col] = b2;
+                    red[(wm * 4 + 3) * BN + col] = b3;
+                }
+            }
+        }
+        if (WM > 1) {
+            static_assert(WM * 4 * BN <= SMEM_WORDS, "statistics scratch must fit the operand buffers");
+            __syncthreads();
+            for (int o = t; o < 4 * BN; o += 256) {
+                const int sidx = o / BN, col = o - sidx * BN;
+                float sum = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WM; ++w2) sum += red[(w2 * 4 + sidx) * BN + col];
+                if (n0 + col < N) p.bn_part[((long)tile_m * 4 + sidx) * N + n0 + col] = sum;
+            }
+        }
+    }
+}
+
 // ---- epilogue shared by the NT kernels.  D[i][j]: lane -> column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5) (the C/D
 // map is the same for the f32 and the bf16 MFMA shapes).
 template <int BM, int BN, int WM, int WN, int EPI, int SMEM_WORDS, int EB = BM / WM / 32>
 __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem, const NtParams& p,
                                             int m0, int n0, int tile_m, long pool_base = -1) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    if constexpr (EPI == EPI_STORE) {
+        if (p.direct) {
+            nt_epilogue_direct<BM, BN, WM, WN, SMEM_WORDS>(acc, smem, p, m0, n0, tile_m);
+            return;
+        }
+    }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane & 31, half = lane >> 5;

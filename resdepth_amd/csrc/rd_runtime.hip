@@ -34,7 +34,7 @@ struct TuneEntry {
 static TuneEntry g_tune[TUNE_COUNT] = {
     {"mfma_f32", 0},   {"nt_tile", -1},      {"nt_halo", -1},    {"nt_skew", 1},     {"tn_tile", -1},     {"tn_blocks", 512}, {"tn_split", -1},
     {"wg_strip", -1},  {"wg_minblocks", 768}, {"wg_blocks", 512}, {"wg_occ", 2}, {"convt_patch", -1}, {"edge_conv", -1}, {"rows_blocks", 512}, {"last_blocks", 2048},
-    {"nt_splitk", -1},
+    {"nt_splitk", -1}, {"nt_epi", -1},
 };
 static int tune_index(const char* name, size_t len) {
     for (int i = 0; i < TUNE_COUNT; ++i)
