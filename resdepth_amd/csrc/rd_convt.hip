@@ -185,10 +185,11 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
             sh1 = p.sk_beta[cod] - p.sk_mean[cod] * sc1;
             slope1 = p.sk_slope_dev ? p.sk_slope_dev[0] : p.sk_slope;
         }
-        const unsigned lane_off_s = p.skip ? lane_off : kOOB;
+
         const unsigned span = (unsigned)(p.TR * (4 * W * p.Cout * 4));
         const __amdgpu_buffer_rsrc_t rsO = make_rsrc(p.out + obased, span), rsS = make_rsrc(p.skip ? p.skip + obased : p.out + obased, span);
         const unsigned lane_off = (unsigned)(4 * half * xstr + (wv * 32 + lrow) * 4);
+        const unsigned lane_off_s = p.skip ? lane_off : kOOB;
         const int rows_left = __builtin_amdgcn_readfirstlane(p.G - g0);         // patch rows inside the stacked image rows
         auto soffd = [&](int i, int r) {
             const int row = i * 32 + (r & 3) + 8 * (r >> 2);                      // + 4 * half in the lane offset

@@ -943,7 +943,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
             p.sk_ticket = tickets;
         }
         p.patch = 2;
-        p.direct = tune(TUNE_NT_EPI) != 0 && !p.shift && !p.pool_out && p.N % 32 == 0;
+        p.direct = tune(TUNE_NT_EPI) != 0 && p.N % 32 == 0;
         p.tiles_n = tiles_n;
         if (tiles_m_out) *tiles_m_out = tiles_m;
         char pc8[64];
@@ -971,7 +971,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     if (halo) {
         // 3x3 convolution on 8x16-pixel patches with halo reuse
         p.patch = 1;
-        p.direct = tune(TUNE_NT_EPI) != 0 && !p.shift && !p.pool_out && p.N % 32 == 0;
+        p.direct = tune(TUNE_NT_EPI) != 0 && p.N % 32 == 0;
         const int tiles_m = (p.M >> 7);       // (H/8) * (W/16) patches per image, 128 pixels each
         if (tiles_m_out) *tiles_m_out = tiles_m;
         if (cfg == 0) {

@@ -94,7 +94,7 @@ __device__ __forceinline__ float skip_act(float y, float slope) { return y > 0.f
 // image, only the second image of a two-image patch (patch == 2) can be absent.
 template <int BM, int BN, int WM, int WN, int SMEM_WORDS>
 __device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem, const NtParams& p,
-                                                   int m0, int n0, int tile_m) {
+                                                   int m0, int n0, int tile_m, long pool_base) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -140,6 +140,43 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][B
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     zr[i][j][r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsZ, ((r >> 2) & 1) ? vo2[j] : vo1[j], soff(i, r), 0));
+    }
+    // ---- inference (eval-mode BatchNorm folded into the weights): C = act(acc + shift[n]) -- one shift value per lane -- and,
+    // on request, MaxPool2d(2, 2) of it from the same registers: the four pixels of a window are elements r, r + 1 (next
+    // column) and r + 8, r + 9 (next patch row) of ONE lane, r in {0, 2, 4, 6}; the pooled row of a 32 x 32 block is again
+    // 128 contiguous bytes per pixel.  Window order and the NaN rule are torch's max_pool2d (first maximum, NaN wins).
+    if (p.shift) {
+        const float slope = p.act_slope;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = ncol0 + j * 32 + lrow;
+            const float sh = n < N ? p.shift[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = skip_act(acc[i][j][r] + sh, slope);
+        }
+        if (p.pool_out && pool_base >= 0) {
+            const int Wp = p.W >> 1;
+            const __amdgpu_buffer_rsrc_t rsP = make_rsrc(p.pool_out + pool_base * N, (unsigned)((3 * Wp + 8) * N * 4));
+            const unsigned lane_off_p = (unsigned)(((2 * half) * N + ncol0 + lrow) * 4);
+            const int prow0 = __builtin_amdgcn_readfirstlane(wm * TM * Wp);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 8; r += 2) {
+                        float mx = acc[i][j][r];
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) {
+                            const float y = acc[i][j][r + (k & 1) + 8 * (k >> 1)];
+                            if (y > mx || y != y) mx = y;
+                        }
+                        const unsigned so = (unsigned)((prow0 + i * Wp + ((r >> 1) & 1) + 4 * ((r >> 2) & 1)) * rowN);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(mx), rsP, ncol0 + j * 32 < N ? lane_off_p + j * 128 : kOOB, so, 0);
+                    }
+        }
     }
     // ---- C
 #pragma unroll
@@ -272,7 +309,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     if constexpr (EPI == EPI_STORE) {
         if (p.direct) {
-            nt_epilogue_direct<BM, BN, WM, WN, SMEM_WORDS>(acc, smem, p, m0, n0, tile_m);
+            nt_epilogue_direct<BM, BN, WM, WN, SMEM_WORDS>(acc, smem, p, m0, n0, tile_m, pool_base);
             return;
         }
     }
