@@ -396,6 +396,24 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
     }
 
     float* out = p.slab + (long)split * p.M * p.N;
+    const int cwu = __builtin_amdgcn_readfirstlane(cw), cbu = __builtin_amdgcn_readfirstlane(cb);
+    if (m0 + 32 * NCO <= p.M && (long)(32 * NCO) * p.N * 4 < 0x7fffffffL) {
+        // whole tile inside the slab (every shape of the network): buffer stores with the row / tap part of the address in
+        // scalar registers and ONE per-lane offset -- 144 stores and no address arithmetic in the vector ALU (r04; the 64-bit
+        // per-element addresses below cost ~6 VALU instructions per store beside a sibling wave's MFMAs)
+        const __amdgpu_buffer_rsrc_t rsO = make_rsrc(out + (long)m0 * p.N + ci0, (unsigned)((long)(32 * NCO) * p.N * 4));
+        const unsigned lane_off = (unsigned)(((4 * half) * p.N + lrow) * 4);
+        const int rowN = __builtin_amdgcn_readfirstlane(p.N * 4);
+        const int base = (cwu * 32) * rowN + cbu * 128;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int tapo = base + tp * p.Cin * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[tp][r]), rsO, lane_off, (unsigned)(tapo + ((r & 3) + 8 * (r >> 2)) * rowN), 0);
+        }
+        return;
+    }
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
         const int n = tp * p.Cin + ci0 + cb * 32 + lrow;
