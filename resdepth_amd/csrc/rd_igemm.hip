@@ -990,6 +990,9 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
         RD_LAUNCH_CHECK(cls);
         return RD_OK;
     }
+    // plain row tiles that are all inside M take the register-direct epilogue too (rd_nt.h: the W = 16 case of its row formula)
+    p.direct = EPI == EPI_STORE && tune(TUNE_NT_EPI) != 0 && p.M % bm == 0 && p.N % 32 == 0 && !p.shift && !p.pool_out &&
+               (long)bm * p.N * 4 < 0x7fffffffL;
     if (split) {
         if (cfg == 2) hipLaunchKernelGGL((igemm_nt_split_kernel<64, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
         else if (cfg == 0) hipLaunchKernelGGL((igemm_nt_split_kernel<128, 128, 1, 4, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
