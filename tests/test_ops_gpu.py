@@ -926,3 +926,64 @@ def test_tail_ops_on_random_shapes_against_the_two_kernel_route():
         want = ops.conv3x3_last_fwd(s, wl, None, None)
         got = ops.conv3x3_last_fwd_tail(skip, ops.tail_t16(xc, v), b9, wl, None, None)
         assert float((got - want).abs().max()) <= 5e-6 * float(want.abs().max() + 1e-30), ("forward",) + tag
+
+
+class _tune:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        from resdepth_amd import _lib
+        self.old = {k: _lib.tune_get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            _lib.tune_set(k, v)
+
+    def __exit__(self, *exc):
+        from resdepth_amd import _lib
+        for k, v in self.old.items():
+            _lib.tune_set(k, v)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [
+    (16, 64, 64, 128, 256),     # conv3_halo_split<128>
+    (8, 64, 64, 128, 64),       # <64>: two wave row-bands (cross-wave statistics exchange)
+    (33, 8, 8, 256, 64),        # two-image patches, odd image count: the last patch's second image is absent
+    (4, 16, 16, 64, 64),        # generic NT kernel, full 64-row tiles
+])
+def test_register_direct_epilogues_equal_the_staged_ones(n, h, w, cin, cout):
+    """r04: the patch kernels (and the generic NT kernels on full tiles) store C, the BatchNorm statistics, the BN-backward hook
+    sums and the inference shift / activation / max-pool straight from the accumulator registers (rd_nt.h: nt_epilogue_direct);
+    `nt_epi = 0` keeps the LDS-staged epilogue.  Same accumulators either way: C, activations and pooled values are the SAME
+    BITS; the statistics are the same sums in another (fixed) order."""
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(n + h + cin + cout)
+    x = torch.randn(n, h, w, cin, generator=g).to(dev())
+    dz = torch.randn(n, h, w, cout, generator=g).to(dev())
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev())
+    wf, wd = ops.pack_conv3x3_weight(wt)
+    zin = torch.randn(n, h, w, cin, generator=g).to(dev())
+    hook = ops.BnHook(zin, (torch.randn(cin, generator=g) * 0.1).to(dev()), (torch.rand(cin, generator=g) + 0.5).to(dev()),
+                      torch.randn(cin, generator=g).to(dev()), (torch.randn(cin, generator=g) * 0.3).to(dev()), 0.01, None, 1)
+    scale = (torch.rand(cout, generator=g) + 0.5).to(dev())
+    shift = (torch.randn(cout, generator=g) * 0.2).to(dev())
+    wfold = ops.pack_conv3x3_weight_folded(wt, scale)
+    pool = w % 16 == 0 and h % 8 == 0 and w > 8
+
+    def run():
+        z, sums = ops.conv3x3_fwd_stats(x, wf)
+        dx, part = ops.conv3x3_bwd_data(dz, wd, hook)
+        hs = ops.bn_bwd_stats_finalize([part], cin) if part[1] > 0 else None
+        a, p = ops.conv3x3_fwd_act(x, wfold, shift, 0.01, pool=pool)
+        torch.cuda.synchronize()
+        return z, sums, dx, hs, a, p
+
+    with _tune(nt_epi=0):
+        z0, s0, dx0, h0, a0, p0 = run()
+    z1, s1, dx1, h1, a1, p1 = run()
+    assert torch.equal(z0, z1) and torch.equal(dx0, dx1) and torch.equal(a0, a1)
+    assert (p0 is None) == (p1 is None) and (p0 is None or torch.equal(p0, p1))
+    close(s1.cpu(), s0.cpu(), tol=1e-6, name="BN statistics")
+    assert (h0 is None) == (h1 is None)
+    if h0 is not None:
+        sc = h0.abs().view(4, cin).amax(1, keepdim=True).expand(4, cin).reshape(-1) + 1e-30
+        assert float(((h1 - h0).abs() / sc).max()) <= 1e-5
