@@ -33,6 +33,10 @@ for name, h, cin, cout in layers:
     x = torch.randn(N, h, h, cin, device=dev)
     dz = torch.randn(N, h, h, cout, device=dev)
     w = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+    if os.environ.get("BL_DATA") == "zero":          # power experiment: no operand toggling in the matrix pipe
+        x.zero_(); dz.zero_(); w.zero_()
+    elif os.environ.get("BL_DATA") == "one":         # exact bf16 values: the mid / lo split terms are all zero
+        x.fill_(1.0); dz.fill_(1.0); w.fill_(0.5)
     wf, wd = ops.pack_conv3x3_weight(w)
     row = f"{name:5s} M={N*h*h:7d} Cin={cin:3d} Cout={cout:3d} "
     if "fwd" in which:
