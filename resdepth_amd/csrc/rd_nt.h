@@ -189,6 +189,7 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][B
     // ---- forward BatchNorm statistics: per-(tile_m) column sums / sums of squares [tiles_m][2][N]
     if (st_on) {
         float* red = smem;                                      // WM > 1: [wm][2][BN]
+        if (WM > 1) __syncthreads();                            // every wave is done with the operand stages this scratch overlays
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float ss = 0.f, qq = 0.f;
@@ -235,7 +236,7 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][B
         const float bslope = p.bn_slope_dev ? p.bn_slope_dev[0] : p.bn_slope;
         const bool mode1 = p.bn_mode == 1;
         float* red = smem;                                      // WM > 1: [wm][4][BN]
-        if (WM > 1 && st_on) __syncthreads();                   // (never both in one launch; keeps the scratch uses apart)
+        if (WM > 1) __syncthreads();                            // operand stages / the statistics scratch above are done with
         // 10 VALU per element: y, y > 0, g * slope, select, xhat as one FMA, three accumulations, and the fourth sum (the
         // learnable slope's gradient: select + FMA; part of the entry points' contract whatever the activation)
         {
