@@ -24,6 +24,9 @@ def sym(name):
     m = re.match(r"void rd::wgrad_tn(_split)?_kernel<(\d+), (\d+), \d+, \d+, (\d+), (\d+)>", name)
     if m:
         return "wgrad_tn%s<%s,%s,%s,%s>" % (m.group(1) or "", m.group(2), m.group(3), m.group(4), m.group(5))
+    m = re.match(r"void rd::conv3_halo_split_kernel<(\d+), \d+, \d+, (\d+), \d+, (\d+)>", name)
+    if m:      # the two-images-per-patch instantiation (last argument 1) is its own row, as rd_prof prints it
+        return "conv3_halo_split<%s%s>" % (m.group(1), ",w8" if m.group(3) == "1" else "")
     m = re.match(r"void rd::conv3_halo_split_kernel<(\d+), \d+, \d+, (\d+)", name)
     if m:
         return "conv3_halo_split<%s>" % m.group(1)
