@@ -10,8 +10,10 @@
 // the 128 columns are one (a, b) quadrant and 128 output channels; for Cout = 64 they are one output row parity `a` with both
 // `b` -- in both cases a tile row (one input pixel) owns 512 CONTIGUOUS bytes of the output, and for Cout = 64 the PW pixels
 // of a patch row own one contiguous PW * 512-byte segment of an output row (the generic NT kernel scattered 16-byte pieces).
-// The epilogue stages 32 rows x 128 columns through LDS and every lane moves 16 bytes: bias, skip tensor and the lazy
-// act(BN(z)) recomputation of the encoder skip ride the same pass; the skip loads are issued before the LDS round trip.
+// Epilogue (r04): straight from the accumulator registers -- a lane holds one output column, lanes 0-31 of a buffer access cover
+// 128 contiguous bytes of one output pixel, the pixel part of the address is a scalar offset: bias, skip tensor and the lazy
+// act(BN(z)) recomputation of the encoder skip without an LDS round trip or a barrier (all skip loads issued first).  The r03
+// epilogue (32 rows x 128 columns staged through LDS, 16 bytes per lane) is kept behind `nt_epi = 0` for A/B runs.
 // Main loop = the split NT pipeline of rd_igemm.hip (global load -> split + LDS write -> fragment read -> MFMA over four
 // K-steps, one barrier per 16-channel step, weights straight from global memory in fragment order).
 #include "rd_common.h"

@@ -1,7 +1,8 @@
-// NT-kernel parameter block and the epilogue shared by the implicit-GEMM kernels (rd_igemm.hip: exact-f32 / split / halo
-// kernels) -- staging through LDS for 16-byte row-contiguous stores, fused BatchNorm
-// forward statistics, transposed-convolution scatter + bias + skip, inference shift / activation / pooling, BN-backward
-// statistics hook.
+// NT-kernel parameter block and the epilogues shared by the implicit-GEMM kernels (rd_igemm.hip: exact-f32 / split / halo
+// kernels; rd_convt.hip: transposed-convolution data gradient) -- fused BatchNorm forward statistics, inference shift /
+// activation / pooling, BN-backward statistics hook, transposed-convolution scatter + bias + skip.  Two forms: the
+// register-direct one (nt_epilogue_direct: patch kernels and full plain-row tiles, r04) and the LDS-staged one (16-byte
+// row-contiguous stores; ragged tiles, the EPI_CONVT scatter, `nt_epi = 0`).
 #pragma once
 #include "rd_common.h"
 #include "rd_mfma_dev.h"

@@ -53,6 +53,8 @@ if "convt" in which:
         skip = torch.randn(N, 2 * h, 2 * h, c, device=dev)
         w = torch.randn(c, c, 2, 2, device=dev) * 0.05
         b = torch.randn(c, device=dev)
+        if os.environ.get("BL_DATA") == "zero":
+            x.zero_(); do.zero_(); skip.zero_(); w.zero_(); b.zero_()
         wtf, wtd = ops.pack_convt2x2_weight(w)
         row = f"{name:5s} M={N*h*h:7d} C={c:3d}          "
         ms, tf = timed(lambda: ops.convt2x2_fwd(x, wtf, b, skip)); row += f"| fwd {ms:6.3f} ms {tf:6.1f} TF "; tot["tfwd"] = tot.get("tfwd", 0) + ms
