@@ -121,10 +121,7 @@ def infer_main(args, world, rank, dev):
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:          # --force-dist without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0", WORLD_SIZE="1")
-        # no device_id=: with the eager communicator initialisation it triggers, every step of this process ran 1.5-2 ms
-        # slower on the MI355X boxes (with or without collectives in flight); torch.cuda.set_device above already pins
-        # the rank to its GPU for the lazily created communicator
-        dist.init_process_group("nccl")
+        init_dist(args)
     torch.manual_seed(0)
     model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).eval()
     model.fold_eval_bn = not args.no_fold
@@ -172,7 +169,8 @@ def infer_main(args, world, rank, dev):
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic raster",
             "config": {"workload": f"cfg-G: {args.raster}x{args.raster} raster, {n_tiles_global} tiles of 256x256 at stride 128, "
-                                   f"eval-mode BN, batch {args.batch}", "parallelism": f"tiles sharded over {world} GPU(s)"},
+                                   f"eval-mode BN, batch {args.batch}",
+                       "parallelism": f"tiles sharded over {world} GPU(s)" + (" (ranks SHARE one GPU: code-path check)" if args.share_gpu else "")},
             "e2e": {"tflops": round(tiles_s / world * fwd_flop / 1e12, 2),
                     "frac_f32_peak": round(tiles_s / world * fwd_flop / 1e12 / PEAK_F32_TFLOPS, 4)},
             "roofline": build_roofline(kern, 1, PMC_SUMMARIES["G"], "HIP events, one instrumented sweep right after the timed "
@@ -428,6 +426,17 @@ def self_launch(n, argv):
     return rc
 
 
+def init_dist(args):
+    """Process group of the benchmark: RCCL (backend "nccl") -- or, for the --share-gpu code-path check, gloo with the
+    device-tensor collectives staged through the host (the test shim keeps RCCL's stream semantics)."""
+    import torch.distributed as dist
+    dist.init_process_group(args.backend or "nccl")
+    if args.share_gpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import host_staged_collectives
+        host_staged_collectives.install()
+
+
 def rendezvous_only(args, world, rank):
     """--rendezvous-only: the launcher path without the workload -- every rank joins the process group (`--backend gloo`
     in the GPU-less build container, nccl = RCCL on the GPU box), all-reduces its rank number and rank 0 prints what it
@@ -477,6 +486,11 @@ def main():
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, join the process group, all-reduce one number, print what rank 0 saw and exit")
     ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; gloo for --rendezvous-only on CPU)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="CODE-PATH CHECK, never a measurement: every rank uses cuda:0 (RCCL refuses two ranks on one device, so "
+                         "this needs --backend gloo; device collectives go through tests/host_staged_collectives.py).  Lets a "
+                         "one-GPU box execute `bench.py --gpus N` end to end: launcher, broadcast, bucketed all-reduce, "
+                         "max-over-ranks timing, rank-0 line")
     ap.add_argument("--no-fold", action="store_true", help="--infer: keep eval-mode BN as separate kernels (A/B of the folded path)")
     ap.add_argument("--prof-all", action="store_true", help="(kept for scripts) same as the default full breakdown")
     ap.add_argument("--force-dist", action="store_true",
@@ -489,7 +503,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the driver's plain `python3 bench.py --gpus N ...`: no launcher set the rank environment, so this process becomes
         # the launcher (one rank per GPU over RCCL, exactly what torch.distributed.run --nproc-per-node N would start)
-        if not args.rendezvous_only and torch.cuda.device_count() < args.gpus:
+        if not args.rendezvous_only and not args.share_gpu and torch.cuda.device_count() < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible", file=sys.stderr)
             sys.exit(2)
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
@@ -500,6 +514,11 @@ def main():
     if args.rendezvous_only:
         return rendezvous_only(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if args.share_gpu:
+        if (args.backend or "nccl") != "gloo":
+            print("bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)", file=sys.stderr)
+            sys.exit(2)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -518,7 +537,7 @@ def main():
         # no device_id=: with the eager communicator initialisation it triggers, every step of this process ran 1.5-2 ms
         # slower on the MI355X boxes (with or without collectives in flight); torch.cuda.set_device above already pins
         # the rank to its GPU for the lazily created communicator
-        dist.init_process_group("nccl")
+        init_dist(args)
     wl = WORKLOADS[args.workload]
     n = args.batch
     tb = TrainBench(wl, n, dev, rank=rank, from_rasters=args.from_rasters)
@@ -587,7 +606,9 @@ def main():
                      if args.from_rasters else "synthetic (randn tiles resident in HBM, default-initialised weights)"),
             "config": {"workload": wl["name"] + ", fwd+loss+bwd+Adam",
                        "tiles_per_gpu": n, "global_batch": n * world,
-                       "parallelism": f"dp{world}" + ("+syncbn" if args.sync_bn else ""),
+                       "parallelism": f"dp{world}" + ("+syncbn" if args.sync_bn else "") +
+                                      (" (ranks SHARE one GPU over gloo: launcher / data-parallel code-path check, not a scaling "
+                                       "number)" if args.share_gpu else ""),
                        "backward": "serial" if args.serial_backward else "two-stream (wgrad || dgrad+BN)"},
             "step_ms_median": round(_median(step_ms), 3),
             "step_ms_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)],

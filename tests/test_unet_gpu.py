@@ -556,6 +556,46 @@ def test_data_parallel_code_path_on_rccl_world1():
         assert o["loss_first_last"] == plain["loss_first_last"], (o["loss_first_last"], plain["loss_first_last"])
 
 
+def test_bench_gpus_2_runs_end_to_end_without_a_launcher_on_one_gpu():
+    """`python3 bench.py --gpus N` exactly as the driver types it (no torch.distributed.run), N = 2, executed for real: the
+    launcher starts two ranks, they rendezvous, broadcast parameters, train with the bucketed all-reduce and the global loss
+    normaliser, take the max-over-ranks time and rank 0 prints ONE line.  RCCL refuses two ranks on one device, so the ranks
+    share cuda:0 over gloo with host-staged device collectives (`--backend gloo --share-gpu`, a code-path check that the
+    line itself labels as such) -- everything else is the code an 8-GPU node runs.  Also the cfg-G sweep (`--infer`)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GLOO_SOCKET_IFNAME"] = "lo"
+    common = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu"]
+    r = subprocess.run(common + ["--steps", "3", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-secondary"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 8 and o["config"]["tiles_per_gpu"] == 4
+    assert o["config"]["parallelism"].startswith("dp2") and "code-path check" in o["config"]["parallelism"]
+    assert o["dist"]["world_size_reported"] == 2 and len(o["dist"]["per_rank_ms_per_step"]) == 2 and o["dist"]["backend"] == "gloo"
+    assert o["value"] > 0 and o["steps"] == 3 and o["scaling"] == "weak"
+    first, last = o["loss_first_last"]
+    assert first == first and last == last and last < first          # finite, and the shared weights are learning
+    assert "secondary" not in o and "cpu_baseline" not in o           # rank-0 extras are world-size-1 only
+    r = subprocess.run(common + ["--infer", "--raster", "1024", "--batch", "8", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    g2 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--infer", "--raster", "1024", "--batch", "8", "--steps", "1",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    g1 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert g2["n_gpus"] == 2 and g2["dist"]["world_size_reported"] == 2 and g2["scaling"] == "strong"
+    # the two ranks' rasters, summed on rank 0, are the one-process raster (49 tiles: 25 + 24)
+    assert abs(g2["raster_checksum"] - g1["raster_checksum"]) <= 1e-9 * abs(g1["raster_checksum"])
+
+
 def _hip_decisions(model, x_dev, spec):
     """The HIP path's own discrete decisions on input x (ReLU / PReLU branch masks, pool arg-max as flat H*W indices, NCHW,
     cropped to the model's real channels when it runs on its zero-padded twin) in the form oracle.forward(decisions=) takes.
