@@ -40,7 +40,7 @@ typedef void* rd_stream_t; /* hipStream_t */
 #define RD_ERR_WS 2
 #define RD_ERR_HIP 3
 
-int rd_version(void);
+int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream) */
 const char* rd_last_error_string(void);
 
 /* ---- weight (re)packing: torch layouts -> GEMM operand layouts ------------------- */

@@ -168,7 +168,7 @@ static void drain_locked() {
 
 extern "C" {
 
-int rd_version(void) { return 100; }
+int rd_version(void) { return 101; }      // 101 (r04): rd_set_splitk_workspace keyed by (device, stream)
 
 const char* rd_last_error_string(void) { return rd::g_err; }
 
