@@ -118,6 +118,15 @@ int rd_conv3x3_bwd_weight(const float* x, const float* dz, float* dw_oihw, int n
 /* ---- first encoder conv: NCHW input with 1..6 channels -> NHWC (lib/UNet.py:159) -- */
 int rd_conv3x3_first_fwd(const float* x_nchw, const float* w_oihw, float* z, int n, int h, int w, int cin, int cout,
                          rd_stream_t s);
+/* Inference: the same convolution with the block's eval-mode BatchNorm (mean / invstd from rd_bn_eval_stats), activation and
+ * MaxPool2d(2,2) in its epilogue (lib/UNet.py:44-47,161 in eval mode, reached from lib/evaluation.py:497):
+ * a[N,H,W,Cout] = act(gamma * (conv(x) - mean) * invstd + beta) and, if `pooled` is non-NULL, pooled[N,H/2,W/2,Cout] = max over
+ * 2x2 windows of a -- the pre-BN tensor is never written.  Same arithmetic, in the same order, as rd_conv3x3_first_fwd followed
+ * by rd_bn_act_pool_fwd (bit-identical a / pooled).  rd_conv3x3_first_fwd_act_available: 1 for the shapes it covers. */
+int rd_conv3x3_first_fwd_act_available(int n, int h, int w, int cin, int cout);
+int rd_conv3x3_first_fwd_act(const float* x_nchw, const float* w_oihw, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, float slope, const float* slope_dev, float* a, float* pooled, int n, int h, int w,
+                             int cin, int cout, rd_stream_t s);
 size_t rd_conv3x3_first_fwd_stats_ws_bytes(int n, int h, int w, int cin, int cout);
 int rd_conv3x3_first_fwd_stats(const float* x_nchw, const float* w_oihw, float* z, double* sums, int n, int h, int w,
                                int cin, int cout, void* ws, size_t ws_bytes, rd_stream_t s);

@@ -50,6 +50,8 @@ SIGNATURES = {
     "rd_conv3x3_first_fwd_stats_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_conv3x3_first_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, P, SZ, P]),
     "rd_conv3x3_first_fwd_bn": (I, [P, P, P, D, F, F, P, P, P, P, P, I, I, I, I, I, P, SZ, P]),
+    "rd_conv3x3_first_fwd_act_available": (I, [I, I, I, I, I]),
+    "rd_conv3x3_first_fwd_act": (I, [P, P, P, P, P, P, F, P, P, P, I, I, I, I, I, P]),
     "rd_conv3x3_first_bwd_weight_ws_bytes": (SZ, [I, I, I, I, I]),
     "rd_tail_available": (I, [I, I]),
     "rd_tail_compose": (I, [P, P, P, P, P, P, P, I, I, P]),

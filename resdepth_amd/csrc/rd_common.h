@@ -138,6 +138,9 @@ struct FirstBnBwd {
     const float* dout;
     const float* w_last;
 };
+int conv_first_fwd_act_launch(const float* x, const float* wt, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, float slope, const float* slope_dev, float* a, float* pooled, int n, int h, int w,
+                              int cin, int cout, hipStream_t s);
 int conv_first_seg_launch(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
                           int w, int cin, int cout, hipStream_t s, const FirstBnBwd* bn = nullptr);
 int conv_last_wgrad_launch(const float* s_in, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s);

@@ -1050,6 +1050,109 @@ __global__ __launch_bounds__(256, 4) void conv_first_fwd_seg_kernel(const float*
     }
 }
 
+// Inference form of the above (r04): eval-mode BatchNorm + activation + MaxPool2d(2, 2) of the first block in the convolution's
+// own epilogue -- a = act(fma(z, invstd*gamma, beta - mean*invstd*gamma)) is what leaves (the same expression, in the same order, as
+// bn_act_pool_fwd_kernel evaluates on a stored z: bit-identical a and pooled values), z itself is never written and the separate
+// pass that read its 537 MB back (cfg-G: 4.6 % of the sweep) is gone.  A thread's segments are ordered so that rows 2k and
+// 2k + 1 follow each other: the 2 x 2 windows of a row pair are the thread's own eight pixels twice (first maximum in window
+// order, NaN wins: torch's max_pool2d).
+template <int CIN, int CQ>
+__global__ __launch_bounds__(256, 2) void conv_first_fwd_act_seg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float slope_val, const float* __restrict__ slope_dev,
+                                                                     float* __restrict__ a, float* __restrict__ pooled, int N, int H,
+                                                                     int W, int tiles_x, int tiles_y) {
+    constexpr int Cout = CQ * 4, SLOTS = 256 / CQ, NSEG = (ET_H * ET_W / 8) / SLOTS;
+    static_assert(NSEG % 2 == 0 && SLOTS % 4 == 0, "row pairs per thread");
+    __shared__ __attribute__((aligned(16))) float X[CIN * FH_PLANE + 9 * CIN * Cout];
+    float* Wl = X + CIN * FH_PLANE;
+    const int t = threadIdx.x, cq = t % CQ, slot = t / CQ;
+    const int tl = blockIdx.x;
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+    const int y0 = ty * ET_H, x0 = tx * ET_W;
+    for (int e = t; e < 9 * CIN * Cout; e += 256) {
+        const int j = e / Cout, co = e - j * Cout;
+        Wl[e] = w[((long)co * CIN + j % CIN) * 9 + j / CIN];
+    }
+    load_x_halo<CIN>(X, x, n, y0, x0, H, W, t);
+    float sc[4], sh[4];
+    {
+        const float4 m4 = *reinterpret_cast<const float4*>(mean + cq * 4), i4 = *reinterpret_cast<const float4*>(invstd + cq * 4);
+        const float4 g4 = *reinterpret_cast<const float4*>(gamma + cq * 4), b4 = *reinterpret_cast<const float4*>(beta + cq * 4);
+        sc[0] = i4.x * g4.x; sc[1] = i4.y * g4.y; sc[2] = i4.z * g4.z; sc[3] = i4.w * g4.w;
+        sh[0] = b4.x - m4.x * sc[0]; sh[1] = b4.y - m4.y * sc[1]; sh[2] = b4.z - m4.z * sc[2]; sh[3] = b4.w - m4.w * sc[3];
+    }
+    const float slope = slope_dev ? slope_dev[0] : slope_val;
+    __syncthreads();
+    const int W2 = W >> 1, H2 = H >> 1;
+    float prev[8][4];
+#pragma unroll 1
+    for (int sg = 0; sg < NSEG; ++sg) {
+        // row pair (sg >> 1) * (SLOTS / 4) + (slot >> 2), row sg & 1 of it; first column (slot & 3) * 8
+        const int py = 2 * ((sg >> 1) * (SLOTS / 4) + (slot >> 2)) + (sg & 1), c0 = (slot & 3) * 8;
+        float acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll 1
+            for (int ci = 0; ci < CIN; ++ci) {
+                float v[10];
+                read_row10(X, ci, py + ky, c0, v);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(Wl + ((ky * 3 + kx) * CIN + ci) * Cout + cq * 4);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        acc[i][0] = fmaf(v[i + kx], w4.x, acc[i][0]);
+                        acc[i][1] = fmaf(v[i + kx], w4.y, acc[i][1]);
+                        acc[i][2] = fmaf(v[i + kx], w4.z, acc[i][2]);
+                        acc[i][3] = fmaf(v[i + kx], w4.w, acc[i][3]);
+                    }
+                }
+            }
+        const int gy = y0 + py;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float y = fmaf(acc[i][k], sc[k], sh[k]);
+                acc[i][k] = y > 0.f ? y : y * slope;
+            }
+            const int gx = x0 + c0 + i;
+            if (gy < H && gx < W)
+                *reinterpret_cast<float4*>(a + (((long)n * H + gy) * W + gx) * Cout + cq * 4) =
+                    make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+        }
+        if ((sg & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) prev[i][k] = acc[i][k];
+        } else if (pooled) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float m[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    m[k] = prev[2 * j][k];
+                    const float c1 = prev[2 * j + 1][k], c2 = acc[2 * j][k], c3 = acc[2 * j + 1][k];
+                    if (c1 > m[k] || c1 != c1) m[k] = c1;
+                    if (c2 > m[k] || c2 != c2) m[k] = c2;
+                    if (c3 > m[k] || c3 != c3) m[k] = c3;
+                }
+                const int gx = x0 + c0 + 2 * j;
+                if (gy < H && gx < W)
+                    *reinterpret_cast<float4*>(pooled + (((long)n * H2 + (gy >> 1)) * W2 + (gx >> 1)) * Cout + cq * 4) =
+                        make_float4(m[0], m[1], m[2], m[3]);
+            }
+        }
+    }
+}
+
 // FUSED: there is no dz tensor.  The first block's BN + activation + pool backward (bn_act_bwd_kernel<true, true> in
 // rd_elementwise.hip, the same expressions in the same order) is evaluated on the operands as they are loaded: dz of level 0 has
 // this kernel as its only reader, so its 537 MB (cfg-S) are neither written nor read back.
@@ -1270,6 +1373,30 @@ int conv_first_seg_launch(bool wgrad, const float* x, const float* wt, float* z,
         case 2: return launch_first_seg<2>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s, bn);
         case 3: return launch_first_seg<3>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s, bn);
         default: return launch_first_seg<4>(wgrad, x, wt, z, dz, partial, n, h, w, cout, s, bn);
+    }
+}
+
+template <int CIN>
+static int launch_first_act(const float* x, const float* wt, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, float slope, const float* slope_dev, float* a, float* pooled, int n, int h, int w,
+                            int cout, hipStream_t s) {
+    const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H), nt = n * tx * ty;
+    if (cout == 64) hipLaunchKernelGGL((conv_first_fwd_act_seg_kernel<CIN, 16>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty);
+    else if (cout == 32) hipLaunchKernelGGL((conv_first_fwd_act_seg_kernel<CIN, 8>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty);
+    else hipLaunchKernelGGL((conv_first_fwd_act_seg_kernel<CIN, 32>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty);
+    RD_LAUNCH_CHECK("conv_first_fwd_act");
+    return RD_OK;
+}
+
+// inference: convolution + BN (given mean / invstd) + activation (+ 2x2 max-pool) in one kernel; shapes of conv_first_seg_tiles
+int conv_first_fwd_act_launch(const float* x, const float* wt, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, float slope, const float* slope_dev, float* a, float* pooled, int n, int h, int w,
+                              int cin, int cout, hipStream_t s) {
+    switch (cin) {
+        case 1: return launch_first_act<1>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s);
+        case 2: return launch_first_act<2>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s);
+        case 3: return launch_first_act<3>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s);
+        default: return launch_first_act<4>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s);
     }
 }
 

@@ -1468,6 +1468,21 @@ int rd_conv3x3_first_fwd(const float* x, const float* wt, float* z, int n, int h
     return rd_conv3x3_first_fwd_stats(x, wt, z, nullptr, n, h, w, cin, cout, nullptr, 0, s);
 }
 
+int rd_conv3x3_first_fwd_act_available(int n, int h, int w, int cin, int cout) {
+    return conv_first_seg_tiles(n, h, w, cin, cout) > 0 && h % 2 == 0 && w % 2 == 0;
+}
+
+int rd_conv3x3_first_fwd_act(const float* x, const float* wt, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, float slope, const float* slope_dev, float* a, float* pooled, int n, int h, int w,
+                             int cin, int cout, rd_stream_t s) {
+    RD_REQUIRE(x && wt && mean && invstd && gamma && beta && a, "rd_conv3x3_first_fwd_act: null pointer");
+    RD_REQUIRE(rd_conv3x3_first_fwd_act_available(n, h, w, cin, cout),
+               "rd_conv3x3_first_fwd_act: shape not covered (1-4 input channels, 32 / 64 / 128 output channels, even H and W)");
+    ProfScope ps((hipStream_t)s, "conv_first_fwd", 2.0 * n * h * w * cout * 9.0 * cin,
+                 4.0 * n * h * w * (double)(cin + cout * (pooled ? 1.25 : 1.0)));
+    return conv_first_fwd_act_launch(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cin, cout, (hipStream_t)s);
+}
+
 size_t rd_conv3x3_first_fwd_stats_ws_bytes(int n, int h, int w, int cin, int cout) {
     if (const int nt2 = conv_first_seg_tiles(n, h, w, cin, cout)) return (size_t)nt2 * 2 * cout * sizeof(float);
     int tx, ty, nt;

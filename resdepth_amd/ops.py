@@ -188,6 +188,24 @@ def conv3x3_first_fwd_bn(x_nchw, w, running_mean, running_var, num_batches_track
     return z, mean, invstd
 
 
+def conv3x3_first_fwd_act_available(x_nchw, cout) -> bool:
+    n, cin, h, w = x_nchw.shape
+    return bool(load().rd_conv3x3_first_fwd_act_available(n, h, w, cin, cout))
+
+
+def conv3x3_first_fwd_act(x_nchw, w, mean, invstd, gamma, beta, slope, slope_dev=None, pool=True):
+    """Inference: first convolution + eval-mode BN + activation (+ MaxPool2d(2, 2)) in one kernel -> (a [N,H,W,Cout], pooled |
+    None); the pre-BN tensor is never written (include/resdepth_hip.h: rd_conv3x3_first_fwd_act)."""
+    n, cin, h, wd = x_nchw.shape
+    cout = w.shape[0]
+    a = torch.empty(n, h, wd, cout, device=x_nchw.device, dtype=torch.float32)
+    pooled = torch.empty(n, h // 2, wd // 2, cout, device=x_nchw.device, dtype=torch.float32) if pool else None
+    check(load().rd_conv3x3_first_fwd_act(ptr(_f32(x_nchw, "x")), ptr(w.detach()), ptr(mean), ptr(invstd), ptr(gamma.detach()),
+                                          ptr(beta.detach()), float(slope), ptr(slope_dev), ptr(a), ptr(pooled), n, h, wd, cin, cout,
+                                          stream_ptr()), "conv3x3_first_fwd_act")
+    return a, pooled
+
+
 def conv3x3_first_bwd_weight_bn_available(x_nchw, cout) -> bool:
     n, cin, h, wd_ = x_nchw.shape
     return bool(load().rd_conv3x3_first_bwd_weight_bn_available(n, h, wd_, cin, int(cout)))

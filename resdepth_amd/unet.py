@@ -137,6 +137,7 @@ class UNet(nn.Module):
         self.fused_bn_bwd_stats = True    # BN-backward sums from the epilogues of the kernels producing the gradient operands
         self.composed_tail = True         # last up-convolution's gradients straight from the 1-channel dout (ops.tail_*)
         self.fused_first_wgrad = True     # level 0: BN / activation / pool backward evaluated inside the first conv's weight gradient
+        self.fused_first_eval = True      # inference: level 0's BN + activation + max-pool inside the first convolution (no z0)
         # loss.backward(retain_graph=True) on the reference keeps the saved activations for a second backward.  A custom
         # autograd.Function cannot see that flag, and keeping 137 MB per tile alive until the loss tensor dies would surprise
         # callers that hold on to losses -- so the activations are released by the first backward unless this is set
@@ -560,12 +561,24 @@ class UNet(nn.Module):
         pk = self._packed()
         fold = self._folded()
         blk = self.encoder[0][0]
-        if self._first_generic():
-            z0 = ops.conv3x3_fwd(ops.nchw_to_nhwc(x), pk.get("enc_first")[0])
-        else:
-            z0 = ops.conv3x3_first_fwd(x, blk[0].weight)
         bn = blk[1]
-        skip0, cur, _, _, _, _ = self._bn_forward(z0, bn, self._act_of(blk, self.act_fn_encoder), True, False, want_a=False)
+        act0 = self._act_of(blk, self.act_fn_encoder)
+        if self.fused_first_eval and not self._first_generic() and ops.conv3x3_first_fwd_act_available(x, blk[0].weight.shape[0]):
+            # level 0 in ONE kernel: convolution + eval-mode BN + activation + max-pool; what leaves is the activation itself,
+            # which the decoder takes as a skip through the identity case (scale 1, shift 0, slope 1: bit-exact) of the
+            # descriptor it evaluates on load
+            mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, eps=bn.eps)
+            slope0, sdev0 = self._split_slope(act0)
+            a0, cur = ops.conv3x3_first_fwd_act(x, blk[0].weight, mean, invstd, bn.weight, bn.bias, slope0, sdev0, pool=True)
+            c0 = a0.shape[-1]
+            one, zero = self._const(c0, 1.0, x.device), self._const(c0, 0.0, x.device)
+            skip0 = {"z": a0, "mean": zero, "invstd": one, "gamma": one, "beta": zero, "slope": 1.0, "slope_dev": None}
+        else:
+            if self._first_generic():
+                z0 = ops.conv3x3_fwd(ops.nchw_to_nhwc(x), pk.get("enc_first")[0])
+            else:
+                z0 = ops.conv3x3_first_fwd(x, blk[0].weight)
+            skip0, cur, _, _, _, _ = self._bn_forward(z0, bn, act0, True, False, want_a=False)
         skips = [skip0]
         for i in range(1, d):
             a, cur = self._conv_act(cur, fold[i - 1], True)

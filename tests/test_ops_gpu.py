@@ -987,3 +987,40 @@ def test_register_direct_epilogues_equal_the_staged_ones(n, h, w, cin, cout):
     if h0 is not None:
         sc = h0.abs().view(4, cin).amax(1, keepdim=True).expand(4, cin).reshape(-1) + 1e-30
         assert float(((h1 - h0).abs() / sc).max()) <= 1e-5
+
+
+@pytest.mark.parametrize("n,cin,h,w,cout,slope,prelu", [
+    (2, 3, 64, 64, 64, 0.0, False), (1, 1, 32, 96, 64, 0.01, False), (3, 2, 24, 40, 32, 0.0, False),    # ragged tiles (16 x 32)
+    (2, 4, 16, 32, 128, 0.0, True), (1, 3, 18, 34, 64, 0.0, False)])
+def test_first_convolution_with_bn_activation_and_pool_in_its_epilogue(n, cin, h, w, cout, slope, prelu):
+    """rd_conv3x3_first_fwd_act (inference, r04) == rd_conv3x3_first_fwd followed by rd_bn_act_pool_fwd, bit for bit: the same
+    fmaf chain for the convolution, the same fma + select for BN + activation, torch's window order / NaN rule for the pool."""
+    from resdepth_amd import ops
+    g = torch.Generator().manual_seed(n * 100 + cin * 10 + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    x[0, 0, 3, 5] = float("nan")                                # a NaN must win its pooling window (and poison its 3 x 3 reach)
+    x = x.to(dev())
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / 3).to(dev())
+    rm, rv = (torch.randn(cout, generator=g) * 0.2).to(dev()), (torch.rand(cout, generator=g) + 0.5).to(dev())
+    gamma, beta = torch.randn(cout, generator=g).to(dev()), (torch.randn(cout, generator=g) * 0.3).to(dev())
+    sdev = torch.tensor([0.25], device=dev()) if prelu else None
+    assert ops.conv3x3_first_fwd_act_available(x, cout)
+    mean, invstd = ops.bn_eval_stats(rm, rv)
+    a, p = ops.conv3x3_first_fwd_act(x, wt, mean, invstd, gamma, beta, slope, sdev, pool=True)
+    z = ops.conv3x3_first_fwd(x, wt)
+    a_ref, p_ref, _ = ops.bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, True, sdev, want_a=True)
+    def same(u, v):
+        return torch.equal(torch.nan_to_num(u, nan=12345.0), torch.nan_to_num(v, nan=12345.0)) and torch.equal(torch.isnan(u), torch.isnan(v))
+
+    assert same(a, a_ref) and same(p, p_ref)
+    assert torch.isnan(p).any()
+    a2, p2 = ops.conv3x3_first_fwd_act(x, wt, mean, invstd, gamma, beta, slope, sdev, pool=False)
+    assert p2 is None and same(a2, a_ref)
+    # against torch on the CPU (no NaN): conv -> eval BatchNorm -> activation -> max-pool
+    xc = torch.randn(n, cin, h, w, generator=g)
+    zt = F.conv2d(xc, wt.cpu(), padding=1)
+    yt = F.batch_norm(zt, rm.cpu(), rv.cpu(), gamma.cpu(), beta.cpu(), False, 0.1, 1e-5)
+    yt = F.prelu(yt, sdev.cpu()) if prelu else F.leaky_relu(yt, slope)
+    a3, p3 = ops.conv3x3_first_fwd_act(xc.to(dev()), wt, mean, invstd, gamma, beta, slope, sdev, pool=True)
+    close(nchw(a3), yt, tol=2e-6, name="a")
+    close(nchw(p3), F.max_pool2d(yt, 2), tol=2e-6, name="pooled")

@@ -556,6 +556,36 @@ def test_data_parallel_code_path_on_rccl_world1():
         assert o["loss_first_last"] == plain["loss_first_last"], (o["loss_first_last"], plain["loss_first_last"])
 
 
+@pytest.mark.parametrize("kw,t", [(dict(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True), 256),
+                                  (dict(n_input_channels=1, start_kernel=32, depth=3, act_fn_encoder="lrelu", bias_conv_layer=True), 64),
+                                  (dict(n_input_channels=2, start_kernel=32, depth=2, act_fn_encoder="prelu", outer_skip=False), 48)])
+def test_inference_level0_in_one_kernel_is_bit_identical(kw, t):
+    """Eval forward with level 0 as ONE kernel (first convolution + eval BN + activation + max-pool, the activation handed to
+    the decoder through the identity case of the lazy-skip descriptor) == the r03 route (convolution, then the BN / pool pass
+    over z0), bit for bit -- composed tail (64 / 32 first-level channels) and the two-kernel route alike."""
+    from resdepth_amd import UNet
+    torch.manual_seed(3)
+    m = UNet(**kw).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for k, v in m.named_buffers():
+            if k.endswith("running_mean"):
+                v.copy_((torch.randn(v.shape, generator=g) * 0.2).to(DEV))
+            if k.endswith("running_var"):
+                v.copy_((torch.rand(v.shape, generator=g) + 0.5).to(DEV))
+    m.eval()
+    x = torch.randn(3, kw["n_input_channels"], t, t, generator=g).to(DEV)
+    with torch.no_grad():
+        m.fused_first_eval = False
+        y0 = m(x)
+        m.fused_first_eval = True
+        y1 = m(x)
+        m.fold_eval_bn = False                   # the unfolded eval path (training kernels with running statistics)
+        y2 = m(x)
+    assert torch.equal(y0, y1)
+    assert float((y2 - y1).abs().max()) <= 1e-4
+
+
 def test_bench_gpus_2_runs_end_to_end_without_a_launcher_on_one_gpu():
     """`python3 bench.py --gpus N` exactly as the driver types it (no torch.distributed.run), N = 2, executed for real: the
     launcher starts two ranks, they rendezvous, broadcast parameters, train with the bucketed all-reduce and the global loss
