@@ -97,18 +97,25 @@ def cpu_baseline(warm=1, timed=3, batch=32):
         if th <= host:
             torch.set_num_threads(th)
             sweep[th] = run(3, 8, 1, 2)["tiles_per_s"]
-    threads = max(sweep, key=sweep.get) if sweep else min(16, host)
+    # the batch-8 sweep only shortlists: per tile the CPU is slower at batch 32 (4.4 GB of saved activations, two sockets) and
+    # the best thread count can differ, so the batch-32 sample runs at the two best settings of the sweep and the better one counts
+    ranked = sorted(sweep, key=sweep.get, reverse=True)[:2] if sweep else [min(16, host)]
+    tried = {}
+    for th in ranked:
+        torch.set_num_threads(th)
+        tried[th] = run(3, batch, warm, timed)
+    threads = max(tried, key=lambda th: tried[th]["tiles_per_s"])
     torch.set_num_threads(threads)
-
-    big = run(3, batch, warm, timed)
+    big = tried[threads]
     c0 = run(1, 4, 2, 5)
     return {"value": big["tiles_per_s"], "unit": "tiles/s", "cores": threads, "kind": "port",
             "host_cores": host, "threads": threads, "cpu_model": _cpu_model(),
             "cfg_S": big, "cfg_0": c0, "thread_sweep_tiles_per_s_at_batch_8": {str(k): v for k, v in sweep.items()},
+            "cfg_S_tiles_per_s_by_threads": {str(k): v["tiles_per_s"] for k, v in tried.items()},
             "sample": f"{warm} warm-up + {timed} timed train steps (fwd+loss+bwd+Adam), median: cfg-S 3-ch 256x256 depth-5 at batch "
                       f"{big['batch']} -- the GPU leg's batch -- ({big['step_s_median'] * 1e3:.0f} ms/step), and cfg-0 1-ch at batch "
                       f"{c0['batch']} ({c0['step_s_median'] * 1e3:.0f} ms/step); torch-CPU oracle, {threads} threads of {host} "
-                      f"hardware threads (thread count swept in this run at batch 8)"}
+                      f"hardware threads (thread count: the better of the two best settings of an in-run sweep at batch 8)"}
 
 
 def infer_main(args, world, rank, dev):
