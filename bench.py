@@ -167,10 +167,11 @@ def infer_main(args, world, rank, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
         dist_info = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size()}
+    record = None
     if rank == 0:
         tiles_s = n_tiles_global * args.steps / dt
         fwd_flop = 19.80e9
-        print(json.dumps({
+        record = {
             "metric": "DSM tiles/sec forward-only tiled inference + linear blend (256x256, 3-ch, depth-5 U-Net)",
             "value": round(tiles_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
@@ -183,10 +184,8 @@ def infer_main(args, world, rank, dev):
             "roofline": build_roofline(kern, 1, PMC_SUMMARIES["G"], "HIP events, one instrumented sweep right after the timed "
                                        "sweeps (this rank's shard of the tiles)", per="sweep"),
             "raster_checksum": float(out.sum()), "dist": dist_info,
-            "kernels": kernel_rows(kern, 1, per="sweep")}), flush=True)
-    if use_dist:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+            "kernels": kernel_rows(kern, 1, per="sweep")}
+    emit_line(record, use_dist)
 
 
 WORKLOADS = {
@@ -433,6 +432,31 @@ def self_launch(n, argv):
     return rc
 
 
+def emit_line(record, use_dist):
+    """Rank 0's ONE JSON line, as the LAST thing on stdout: the process group is torn down first and the C library's stdout buffer
+    is flushed before the line goes out -- RCCL prints a version banner through C stdio when the communicator is created, which on
+    a pipe would otherwise surface at exit, after the line."""
+    if use_dist:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:       # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    if record is not None:
+        print(json.dumps(record), flush=True)
+
+
+def quiet_non_zero_ranks(rank):
+    """Ranks other than 0 print nothing on stdout -- neither python nor a C library in their process (RCCL's banner): fd 1 is
+    pointed at stderr, whatever launcher started them."""
+    if rank != 0:
+        sys.stdout.flush()
+        os.dup2(2, 1)
+
+
 def init_dist(args):
     """Process group of the benchmark: RCCL (backend "nccl") -- or, for the --share-gpu code-path check, gloo with the
     device-tensor collectives staged through the host (the test shim keeps RCCL's stream semantics)."""
@@ -457,11 +481,12 @@ def rendezvous_only(args, world, rank):
     dist.init_process_group(backend)
     t = torch.tensor([float(rank)], device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(t)
+    record = None
     if rank == 0:
-        print(json.dumps({"rendezvous": "ok", "backend": dist.get_backend(), "world_size_reported": dist.get_world_size(),
-                          "n_gpus": world, "rank_sum": float(t), "self_launched": bool(os.environ.get("RD_BENCH_SELF_LAUNCHED")),
-                          "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
-    dist.destroy_process_group()
+        record = {"rendezvous": "ok", "backend": dist.get_backend(), "world_size_reported": dist.get_world_size(),
+                  "n_gpus": world, "rank_sum": float(t), "self_launched": bool(os.environ.get("RD_BENCH_SELF_LAUNCHED")),
+                  "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    emit_line(record, True)
 
 
 def main():
@@ -490,6 +515,7 @@ def main():
                     help="measure the tiled full-raster inference sweep instead (BASELINE configs[4], cfg-G: 3-ch tiles of "
                          "256x256 at stride 128 over a synthetic --raster x --raster DSM, eval-mode BN, linear blend)")
     ap.add_argument("--raster", type=int, default=8192, help="--infer: side of the synthetic raster (SURVEY 8d: 8192 -> 3969 tiles)")
+    ap.add_argument("--bucket-mb", type=int, default=16, help="gradient all-reduce bucket size (resdepth_amd.dp.attach)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, join the process group, all-reduce one number, print what rank 0 saw and exit")
     ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; gloo for --rendezvous-only on CPU)")
@@ -518,6 +544,7 @@ def main():
         print(f"bench.py: --gpus {args.gpus} under a launcher that started {world} rank(s) (WORLD_SIZE={world}): "
               f"start it with --nproc-per-node {args.gpus}, or with no launcher at all", file=sys.stderr)
         sys.exit(2)
+    quiet_non_zero_ranks(rank)
     if args.rendezvous_only:
         return rendezvous_only(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
@@ -549,7 +576,7 @@ def main():
     n = args.batch
     tb = TrainBench(wl, n, dev, rank=rank, from_rasters=args.from_rasters)
     if use_dist:
-        gs = dp.attach(tb.model, sync_bn=args.sync_bn)
+        gs = dp.attach(tb.model, sync_bn=args.sync_bn, bucket_bytes=args.bucket_mb << 20)
         tb.gs = gs
         dp.broadcast_parameters(tb.model, 0)
     tb.attach_optimizer()
@@ -636,10 +663,7 @@ def main():
             out["secondary"] = secondary_measurements(args, dev, tb)
         if world == 1 and not args.no_cpu_baseline and args.workload == "S":
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if use_dist:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    emit_line(out if rank == 0 else None, use_dist)
 
 
 if __name__ == "__main__":
