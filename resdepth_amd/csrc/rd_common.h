@@ -43,7 +43,7 @@ enum TuneKey {
     TUNE_TN_TILE,          // -1 auto | bm*1000 + bn
     TUNE_TN_BLOCKS,        // target block count of the split-K TN kernels
     TUNE_TN_SPLIT,         // -1 auto | 0/1 force the split-bf16 TN kernel off/on
-    TUNE_WG_STRIP,         // -1 auto | 0: never use the strip weight-gradient kernel | 1: its register-transpose version (r02)
+    TUNE_WG_STRIP,         // -1 auto | 0: never use the strip weight-gradient kernel | 1: its register-transpose version (r02) | 4: no image-pair form for 8 x 8 images
     TUNE_WG_MINBLOCKS,     // strip kernel: minimum blocks before image rows are chunked
     TUNE_WG_BLOCKS,        // strip kernel: target block count
     TUNE_WG_OCC,           // strip kernel: 2 (default) = register budget for two waves per SIMD, 1 = one wave (accumulators in AGPRs)

@@ -27,6 +27,7 @@ struct WsParams {
     int strips_x, chunks_y, rows_per_chunk, reps;
     int tiles_ci, tiles_mn;
     unsigned a_bytes, b_bytes;
+    int n_img;          // W8 form: images in the batch (a strip is a PAIR of 8 x 8 images; the last pair may lack its second one)
 };
 
 template <int OCC>
@@ -234,7 +235,13 @@ __device__ __forceinline__ bf16x8 lds_tr2(const float* smem_base, int byte_off, 
 // NCO x NCI = 4 waves: wave (cw, cb) owns output channels [32 cw, +32) x input channels [32 cb, +32) of the block tile.
 //   <4, 1>: 128 co x 32 ci (the r02 tile): 2048 + 576 = 2624 staged elements per K-step
 //   <2, 2>:  64 co x 64 ci               : 1024 + 1152 = 2176 (-17 %), needs Cin % 64 == 0
-template <int OCC, int NCO, int NCI>
+//
+// W8 (r04): 8 x 8 images (the bottleneck level).  A "strip" is a PAIR of images side by side: row y of the strip = row y of both
+// images, so a K-step is still 16 pixels (k 0-7: first image, 8-15: second).  Each image brings its own zero border: the halo row
+// has 2 x 10 pixels, and the fragment reads of the second image's pixels start two halo pixels later (a per-lane constant, as in
+// the W8 form of conv3_halo_split_kernel) -- the tap shifts stay compile-time row offsets.  Replaces the generic TN kernel for this
+// level (two register transposes per operand, 7 VALU per MFMA: 99 TFLOP/s).
+template <int OCC, int NCO, int NCI, bool W8 = false>
 __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
     static_assert(NCO * NCI == 4, "four waves");
     constexpr int TA = 64 * NCO, TB = 64 * NCI;                // bytes of one term of one pixel (32 channels x 2 B per wave column)
@@ -243,10 +250,11 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
     constexpr int APX = 3 * TA + (NCO == 4 ? 64 : NCO == 2 ? 64 : 0), BPX = 3 * TB + (NCI == 2 ? 64 : 0);
     static_assert((APX / 4) % 64 == 16 || (APX / 4) % 64 == 48, "dz pixel stride");
     static_assert((BPX / 4) % 64 == 16 || (BPX / 4) % 64 == 48, "x pixel stride");
-    constexpr int ASTAGE = 16 * APX, BSLOT = 18 * BPX;         // bytes per dz stage / per halo ring slot
+    constexpr int HPX = W8 ? 20 : 18;                          // halo pixels of an x row (W8: two images with their own borders)
+    constexpr int ASTAGE = 16 * APX, BSLOT = HPX * BPX;        // bytes per dz stage / per halo ring slot
     constexpr int RINGB = 2 * ASTAGE;                          // byte offset of the halo ring
     constexpr int AQ = 8 * NCO, BQ = 8 * NCI;                  // channel quads per pixel
-    constexpr int AI = 16 * AQ / 256, BI = (18 * BQ + 255) / 256;      // staging items (float4) per thread
+    constexpr int AI = 16 * AQ / 256, BI = (HPX * BQ + 255) / 256;     // staging items (float4) per thread
     __shared__ __attribute__((aligned(16))) float smem[(2 * ASTAGE + 4 * BSLOT) / 4];
 
     const int gb = xcd_remap(blockIdx.x, gridDim.x);
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
 #pragma unroll
     for (int k = 0; k < BI; ++k) {
         const int e = t + 256 * k, cq = e % BQ, hp = e / BQ;
-        b_act[k] = e < 18 * BQ;
+        b_act[k] = e < HPX * BQ;
         b_hp[k] = hp;
         b_ch[k] = (b_act[k] && ci0 + cq * 4 < p.Cin) ? ci0 + cq * 4 : -1;
         b_wr[k] = hp * BPX + cq * 8;
@@ -288,8 +296,23 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
         x0 = sx * 16;
         ya = cy * p.rows_per_chunk;
         yb = ya + p.rows_per_chunk;
+        if (W8) img *= 2;                                       // first image of the pair
         baseA = (unsigned)img * H * rowA;
         baseB = (unsigned)img * H * rowB;
+        if (W8) {
+            const bool two = img + 1 < p.n_img;
+#pragma unroll
+            for (int k = 0; k < AI; ++k) {
+                const int sub = a_px[k] >> 3, xx = a_px[k] & 7;
+                voffA[k] = (a_ch[k] >= 0 && (sub == 0 || two)) ? (unsigned)(((sub * 64 + xx) * p.Cout + a_ch[k]) * 4) : kOOB;
+            }
+#pragma unroll
+            for (int k = 0; k < BI; ++k) {
+                const int sub = b_hp[k] >= 10 ? 1 : 0, px = b_hp[k] - 10 * sub - 1;
+                voffB[k] = (b_ch[k] >= 0 && (unsigned)px < 8u && (sub == 0 || two)) ? (unsigned)(((sub * 64 + px) * p.Cin + b_ch[k]) * 4) : kOOB;
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < AI; ++k) voffA[k] = a_ch[k] >= 0 ? (unsigned)(((x0 + a_px[k]) * p.Cout + a_ch[k]) * 4) : kOOB;
 #pragma unroll
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
     // fragment addressing: lane -> 16-lane group g (n-block nb = g & 1, k-octet h = g >> 1), i = lane & 15
     const int li = lane & 15, lg = lane >> 4, nb = lg & 1, hk = lg >> 1;
     const int a_rd = (8 * hk + (li >> 2)) * APX + (32 * cw + 16 * nb + 4 * (li & 3)) * 2;
-    const int b_rd = (8 * hk + (li >> 2)) * BPX + (32 * cb + 16 * nb + 4 * (li & 3)) * 2;
+    const int b_rd = (8 * hk + (li >> 2) + (W8 ? 2 * hk : 0)) * BPX + (32 * cb + 16 * nb + 4 * (li & 3)) * 2;   // W8: second image's halo
     const int lrow = lane & 31, half = lane >> 5;
 
     f32x16 acc[9];
@@ -428,6 +451,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
 struct WsPlan {
     int ok, swapped, rows_per_chunk, chunks_y, strips_x, tiles_m, tiles_ci, reps, splits;
     int sq;         // 1: 64 co x 64 ci block tile (transpose-read kernel <2, 2>), 0: 128 co x 32 ci
+    int w8;         // 1: 8 x 8 images, strips are image pairs (wgrad_strip_tr_kernel<.., W8>)
 };
 
 // The strip kernel needs W >= 16, the shifted operand's channels % 32 == 0 and a full 128-channel block on the other
@@ -437,7 +461,9 @@ struct WsPlan {
 static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
     WsPlan pl = {};
     const int force = tune(TUNE_WG_STRIP);
-    if (!mfma_split() || force == 0 || w % 16 != 0 || h < 4 || h % 2 != 0) return pl;   // 16-pixel strips, rows in pairs
+    // 8 x 8 images (W8 form of the transpose-read kernel): pairs of images are the strips; square 64 x 64 tiles only
+    const bool w8 = w == 8 && h == 8 && cout % 64 == 0 && cin % 64 == 0 && force != 1 && force != 3 && tune(TUNE_WG_STRIP) != 4;
+    if (!mfma_split() || force == 0 || (!w8 && w % 16 != 0) || h < 4 || h % 2 != 0) return pl;   // 16-pixel strips, rows in pairs
     // square tile: both channel counts multiples of 64 (every cfg-S / cfg-M layer) -- fewer staged elements per MFMA and no
     // operand swap; wg_strip = 3 keeps the 128 x 32 tile of the transpose-read kernel for A/B runs
     if (force != 1 && force != 3 && cout % 64 == 0 && cin % 64 == 0) {
@@ -451,7 +477,9 @@ static WsPlan plan_strip(int n, int h, int w, int cin, int cout) {
         return pl;
     }
     pl.ok = 1;
-    pl.strips_x = w / 16;
+    pl.w8 = w8;
+    if (w8) n = (n + 1) / 2;                      // strips = image pairs
+    pl.strips_x = w8 ? 1 : w / 16;
     pl.tiles_m = cdiv(cout, pl.sq ? 64 : 128);
     pl.tiles_ci = cin / (pl.sq ? 64 : 32);
     const long base = (long)pl.tiles_m * pl.tiles_ci * n * pl.strips_x;
@@ -496,12 +524,14 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     q.H = h; q.W = w;
     q.strips_x = wp.strips_x; q.chunks_y = wp.chunks_y; q.rows_per_chunk = wp.rows_per_chunk; q.reps = wp.reps;
     q.tiles_ci = wp.tiles_ci; q.tiles_mn = wp.tiles_m * wp.tiles_ci;
+    q.n_img = n;
     const double ab = 4.0 * n * h * w * (double)cout, bb = 4.0 * n * h * w * (double)cin;
     RD_REQUIRE(ab < 4294967040.0 && bb < 4294967040.0, "rd_conv3x3_bwd_weight: operand beyond the 4 GiB descriptor range");
     q.a_bytes = (unsigned)ab; q.b_bytes = (unsigned)bb;
     const int occ_ = tune(TUNE_WG_OCC) == 2 ? 2 : 1;
     char pcls[64];      // "<operation>|<kernel symbol as rocprofv3 prints it, summarize_prof.py form>"
-    if (wp.sq) snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip_tr<%d,2,2>", occ_);
+    if (wp.w8) snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip_tr<%d,2,2,w8>", occ_);
+    else if (wp.sq) snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip_tr<%d,2,2>", occ_);
     else if (tune(TUNE_WG_STRIP) != 1) snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip_tr<%d,4,1>", occ_);
     else snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip<%d>", occ_);
     ProfScope ps(s, pcls, 2.0 * cout * 9.0 * cin * (double)n * h * w, ab + bb + 4.0 * cout * 9.0 * cin, true);
@@ -510,7 +540,9 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     const bool tr = tune(TUNE_WG_STRIP) != 1;
     const dim3 grid(q.tiles_mn * wp.splits);
     const int occ = tune(TUNE_WG_OCC);
-    if (wp.sq && occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 2, 2>), grid, dim3(256), 0, s, q);
+    if (wp.w8 && occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 2, 2, true>), grid, dim3(256), 0, s, q);
+    else if (wp.w8) hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 2, 2, true>), grid, dim3(256), 0, s, q);
+    else if (wp.sq && occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 2, 2>), grid, dim3(256), 0, s, q);
     else if (wp.sq) hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 2, 2>), grid, dim3(256), 0, s, q);
     else if (tr && occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 4, 1>), grid, dim3(256), 0, s, q);
     else if (tr) hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 4, 1>), grid, dim3(256), 0, s, q);

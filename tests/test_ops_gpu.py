@@ -63,8 +63,10 @@ CONV_SHAPES = [  # n, h, w, cin, cout
     (4, 32, 32, 160, 32),     # strip weight gradient <*,4,1> with swapped operand roles (Cout < 128 <= Cin, Cin % 64 != 0)
     (4, 32, 32, 96, 160),     # ... un-swapped with a ragged second row tile (Cout = 128 + 32)
     (2, 16, 32, 192, 320),    # square-tile strip kernel <*,2,2>: 5 x 3 tiles, two strips per image row
-    (32, 8, 8, 512, 512),     # the cfg-S bottleneck (8 x 8 images: generic 64 x 64 kernel, TN weight gradient)
-    (33, 8, 8, 64, 256),      # ... with an odd image count and Cin != Cout
+    (32, 8, 8, 512, 512),     # the cfg-S bottleneck (8 x 8 images: two-image patches; weight gradient on image-PAIR strips, r04)
+    (33, 8, 8, 64, 256),      # ... with an odd image count (the last pair lacks its second image) and Cin != Cout
+    (1, 8, 8, 64, 64),        # a single 8 x 8 image: one half-empty pair
+    (5, 8, 8, 128, 192),      # three pairs, 3 x 2 tiles
 ]
 
 
