@@ -132,3 +132,47 @@ def test_sweep_reduce_on_rccl_world1_equals_the_plain_sweep():
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[1]["dist"] == {"backend": "nccl", "world_size_reported": 1} and outs[0]["dist"] is None
     assert outs[0]["raster_checksum"] == outs[1]["raster_checksum"]
+
+
+def test_cfg_g_at_the_survey_size_properties():
+    """BASELINE configs[4] at SURVEY 8d's size -- 8192 x 8192 raster, 3 969 tiles of 256 x 256 at stride 128, the cfg-S architecture
+    in eval mode -- through size-independent properties (an oracle sweep of 3 969 tiles is hours of CPU):
+      * the sweep does not depend on how the tiles are batched (32 per batch vs ragged batches of 13): same raster BITS;
+      * tile shards (0, 2) + (1, 2) sum to the unsharded raster (what the rank-sharded sweep reduces on rank 0);
+      * with the network's residual branch switched off (last layer zeroed) the prediction is the input DSM, and blending the
+        de-normalised tiles must give back the raster itself: partition of unity of the blend weights over the whole grid."""
+    from resdepth_amd import UNet, SyntheticRasterTiles, predict_linear_blend
+    R = 8192
+    torch.manual_seed(0)
+    model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(DEV).eval()
+
+    class Loader(list):
+        dataset = None
+
+    def staged(ds, bs):
+        ld = Loader({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()} for b in DataLoader(ds, batch_size=bs, shuffle=False))
+        ld.dataset = ds
+        return ld
+
+    ds = SyntheticRasterTiles(R, R, 3, tile_size=256, seed=1)
+    assert len(ds) == 3969
+    full = predict_linear_blend(staged(ds, 32), model)
+    assert full.shape == (R, R) and np.isfinite(full).all()
+    ragged = predict_linear_blend(staged(ds, 13), model)
+    assert np.array_equal(full, ragged)
+    del ragged
+    def shard(r):                                    # every second tile of the SAME dataset (what shard=(r, 2) builds; no second raster)
+        import copy
+        sh = copy.copy(ds)
+        sh.pos, sh.reg = ds.pos[r::2], ds.reg[r::2]
+        return sh
+
+    parts = [predict_linear_blend(staged(shard(r), 32), model) for r in range(2)]
+    np.testing.assert_allclose(parts[0] + parts[1], full, rtol=1e-9, atol=1e-9)
+    del parts
+    with torch.no_grad():
+        model.last_layer.weight.zero_()
+        model.last_layer.bias.zero_()
+    ident = predict_linear_blend(staged(ds, 32), model)
+    dsm = ds.raster[0].double().numpy()
+    assert float(np.abs(ident - dsm).max()) <= 2e-4 * 3.0 + 1e-3          # fp32 normalise / de-normalise of heights around 400 m
