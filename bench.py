@@ -65,6 +65,93 @@ def _cpu_model():
     return "unknown"
 
 
+def _parse_cpulist(text):
+    """'0-15,128-143' -> [0..15, 128..143] (the format of /sys/.../local_cpulist)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.extend(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _gpu_local_cpus(index):
+    """CPUs of the NUMA node HIP device `index` hangs off, from the PCI address torch reports for it:
+    /sys/bus/pci/devices/<domain:bus:device.0>/{numa_node,local_cpulist}.  -> (numa_node | None, [cpu, ...] | None)."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        base = os.path.join("/sys/bus/pci/devices", bdf)
+        with open(os.path.join(base, "numa_node")) as f:
+            node = int(f.read())
+        with open(os.path.join(base, "local_cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        return node, (cpus or None)
+    except Exception:       # noqa: BLE001 -- containers without sysfs PCI topology, older torch: no pinning
+        return None, None
+
+
+def _core_groups(cpus):
+    """Group hardware threads into physical cores (thread_siblings_list), keeping the order of first appearance."""
+    seen, groups = set(), []
+    allowed = set(cpus)
+    for c in cpus:
+        if c in seen:
+            continue
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                sib = [x for x in _parse_cpulist(f.read()) if x in allowed]
+        except Exception:   # noqa: BLE001
+            sib = [c]
+        sib = sib or [c]
+        groups.append(sib)
+        seen.update(sib)
+    return groups
+
+
+def pin_rank_to_gpu_numa(local_rank, n_local, device_index):
+    """Bind this rank (its launch thread and every thread it starts later: OpenMP, the autograd worker) to CPUs of its GPU's
+    NUMA node.  Ranks whose GPUs share a node split its physical cores into disjoint contiguous slices (both hardware
+    threads of a core stay together), so eight launch threads neither float across the two sockets nor share cores.
+    Falls back silently -- and says so in the returned record -- when the topology is not visible (numa_node -1 / no sysfs)
+    or the slice would be empty.  -> dict for the `dist.affinity` field."""
+    info = {"pinned": False}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        node, cpus = _gpu_local_cpus(device_index)
+        info.update(numa_node=node, cpus_before=len(allowed))
+        if not cpus:
+            info["reason"] = "no local_cpulist for the device's PCI address"
+            return info
+        cpus = [c for c in cpus if c in set(allowed)]
+        if not cpus or (node is not None and node < 0 and len(cpus) == len(allowed)):
+            info["reason"] = "the device reports no NUMA locality (numa_node -1 / all CPUs local)"
+            return info
+        # ranks that share this CPU set: every local rank whose device reports the same list
+        sharers = []
+        for r in range(n_local):
+            _, other = _gpu_local_cpus(r if device_index == local_rank else device_index)
+            if other and [c for c in other if c in set(allowed)] == cpus:
+                sharers.append(r)
+        if local_rank not in sharers:
+            sharers.append(local_rank)
+        sharers.sort()
+        cores = _core_groups(cpus)
+        k, m = sharers.index(local_rank), len(sharers)
+        per = len(cores) // m
+        if per < 1:
+            info["reason"] = f"{len(cores)} cores for {m} ranks"
+            return info
+        mine = [c for grp in cores[k * per:(k + 1) * per] for c in grp]
+        os.sched_setaffinity(0, mine)
+        info.update(pinned=True, cpus=len(mine), cpu_first_last=[min(mine), max(mine)], ranks_on_node=m,
+                    cores=per)
+    except Exception as e:  # noqa: BLE001 -- never take the benchmark down for an affinity call
+        info["reason"] = repr(e)[:120]
+    return info
+
+
 def cpu_baseline(warm=1, timed=3, batch=32):
     """BASELINE.md section 4 / SURVEY 8d: the oracle's train step (same module graph / loss / Adam as the reference; the
     oracle is the CPU restatement pinned on the reference, oracle/unet_oracle.py) on this box's host cores -- cfg-S (3-ch)
@@ -120,7 +207,8 @@ def cpu_baseline(warm=1, timed=3, batch=32):
 
 def infer_main(args, world, rank, dev):
     """cfg-G: forward-only sweep of a raster with overlapping tiles + linear blend (lib/evaluation.py:460-513).
-    `steps` = number of full sweeps timed.  Tiles are sharded round-robin over the ranks; rasters are summed on rank 0."""
+    `steps` = number of full sweeps timed.  Tiles are sharded over the ranks by row bands (resdepth_amd.tiling.band_shards):
+    band-sized private rasters, the shared rows exchanged point to point, every rank's rows copied into one shared host array."""
     from torch.utils.data import DataLoader
     from resdepth_amd import UNet, SyntheticRasterTiles, predict_linear_blend, _lib
     use_dist = world > 1 or args.force_dist          # --force-dist: the RCCL reduce of the sweep at world size 1
@@ -141,9 +229,9 @@ def infer_main(args, world, rank, dev):
     class Loader(list):
         dataset = ds
     loader = Loader(batches)
-    n_tiles_global = len(SyntheticRasterTiles(args.raster, args.raster, 3, tile_size=256, seed=1).pos)
+    n_tiles_global = ds.shard_plan[-1]["i1"]
     for _ in range(max(1, args.warmup)):
-        predict_linear_blend(loader, model)
+        predict_linear_blend(loader, model, host="reuse")
     torch.cuda.synchronize()
     if use_dist:
         import torch.distributed as dist
@@ -151,9 +239,10 @@ def infer_main(args, world, rank, dev):
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = predict_linear_blend(loader, model)
+        out = predict_linear_blend(loader, model, host="reuse")      # same pinned / shared host array every sweep
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    checksum = float(out.sum())
     kern = []
     if not args.no_prof:        # one more sweep, instrumented with HIP events per kernel class (never part of `value`)
         _lib.prof_reset(); _lib.prof_enable(2)
@@ -168,6 +257,12 @@ def infer_main(args, world, rank, dev):
         dt = float(t)
         dist_info = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size()}
     record = None
+    me = ds.shard_plan[rank]
+    sweep_info = {"sharding": "row bands (tiling.band_shards)", "tiles_per_rank": [p["i1"] - p["i0"] for p in ds.shard_plan],
+                  "private_raster_rows_rank0": me["hi"] - me["lo"], "owned_rows_per_rank": [p["c1"] - p["c0"] for p in ds.shard_plan],
+                  "exchanged_mbytes_per_boundary": round((256 - 128) * args.raster * 8 / 2 ** 20, 2) if world > 1 else 0.0,
+                  "host_array": "shared memory, page-locked per rank" if use_dist else "pinned",
+                  "d2h": "row stripes on a copy stream during the sweep"}
     if rank == 0:
         tiles_s = n_tiles_global * args.steps / dt
         fwd_flop = 19.80e9
@@ -183,7 +278,7 @@ def infer_main(args, world, rank, dev):
                     "frac_f32_peak": round(tiles_s / world * fwd_flop / 1e12 / PEAK_F32_TFLOPS, 4)},
             "roofline": build_roofline(kern, 1, PMC_SUMMARIES["G"], "HIP events, one instrumented sweep right after the timed "
                                        "sweeps (this rank's shard of the tiles)", per="sweep"),
-            "raster_checksum": float(out.sum()), "dist": dist_info,
+            "raster_checksum": checksum, "dist": dist_info, "sweep": sweep_info,
             "kernels": kernel_rows(kern, 1, per="sweep")}
     emit_line(record, use_dist)
 
@@ -361,6 +456,82 @@ def infer_sweep(dev, raster, batch, sweeps, warm=1):
     return len(ds) * sweeps / (time.perf_counter() - t0), len(ds)
 
 
+class _CyclingLoader:
+    """`n_iter` iterations over a few HOST-resident pinned batch dicts (what a DataLoader(pin_memory=True) hands the Trainer,
+    train.py:146-161), cycled: every iteration moves a full batch host -> device."""
+
+    def __init__(self, batches, n_iter):
+        self.batches, self.n_iter, self.dataset = batches, n_iter, list(range(n_iter * batches[0]["input"].shape[0]))
+        self.drop_last = True
+
+    def __len__(self):
+        return self.n_iter
+
+    def __iter__(self):
+        for i in range(self.n_iter):
+            yield self.batches[i % len(self.batches)]
+
+
+def trainer_loop_measurement(dev, wl, n, iters=24, prefetch=1):
+    """tiles/s of the drop-in loop itself -- resdepth_amd.Trainer.inference_one_epoch('train') over `iters` host-resident
+    pinned batches (lib/Trainer.py:159-222 driven as train.py does) -- next to the bare resident-batch step of `value`."""
+    import tempfile
+    import types
+    from resdepth_amd import UNet, FusedAdam, Trainer, synthetic_batch
+    torch.manual_seed(0)
+    model = UNet(n_input_channels=wl["c"], start_kernel=64, depth=wl["depth"], bias_conv_layer=True).to(dev).train()
+    opt = FusedAdam(model.parameters(), lr=2e-4, weight_decay=1e-5)
+    host = []
+    for k in range(4):
+        b = synthetic_batch(n, wl["c"], wl["t"], seed=4321 + k)
+        host.append({k_: (v.pin_memory() if torch.is_tensor(v) else v) for k_, v in b.items()})
+    tmp = tempfile.mkdtemp(prefix="rd_bench_trainer_")
+    mk = lambda it: _CyclingLoader(host, it)
+    a = types.SimpleNamespace(model=model, optimizer=opt, scheduler=None, criterion=torch.nn.L1Loss(reduction="mean"),
+                              trainloader=mk(iters), valloader=None, n_epochs=1, evaluate_rate=1, save_model_rate=10 ** 9,
+                              freq_average_train_loss=10 ** 9, save_dir=tmp, log_file=None,
+                              checkpoint_dir=os.path.join(tmp, "ck"), tboard_log_dir=os.path.join(tmp, "tb"),
+                              pretrained_path=None, prefetch_batches=prefetch)
+    tr = Trainer(a)
+    tr.logger.handlers.clear()
+    tr.loader["train"] = mk(6)
+    tr.inference_one_epoch(0, "train")               # warm-up epoch (allocator, pinned staging, packed weights)
+    torch.cuda.synchronize()
+    tr.loader["train"] = mk(iters)
+    t0 = time.perf_counter()
+    meters = tr.inference_one_epoch(1, "train")      # ends with ONE read-back of the epoch's losses
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del tr, model, opt
+    return {"tiles_per_s": round(n * iters / dt, 1), "ms_per_iteration": round(dt / iters * 1e3, 3), "iterations": iters,
+            "prefetch_batches": prefetch, "loss_avg": round(float(meters["MAE_metric"].avg), 6),
+            "h2d_mbytes_per_iteration": round(sum(v.numel() * v.element_size() for v in host[0].values() if torch.is_tensor(v)) / 2 ** 20, 1)}
+
+
+def eval_stats_measurement(dev, side=8192):
+    """resdepth_amd.evaluation.get_statistics (lib/evaluation.py:11-131: masked MAE / RMSE / medians / NMAD) on rasters resident
+    in HBM: pixels/s and algorithmic GB/s (one read of the fp64 raster, the fp32 ground truth and the mask per pass: the
+    single reduction pass + 8 radix-select passes x 3 medians are what the kernel actually issues)."""
+    from resdepth_amd.evaluation import get_statistics
+    g = torch.Generator(device="cpu").manual_seed(5)
+    gt = (torch.randn(side, side, generator=g) * 3.0 + 400.0).to(dev)
+    ras = gt.double() + torch.randn(side, side, generator=g).to(dev).double() * 0.5
+    mask = (torch.rand(side, side, generator=g) > 0.05).to(dev)
+    get_statistics(ras, gt, -9999.0, mask, None, device=dev)
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        st = get_statistics(ras, gt, -9999.0, mask, None, device=dev)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    px = side * side
+    return {"mpixels_per_s": round(px / dt / 1e6, 1), "ms_per_call": round(dt * 1e3, 3), "raster": f"{side}x{side}",
+            "alg_gbs_one_pass": round(px * 13 / dt / 1e9, 1), "MAE": round(st["MAE"], 6), "NMAD": round(st["NMAD"], 6),
+            "note": "full statistics incl. exact median / absolute median / NMAD; alg_gbs_one_pass counts ONE read of raster "
+                    "(f64) + ground truth (f32) + mask (u8) per call"}
+
+
 def secondary_measurements(args, dev, tb):
     """Numbers DESIGN.md quotes beside the headline, measured in the same invocation (few steps each; never `value`)."""
     from resdepth_amd import _lib
@@ -371,11 +542,59 @@ def secondary_measurements(args, dev, tb):
         dt, ev = tb.timed(5, 2)
         out["exact_f32"] = {"tiles_per_s": round(tb.n * 5 / dt, 1), "step_ms_median": round(_median(ev), 3),
                             "note": "same step on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32), 5 timed steps"}
+        # its own roofline: the dominant exact-f32 kernel against the f32-input MFMA peak (serialized instrumented pass)
+        two = tb.model.two_stream_backward
+        tb.model.two_stream_backward = False
+        tb.step()
+        torch.cuda.synchronize()
+        _lib.prof_reset(); _lib.prof_enable(2)
+        for _ in range(2):
+            tb.step()
+        torch.cuda.synchronize()
+        _lib.prof_enable(0)
+        kern = _lib.prof_collect()
+        tb.model.two_stream_backward = two
+        out["exact_f32"]["roofline"] = build_roofline(kern, 2, (), "HIP events, serialized pass of 2 steps in exact-f32 mode")
+        out["exact_f32"]["e2e_frac_f32_peak"] = round(tb.n * 5 / dt * tb.wl["flop"] / 1e12 / PEAK_F32_TFLOPS, 4)
     except Exception as e:      # noqa: BLE001 -- a secondary number must never take the headline down
-        out["exact_f32"] = {"error": repr(e)[:200]}
+        out["exact_f32"] = dict(out.get("exact_f32") or {}, error=repr(e)[:200])
     finally:
         _lib.tune_set("mfma_f32", 0)
         tb.model.invalidate_packed()
+        _lib.prof_enable(0)
+    try:        # the drop-in loop: Trainer.inference_one_epoch over host-resident pinned batches, H2D prefetch on / off
+        on = trainer_loop_measurement(dev, tb.wl, tb.n, prefetch=1)
+        off = trainer_loop_measurement(dev, tb.wl, tb.n, iters=12, prefetch=0)
+        out["trainer_loop"] = dict(on, without_prefetch_tiles_per_s=off["tiles_per_s"],
+                                   note="resdepth_amd.Trainer.inference_one_epoch('train'): 4 distinct pinned host batches cycled, "
+                                        "every iteration copies its batch host->device (DevicePrefetcher: next batch staged on a "
+                                        "copy stream under the current step); deferred loss read-back, FusedAdam")
+    except Exception as e:      # noqa: BLE001
+        out["trainer_loop"] = {"error": repr(e)[:300]}
+    try:        # sample assembly on the GPU inside every step
+        tr = TrainBench(tb.wl, tb.n, dev, from_rasters=True)
+        tr.attach_optimizer()
+        dt, ev = tr.timed(10, 3)
+        # the sampler alone (no train step): batches/s of rd_patch_sums + rd_assemble_patches
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            tr.sampler.random_batch(tr.n, tr.pair, generator=tr.gr)
+        torch.cuda.synchronize()
+        ds = (time.perf_counter() - t0) / 20
+        out["from_rasters"] = {"tiles_per_s": round(tr.n * 10 / dt, 1), "step_ms_median": round(_median(ev), 3),
+                               "sampler_alone_tiles_per_s": round(tr.n / ds, 1), "sampler_alone_ms_per_batch": round(ds * 1e3, 3),
+                               "note": "GpuPatchSampler.random_batch (patch extraction, masked mean centring, normalisation, "
+                                       "rot90/flip, loss mask; lib/DsmOrthoDataset.py:161-291) from 4096^2 rasters resident in HBM "
+                                       "+ the train step, 10 timed steps"}
+        del tr
+    except Exception as e:      # noqa: BLE001
+        out["from_rasters"] = {"error": repr(e)[:300]}
+    try:
+        out["eval_stats"] = eval_stats_measurement(dev)
+    except Exception as e:      # noqa: BLE001
+        out["eval_stats"] = {"error": repr(e)[:300]}
+    torch.cuda.empty_cache()
     try:
         wl = WORKLOADS["M"]
         tm = TrainBench(wl, 32, dev)
@@ -396,6 +615,78 @@ def secondary_measurements(args, dev, tb):
     except Exception as e:      # noqa: BLE001
         out["cfg_G"] = {"error": repr(e)[:200]}
     torch.cuda.empty_cache()
+    return out
+
+
+def diagnostics_pass(tb, gs, steps, barrier):
+    """A few steps AFTER the timed region with the exchange points bracketed by HIP events (resdepth_amd.dp.Probe) and the
+    host side clocked: what the first multi-GPU run needs to be read, not just quoted.  Never part of `value`.
+      host_enqueue_ms   wall time of one step() on the launching thread, GPU queue never full (median): must stay well under
+                        the step time or the GPU starves (8 ranks x ~110 launches through ctypes on two sockets);
+      grad_wait         main stream blocked in GradSync.finish after all of its own work: the EXPOSED gradient all-reduce;
+      loss_norm         the blocking two-scalar all-reduce between the loss reduction and its finishing kernel;
+      bn_fwd / bn_bwd   SyncBN exchanges (strict-parity mode only);
+      bucket_issue_ms_after_step_start   when each gradient bucket's collective was issued on the weight-gradient stream."""
+    from resdepth_amd import dp
+    probe = dp.Probe()
+    if gs is not None:
+        gs.probe = probe
+    barrier()
+    host, evs = [], []
+    for _ in range(steps):
+        if gs is not None:
+            probe.mark_step_start()
+        a = torch.cuda.Event(enable_timing=True)
+        a.record()
+        t0 = time.perf_counter()
+        tb.step()
+        host.append((time.perf_counter() - t0) * 1e3)
+        b = torch.cuda.Event(enable_timing=True)
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    if gs is not None:
+        gs.probe = None
+    out = {"host_enqueue_ms": round(_median(host), 3), "host_enqueue_ms_min_max": [round(min(host), 3), round(max(host), 3)],
+           "step_ms_under_probe": round(_median([a.elapsed_time(b) for a, b in evs]), 3), "probe_steps": steps}
+    if gs is not None:
+        out.update(probe.summary(steps))
+        out["plan"] = gs.describe()
+    return out
+
+
+def summarize_ranks(per_rank_ms, diags, args):
+    """rank 0: the per-rank diagnostics -> the `dist` fields (DESIGN.md section 6 says how to read each one)."""
+    def col(key, sub=None):
+        vals = []
+        for d in diags:
+            v = (d or {}).get(key)
+            if sub is not None and isinstance(v, dict):
+                v = v.get(sub)
+            vals.append(v)
+        return vals
+
+    lo, hi = min(per_rank_ms), max(per_rank_ms)
+    out = {"rank_step_ms_min_max_skew": [round(lo, 3), round(hi, 3), round(hi - lo, 3)],
+           "slowest_rank": per_rank_ms.index(hi),
+           "step_ms_median_hip_events_per_rank": col("step_ms_median_hip_events"),
+           "host_enqueue_ms_per_rank": col("host_enqueue_ms"),
+           "exposed_grad_allreduce_ms_per_rank": col("grad_wait", "device_ms_per_step"),
+           "grad_wait_host_ms_per_rank": col("grad_wait", "host_ms_per_step"),
+           "loss_normaliser_allreduce_ms_per_rank": col("loss_norm", "device_ms_per_step"),
+           "affinity_per_rank": col("affinity")}
+    d0 = diags[0] or {}
+    if "plan" in d0:
+        out["gradient_buckets"] = d0["plan"]
+    if "bucket_issue_ms_after_step_start" in d0:
+        out["bucket_issue_ms_after_step_start_rank0"] = d0["bucket_issue_ms_after_step_start"]
+        out["step_ms_under_probe_rank0"] = d0.get("step_ms_under_probe")
+    if "bn_fwd" in d0 or "bn_bwd" in d0:
+        out["syncbn_rank0"] = {"fwd": d0.get("bn_fwd"), "bwd": d0.get("bn_bwd")}
+    out["how_to_read"] = ("exposed_grad_allreduce >> 0.1 ms: buckets finish after the backward (raise --bucket-mb / check "
+                          "bucket_issue times against step_ms); loss_normaliser >> 0.05 ms: small-message latency; "
+                          "host_enqueue close to step_ms or differing between ranks: host-bound launch thread (affinity); "
+                          "skew: a slow rank stalls everyone in the first collective")
     return out
 
 
@@ -458,14 +749,11 @@ def quiet_non_zero_ranks(rank):
 
 
 def init_dist(args):
-    """Process group of the benchmark: RCCL (backend "nccl") -- or, for the --share-gpu code-path check, gloo with the
-    device-tensor collectives staged through the host (the test shim keeps RCCL's stream semantics)."""
+    """Process group of the benchmark: RCCL (backend "nccl") -- or, for the --share-gpu code-path check, gloo, whose
+    collectives take device tensors in this torch build (staged through the host by the backend itself; nothing from
+    tests/ is imported here)."""
     import torch.distributed as dist
     dist.init_process_group(args.backend or "nccl")
-    if args.share_gpu:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import host_staged_collectives
-        host_staged_collectives.install()
 
 
 def rendezvous_only(args, world, rank):
@@ -528,6 +816,11 @@ def main():
     ap.add_argument("--prof-all", action="store_true", help="(kept for scripts) same as the default full breakdown")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the data-parallel code path (RCCL process group, bucketed all-reduce) even at world size 1")
+    ap.add_argument("--no-pin", action="store_true",
+                    help="N > 1: do not bind the rank to the CPUs of its GPU's NUMA node (pin_rank_to_gpu_numa)")
+    ap.add_argument("--diag-steps", type=int, default=5,
+                    help="steps of the diagnostics pass after the timed region (host enqueue time; N > 1 / --force-dist: exposed "
+                         "all-reduce wait, loss-normaliser latency, bucket issue times); 0 = skip")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -555,6 +848,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    affinity = None
+    if world > 1 and not args.no_pin:
+        # before the first kernel launch / OpenMP region: threads started later inherit the mask
+        affinity = pin_rank_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)),
+                                        local_rank)
 
     from resdepth_amd import _lib, dp
     _lib.load()
@@ -591,6 +889,9 @@ def main():
 
     dt, step_ms = tb.timed(args.steps, args.warmup, barrier)
     timed_losses = list(tb.losses)
+    # ---- diagnostics pass (after the timed region, production two-stream mode): host enqueue time and, with a process
+    # group, the exposed part of every exchange point
+    diag = diagnostics_pass(tb, gs, args.diag_steps, barrier) if args.diag_steps > 0 else None
     # ---- per-kernel roofline pass.  In the timed region the weight-gradient kernels run concurrently with the
     # dgrad/BN chain on a second stream, so a kernel's event-to-event duration there includes time shared with another
     # kernel; the roofline numbers therefore come from a SERIALIZED pass of the same step, in this process, right after
@@ -618,8 +919,12 @@ def main():
         dist.all_gather(every, mine)
         per_rank_ms = [float(v) / args.steps * 1e3 for v in every]
         dt = max(float(v) for v in every)               # MAX over ranks
+        mine_diag = dict(diag or {}, step_ms_median_hip_events=round(_median(step_ms), 3), affinity=affinity, rank=rank)
+        every_diag = [None] * dist.get_world_size()
+        dist.all_gather_object(every_diag, mine_diag)
         dist_info = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size(),
                      "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms]}
+        dist_info.update(summarize_ranks(per_rank_ms, every_diag, args))
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -659,6 +964,10 @@ def main():
         }
         if dist_info:
             out["dist"] = dist_info
+        if diag is not None:
+            out["host_enqueue_ms"] = diag["host_enqueue_ms"]
+            out["host_enqueue_note"] = ("wall time of one step() on the launching thread (median of the diagnostics pass, GPU "
+                                        "queue never full): every kernel launch, allocation and event of the step through ctypes")
         if world == 1 and not args.no_secondary and args.workload == "S" and not args.from_rasters and not use_dist:
             out["secondary"] = secondary_measurements(args, dev, tb)
         if world == 1 and not args.no_cpu_baseline and args.workload == "S":

@@ -40,7 +40,7 @@ typedef void* rd_stream_t; /* hipStream_t */
 #define RD_ERR_WS 2
 #define RD_ERR_HIP 3
 
-int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream) */
+int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream); 102: rd_host_register & co */
 const char* rd_last_error_string(void);
 
 /* ---- weight (re)packing: torch layouts -> GEMM operand layouts ------------------- */
@@ -363,6 +363,15 @@ int rd_sgd_step(float* p, const float* g, float* momentum_buf, long long numel, 
  * np.linspace(0,1,overlap)).  pos = int32 [n][2] (offset_y, offset_x); reg = int32 [n][4] (uly, ulx, lry, lrx). */
 int rd_blend_accumulate(const float* pred, const float* mean, const float* std, const int* pos, const int* reg, int n,
                         int tile_size, int stride, double* raster, int rows, int cols, rd_stream_t s);
+
+/* Host side of the sweep's raster read-back (lib/evaluation.py:510-513 returns the blended raster as a host array).  A multi-GPU
+ * sweep lets every rank write ITS band of the raster straight into one host buffer shared by the ranks of the node (POSIX
+ * shared memory mapped by each of them): rd_host_register page-locks and maps [p, p + bytes) of such a mapping for the
+ * current device (hipHostRegister, portable), rd_copy_to_host_async enqueues device -> host on `s` (truly asynchronous for
+ * registered / pinned destinations), rd_host_unregister undoes the registration.  Plain pointers; no torch types. */
+int rd_host_register(void* p, size_t bytes);
+int rd_host_unregister(void* p);
+int rd_copy_to_host_async(void* dst_host, const void* src_dev, size_t bytes, rd_stream_t s);
 
 /* ---- training-sample assembly from rasters resident in HBM (lib/DsmOrthoDataset.py:161-291, lib/torch_transforms.py) */
 /* sums[i] = (sum, count) over the T x T patch at pos[i] = (y, x) of the planes plane_idx[i*P .. i*P+P-1] of a planar

@@ -107,6 +107,9 @@ SIGNATURES = {
     "rd_adam_step": (I, [P, P, P, P, LL, D, D, F, F, F, F, F, P]),
     "rd_sgd_step": (I, [P, P, P, LL, F, F, F, F, I, I, F, P]),
     "rd_blend_accumulate": (I, [P, P, P, P, P, I, I, I, P, I, I, P]),
+    "rd_host_register": (I, [P, SZ]),
+    "rd_host_unregister": (I, [P]),
+    "rd_copy_to_host_async": (I, [P, P, SZ, P]),
     "rd_patch_sums": (I, [P, LL, P, I, P, I, I, I, F, I, P, P]),
     "rd_assemble_patches": (I, [P, P, P, LL, P, I, P, P, P, F, P, F, F, I, I, I, P, P, P, P]),
     "rd_residual_stats_ws_bytes": (SZ, [LL]),
@@ -200,35 +203,52 @@ def workspace(nbytes: int, device, slot: int = 0) -> torch.Tensor:
 
 
 _splitk = {}
+_splitk_clock = 0
 # the most a launch uses: tiles * ranges <= 1024 partial tiles of 128 x 64 floats (csrc/rd_igemm.hip launch_nt) + 64 KB of tickets
 SPLITK_BYTES = (32 << 20) + (64 << 10)
-SPLITK_MAX_STREAMS = 8          # per device; further streams run the same kernel unsplit (same bits, fewer blocks)
+SPLITK_MAX_STREAMS = 8          # per device; a ninth stream takes over the least recently used registration
 
 
 def ensure_splitk_workspace(device, nbytes: int = SPLITK_BYTES) -> None:
     """Register (once per device and stream) the split-K scratch of the 8 x 8 convolution kernel for the CURRENT stream of
     `device` (include/resdepth_hip.h: rd_set_splitk_workspace; the library keys it by (device, stream) too).  The engine
     entry points call this; direct users of the op wrappers may too -- without it those layers run the same kernel unsplit
-    (same bits, fewer blocks at small batches).  At most SPLITK_MAX_STREAMS streams per device get a buffer, so a server
-    running requests on many short-lived streams does not grow device memory by one scratch per stream handle."""
+    (same bits, fewer blocks at small batches).  At most SPLITK_MAX_STREAMS streams per device hold a buffer, so a server
+    running requests on many short-lived streams does not grow device memory by one scratch per stream handle; beyond that
+    the least recently used registration is evicted and its buffer re-used."""
     dev = torch.device(device)
     index = dev.index if dev.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(index).cuda_stream
     key = (index, stream)
+    global _splitk_clock
     with _ws_lock:
+        _splitk_clock += 1
         if key in _splitk:
+            _splitk[key][1] = _splitk_clock
             return
-        if sum(1 for k in _splitk if k[0] == index) >= SPLITK_MAX_STREAMS:
-            return
-        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=torch.device("cuda", index))
+        mine = [k for k in _splitk if k[0] == index]
+        buf = None
+        if len(mine) >= SPLITK_MAX_STREAMS:
+            # evict the least recently used registration of this device and hand its scratch to the new stream: a process that
+            # touched eight short-lived streams must not lose the split-K path on every later one.  The old stream's pending
+            # launches still reference the buffer, so the new stream first waits for everything enqueued on the device
+            # (rare: only when a ninth stream appears)
+            victim = min(mine, key=lambda k: _splitk[k][1])
+            with torch.cuda.device(index):
+                check(load().rd_set_splitk_workspace(None, 0, victim[1]), "set_splitk_workspace")
+                torch.cuda.synchronize(index)
+            buf = _splitk.pop(victim)[0]
+        if buf is None or buf.numel() < int(nbytes):
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=torch.device("cuda", index))
         with torch.cuda.device(index):
             check(load().rd_set_splitk_workspace(buf.data_ptr(), buf.numel(), stream), "set_splitk_workspace")
-        _splitk[key] = buf          # kept alive for the life of the process (the library holds the raw pointer)
+        _splitk[key] = [buf, _splitk_clock]     # kept alive while registered (the library holds the raw pointer)
 
 
 # ---- parameter generation counter (bumped by in-place updates done through raw pointers) -------
 _param_gen = {}
 _global_gen = 0
+_PARAM_GEN_MAX = 1 << 16        # ~1500 models' worth of parameter pointers
 
 
 def bump_param_generation(flat_ptr=None):
@@ -239,6 +259,11 @@ def bump_param_generation(flat_ptr=None):
     if flat_ptr is None:
         _global_gen += 1
     else:
+        if len(_param_gen) >= _PARAM_GEN_MAX and flat_ptr not in _param_gen:
+            # entries of freed models are never removed one by one (a raw pointer has no owner to ask): when the table is
+            # full it is dropped whole and the global counter moves, which makes every live cache re-validate once
+            _param_gen.clear()
+            _global_gen += 1
         _param_gen[flat_ptr] = _param_gen.get(flat_ptr, 0) + 1
 
 

@@ -990,7 +990,13 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
         RD_LAUNCH_CHECK(cls);
         return RD_OK;
     }
-    // plain row tiles that are all inside M take the register-direct epilogue too (rd_nt.h: the W = 16 case of its row formula)
+    // plain row tiles that are all inside M take the register-direct epilogue too (rd_nt.h: the W = 16 case of its row formula).
+    // NOTE on batch-size independence: C is the same bits under either epilogue, but the BN-statistics / BN-backward partial
+    // rows are summed in a different (fixed) order by the direct and the staged form, and `p.M % bm == 0` depends on the pixel
+    // count, i.e. on the batch.  The "an image's result does not depend on the batch it is in" statement of the 8 x 8 split-K
+    // path therefore covers C (and everything inference uses); training-mode statistics of these generic row-tile layers can
+    // differ in the last bits between batch sizes that flip this predicate -- as they already do between batch sizes that
+    // select different kernels.
     p.direct = EPI == EPI_STORE && tune(TUNE_NT_EPI) != 0 && p.M % bm == 0 && p.N % 32 == 0 && !p.shift && !p.pool_out &&
                (long)bm * p.N * 4 < 0x7fffffffL;
     if (split) {

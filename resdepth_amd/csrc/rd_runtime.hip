@@ -168,7 +168,7 @@ static void drain_locked() {
 
 extern "C" {
 
-int rd_version(void) { return 101; }      // 101 (r04): rd_set_splitk_workspace keyed by (device, stream)
+int rd_version(void) { return 102; }      // 101 (r04): rd_set_splitk_workspace keyed by (device, stream); 102 (r05): rd_host_register
 
 const char* rd_last_error_string(void) { return rd::g_err; }
 
@@ -253,4 +253,24 @@ extern "C" int rd_set_splitk_workspace(void* ws, size_t bytes, rd_stream_t strea
     if (int e = check_hip(hipMemsetAsync(ws, 0, kSkTicketBytes, s), "rd_set_splitk_workspace")) return e;
     g_sk.push_back({dev, s, (char*)ws, bytes});
     return RD_OK;
+}
+
+// ---- host side of the sweep's raster read-back (include/resdepth_hip.h) ---------------------------------------------
+extern "C" int rd_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) {
+        rd::set_error("rd_host_register: null range");
+        return RD_ERR_ARG;
+    }
+    return rd::check_hip(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped), "rd_host_register");
+}
+
+extern "C" int rd_host_unregister(void* p) { return rd::check_hip(hipHostUnregister(p), "rd_host_unregister"); }
+
+extern "C" int rd_copy_to_host_async(void* dst_host, const void* src_dev, size_t bytes, rd_stream_t stream) {
+    if (!bytes) return RD_OK;
+    if (!dst_host || !src_dev) {
+        rd::set_error("rd_copy_to_host_async: null pointer");
+        return RD_ERR_ARG;
+    }
+    return rd::check_hip(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "rd_copy_to_host_async");
 }

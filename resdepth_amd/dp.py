@@ -30,6 +30,80 @@ import torch
 import torch.distributed as dist
 
 
+class Probe:
+    """Optional per-step timing of the exchange points, for the benchmark's `dist` block (never on by default: it
+    records two HIP events per bracket on the stream the collective is ordered on).  A bracket is the time THAT stream
+    spends between "everything before the collective is done" and "the collective's result is visible to it", i.e. the
+    part of the collective the stream could not hide:
+      grad_wait   GradSync.finish: main stream blocked on the gradient buckets after its own backward work (and the
+                  weight-gradient stream's) has finished -- the EXPOSED part of the all-reduce;
+      loss_norm   the two-scalar loss-normaliser all-reduce (blocking, between the loss reduction and its finish kernel);
+      bn_fwd / bn_bwd   SyncBN statistics exchanges (2 x 10 per step in strict-parity mode).
+    Host values: `host_ms[name]` = wall time the launching thread spent inside the bracket (enqueue + any host wait)."""
+
+    def __init__(self):
+        self.pairs = {}
+        self.host_ms = {}
+        self.launch_ev = []          # (bucket index, event recorded where the bucket's collective was issued)
+        self.step_start = None
+
+    class _Bracket:
+        def __init__(self, probe, name):
+            self.probe, self.name = probe, name
+
+        def __enter__(self):
+            import time
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+            self.t0 = time.perf_counter()
+
+        def __exit__(self, *exc):
+            import time
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.probe.pairs.setdefault(self.name, []).append((self.a, b))
+            self.probe.host_ms.setdefault(self.name, []).append((time.perf_counter() - self.t0) * 1e3)
+
+    def bracket(self, name):
+        return Probe._Bracket(self, name)
+
+    def mark_step_start(self):
+        self.step_start = torch.cuda.Event(enable_timing=True)
+        self.step_start.record()
+
+    def mark_bucket(self, bi, stream):
+        if self.step_start is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            self.launch_ev.append((bi, self.step_start, ev))
+
+    def summary(self, steps: int) -> dict:
+        """Call after torch.cuda.synchronize().  Per-step means in ms."""
+        out = {}
+        for name, pairs in self.pairs.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = {"calls_per_step": round(len(ms) / max(1, steps), 2), "device_ms_per_step": round(sum(ms) / max(1, steps), 4),
+                         "device_ms_max_call": round(max(ms), 4),
+                         "host_ms_per_step": round(sum(self.host_ms[name]) / max(1, steps), 4)}
+        if self.launch_ev:
+            by = {}
+            for bi, s, e in self.launch_ev:
+                by.setdefault(bi, []).append(s.elapsed_time(e))
+            out["bucket_issue_ms_after_step_start"] = {str(bi): round(sum(v) / len(v), 3) for bi, v in sorted(by.items())}
+        return out
+
+
+class _NoBracket:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_BRACKET = _NoBracket()
+
+
 class GradSync:
     def __init__(self, process_group=None, bucket_bytes: int = 16 << 20):
         if not dist.is_available() or not dist.is_initialized():
@@ -44,11 +118,23 @@ class GradSync:
         self._handles = []
         self._model_key = None
         self.launch_stream = None   # set by the two-stream backward: the stream the wgrad kernels run on
+        self.probe: Optional[Probe] = None      # bench.py's diagnostics pass sets a Probe; None = no events recorded
+
+    def _t(self, name):
+        return self.probe.bracket(name) if self.probe is not None else _NO_BRACKET
+
+    def describe(self) -> dict:
+        """Static facts of the exchange plan (after the first backward): bucket count / sizes in the order they are issued."""
+        b = self._buckets or []
+        return {"world": self.world, "bucket_bytes_target": self.bucket_bytes, "n_buckets": len(b),
+                "bucket_mbytes": [round((x["hi"] - x["lo"]) * 4 / 2 ** 20, 2) for x in b],
+                "bucket_params": [len(x["params"]) for x in b]}
 
     # ---- small collectives ---------------------------------------------------------------------
     def allreduce_loss_sums(self, sums: torch.Tensor, numel: int) -> int:
         """(sum |d|, #valid) -> global; returns the global element count."""
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
+        with self._t("loss_norm"):
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
         return numel * self.world
 
     def allreduce_stats(self, sums: torch.Tensor, count: int) -> int:
@@ -56,7 +142,8 @@ class GradSync:
         hold the same per-rank batch: `shard_batch` guarantees it, `check_equal_across_ranks` (called by the Trainer
         for its loaders) verifies it for user-built shards -- a smaller batch on one rank would silently bias the
         statistics, since the count is not part of the exchange (it stays a host value; no device read-back)."""
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
+        with self._t("bn_fwd"):
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
         return count * self.world
 
     def check_equal_across_ranks(self, value: int, what: str) -> None:
@@ -73,7 +160,8 @@ class GradSync:
 
     def allreduce_sums(self, sums: torch.Tensor) -> None:
         """SyncBN backward: (sum g', sum g'*xhat, ...) -> global, in place."""
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
+        with self._t("bn_bwd"):
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
 
     # ---- gradient buckets ------------------------------------------------------------------------
     @staticmethod
@@ -123,6 +211,8 @@ class GradSync:
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._handles.append(h)
         self._launched[bi] = True
+        if self.probe is not None and view.is_cuda:
+            self.probe.mark_bucket(bi, self.launch_stream if self.launch_stream is not None else torch.cuda.current_stream())
 
     def params_ready(self, model, indices) -> None:
         """Called by the backward pass after the kernels writing these parameter gradients were enqueued."""
@@ -140,8 +230,9 @@ class GradSync:
         for bi in range(len(self._buckets)):
             if not self._launched[bi]:
                 self._launch(model, bi)
-        for h in self._handles:
-            h.wait()
+        with self._t("grad_wait"):
+            for h in self._handles:
+                h.wait()
         self._handles = []
         self._ready = set()
         self._launched = [False] * len(self._buckets)
@@ -174,6 +265,10 @@ def broadcast_parameters(model, src: int = 0, process_group=None) -> None:
     for t in model.buffers():
         dist.broadcast(t.data, src=src, group=process_group)
     _lib.bump_param_generation(None)
+    # ... and the generation of every tensor written: a graph whose forward ran BEFORE the broadcast must not run its backward on
+    # the new weights (UNet._engine_backward compares the model's own parameter key, which reads these)
+    for t in params:
+        _lib.bump_param_generation(t.data_ptr())
     if hasattr(model, "invalidate_packed"):
         model.invalidate_packed()
 

@@ -127,7 +127,10 @@ class FusedAdam(torch.optim.Optimizer):
             pflat = _as_flat(params[0].data, total)
             gflat = _as_flat(params[0].grad, total)
             ops.adam_step(pflat, gflat, flat[1], flat[2], b1, b2, eps, wd, step_size, bc2_sqrt, self.grad_scale)
-            _lib.bump_param_generation(flat[0])
+            # every parameter pointer of the group, not only the flat buffer's first: a model's pack key reads the generations
+            # of ITS OWN parameters, and one group may span several models' (contiguously allocated) flat buffers
+            for p in params:
+                _lib.bump_param_generation(p.data_ptr())
         else:
             for p in active:
                 st = self.state[p]
@@ -225,7 +228,8 @@ class FusedSGD(torch.optim.Optimizer):
                     buf = have[1]
             ops.sgd_step(_as_flat(params[0].data, total), _as_flat(params[0].grad, total), buf, lr, wd, mom, damp, nest,
                          first, self.grad_scale)
-            _lib.bump_param_generation(pr[0])
+            for p in params:                  # every pointer of the group (see FusedAdam._step_group)
+                _lib.bump_param_generation(p.data_ptr())
             return
         for p in params:
             if p.grad is None:

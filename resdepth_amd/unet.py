@@ -565,8 +565,10 @@ class UNet(nn.Module):
         act0 = self._act_of(blk, self.act_fn_encoder)
         if self.fused_first_eval and not self._first_generic() and ops.conv3x3_first_fwd_act_available(x, blk[0].weight.shape[0]):
             # level 0 in ONE kernel: convolution + eval-mode BN + activation + max-pool; what leaves is the activation itself,
-            # which the decoder takes as a skip through the identity case (scale 1, shift 0, slope 1: bit-exact) of the
-            # descriptor it evaluates on load
+            # which the decoder takes as a skip through the identity case (scale 1, shift 0, slope 1) of the descriptor it
+            # evaluates on load: value-exact -- fma(a0, 1, 0) returns a0 for every a0 except that -0.0 becomes +0.0, which no
+            # consumer distinguishes (the skip is added to the up-convolution's output).  Only the folded eval path takes this
+            # kernel; eval forwards with fold_eval_bn = False or in exact-f32 mode write z0 and run the separate BN pass
             mean, invstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, eps=bn.eps)
             slope0, sdev0 = self._split_slope(act0)
             a0, cur = ops.conv3x3_first_fwd_act(x, blk[0].weight, mean, invstd, bn.weight, bn.bias, slope0, sdev0, pool=True)

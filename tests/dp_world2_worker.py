@@ -8,7 +8,8 @@ modes:
   train  -- cfg-S architecture, global batch B cut into contiguous shards (dp.shard_batch), dp.attach (+/- SyncBN),
             two-stream backward, FusedAdam, K steps; rank != 0 starts from DIFFERENT weights and adopts rank 0's through
             dp.broadcast_parameters.  Writes losses, step-0 gradients (after the all-reduce), final parameters + buffers.
-  infer  -- cfg-G: predict_linear_blend over this rank's tile shard, rasters summed on rank 0 (torch.distributed.reduce)
+  infer  -- cfg-G: predict_linear_blend over this rank's tile shard: row bands (shared rows exchanged point to point, every rank
+            delivers its rows into one shared host array) or --shard-mode stride (full rasters summed on rank 0, torch.distributed.reduce)
   trainer -- resdepth_amd.Trainer (lib/Trainer.py surface) under data parallelism: every rank its own loader shard and its own
             output directory, ReduceLROnPlateau driven by the (global) validation loss, four epochs; --ragged 1 / 2 gives
             rank 1 a shard with one more batch / a smaller last batch, which the constructor must refuse on EVERY rank
@@ -117,6 +118,9 @@ def main():
     ap.add_argument("--world", type=int, default=2)
     ap.add_argument("--port", type=int, required=True)
     ap.add_argument("--coll", default="staged", choices=["native", "staged"])
+    ap.add_argument("--shard-mode", default="bands", choices=["bands", "stride"])
+    ap.add_argument("--save-decisions", type=int, default=0,
+                    help="train: also save the HIP path's discrete decisions (activation masks, pool arg-max) on this rank's shard at step 0")
     ap.add_argument("--sync-bn", type=int, default=0)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tile", type=int, default=256)
@@ -166,8 +170,15 @@ def main():
             opt = FusedAdam(model.parameters(), lr=2e-4, weight_decay=1e-5)
             losses, grads0, bufs0 = [], None, None
             n_buckets = None
+            dec0 = None
             for step in range(a.steps):
                 local = dp.shard_batch(make_batch(a.batch, step, a.tile, ARCH[a.arch]["n_input_channels"]), a.rank, a.world)
+                if step == 0 and a.save_decisions:
+                    # one more training-mode engine forward (with the SyncBN exchanges, in lock-step on every rank); restores
+                    # the BN buffers afterwards
+                    from oracle import unet_oracle as O_
+                    from test_unet_gpu import _hip_decisions
+                    dec0 = _hip_decisions(model, local["input"].to(dev), O_.Spec(**ARCH[a.arch]))
                 y = model(local["input"].to(dev))
                 loss = masked_l1_loss(y, local["target"], local["loss_mask"], local["dsm_mean"], local["dsm_std"], grad_sync=gs)
                 loss.backward()
@@ -181,14 +192,14 @@ def main():
                     p.grad = None
                 losses.append(float(loss))
             torch.cuda.synchronize()
-            torch.save({"losses": losses, "y0": y0, "grads0": grads0, "bufs0": bufs0, "n_buckets": n_buckets,
+            torch.save({"losses": losses, "y0": y0, "grads0": grads0, "bufs0": bufs0, "n_buckets": n_buckets, "dec0": dec0,
                         "state": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}, a.out)
         elif a.mode == "infer":
             from torch.utils.data import DataLoader
             from resdepth_amd import SyntheticRasterTiles, predict_linear_blend
             model = make_infer_model(dev)
             ds = SyntheticRasterTiles(INFER_RASTER["rows"], INFER_RASTER["cols"], 3, tile_size=256, seed=5,
-                                      areas=INFER_RASTER["areas"], shard=(a.rank, a.world))
+                                      areas=INFER_RASTER["areas"], shard=(a.rank, a.world), shard_mode=a.shard_mode)
             out = predict_linear_blend(DataLoader(ds, batch_size=5, shuffle=False), model)      # reduce_to_rank0 default
             torch.save({"raster": torch.from_numpy(out.copy()), "n_tiles": len(ds)}, a.out)
         elif a.mode == "trainer":

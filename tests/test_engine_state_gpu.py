@@ -129,3 +129,67 @@ def test_second_backward_with_retained_activations_on_the_composed_tail_route():
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError):
         loss.backward()
+
+
+def test_broadcast_between_forward_and_backward_raises():
+    """dp.broadcast_parameters rewrites every parameter through `.data`; a graph whose forward ran before it must
+    not run its backward on the new weights (the persistent packed operands would be re-packed under it).  RCCL at world 1."""
+    import os
+    import torch.distributed as dist
+    from resdepth_amd import UNet, dp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl")
+    try:
+        torch.manual_seed(0)
+        A = UNet(n_input_channels=3, start_kernel=16, depth=3, bias_conv_layer=True).to(DEV).train()
+        b = _batch(4, 3, 64)
+        la = _loss(A, b)
+        dp.broadcast_parameters(A, 0)
+        with pytest.raises(RuntimeError, match="modified"):
+            la.backward()
+        for p in A.parameters():
+            p.grad = None
+        _loss(A, b).backward()                       # a fresh graph runs
+        assert all(p.grad is not None for p in A.parameters())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_flat_optimizer_step_over_two_models_invalidates_both():
+    """an optimizer whose single group holds the parameters of TWO models takes the flat path only when their flat
+    buffers are contiguous; whichever path it takes, BOTH models' packed operands must be rebuilt: after the step each model's
+    forward equals a fresh model's carrying the same weights."""
+    from resdepth_amd import UNet, FusedAdam
+    kw = dict(n_input_channels=3, start_kernel=16, depth=3, bias_conv_layer=True)
+    torch.manual_seed(0)
+    A = UNet(**kw).to(DEV).train()
+    torch.manual_seed(1)
+    B = UNet(**kw).to(DEV).train()
+    opt = FusedAdam(list(A.parameters()) + list(B.parameters()), lr=1e-2)
+    b = _batch(4, 3, 64)
+    (_loss(A, b) + _loss(B, b)).backward()
+    keyA, keyB = A._own_param_key(), B._own_param_key()
+    opt.step()
+    assert A._own_param_key() != keyA and B._own_param_key() != keyB
+    for M in (A, B):
+        torch.manual_seed(5)
+        F = UNet(**kw).to(DEV)
+        F.load_state_dict(M.state_dict())
+        M.eval(); F.eval()
+        with torch.no_grad():
+            x = b["input"].to(DEV)
+            assert torch.equal(M(x), F(x))
+
+
+def test_a_ninth_stream_takes_over_the_least_recently_used_splitk_registration():
+    """the split-K scratch registrations are capped per device; the cap now evicts instead of refusing."""
+    from resdepth_amd import _lib
+    _lib.load()
+    streams = [torch.cuda.Stream() for _ in range(_lib.SPLITK_MAX_STREAMS + 3)]
+    for s in streams:
+        with torch.cuda.stream(s):
+            _lib.ensure_splitk_workspace(torch.device(DEV))
+    keys = [k for k in _lib._splitk if k[0] == 0]
+    assert len(keys) <= _lib.SPLITK_MAX_STREAMS
+    assert (0, streams[-1].cuda_stream) in _lib._splitk           # the newest stream holds a registration
+    torch.cuda.synchronize()

@@ -72,3 +72,42 @@ def test_trainer_train_checkpoint_resume_and_metric_parity(tmp_path):
     assert float(p0["step"]) == 4.0                                   # 2 epochs x 2 iterations
     tr2.train()
     assert os.path.isfile(os.path.join(str(tmp_path / "resume"), "checkpoints", "Model_last.pth"))
+
+
+def test_h2d_prefetch_on_a_copy_stream_changes_no_bit(tmp_path):
+    """DevicePrefetcher (batch k + 1 staged on a copy stream while batch k computes) against the copies on the compute stream in
+    front of the forward (prefetch_batches=0, the reference's order, lib/Trainer.py:165-168): same weights, same logged losses,
+    bit for bit -- with pageable and with pinned host batches, and with a ragged number of batches."""
+    import types
+    from resdepth_amd import UNet, FusedAdam, Trainer, SyntheticDsmOrthoDataset, DevicePrefetcher
+    kw = dict(n_input_channels=3, start_kernel=8, depth=3, bias_conv_layer=True)
+    out = {}
+    for pin in (False, True):
+        for pf in (0, 1, 2):
+            ds = SyntheticDsmOrthoDataset(20, 3, 64, seed=3)
+            train = DataLoader(ds, batch_size=4, shuffle=False, pin_memory=pin)
+            torch.manual_seed(0)
+            model = UNet(**kw)
+            opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+            a = _args(tmp_path / f"p{int(pin)}{pf}", model, opt, None, train, None, n_epochs=1)
+            a.prefetch_batches = pf
+            tr = Trainer(a)
+            m0 = tr.inference_one_epoch(0, "train")
+            m1 = tr.inference_one_epoch(1, "train")
+            torch.cuda.synchronize()
+            out[(pin, pf)] = (m0["MAE_metric"].avg, m1["MAE_metric"].avg, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    ref = out[(False, 0)]
+    for key, (a0, a1, sd) in out.items():
+        assert a0 == ref[0] and a1 == ref[1], key
+        for k, v in sd.items():
+            assert torch.equal(v, ref[2][k]), (key, k)
+    # the iterator itself: device tensors for the five staged fields, everything else handed on, order kept
+    ds = SyntheticDsmOrthoDataset(6, 3, 64, seed=4)
+    plain = list(DataLoader(ds, batch_size=4, shuffle=False))
+    staged = list(DevicePrefetcher(DataLoader(ds, batch_size=4, shuffle=False), "cuda:0", depth=1))
+    assert len(staged) == len(plain) == 2
+    for b, s_ in zip(plain, staged):
+        for k in ("input", "target", "loss_mask"):
+            assert s_[k].is_cuda and torch.equal(s_[k].cpu(), b[k])
+        assert s_["dsm_mean"].is_cuda and s_["dsm_mean"].dtype == torch.float32
+        assert not s_["patch_offset_x"].is_cuda

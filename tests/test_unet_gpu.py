@@ -590,8 +590,10 @@ def test_bench_gpus_2_runs_end_to_end_without_a_launcher_on_one_gpu():
     """`python3 bench.py --gpus N` exactly as the driver types it (no torch.distributed.run), N = 2, executed for real: the
     launcher starts two ranks, they rendezvous, broadcast parameters, train with the bucketed all-reduce and the global loss
     normaliser, take the max-over-ranks time and rank 0 prints ONE line.  RCCL refuses two ranks on one device, so the ranks
-    share cuda:0 over gloo with host-staged device collectives (`--backend gloo --share-gpu`, a code-path check that the
-    line itself labels as such) -- everything else is the code an 8-GPU node runs.  Also the cfg-G sweep (`--infer`)."""
+    share cuda:0 over gloo on device tensors (`--backend gloo --share-gpu`, a code-path check that the line itself labels as
+    such; bench.py imports nothing from tests/) -- everything else is the code an 8-GPU node runs, including the diagnostics
+    block of the first multi-GPU run (exposed all-reduce wait, bucket plan, loss-normaliser latency, rank skew, host enqueue
+    time, CPU affinity).  Also the cfg-G sweep (`--infer`), sharded by row bands."""
     import json
     import os
     import subprocess
@@ -613,6 +615,21 @@ def test_bench_gpus_2_runs_end_to_end_without_a_launcher_on_one_gpu():
     first, last = o["loss_first_last"]
     assert first == first and last == last and last < first          # finite, and the shared weights are learning
     assert "secondary" not in o and "cpu_baseline" not in o           # rank-0 extras are world-size-1 only
+    d = o["dist"]
+    lo, hi, skew = d["rank_step_ms_min_max_skew"]
+    assert 0 < lo <= hi and abs(skew - (hi - lo)) < 1e-2 and d["slowest_rank"] in (0, 1)
+    for key in ("host_enqueue_ms_per_rank", "exposed_grad_allreduce_ms_per_rank", "loss_normaliser_allreduce_ms_per_rank",
+                "step_ms_median_hip_events_per_rank", "affinity_per_rank"):
+        assert len(d[key]) == 2, key
+    assert all(v is not None and 0 < v < 1e4 for v in d["host_enqueue_ms_per_rank"])
+    assert all(v is not None and 0 <= v < 1e4 for v in d["exposed_grad_allreduce_ms_per_rank"])
+    assert all(v is not None and 0 < v < 1e4 for v in d["loss_normaliser_allreduce_ms_per_rank"])
+    plan = d["gradient_buckets"]
+    assert plan["world"] == 2 and plan["n_buckets"] == len(plan["bucket_mbytes"]) >= 2
+    assert abs(sum(plan["bucket_mbytes"]) - 12625345 * 4 / 2 ** 20) < 0.1            # the whole flat gradient buffer, once
+    assert len(d["bucket_issue_ms_after_step_start_rank0"]) == plan["n_buckets"]
+    assert all(isinstance(a, dict) and "pinned" in a for a in d["affinity_per_rank"])
+    assert o["host_enqueue_ms"] > 0
     r = subprocess.run(common + ["--infer", "--raster", "1024", "--batch", "8", "--steps", "1", "--warmup", "1"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -657,12 +674,13 @@ def _hip_decisions(model, x_dev, spec):
     return dec
 
 
-def _oracle_fp64_under_hip_decisions(model, sd0, spec, x, y, mask, mean, std, yp, want_dx=False):
+def _oracle_fp64_under_hip_decisions(model, sd0, spec, x, y, mask, mean, std, yp, want_dx=False, dec=None):
     """fp64 oracle forward / loss / gradients with the HIP path's discrete decisions imposed (masks, arg-max, and the
     sign(p - t) of the L1 loss evaluated with the kernel's own fp32 de-normalisation, lib/data_normalization.py:29-38),
     after checking that those decisions differ from the oracle's OWN in at most a vanishing fraction of the places.
     -> (y_oracle, loss_oracle, [parameter gradients in O.param_keys order (+ d loss / d x)], work state dict)"""
-    dec = _hip_decisions(model, x.to(DEV), spec)
+    if dec is None:        # (callers that ran the HIP path elsewhere -- the world-2 workers -- hand its decisions in)
+        dec = _hip_decisions(model, x.to(DEV), spec)
     keep = {}
     with torch.no_grad():
         O.forward({k: v.clone() for k, v in sd0.items()}, x, spec, training=True, update_running=False, keep=keep)
