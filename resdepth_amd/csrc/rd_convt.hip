@@ -43,6 +43,15 @@ struct CtParams {
 
 __device__ __forceinline__ float ct_act(float y, float slope) { return y > 0.f ? y : y * slope; }
 
+// Staging task -> tile row.  A ds_write_b64 is serviced in groups of 16 CONTIGUOUS lanes with 32 dword banks; with the natural
+// assignment (task idx -> row idx) a group writes rows r .. r+3, whose 8-bank windows at the 28-word row pitch start at banks
+// 0, 28, 24, 20: neighbouring windows overlap by half (2-way conflict on every staging write: SQ_LDS_BANK_CONFLICT = 25 % of the
+// LDS cycles of convt_fwd / convt_dgrad in profiles/r04_summary.json, 9-15 % in the halo kernel, whose fragment READS were
+// conflict-free already).  Rows r, r+2, r+4, r+6 start at banks 0, 24, 16, 8: disjoint.  So the 32 tasks of an aligned block of
+// eight rows are dealt out as (low bits w2 w1 w0 of idx) -> row (w1 w0 w2): lane group {p = w2} takes rows p, p+2, p+4, p+6.
+// Which pixel a 4-lane cluster loads does not matter to the global loads (64 contiguous bytes per cluster either way).
+__device__ __forceinline__ int stage_row(int idx) { return (idx & ~7) | ((idx & 3) << 1) | ((idx >> 2) & 1); }
+
 template <int TM>
 __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
     constexpr int BM = 32 * TM, RS = 28;                  // LDS row = 3 terms x 16 bf16 + 16 B pad (conflict-free b128 reads)
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
     const int c4 = t & 3;
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-        const int row = (t + 256 * k) >> 2;
+        const int row = stage_row((t + 256 * k) >> 2);
         const int g = g0 + (row >> logPW), xx = x0 + (row & pwm);
         const bool ok = row < BM && g < p.G;
         s_off[k] = ok ? (unsigned)((((long)g * W + xx) * p.Cin + c4 * 4) * 4) : kOOB;
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
     const int c4 = t & 3;
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-        const int row = (t + 256 * k) >> 2;
+        const int row = stage_row((t + 256 * k) >> 2);
         const int m = m0 + row;
         const int g = (int)fd_div((unsigned)m, p.pd.w), x = m - g * W;       // stacked image rows: g = n*H + y
         const bool ok = row < BM && m < p.M;

@@ -407,7 +407,12 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     const int c4 = t & 3;
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-        const int e = t + 256 * k, hr = e >> 2;
+        // halo pixel of this task: aligned blocks of eight pixels are dealt out so that a 16-lane group of a ds_write_b64 gets
+        // pixels p, p+2, p+4, p+6 (bank windows 0 / 24 / 16 / 8 at the 28-word pitch: disjoint) instead of p .. p+3 (windows
+        // overlapping by half: a 2-way conflict on every staging write, the whole of this kernel's SQ_LDS_BANK_CONFLICT in r04);
+        // blocks that straddle two halo rows (7 of 23) keep one overlapping pair, the ragged last block its natural order
+        const int e = t + 256 * k, hr0 = e >> 2;
+        const int hr = (hr0 | 7) < HROWS ? ((hr0 & ~7) | ((hr0 & 3) << 1) | ((hr0 >> 2) & 1)) : hr0;
         const int hy = hr / HW_, hx = hr - hy * HW_;
         const int sub = W8 ? hx / 10 : 0;                     // W8: which of the patch's two images
         const int y = y0 - 1 + hy, x = W8 ? hx - sub * 10 - 1 : x0 - 1 + hx;

@@ -257,8 +257,10 @@ def broadcast_parameters(model, src: int = 0, process_group=None) -> None:
     from . import _lib
     flat = getattr(model, "_flat_param", None)
     params = list(model.parameters())
-    if flat is not None and params and params[0].data_ptr() == flat.data_ptr():
-        dist.broadcast(flat, src=src, group=process_group)
+    lo, hi = (flat.data_ptr(), flat.data_ptr() + flat.numel() * 4) if flat is not None else (0, 0)
+    if flat is not None and params and all(lo <= t.data_ptr() < hi for t in params) \
+            and sum(t.numel() for t in params) == flat.numel():
+        dist.broadcast(flat, src=src, group=process_group)       # every parameter is a view of the flat buffer (any layout)
     else:
         for t in params:
             dist.broadcast(t.data, src=src, group=process_group)

@@ -39,14 +39,23 @@ class FusedAdam(torch.optim.Optimizer):
 
     @staticmethod
     def _flat_range(tensors):
-        """(base_ptr, numel) if the tensors tile one contiguous fp32 range in order, else None."""
-        base = tensors[0].data_ptr()
+        """(base_ptr, numel, index of the tensor at the base) if the tensors tile one contiguous fp32 range -- in ANY order:
+        resdepth_amd.UNet lays its flat buffers out by gradient COMPLETION order, not by parameters() order
+        (UNet._flat_layout) -- else None."""
+        order = sorted(range(len(tensors)), key=lambda i: tensors[i].data_ptr())
+        base = tensors[order[0]].data_ptr()
         off = 0
-        for t in tensors:
+        for i in order:
+            t = tensors[i]
             if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() != base + 4 * off:
                 return None
             off += t.numel()
-        return base, off
+        return base, off, order[0]
+
+    @staticmethod
+    def _same_layout(params, pr, gr):
+        """Do the gradients sit at the same offsets of their flat range as the parameters of theirs?"""
+        return all(p.grad.data_ptr() - gr[0] == p.data_ptr() - pr[0] for p in params)
 
     def _ensure_state(self, group, gi):
         params = [p for p in group["params"]]
@@ -58,17 +67,15 @@ class FusedAdam(torch.optim.Optimizer):
             if have is None or have[0] != fr[0] or have[1].numel() != total:
                 m = torch.zeros(total, device=dev, dtype=torch.float32)
                 v = torch.zeros(total, device=dev, dtype=torch.float32)
-                off = 0
                 for p in params:
                     st = self.state[p]
-                    n = p.numel()
+                    n, off = p.numel(), (p.data_ptr() - fr[0]) // 4      # the moments mirror the parameters' layout
                     if "exp_avg" in st:          # e.g. after load_state_dict
                         m[off:off + n].copy_(st["exp_avg"].reshape(-1))
                         v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
                     st["exp_avg"] = m[off:off + n].view(p.shape)
                     st["exp_avg_sq"] = v[off:off + n].view(p.shape)
                     st.setdefault("step", torch.tensor(0.0))
-                    off += n
                 self._flat_state[gi] = (fr[0], m, v)
             return self._flat_state[gi]
         for p in params:
@@ -122,10 +129,11 @@ class FusedAdam(torch.optim.Optimizer):
         bc2 = 1.0 - b2 ** t
         step_size = lr / bc1
         bc2_sqrt = math.sqrt(bc2)
-        if flat is not None and gr is not None and gr[1] == flat[1].numel():
+        pr = self._flat_range([p.data for p in params]) if flat is not None and gr is not None else None
+        if pr is not None and gr[1] == flat[1].numel() and pr[0] == flat[0] and self._same_layout(params, pr, gr):
             total = gr[1]
-            pflat = _as_flat(params[0].data, total)
-            gflat = _as_flat(params[0].grad, total)
+            pflat = _as_flat(params[pr[2]].data, total)
+            gflat = _as_flat(params[gr[2]].grad, total)
             ops.adam_step(pflat, gflat, flat[1], flat[2], b1, b2, eps, wd, step_size, bc2_sqrt, self.grad_scale)
             # every parameter pointer of the group, not only the flat buffer's first: a model's pack key reads the generations
             # of ITS OWN parameters, and one group may span several models' (contiguously allocated) flat buffers
@@ -205,7 +213,7 @@ class FusedSGD(torch.optim.Optimizer):
         # cannot express -- this step goes per tensor (below), after which every parameter has a buffer
         n_buf = sum(1 for p in params if self.state[p].get("momentum_buffer") is not None) if mom != 0 else 0
         mixed = 0 < n_buf < len(params)
-        if pr is not None and gr is not None and gr[1] == pr[1] and not mixed:
+        if pr is not None and gr is not None and gr[1] == pr[1] and not mixed and FusedAdam._same_layout(params, pr, gr):
             total = pr[1]
             have = self._flat_state.get(gi)
             buf, first = None, False
@@ -216,17 +224,15 @@ class FusedSGD(torch.optim.Optimizer):
                     # a loaded / per-tensor state is copied into the flat buffer
                     first = not any("momentum_buffer" in self.state[p] and self.state[p]["momentum_buffer"] is not None
                                     for p in params)
-                    off = 0
                     for p in params:
-                        st, n = self.state[p], p.numel()
+                        st, n, off = self.state[p], p.numel(), (p.data_ptr() - pr[0]) // 4
                         if st.get("momentum_buffer") is not None:
                             buf[off:off + n].copy_(st["momentum_buffer"].reshape(-1))
                         st["momentum_buffer"] = buf[off:off + n].view(p.shape)
-                        off += n
                     self._flat_state[gi] = (pr[0], buf)
                 else:
                     buf = have[1]
-            ops.sgd_step(_as_flat(params[0].data, total), _as_flat(params[0].grad, total), buf, lr, wd, mom, damp, nest,
+            ops.sgd_step(_as_flat(params[pr[2]].data, total), _as_flat(params[gr[2]].grad, total), buf, lr, wd, mom, damp, nest,
                          first, self.grad_scale)
             for p in params:                  # every pointer of the group (see FusedAdam._step_group)
                 _lib.bump_param_generation(p.data_ptr())

@@ -237,21 +237,60 @@ class UNet(nn.Module):
     def _param_list(self) -> List[nn.Parameter]:
         return list(self.parameters())
 
+    def _flat_layout(self, params):
+        """Order of the parameters inside the flat buffers: parameters() order, except that the bias of every up-convolution
+        (ConvTranspose2d / the bilinear branch's conv1x1) of decoder level j sits right behind the parameters of ENCODER level
+        d - 1 - j.  Why: the backward fills the flat gradient buffer from its END towards its start and the data-parallel
+        buckets (resdepth_amd.dp) are contiguous ranges launched as soon as all their gradients exist -- and an up-convolution's
+        bias gradient is a by-product of the BatchNorm backward of the encoder level whose skip it was added to (the per-channel
+        sum of the skip gradient), i.e. it completes LATE, with that encoder level.  In parameters() order those 5 small tensors
+        sat inside the first (20 MB) bucket and held it back until the end of the backward (r05 diagnostics, world 1:
+        bucket 0 issued 10.0 ms into a 10.2 ms step); in completion order every bucket goes out when its last weight gradient
+        is done.  Optimizers and checkpoints do not see the layout (state_dict / parameters() order is unchanged; the flat
+        Adam / SGD kernels are element-wise)."""
+        d = self.depth
+        late = {}
+        for j in range(d):
+            b = getattr(self._up_of(j), "bias", None)
+            if b is not None:
+                late[id(b)] = d - 1 - j
+        enc_last = {}                     # encoder level -> index (in `params`) of its last own parameter
+        pid = {id(p): i for i, p in enumerate(params)}
+        for i in range(d):
+            own = [pid[id(p)] for p in self.encoder[i].parameters() if id(p) in pid]
+            if own:
+                enc_last[i] = max(own)
+        order = []
+        moved = {lvl: [pid[k] for k in late if late[k] == lvl and k in pid] for lvl in range(d)}
+        skip = {i for v in moved.values() for i in v}
+        for i in range(len(params)):
+            if i in skip:
+                continue
+            order.append(i)
+            for lvl, last in enc_last.items():
+                if last == i:
+                    order.extend(sorted(moved.get(lvl, [])))
+        if sorted(order) != list(range(len(params))):      # an encoder level without parameters: keep the plain order
+            order = list(range(len(params)))
+        return order
+
     def flatten_parameters(self):
         """Re-home every parameter into one flat fp32 buffer (same values, same Parameter objects) so the
-        gradient all-reduce and the fused Adam step run over one contiguous range."""
+        gradient all-reduce and the fused Adam step run over one contiguous range.  `_offsets[i]` = element offset of
+        parameter i (parameters() order) inside the flat buffers; the layout itself follows `_flat_layout`."""
         params = self._param_list()
         dev = params[0].device
         total = sum(p.numel() for p in params)
         flat = torch.empty(total, device=dev, dtype=torch.float32)
-        offs = []
+        offs = [0] * len(params)
         o = 0
         with torch.no_grad():
-            for p in params:
+            for i in self._flat_layout(params):
+                p = params[i]
                 n = p.numel()
                 flat[o:o + n].copy_(p.data.reshape(-1))
                 p.data = flat[o:o + n].view(p.shape)
-                offs.append(o)
+                offs[i] = o
                 o += n
         self._flat_param = flat
         self._flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)

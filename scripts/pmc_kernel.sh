@@ -14,6 +14,7 @@ CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
 have() { grep -qw "$1" "$AVAIL"; }
 run() {
   d=$1; shift; L=""
+  case " ${PMC_GROUPS:-g1 g2 g3 g4 g5 g6 g7 g8 g9} " in *" $d "*) ;; *) return ;; esac      # PMC_GROUPS="g3 g4": only those passes
   for c in "$@"; do if have "$c"; then L="$L $c"; else echo "counter $c: not offered by this box" >> "$OUT/dropped.txt"; fi; done
   [ -z "$L" ] && return
   rocprofv3 --kernel-trace --kernel-include-regex "$REGEX" --pmc $L -d "$OUT/$d" -o p --output-format csv -- $CMD > /dev/null 2> "$OUT/$d.err"
@@ -27,37 +28,5 @@ run g6 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDRE
 run g7 TA_BUSY_sum TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum
 run g8 FETCH_SIZE
 run g9 WRITE_SIZE
-python - "$OUT" <<'PY'
-import csv, sys, glob, collections, json
-out = sys.argv[1]
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-durs = collections.defaultdict(list)
-for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
-    per = collections.defaultdict(dict)
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void rd::", "")[:90]
-        per[(r["Dispatch_Id"], k)][r["Counter_Name"]] = per[(r["Dispatch_Id"], k)].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-        per[(r["Dispatch_Id"], k)]["_dur"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    for (_, k), d in per.items():
-        for c, v in d.items():
-            agg[k][c].append(v)
-res = {}
-for k, d in agg.items():
-    m = {c: sum(v) / len(v) for c, v in d.items()}
-    res[k] = m
-    dur = m.pop("_dur")
-    print("==", k, "avg_us %.1f" % (dur / 1e3), "launches/pass", len(d["_dur"]) // max(1, len([c for c in d if c != "_dur"])) or len(d["_dur"]))
-    gui = m.get("GRBM_GUI_ACTIVE")
-    if gui:
-        cyc = gui / 8
-        print("   clock_GHz %.3f  cycles %.0f" % (cyc / dur, cyc))
-        wc = m.get("SQ_WAVE_CYCLES", 0)
-        if wc:
-            print("   waves/SIMD %.2f  wait_inst_any/wave %.3f  wait_any/wave %.3f  active_inst_any/wave %.3f" % (
-                wc * 4 / 1024 / cyc, m.get("SQ_WAIT_INST_ANY", 0) / wc, m.get("SQ_WAIT_ANY", 0) / wc, m.get("SQ_ACTIVE_INST_ANY", 0) / wc))
-    for c in sorted(m):
-        print("   %-44s %16.1f" % (c, m[c]))
-    m["_dur_ns"] = dur
-json.dump(res, open(out + "/summary.json", "w"), indent=1)
-PY
+python "$REPO/scripts/pmc_kernel_summary.py" "$OUT"
 rm -rf "$OUT"/g*/   # raw CSVs are large; the summary and the .err files stay

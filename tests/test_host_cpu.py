@@ -142,3 +142,108 @@ def test_bench_under_a_launcher_of_the_wrong_size_is_refused():
     r = _run_bench(["--gpus", "4", "--rendezvous-only", "--backend", "gloo"],
                    env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29655"})
     assert r.returncode == 2 and "--nproc-per-node 4" in r.stderr
+
+
+def test_band_shards_partition_the_sweep_by_tile_rows():
+    """tiling.band_shards (cfg-G's multi-GPU sharding): contiguous chunks cut at tile-row boundaries, balanced by tile
+    count; the ownership cuts partition [0, rows); a rank's extent leaks into other ranks' rows only by the tile overlap."""
+    from resdepth_amd.tiling import band_shards, regular_grid
+    pos, _ = regular_grid([(0, 8191)], [(0, 8191)], 256, 128)
+    assert len(pos) == 3969
+    for world in (1, 2, 3, 4, 8, 16):
+        plan = band_shards(pos, 256, 8192, world)
+        assert len(plan) == world and plan[0]["monotonic"]
+        assert plan[0]["i0"] == 0 and plan[-1]["i1"] == len(pos)
+        assert all(plan[r]["i1"] == plan[r + 1]["i0"] for r in range(world - 1))
+        assert plan[0]["c0"] == 0 and plan[-1]["c1"] == 8192 and all(plan[r]["c1"] == plan[r + 1]["c0"] for r in range(world - 1))
+        counts = [p["i1"] - p["i0"] for p in plan]
+        assert max(counts) - min(counts) <= 63 and min(counts) > 0            # within one tile row (63 tiles) of each other
+        for p in plan:
+            assert all(pos[i][0] != pos[i - 1][0] for i in (p["i0"],) if i > 0)        # cut at a tile-row start
+            ys = [pos[i][0] for i in range(p["i0"], p["i1"])]
+            assert p["y0"] == min(ys) and p["y1"] == max(ys) + 256 and p["lo"] <= p["y0"] and p["hi"] >= p["y1"]
+            assert p["c0"] == (0 if p is plan[0] else p["y0"])
+        for r in range(world - 1):                                              # a band reaches T - stride rows into the next one's
+            assert 0 <= plan[r]["y1"] - plan[r + 1]["c0"] <= 256 - 128 + 127    # (+ the inward shift of the last tile row)
+    # at 8 ranks a private raster is 1152 rows (75 MB) instead of 8192 (537 MB)
+    plan = band_shards(pos, 256, 8192, 8)
+    assert max(p["hi"] - p["lo"] for p in plan) == 1152
+    # more ranks than tile rows: the surplus ranks get nothing and own nothing
+    one, _ = regular_grid([(0, 255)], [(0, 255)], 256, 128)
+    plan = band_shards(one, 256, 256, 4)
+    assert [p["i1"] - p["i0"] for p in plan] == [1, 0, 0, 0] and [p["c1"] - p["c0"] for p in plan] == [256, 0, 0, 0]
+    # areas that go back up the raster: the cuts stop being monotonic for some world sizes -- flagged, never mis-assigned
+    pos2, _ = regular_grid([(0, 559), (300, 899)], [(0, 383), (200, 639)], 64, 32)
+    flags = {w: band_shards(pos2, 64, 640, w)[0]["monotonic"] for w in (2, 3, 4, 7)}
+    assert flags[2] and flags[3] and flags[4] and not flags[7]
+
+
+def test_sweep_frontiers_and_cpu_list_parsing():
+    import importlib.util
+    from resdepth_amd.inference import _frontiers
+    assert _frontiers([0, 0, 128, 128], 256, 512) == [0, 0, 128, 128, 512]
+    assert _frontiers([0, 128, 0, 128], 256, 512) == [0, 0, 0, 128, 512]          # a second area that starts over at the top
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and bench._parse_cpulist("") == []
+    groups = bench._core_groups(sorted(os.sched_getaffinity(0)))
+    assert sorted(c for g in groups for c in g) == sorted(os.sched_getaffinity(0))
+    info = bench.pin_rank_to_gpu_numa(0, 1, 0)            # no GPU here: must report, not raise, and leave the mask alone
+    assert info["pinned"] is False and sorted(os.sched_getaffinity(0)) == sorted(c for g in groups for c in g)
+
+
+@pytest.mark.parametrize("kw", [dict(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True),
+                                dict(n_input_channels=2, start_kernel=8, depth=3, up_mode="bilinear", outer_skip_BN=True),
+                                dict(n_input_channels=1, start_kernel=8, depth=2, do_BN=False, act_fn_encoder="prelu")])
+def test_flat_buffer_layout_follows_gradient_completion_order(kw):
+    """UNet._flat_layout: the backward completes gradients head -> decoder -> bottleneck -> encoder d-1 .. 0, an up-convolution's
+    bias with the ENCODER level whose skip it was added to; the flat buffers are laid out so that this order runs from the END of
+    the buffer to its start -- then every data-parallel bucket (a contiguous range planned from the end, dp.plan_buckets) is
+    complete, and its all-reduce launched, as soon as its last weight gradient is written, instead of the first 20 MB bucket
+    waiting for five bias vectors until the end of the backward."""
+    from resdepth_amd import UNet
+    from resdepth_amd.dp import GradSync
+    torch.manual_seed(0)
+    m = UNet(**kw)
+    params = list(m.parameters())
+    names = [n for n, _ in m.named_parameters()]
+    order = m._flat_layout(params)
+    assert sorted(order) == list(range(len(params)))
+    d = m.depth
+    up_bias = {id(m._up_of(j).bias): d - 1 - j for j in range(d) if getattr(m._up_of(j), "bias", None) is not None}
+
+    def stage(i):
+        """larger = completes later in UNet._engine_backward"""
+        n, p = names[i], params[i]
+        if id(p) in up_bias:
+            return 100 + (d - 1 - up_bias[id(p)])               # with encoder level up_bias[...]: level d-1 first, level 0 last
+        if n.startswith("layer_outer_skip") or n.startswith("last_layer"):
+            return 0
+        if n.startswith("decoder."):
+            return 1 + (d - 1 - int(n.split(".")[1]))           # decoder.(d-1) first
+        if n.startswith("bottleneck"):
+            return 50
+        return 100 + (d - 1 - int(n.split(".")[1]))             # encoder.i
+    pos = {i: k for k, i in enumerate(order)}                    # position inside the flat buffer
+    for a in range(len(params)):
+        for b in range(len(params)):
+            if stage(a) < stage(b):
+                assert pos[a] > pos[b], (names[a], names[b])     # earlier completion = nearer the end
+    # the bucket plan over that layout: replay the completion order and check that buckets complete in plan order
+    sizes = [p.numel() for p in params]
+    offs, o = [0] * len(params), 0
+    for i in order:
+        offs[i] = o
+        o += sizes[i]
+    buckets = GradSync.plan_buckets(offs, sizes, max(1, o // 4))
+    done, launched = set(), []
+    for i in sorted(range(len(params)), key=lambda i: (stage(i), -pos[i])):
+        done.add(i)
+        for bi, b in enumerate(buckets):
+            if bi not in launched and b["params"] <= done:
+                launched.append(bi)
+        # no bucket may be held back by a parameter of a LATER stage than its own latest weight
+    assert launched == list(range(len(buckets)))
+    last_stage = [max(stage(i) for i in b["params"]) for b in buckets]
+    assert last_stage == sorted(last_stage)
