@@ -105,13 +105,14 @@ _NO_BRACKET = _NoBracket()
 
 
 class GradSync:
-    def __init__(self, process_group=None, bucket_bytes: int = 16 << 20):
+    def __init__(self, process_group=None, bucket_bytes: int = 16 << 20, tail_bytes: int = 2 << 20):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("GradSync needs an initialised torch.distributed process group")
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.bucket_bytes = int(bucket_bytes)
+        self.tail_bytes = int(tail_bytes)      # size cap of the final (exposed) bucket; 0 = the leftover as it comes
         self._buckets = None      # list of dicts: lo, hi (element offsets), params (set of indices)
         self._ready = set()
         self._launched = []
@@ -165,9 +166,14 @@ class GradSync:
 
     # ---- gradient buckets ------------------------------------------------------------------------
     @staticmethod
-    def plan_buckets(offsets: List[int], sizes: List[int], bucket_elems: int):
+    def plan_buckets(offsets: List[int], sizes: List[int], bucket_elems: int, tail_elems: int = 0):
         """Contiguous flat ranges covering every parameter, built from the END of the buffer (the
-        order the backward produces gradients in).  Pure function (unit-tested on CPU)."""
+        order the backward produces gradients in).  Pure function (unit-tested on CPU).
+
+        tail_elems > 0: the LAST bucket -- the one whose all-reduce nothing can hide, it is issued when the backward is
+        over -- is cut once more so that its final piece holds at most `tail_elems` elements (whole tensors; at least one):
+        for cfg-S the leftover [enc3 .. enc0] = 5.9 MB becomes [enc3] 4.4 MB, issued ~1 ms before the end, + [enc2, enc1,
+        enc0] 1.5 MB exposed."""
         order = sorted(range(len(offsets)), key=lambda i: offsets[i], reverse=True)
         buckets = []
         cur = None
@@ -184,13 +190,28 @@ class GradSync:
                 cur = None
         if cur is not None:
             buckets.append(cur)
+        if tail_elems > 0 and buckets and buckets[-1]["hi"] - buckets[-1]["lo"] > tail_elems and len(buckets[-1]["params"]) > 1:
+            last = buckets.pop()
+            members = sorted(last["params"], key=lambda i: offsets[i])          # from the START of the buffer = completed last
+            tail, n = set(), 0
+            for i in members:
+                if tail and n + sizes[i] > tail_elems:
+                    break
+                tail.add(i)
+                n += sizes[i]
+            if len(tail) < len(members):
+                cut = last["lo"] + n
+                buckets.append({"lo": cut, "hi": last["hi"], "params": last["params"] - tail})
+                buckets.append({"lo": last["lo"], "hi": cut, "params": tail})
+            else:
+                buckets.append(last)
         return buckets
 
     def _ensure_plan(self, model):
         key = (id(model), model._flat_grad.data_ptr(), model._flat_grad.numel())
         if self._model_key != key:
             sizes = [p.numel() for p in model.parameters()]
-            self._buckets = self.plan_buckets(list(model._offsets), sizes, max(1, self.bucket_bytes // 4))
+            self._buckets = self.plan_buckets(list(model._offsets), sizes, max(1, self.bucket_bytes // 4), self.tail_bytes // 4)
             self._model_key = key
             self._ready = set()
             self._launched = [False] * len(self._buckets)
@@ -241,10 +262,10 @@ class GradSync:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
 
 
-def attach(model, process_group=None, sync_bn: bool = False, bucket_bytes: int = 16 << 20) -> GradSync:
+def attach(model, process_group=None, sync_bn: bool = False, bucket_bytes: int = 16 << 20, tail_bytes: int = 2 << 20) -> GradSync:
     """Make `model` (a resdepth_amd.UNet) data parallel: its backward all-reduces gradients, its loss must be
     built with `grad_sync=` the returned object (global normaliser)."""
-    gs = GradSync(process_group, bucket_bytes)
+    gs = GradSync(process_group, bucket_bytes, tail_bytes)
     model.grad_sync = gs
     model.sync_bn = bool(sync_bn)
     return gs

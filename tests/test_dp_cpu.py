@@ -48,6 +48,16 @@ def test_plan_buckets_tiles_the_buffer_from_the_end():
         assert x["lo"] == y["hi"]
     assert set().union(*[x["params"] for x in b]) == set(range(6))
     assert all(x["hi"] - x["lo"] >= 32 for x in b[:-1])
+    # tail cap: the last bucket [0, 13) = tensors 0 (10) and 1 (3) is cut so that its final piece -- the one whose all-reduce
+    # nothing overlaps -- holds at most 10 elements: [tensor 1] goes out earlier, [tensor 0] stays the tail
+    c = dp.GradSync.plan_buckets(offs, sizes, 32, tail_elems=10)
+    assert [(x["lo"], x["hi"]) for x in c[:-2]] == [(x["lo"], x["hi"]) for x in b[:-1]]
+    assert (c[-2]["lo"], c[-2]["hi"], c[-2]["params"]) == (10, 13, {1}) and (c[-1]["lo"], c[-1]["hi"], c[-1]["params"]) == (0, 10, {0})
+    for x, y in zip(c[:-1], c[1:]):
+        assert x["lo"] == y["hi"]
+    # a tail that already fits, or that is one tensor, is left alone; a cap smaller than the last tensor keeps that tensor whole
+    assert dp.GradSync.plan_buckets(offs, sizes, 32, tail_elems=13) == b
+    assert dp.GradSync.plan_buckets(offs, sizes, 32, tail_elems=4)[-1]["params"] == {0}
 
 
 def test_shard_batch():
