@@ -110,43 +110,54 @@ def _core_groups(cpus):
     return groups
 
 
+def plan_rank_affinity(n_local, device_of_rank, allowed):
+    """CPU slice of EVERY local rank (pure function of the sysfs topology, so every rank computes the same plan):
+    rank -> [cpu, ...], the CPUs of its GPU's NUMA node that this process may use, with the physical cores of a node split
+    evenly between the ranks whose GPUs hang off it (both hardware threads of a core stay together).  -> (plan, reason): plan is
+    None -- nobody pins -- unless EVERY rank gets at least two physical cores: a mix of pinned and floating ranks would put
+    the floating ones on the pinned ones' cores."""
+    allowed_set = set(allowed)
+    local = {}
+    for r in range(n_local):
+        node, cpus = _gpu_local_cpus(device_of_rank(r))
+        cpus = [c for c in (cpus or []) if c in allowed_set]
+        if not cpus:
+            return None, f"rank {r}: no local_cpulist for its device's PCI address inside this process's CPU mask"
+        local[r] = (node, tuple(cpus))
+    if len({v[1] for v in local.values()}) == 1 and len(local[0][1]) == len(allowed) and all(v[0] is None or v[0] < 0 for v in local.values()):
+        return None, "the devices report no NUMA locality (numa_node -1, every CPU local)"
+    plan = {}
+    for key in {v[1] for v in local.values()}:
+        sharers = sorted(r for r, v in local.items() if v[1] == key)
+        cores = _core_groups(list(key))
+        per = len(cores) // len(sharers)
+        if per < 2:
+            return None, f"{len(cores)} physical cores for the {len(sharers)} ranks of one NUMA node"
+        for k, r in enumerate(sharers):
+            plan[r] = [c for grp in cores[k * per:(k + 1) * per] for c in grp]
+    return plan, None
+
+
 def pin_rank_to_gpu_numa(local_rank, n_local, device_index):
-    """Bind this rank (its launch thread and every thread it starts later: OpenMP, the autograd worker) to CPUs of its GPU's
-    NUMA node.  Ranks whose GPUs share a node split its physical cores into disjoint contiguous slices (both hardware
-    threads of a core stay together), so eight launch threads neither float across the two sockets nor share cores.
-    Falls back silently -- and says so in the returned record -- when the topology is not visible (numa_node -1 / no sysfs)
-    or the slice would be empty.  -> dict for the `dist.affinity` field."""
+    """Bind this rank (its launch thread and every thread it starts later: OpenMP, the autograd worker) to the CPUs
+    `plan_rank_affinity` gives it: eight launch threads then neither float across the two sockets nor share cores.  Falls back
+    silently -- and says why in the returned record -- when the topology is not visible or not every rank can be pinned.
+    -> dict for the `dist.affinity_per_rank` field."""
     info = {"pinned": False}
     try:
         allowed = sorted(os.sched_getaffinity(0))
-        node, cpus = _gpu_local_cpus(device_index)
-        info.update(numa_node=node, cpus_before=len(allowed))
-        if not cpus:
-            info["reason"] = "no local_cpulist for the device's PCI address"
+        info["cpus_before"] = len(allowed)
+        # --share-gpu (all ranks on one device) maps every rank to that device; otherwise rank r drives GPU r
+        dev_of = (lambda r: r) if device_index == local_rank else (lambda r: device_index)
+        plan, why = plan_rank_affinity(n_local, dev_of, allowed)
+        info["numa_node"] = _gpu_local_cpus(device_index)[0]
+        if plan is None:
+            info["reason"] = why
             return info
-        cpus = [c for c in cpus if c in set(allowed)]
-        if not cpus or (node is not None and node < 0 and len(cpus) == len(allowed)):
-            info["reason"] = "the device reports no NUMA locality (numa_node -1 / all CPUs local)"
-            return info
-        # ranks that share this CPU set: every local rank whose device reports the same list
-        sharers = []
-        for r in range(n_local):
-            _, other = _gpu_local_cpus(r if device_index == local_rank else device_index)
-            if other and [c for c in other if c in set(allowed)] == cpus:
-                sharers.append(r)
-        if local_rank not in sharers:
-            sharers.append(local_rank)
-        sharers.sort()
-        cores = _core_groups(cpus)
-        k, m = sharers.index(local_rank), len(sharers)
-        per = len(cores) // m
-        if per < 1:
-            info["reason"] = f"{len(cores)} cores for {m} ranks"
-            return info
-        mine = [c for grp in cores[k * per:(k + 1) * per] for c in grp]
+        mine = plan[local_rank]
         os.sched_setaffinity(0, mine)
-        info.update(pinned=True, cpus=len(mine), cpu_first_last=[min(mine), max(mine)], ranks_on_node=m,
-                    cores=per)
+        info.update(pinned=True, cpus=len(mine), cpu_first_last=[min(mine), max(mine)],
+                    ranks_on_node=sum(1 for r in plan if set(plan[r]) & set(_gpu_local_cpus(device_index)[1] or [])))
     except Exception as e:  # noqa: BLE001 -- never take the benchmark down for an affinity call
         info["reason"] = repr(e)[:120]
     return info
@@ -313,6 +324,8 @@ class TrainBench:
                                            torch.rand(wl["c"] - 1, R, R, generator=self.gr) * 200, tile_size=wl["t"], dsm_std=3.0,
                                            ortho_mean=100.0, ortho_std=50.0, device=dev)
             self.pair = list(range(wl["c"] - 1))
+            # batch k + 1 is assembled on the sampler's side stream while batch k trains (GpuPatchSampler.stream_batches)
+            self.batch_iter = self.sampler.stream_batches(10 ** 9, n, self.pair, generator=self.gr, prefetch=1)
 
     def attach_optimizer(self):
         from resdepth_amd import FusedAdam
@@ -322,7 +335,7 @@ class TrainBench:
     def step(self):
         from resdepth_amd import masked_l1_loss
         if self.sampler is not None:
-            bb = self.sampler.random_batch(self.n, self.pair, generator=self.gr)
+            bb = next(self.batch_iter)
             xx, yy, mm, me, sd_ = bb["input"], bb["target"], bb["loss_mask"], bb["dsm_mean"], bb["dsm_std"]
         else:
             xx, yy, mm, me, sd_ = self.x, self.y, self.mask, self.mean, self.std
@@ -356,8 +369,8 @@ class TrainBench:
 
 # committed rocprofv3 PMC summaries (scripts/profile.sh + scripts/summarize_prof.py) per workload, newest first: the source
 # of `roofline.traffic` / `roofline.pmc` -- counters are never collected by bench.py itself
-PMC_SUMMARIES = {"S": ("r04_summary.json", "r03_summary.json", "r02_summary.json", "r01_summary.json"),
-                 "M": ("r04_cfgM_summary.json",), "G": ("r04_cfgG_summary.json",)}
+PMC_SUMMARIES = {"S": ("r05_summary.json", "r05a_summary.json", "r04_summary.json", "r03_summary.json", "r02_summary.json", "r01_summary.json"),
+                 "M": ("r05_cfgM_summary.json", "r04_cfgM_summary.json"), "G": ("r05_cfgG_summary.json", "r04_cfgG_summary.json")}
 
 
 def kernel_rows(kern, prof_steps, per="step"):
@@ -584,9 +597,10 @@ def secondary_measurements(args, dev, tb):
         ds = (time.perf_counter() - t0) / 20
         out["from_rasters"] = {"tiles_per_s": round(tr.n * 10 / dt, 1), "step_ms_median": round(_median(ev), 3),
                                "sampler_alone_tiles_per_s": round(tr.n / ds, 1), "sampler_alone_ms_per_batch": round(ds * 1e3, 3),
-                               "note": "GpuPatchSampler.random_batch (patch extraction, masked mean centring, normalisation, "
-                                       "rot90/flip, loss mask; lib/DsmOrthoDataset.py:161-291) from 4096^2 rasters resident in HBM "
-                                       "+ the train step, 10 timed steps"}
+                               "note": "GpuPatchSampler.stream_batches (patch extraction, masked mean centring, normalisation, "
+                                       "rot90/flip, loss mask; lib/DsmOrthoDataset.py:161-291; the next batch assembled on a side "
+                                       "stream under the current step) from 4096^2 rasters resident in HBM + the train step, 10 "
+                                       "timed steps"}
         del tr
     except Exception as e:      # noqa: BLE001
         out["from_rasters"] = {"error": repr(e)[:300]}

@@ -94,3 +94,35 @@ class GpuPatchSampler:
         if pair.dim() == 1:
             pair = pair.unsqueeze(0).expand(n, -1)
         return self.sample(torch.stack([ys, xs], 1), pair, aug)
+
+    def stream_batches(self, n_batches: int, batch_size: int, pairs, generator=None, augment: bool = True, prefetch: int = 1):
+        """Generator of `n_batches` random training batches (the dict of `random_batch`) assembled `prefetch` batches AHEAD on a
+        side stream, so that the two assembly kernels of batch k + 1 (0.26 ms for 32 tiles of 256 x 256 x 3) run under batch k's
+        forward / backward instead of in front of its own: the consumer's stream waits on one event per batch and the tensors
+        are pinned to it with `record_stream`.  The positions / augmentation draws come from `generator` in the same order as
+        consecutive `random_batch` calls, so the stream of batches is the same with or without prefetch."""
+        side = torch.cuda.Stream(device=self.device)
+        queue = []
+
+        def produce():
+            with torch.cuda.stream(side):
+                b = self.random_batch(batch_size, pairs, generator=generator, augment=augment)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return b, ev
+
+        for k in range(n_batches):
+            queue.append(produce())
+            if len(queue) > max(0, int(prefetch)):
+                yield self._hand_over(queue.pop(0))
+        while queue:
+            yield self._hand_over(queue.pop(0))
+
+    def _hand_over(self, item):
+        b, ev = item
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        for v in b.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        return b

@@ -1,7 +1,7 @@
 # GPU idle time inside the cfg-G inference sweep (rocprofv3 --kernel-trace of bench.py --infer): bash scripts/gaps_infer.sh
 REPO="$(pwd)"; OUT="$REPO/gpurun_out/gaps_infer"; rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d "$OUT" -o g --output-format csv -- python $REPO/bench.py --infer --steps 2 --warmup 1 --no-prof > "$OUT/bench.json" 2> "$OUT/err.txt"
+rocprofv3 --kernel-trace --memory-copy-trace -d "$OUT" -o g --output-format csv -- python $REPO/bench.py --infer --steps 2 --warmup 1 --no-prof > "$OUT/bench.json" 2> "$OUT/err.txt"
 tail -c 400 "$OUT/bench.json"
 python - "$OUT" <<'PY'
 import csv, sys, glob, collections
@@ -27,3 +27,4 @@ for s, e, n in ev:
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:18]:
     print("%8.2f ms %6d  %s" % (t / 1e6, c, n))
 PY
+python "$REPO/scripts/copy_overlap.py" "$OUT" D2H 50

@@ -191,6 +191,20 @@ def test_sweep_frontiers_and_cpu_list_parsing():
     assert sorted(c for g in groups for c in g) == sorted(os.sched_getaffinity(0))
     info = bench.pin_rank_to_gpu_numa(0, 1, 0)            # no GPU here: must report, not raise, and leave the mask alone
     assert info["pinned"] is False and sorted(os.sched_getaffinity(0)) == sorted(c for g in groups for c in g)
+    # the affinity plan on a made-up two-socket node: 8 GPUs, 4 per NUMA node, 64 cores x 2 hardware threads per node
+    topo = {r: (r // 4, list(range((r // 4) * 64, (r // 4) * 64 + 64)) + list(range(128 + (r // 4) * 64, 128 + (r // 4) * 64 + 64)))
+            for r in range(8)}
+    bench._gpu_local_cpus = lambda i: topo[i]
+    bench._core_groups = lambda cpus: [[c, c + 128] for c in cpus if c < 128]
+    plan, why = bench.plan_rank_affinity(8, lambda r: r, list(range(256)))
+    assert why is None and sorted(plan) == list(range(8)) and all(len(v) == 32 for v in plan.values())
+    assert len(set(c for v in plan.values() for c in v)) == 256                                  # disjoint slices, nothing left over
+    assert all(set(plan[r]) <= set(topo[r][1]) for r in range(8))                                # on the GPU's own node
+    assert all((c + 128) in plan[r] for r in range(8) for c in plan[r] if c < 128)               # SMT siblings stay together
+    plan, why = bench.plan_rank_affinity(8, lambda r: r, list(range(16)))                        # a CPU mask that covers one node only
+    assert plan is None and "rank 4" in why                                                     # nobody pins (no pinned / floating mix)
+    plan, why = bench.plan_rank_affinity(2, lambda r: 0, list(range(256)))                       # --share-gpu: both ranks on GPU 0
+    assert why is None and not set(plan[0]) & set(plan[1]) and len(plan[0]) == 64
 
 
 @pytest.mark.parametrize("kw", [dict(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True),
