@@ -12,8 +12,12 @@ kf = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
 mf = glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True)
 if not kf or not mf:
     sys.exit("no kernel / memory-copy trace under " + d)
-ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(kf[0])))
-ev = ev[len(ev) // 3:]
+rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(kf[0])))
+rows = rows[len(rows) // 3:]
+# copies to / from page-locked host memory may run as a BLIT KERNEL (__amd_rocclr_copyBuffer) instead of an SDMA transfer: those
+# show up in the kernel trace, not in the memory-copy trace
+blit = [(s, e) for s, e, n in rows if "copyBuffer" in n and e - s >= min_ns]
+ev = [(s, e) for s, e, n in rows if "copyBuffer" not in n]
 iv, (cs, ce) = [], ev[0]
 for s, e in ev[1:]:
     if s > ce:
@@ -28,6 +32,9 @@ for r in csv.DictReader(open(mf[0])):
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     if key in kind and s >= ev[0][0] and e - s >= min_ns:
         cp.append((s, e))
+if not cp and blit:
+    print(f"(no {want} record in the memory-copy trace: using the {len(blit)} blit kernels >= {min_ns / 1e3:.0f} us of the kernel trace)")
+    cp = blit
 cp.sort()
 tot = sum(e - s for s, e in cp)
 under = 0
