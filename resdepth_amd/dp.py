@@ -105,7 +105,7 @@ _NO_BRACKET = _NoBracket()
 
 
 class GradSync:
-    def __init__(self, process_group=None, bucket_bytes: int = 16 << 20, tail_bytes: int = 2 << 20):
+    def __init__(self, process_group=None, bucket_bytes: int = 16 << 20, tail_bytes: int = 512 << 10):
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("GradSync needs an initialised torch.distributed process group")
         self.pg = process_group
@@ -171,9 +171,9 @@ class GradSync:
         order the backward produces gradients in).  Pure function (unit-tested on CPU).
 
         tail_elems > 0: the LAST bucket -- the one whose all-reduce nothing can hide, it is issued when the backward is
-        over -- is cut once more so that its final piece holds at most `tail_elems` elements (whole tensors; at least one):
-        for cfg-S the leftover [enc3 .. enc0] = 5.9 MB becomes [enc3] 4.4 MB, issued ~1 ms before the end, + [enc2, enc1,
-        enc0] 1.5 MB exposed."""
+        over -- is cut again, geometrically: its final piece holds at most `tail_elems` elements (whole tensors; at least
+        one), the piece before it at most 4 x that, and so on.  cfg-S with 512 KB: the leftover [enc3 .. enc0] = 5.9 MB becomes
+        [enc3] 4.5 MB (issued ~1.8 ms before the end of the step), [enc2] 1.2 MB (~0.5 ms before), [enc1, enc0] 0.3 MB exposed."""
         order = sorted(range(len(offsets)), key=lambda i: offsets[i], reverse=True)
         buckets = []
         cur = None
@@ -190,21 +190,25 @@ class GradSync:
                 cur = None
         if cur is not None:
             buckets.append(cur)
-        if tail_elems > 0 and buckets and buckets[-1]["hi"] - buckets[-1]["lo"] > tail_elems and len(buckets[-1]["params"]) > 1:
+        # geometric tail: the final piece <= tail_elems, the one before it <= 4 x that, ... until what is left fits its cap
+        cap, pieces = int(tail_elems), []
+        while cap > 0 and buckets and buckets[-1]["hi"] - buckets[-1]["lo"] > cap and len(buckets[-1]["params"]) > 1:
             last = buckets.pop()
             members = sorted(last["params"], key=lambda i: offsets[i])          # from the START of the buffer = completed last
             tail, n = set(), 0
             for i in members:
-                if tail and n + sizes[i] > tail_elems:
+                if tail and n + sizes[i] > cap:
                     break
                 tail.add(i)
                 n += sizes[i]
-            if len(tail) < len(members):
-                cut = last["lo"] + n
-                buckets.append({"lo": cut, "hi": last["hi"], "params": last["params"] - tail})
-                buckets.append({"lo": last["lo"], "hi": cut, "params": tail})
-            else:
+            if len(tail) == len(members):
                 buckets.append(last)
+                break
+            cut = last["lo"] + n
+            pieces.append({"lo": last["lo"], "hi": cut, "params": tail})
+            buckets.append({"lo": cut, "hi": last["hi"], "params": last["params"] - tail})
+            cap *= 4
+        buckets.extend(reversed(pieces))
         return buckets
 
     def _ensure_plan(self, model):
@@ -262,7 +266,7 @@ class GradSync:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
 
 
-def attach(model, process_group=None, sync_bn: bool = False, bucket_bytes: int = 16 << 20, tail_bytes: int = 2 << 20) -> GradSync:
+def attach(model, process_group=None, sync_bn: bool = False, bucket_bytes: int = 16 << 20, tail_bytes: int = 512 << 10) -> GradSync:
     """Make `model` (a resdepth_amd.UNet) data parallel: its backward all-reduces gradients, its loss must be
     built with `grad_sync=` the returned object (global normaliser)."""
     gs = GradSync(process_group, bucket_bytes, tail_bytes)

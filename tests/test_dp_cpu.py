@@ -58,6 +58,11 @@ def test_plan_buckets_tiles_the_buffer_from_the_end():
     # a tail that already fits, or that is one tensor, is left alone; a cap smaller than the last tensor keeps that tensor whole
     assert dp.GradSync.plan_buckets(offs, sizes, 32, tail_elems=13) == b
     assert dp.GradSync.plan_buckets(offs, sizes, 32, tail_elems=4)[-1]["params"] == {0}
+    # geometric: a long leftover is cut repeatedly, caps 2, 8, 32 from the start of the buffer
+    sizes2, offs2 = [2, 6, 20, 40, 100], [0, 2, 8, 28, 68]
+    g = dp.GradSync.plan_buckets(offs2, sizes2, 90, tail_elems=2)
+    assert [(x["lo"], x["hi"]) for x in g] == [(68, 168), (28, 68), (8, 28), (2, 8), (0, 2)]
+    assert [x["params"] for x in g] == [{4}, {3}, {2}, {1}, {0}]
 
 
 def test_shard_batch():
