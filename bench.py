@@ -447,14 +447,17 @@ def _median(v):
     return v[len(v) // 2] if v else None
 
 
-def infer_sweep(dev, raster, batch, sweeps, warm=1):
-    """cfg-G on one GPU: `sweeps` full sweeps of a raster x raster synthetic DSM (tiles resident in HBM) -> (tiles/s, n_tiles)."""
+def infer_sweep(dev, raster, batch, sweeps, warm=1, host_batches=False):
+    """cfg-G on one GPU: `sweeps` full sweeps of a raster x raster synthetic DSM -> (tiles/s, n_tiles).  Tiles resident in HBM
+    (the metric's convention: staging excluded), or host_batches=True: pinned HOST batch dicts, what a DataLoader(pin_memory=True)
+    hands lib/evaluation.py:486-498 -- every tile crosses PCIe inside the timed sweep."""
     from torch.utils.data import DataLoader
     from resdepth_amd import UNet, SyntheticRasterTiles, predict_linear_blend
     torch.manual_seed(0)
     model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).eval()
     ds = SyntheticRasterTiles(raster, raster, 3, tile_size=256, seed=1)
-    batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in DataLoader(ds, batch_size=batch, shuffle=False)]
+    move = (lambda v: v.pin_memory()) if host_batches else (lambda v: v.to(dev))
+    batches = [{k: (move(v) if torch.is_tensor(v) else v) for k, v in b.items()} for b in DataLoader(ds, batch_size=batch, shuffle=False)]
 
     class Loader(list):
         dataset = ds
@@ -628,6 +631,16 @@ def secondary_measurements(args, dev, tb):
                                     "eval-mode BN folded, batch 32, forward + linear blend, 2 timed sweeps"}
     except Exception as e:      # noqa: BLE001
         out["cfg_G"] = {"error": repr(e)[:200]}
+    try:        # the same sweep fed from HOST batches (the drop-in call: a DataLoader's pinned batch dicts), 4096^2 raster
+        res, _ = infer_sweep(dev, 4096, 32, 2)
+        hst, nt = infer_sweep(dev, 4096, 32, 2, host_batches=True)
+        out["cfg_G_host_batches"] = {"tiles_per_s": round(hst, 1), "tiles_per_s_resident": round(res, 1), "tiles": nt,
+                                     "h2d_mbytes_per_sweep": round(nt * 3 * 256 * 256 * 4 / 2 ** 20, 1),
+                                     "workload": "4096x4096 raster, 961 tiles, batch 32, 2 timed sweeps: pinned host batch dicts (input "
+                                                 "staged on a copy stream one batch ahead, offsets / boxes as one pinned block per batch) "
+                                                 "vs the same tiles resident in HBM"}
+    except Exception as e:      # noqa: BLE001
+        out["cfg_G_host_batches"] = {"error": repr(e)[:200]}
     torch.cuda.empty_cache()
     return out
 

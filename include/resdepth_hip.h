@@ -367,8 +367,9 @@ int rd_blend_accumulate(const float* pred, const float* mean, const float* std, 
 /* Host side of the sweep's raster read-back (lib/evaluation.py:510-513 returns the blended raster as a host array).  A multi-GPU
  * sweep lets every rank write ITS band of the raster straight into one host buffer shared by the ranks of the node (POSIX
  * shared memory mapped by each of them): rd_host_register page-locks and maps [p, p + bytes) of such a mapping for the
- * current device (hipHostRegister, portable), rd_copy_to_host_async enqueues device -> host on `s` (truly asynchronous for
- * registered / pinned destinations), rd_host_unregister undoes the registration.  Plain pointers; no torch types. */
+ * current device (hipHostRegister, portable + mapped), rd_copy_to_host_async enqueues device -> host on `s` (hipMemcpyAsync:
+ * asynchronous for page-locked destinations; knob d2h_blocks > 0 selects a small-grid copy kernel storing into the mapped range
+ * instead, measured slower), rd_host_unregister undoes the registration.  Plain pointers; no torch types. */
 int rd_host_register(void* p, size_t bytes);
 int rd_host_unregister(void* p);
 int rd_copy_to_host_async(void* dst_host, const void* src_dev, size_t bytes, rd_stream_t s);
@@ -412,7 +413,7 @@ typedef struct {
 } rd_prof_entry;
 /* Diagnosis knobs (tile-shape / kernel-selection overrides used by scripts/; never needed in production).  Names:
  * mfma_f32 nt_tile nt_halo nt_skew nt_splitk tn_tile tn_blocks tn_split wg_strip wg_minblocks wg_blocks wg_occ convt_patch edge_conv
- * rows_blocks last_blocks
+ * rows_blocks last_blocks nt_epi d2h_blocks
  * (resdepth_amd/csrc/rd_common.h: TuneKey).  Also settable at load time: RD_TUNE="name=value,..." */
 int rd_tune_set(const char* name, int value);
 int rd_tune_get(const char* name, int* value);

@@ -53,6 +53,7 @@ enum TuneKey {
     TUNE_LAST_BLOCKS,      // first-stage blocks of the last-conv gradient kernels
     TUNE_NT_SPLITK,        // -1 auto | 0: never use the split-K patch kernel for 8 x 8 images (needs rd_set_splitk_workspace)
     TUNE_NT_EPI,           // -1 auto | 0: patch kernels keep the LDS-staged epilogue (r03) instead of the register-direct one
+    TUNE_D2H_BLOCKS,       // rd_copy_to_host_async: 0 (default) = hipMemcpyAsync (the runtime's blit kernel) | n > 0: own copy kernel with n workgroups (r05 experiment: slower)
     TUNE_COUNT
 };
 int tune(int key);

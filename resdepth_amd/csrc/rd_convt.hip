@@ -208,8 +208,11 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
         };
         auto rowok = [&](int i, int r) { return ((i * 32 + (r & 3) + 8 * (r >> 2)) >> logPW) < rows_left; };
         // FULL: every patch row of the tile exists (all tiles but the last row band of a ragged grid) -- no per-row select
-        auto emit = [&](auto full_c) {
-            constexpr bool FULL = decltype(full_c)::value;
+        // BNSKIP = false: the skip is a materialised tensor (or absent): a plain add -- the identity case of the lazy form would
+        // spend a multiply-add, a compare, a multiply and a select per element on (1, 0, slope 1) (inference: every level but
+        // the first hands its activation on as a tensor; 4 of the ~10 vector instructions per output element of this epilogue)
+        auto emit = [&](auto full_c, auto bn_c) {
+            constexpr bool FULL = decltype(full_c)::value, BNSKIP = decltype(bn_c)::value;
             auto voff = [&](int i, int r) { return FULL || rowok(i, r) ? lane_off : kOOB; };
             auto voff_s = [&](int i, int r) { return FULL || rowok(i, r) ? lane_off_s : kOOB; };
             float skv[TM][16];
@@ -223,12 +226,17 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = merge_hi_lo(acc[i][r], lo[i][r]) + bias1;
-                    const float s1 = ct_act(fmaf(skv[i][r], sc1, sh1), slope1);
+                    const float s1 = BNSKIP ? ct_act(fmaf(skv[i][r], sc1, sh1), slope1) : skv[i][r];
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(s1 + v), rsO, voff(i, r), soffd(i, r), 0);
                 }
         };
-        if (rows_left >= p.TR) emit(std::true_type());
-        else emit(std::false_type());
+        if (p.sk_mean) {
+            if (rows_left >= p.TR) emit(std::true_type(), std::true_type());
+            else emit(std::false_type(), std::true_type());
+        } else {
+            if (rows_left >= p.TR) emit(std::true_type(), std::false_type());
+            else emit(std::false_type(), std::false_type());
+        }
         return;
     }
     // ---- epilogue: 32-row passes through LDS; tile row r = (gy, px) owns 128 contiguous floats of the output

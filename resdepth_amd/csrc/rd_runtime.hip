@@ -34,7 +34,7 @@ struct TuneEntry {
 static TuneEntry g_tune[TUNE_COUNT] = {
     {"mfma_f32", 0},   {"nt_tile", -1},      {"nt_halo", -1},    {"nt_skew", 1},     {"tn_tile", -1},     {"tn_blocks", 512}, {"tn_split", -1},
     {"wg_strip", -1},  {"wg_minblocks", 768}, {"wg_blocks", 512}, {"wg_occ", 2}, {"convt_patch", -1}, {"edge_conv", -1}, {"rows_blocks", 512}, {"last_blocks", 2048},
-    {"nt_splitk", -1}, {"nt_epi", -1},
+    {"nt_splitk", -1}, {"nt_epi", -1}, {"d2h_blocks", 0},
 };
 static int tune_index(const char* name, size_t len) {
     for (int i = 0; i < TUNE_COUNT; ++i)
@@ -266,11 +266,36 @@ extern "C" int rd_host_register(void* p, size_t bytes) {
 
 extern "C" int rd_host_unregister(void* p) { return rd::check_hip(hipHostUnregister(p), "rd_host_unregister"); }
 
+// Device -> page-locked host memory with a SMALL grid -- an r05 experiment kept behind the knob `d2h_blocks` (default 0 = off).
+// hipMemcpyAsync to pinned memory runs as the runtime's blit kernel on this stack (`__amd_rocclr_copyBuffer` in the kernel trace,
+// nothing in the memory-copy trace): a 33 MB raster stripe at the PCIe rate (0.62 ms), and for 45 % of that time no kernel of the
+// sweep runs beside it (scripts/gaps_infer.sh) -- streamed under the sweep the read-back costs about half of what the serial copy
+// did, not nothing.  Hypothesis: a PCIe-bound copy needs a few dozen waves, not the chip's wave slots.  Measured (cfg-G, 8192^2,
+// interleaved on one box, ms per sweep): hipMemcpyAsync 393.2 / 393.9; this kernel with 16 / 48 / 128 workgroups 398.3-399.1 /
+// 400.5-401.6 / 401.1-401.2 -- 1.3-2 % SLOWER (posted stores from a few waves do not reach the PCIe rate, and the longer the copy
+// runs the longer it shares HBM and the fabric with the sweep).  The runtime's copy stays the default.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_to_host_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const u32x4 v = __builtin_nontemporal_load(src + i);
+        __builtin_nontemporal_store(v, dst + i);
+    }
+}
+
 extern "C" int rd_copy_to_host_async(void* dst_host, const void* src_dev, size_t bytes, rd_stream_t stream) {
     if (!bytes) return RD_OK;
     if (!dst_host || !src_dev) {
         rd::set_error("rd_copy_to_host_async: null pointer");
         return RD_ERR_ARG;
     }
+    const int blocks = rd::tune(rd::TUNE_D2H_BLOCKS);
+    void* dmap = nullptr;
+    if (blocks > 0 && bytes % 16 == 0 && ((size_t)dst_host % 16) == 0 && ((size_t)src_dev % 16) == 0 &&
+        hipHostGetDevicePointer(&dmap, dst_host, 0) == hipSuccess && dmap) {
+        hipLaunchKernelGGL(copy_to_host_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const u32x4*>(src_dev), reinterpret_cast<u32x4*>(dmap), bytes / 16);
+        return rd::check_hip(hipGetLastError(), "rd_copy_to_host_async");
+    }
+    (void)hipGetLastError();          // not mapped host memory (pageable destination): the runtime's staged copy
     return rd::check_hip(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "rd_copy_to_host_async");
 }

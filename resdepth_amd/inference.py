@@ -249,20 +249,32 @@ def predict_linear_blend(dataloader, model, reduce_to_rank0: bool = True, host=N
         copier = _StripeCopier(raster, lo, host, early, device)
     front = _frontiers(tile_rows, tile_size, rows) if tile_rows is not None else None
     done = 0
+    # host batches (a DataLoader's): input / dsm_mean / dsm_std of batch k + 1 go to the device on a copy stream while batch k
+    # computes (trainer.DevicePrefetcher; device-resident batches pass through untouched); the per-tile offsets and valid-pixel
+    # boxes travel as ONE pinned int32 block per batch, asynchronously -- a pageable `.to(device)` per field would block the host
+    # behind everything already enqueued, once per field and batch
+    from .trainer import DevicePrefetcher
+    meta_keys = ("patch_offset_y", "patch_offset_x", "patch_valid_pixels_uly", "patch_valid_pixels_ulx", "patch_valid_pixels_lry",
+                 "patch_valid_pixels_lrx")
+    lo_t = torch.tensor([lo, 0], dtype=torch.int32, device=device) if lo else None
     with torch.no_grad():
-        for batch in dataloader:
+        for batch in DevicePrefetcher(dataloader, device, 1):
             x = batch["input"].to(device, non_blocking=True)
             n = x.shape[0]
             y_pred = model(x)
             mean = torch.as_tensor(batch["dsm_mean"]).flatten().to(torch.float32).to(device)
             std = torch.as_tensor(batch["dsm_std"]).flatten().to(torch.float32).to(device)
-            pos = torch.stack([torch.as_tensor(batch["patch_offset_y"]).flatten(),
-                               torch.as_tensor(batch["patch_offset_x"]).flatten()], 1).to(torch.int32).to(device)
-            if lo:
-                pos = pos - torch.tensor([lo, 0], dtype=torch.int32, device=device)
-            reg = torch.stack([torch.as_tensor(batch[k]).flatten() for k in
-                               ("patch_valid_pixels_uly", "patch_valid_pixels_ulx", "patch_valid_pixels_lry",
-                                "patch_valid_pixels_lrx")], 1).to(torch.int32).to(device)
+            cols6 = [torch.as_tensor(batch[k]).flatten() for k in meta_keys]
+            if any(c.is_cuda for c in cols6):
+                cols6 = [c.to(device) for c in cols6]
+                pos = torch.stack(cols6[0:2], 1).to(torch.int32)
+                reg = torch.stack(cols6[2:6], 1).to(torch.int32)
+            else:           # [pos (n x 2) | reg (n x 4)] in one pinned block, one asynchronous copy, two contiguous views
+                blk = torch.cat([torch.stack(cols6[0:2], 1).flatten(), torch.stack(cols6[2:6], 1).flatten()]).to(torch.int32)
+                blk = blk.pin_memory().to(device, non_blocking=True)
+                pos, reg = blk[:2 * n].view(n, 2), blk[2 * n:].view(n, 4)
+            if lo_t is not None:
+                pos = pos - lo_t
             if mean.numel() != n or pos.shape[0] != n:
                 raise ValueError("batch dict fields must hold one value per tile")
             with _lib.device_of(raster):

@@ -120,14 +120,17 @@ class DevicePrefetcher:
                 v = batch.get(k) if isinstance(batch, dict) else None
                 if v is None:
                     continue
-                t = torch.as_tensor(v)
-                if k in self.SCALARS:
-                    t = t.flatten().to(torch.float32)       # what masked_l1_loss feeds its kernels (lib/Trainer.py:174-175)
+                t = src = torch.as_tensor(v)
+                if k in self.SCALARS and not src.is_cuda:
+                    # what masked_l1_loss feeds its kernels (lib/Trainer.py:174-175); device-resident scalars are left to the
+                    # consumer (a conversion kernel launched HERE would run on the copy stream)
+                    t = t.flatten().to(torch.float32)
                 if not t.is_cuda:
                     if not t.is_pinned():
                         t = t.pin_memory()
                     t = t.to(self.device, non_blocking=True)
-                    moved.append(t)
+                if t.is_cuda and t is not src:
+                    moved.append(t)          # born on the copy stream: pinned to the consumer's stream at hand-over
                 out[k] = t
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
