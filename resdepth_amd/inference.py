@@ -7,8 +7,9 @@ complete, and de-normalisation + blend weights + accumulation are one kernel per
 (fp64 accumulation in the reference's order => run-to-run deterministic, no atomics).
 
 The raster goes back to the host in ROW STRIPES on a copy stream while later tiles are still computing: a stripe leaves
-as soon as no remaining tile touches it (the sweep is row-major, lib/rasterutils.py:100-191), so only the last stripe's
-copy is exposed (r04: one 537 MB copy after the last tile = 2.6 % of an 8192^2 sweep).
+as soon as no remaining tile touches it (the sweep is row-major, lib/rasterutils.py:100-191).  (Measured, N = 1: the copies
+run as the runtime's blit kernels at the PCIe rate, about half of their time under the sweep's kernels -- a few tenths of a
+per cent of the sweep against r04's single 537 MB copy after the last tile; the design pays off at N > 1.)
 
 Multi-GPU sweep: tiles are sharded by ROW BANDS (`tiling.band_shards`).  A rank's private raster covers its
 band only (8192^2 on 8 GPUs: 75 MB instead of 537 MB); the T - stride rows a band shares with the next one go to their
