@@ -156,8 +156,9 @@ def pin_rank_to_gpu_numa(local_rank, n_local, device_index):
             return info
         mine = plan[local_rank]
         os.sched_setaffinity(0, mine)
+        node_cpus = set(_gpu_local_cpus(device_index)[1] or [])
         info.update(pinned=True, cpus=len(mine), cpu_first_last=[min(mine), max(mine)],
-                    ranks_on_node=sum(1 for r in plan if set(plan[r]) & set(_gpu_local_cpus(device_index)[1] or [])))
+                    ranks_on_node=sum(1 for cpus in plan.values() if node_cpus.intersection(cpus)))
     except Exception as e:  # noqa: BLE001 -- never take the benchmark down for an affinity call
         info["reason"] = repr(e)[:120]
     return info

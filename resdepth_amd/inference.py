@@ -29,6 +29,7 @@ from torch.utils.data import Dataset
 
 from . import _lib, ops
 from .tiling import band_shards, regular_grid
+from .trainer import DevicePrefetcher
 
 STRIPE_ROWS = 512          # granularity of the streamed device->host copies (8192 columns: 32 MB per stripe)
 
@@ -254,7 +255,6 @@ def predict_linear_blend(dataloader, model, reduce_to_rank0: bool = True, host=N
     # computes (trainer.DevicePrefetcher; device-resident batches pass through untouched); the per-tile offsets and valid-pixel
     # boxes travel as ONE pinned int32 block per batch, asynchronously -- a pageable `.to(device)` per field would block the host
     # behind everything already enqueued, once per field and batch
-    from .trainer import DevicePrefetcher
     meta_keys = ("patch_offset_y", "patch_offset_x", "patch_valid_pixels_uly", "patch_valid_pixels_ulx", "patch_valid_pixels_lry",
                  "patch_valid_pixels_lrx")
     lo_t = torch.tensor([lo, 0], dtype=torch.int32, device=device) if lo else None
