@@ -223,6 +223,37 @@ int main() {
         for (void* p : {(void*)d_x8, (void*)d_w8, (void*)d_z8, (void*)d_pk, (void*)d_sk}) (void)hipFree(p);
     }
 
+    // ---- host side of a sweep's raster read-back (rd_host_register / rd_copy_to_host_async / rd_host_unregister): a plain
+    // malloc'ed (page-aligned) host range is page-locked, receives a device buffer asynchronously -- through the runtime's copy and
+    // through the library's own small-grid copy kernel (knob d2h_blocks) -- and is released again
+    {
+        const size_t n = 1u << 20;                                   // doubles: 8 MB
+        std::vector<double> src(n);
+        for (size_t i = 0; i < n; ++i) src[i] = (double)rnd() * 1000.0 + (double)i;
+        double* d_r = dev_alloc<double>(n);
+        void* raw = nullptr;
+        if (!d_r || posix_memalign(&raw, 4096, n * sizeof(double))) return 2;
+        double* h_r = static_cast<double*>(raw);
+        HIP_OK(hipMemcpyAsync(d_r, src.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
+        RD_OK_(rd_host_register(h_r, n * sizeof(double)));
+        int same = 1;
+        for (int blocks : {0, 32}) {
+            RD_OK_(rd_tune_set("d2h_blocks", blocks));
+            std::memset(h_r, 0, n * sizeof(double));
+            RD_OK_(rd_copy_to_host_async(h_r, d_r, n * sizeof(double), stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            same = same && !std::memcmp(h_r, src.data(), n * sizeof(double));
+        }
+        RD_OK_(rd_tune_set("d2h_blocks", 0));
+        RD_OK_(rd_host_unregister(h_r));
+        const int r_null = rd_host_register(nullptr, 4096), r_copy = rd_copy_to_host_async(nullptr, d_r, 16, stream);
+        std::printf("host read-back: registered range filled by the runtime's copy and by the copy kernel: %s; null range -> %d, null "
+                    "destination -> %d\n", same ? "same bytes" : "DIFFERENT BYTES", r_null, r_copy);
+        if (!same || r_null != RD_ERR_ARG || r_copy != RD_ERR_ARG) bad = 1;
+        std::free(raw);
+        (void)hipFree(d_r);
+    }
+
     // error contract: Cin must be a multiple of 4 here -> non-zero return, message names the argument, nothing launched
     const int rc = rd_conv3x3_fwd(d_x, (const float*)d_wf, d_z, N, H, W, 3, CO, stream);
     const char* msg = rd_last_error_string();

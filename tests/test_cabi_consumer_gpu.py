@@ -20,3 +20,5 @@ def test_hip_runtime_only_consumer_runs_one_layer_through_the_c_abi(tmp_path):
     # rd_set_splitk_workspace: register for (device, stream) / run / un-register, and its argument checks
     assert any("split-K scratch" in ln and "same bits" in ln for ln in lines), r.stdout
     assert any("host pointer -> 1, misaligned -> 1, too small -> 1" in ln for ln in lines), r.stdout
+    # host side of the sweep's read-back: page-lock a plain host range, fill it through both copy routes, release it
+    assert any("host read-back" in ln and "same bytes" in ln and "null range -> 1, null destination -> 1" in ln for ln in lines), r.stdout
