@@ -591,6 +591,9 @@ def secondary_measurements(args, dev, tb):
     try:        # sample assembly on the GPU inside every step
         tr = TrainBench(tb.wl, tb.n, dev, from_rasters=True)
         tr.attach_optimizer()
+        # the part runs hot by now (clocks drift over a long run): the resident-batch step is re-timed right beside it so that the
+        # two numbers are comparable (scripts/from_rasters_probe.py: interleaved, a fresh sampler batch per step costs +0.9 %)
+        _, ev_res = tb.timed(10, 3)
         dt, ev = tr.timed(10, 3)
         # the sampler alone (no train step): batches/s of rd_patch_sums + rd_assemble_patches
         torch.cuda.synchronize()
@@ -600,6 +603,7 @@ def secondary_measurements(args, dev, tb):
         torch.cuda.synchronize()
         ds = (time.perf_counter() - t0) / 20
         out["from_rasters"] = {"tiles_per_s": round(tr.n * 10 / dt, 1), "step_ms_median": round(_median(ev), 3),
+                               "resident_batch_step_ms_median_beside_it": round(_median(ev_res), 3),
                                "sampler_alone_tiles_per_s": round(tr.n / ds, 1), "sampler_alone_ms_per_batch": round(ds * 1e3, 3),
                                "note": "GpuPatchSampler.stream_batches (patch extraction, masked mean centring, normalisation, "
                                        "rot90/flip, loss mask; lib/DsmOrthoDataset.py:161-291; the next batch assembled on a side "
