@@ -126,3 +126,25 @@ class GpuPatchSampler:
             if torch.is_tensor(v) and v.is_cuda:
                 v.record_stream(cur)
         return b
+
+
+class SamplerLoader:
+    """A `trainloader` for resdepth_amd.Trainer (lib/Trainer.py:61-64,165: anything with `len()` that yields batch dicts) fed by a
+    GpuPatchSampler: `n_batches` random augmented batches per epoch, assembled on the GPU one batch ahead (`stream_batches`).
+    Takes the place of DataLoader(DsmOrthoDataset(...)) when the rasters fit in HBM (lib/DsmOrthoDataset.py:161-291 does the same
+    per-sample work on the CPU).  `generator`: a CPU torch.Generator for the positions / augmentation draws (its state advances
+    from epoch to epoch, as a shuffling DataLoader's does)."""
+
+    def __init__(self, sampler: GpuPatchSampler, n_batches: int, batch_size: int, pairs, generator=None, augment: bool = True,
+                 prefetch: int = 1):
+        self.sampler, self.n_batches, self.batch_size = sampler, int(n_batches), int(batch_size)
+        self.pairs, self.generator, self.augment, self.prefetch = pairs, generator, augment, prefetch
+        self.dataset = range(self.n_batches * self.batch_size)       # len(loader.dataset), as the Trainer's shard checks read it
+        self.drop_last = True
+
+    def __len__(self):
+        return self.n_batches
+
+    def __iter__(self):
+        return self.sampler.stream_batches(self.n_batches, self.batch_size, self.pairs, generator=self.generator,
+                                           augment=self.augment, prefetch=self.prefetch)

@@ -97,3 +97,54 @@ def test_stream_batches_equals_consecutive_random_batches():
                 assert torch.equal(a[k], b[k]), (depth, k)
         for k, v in ref[2].items():
             assert torch.equal(got[2][k], v), (depth, k)
+
+
+def test_sampler_loader_drives_the_trainer_shell(tmp_path):
+    """SamplerLoader as the Trainer's `trainloader` (lib/Trainer.py:61-64,159-222 consume any iterable of batch dicts with a
+    length): two epochs of GPU-assembled batches through resdepth_amd.Trainer give the losses and weights of the same batches fed
+    by hand, bit for bit."""
+    import types
+    from resdepth_amd import GpuPatchSampler, SamplerLoader, UNet, FusedAdam, Trainer, masked_l1_loss
+    g0 = torch.Generator().manual_seed(5)
+    H = W = 384
+    dsm = torch.randn(H, W, generator=g0) * 3 + 400
+    smp = GpuPatchSampler(dsm, dsm + torch.randn(H, W, generator=g0), torch.rand(2, H, W, generator=g0) * 200, tile_size=64,
+                          dsm_std=3.0, ortho_mean=100.0, ortho_std=50.0)
+    kw = dict(n_input_channels=3, start_kernel=8, depth=3, bias_conv_layer=True)
+
+    torch.manual_seed(0)
+    model = UNet(**kw)
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    loader = SamplerLoader(smp, 5, 4, [0, 1], generator=torch.Generator().manual_seed(21))
+    args = types.SimpleNamespace(model=model, optimizer=opt, scheduler=None, criterion=torch.nn.L1Loss(reduction="mean"),
+                                 trainloader=loader, valloader=None, n_epochs=2, evaluate_rate=10, save_model_rate=10 ** 9,
+                                 freq_average_train_loss=10 ** 9, save_dir=str(tmp_path), log_file=None,
+                                 checkpoint_dir=str(tmp_path / "ck"), tboard_log_dir=str(tmp_path / "tb"), pretrained_path=None)
+    tr = Trainer(args)
+    assert tr.batch_size == 4 and len(loader) == 5
+    meters = [tr.inference_one_epoch(e, "train")["MAE_metric"].avg for e in range(2)]
+    torch.cuda.synchronize()
+
+    # by hand: the Trainer's constructor peeked at the first batch (lib/Trainer.py:61-64) -- with prefetch 1 the abandoned iterator
+    # had drawn two --, then two epochs of five
+    torch.manual_seed(0)
+    ref = UNet(**kw).to("cuda:0").train()
+    ropt = FusedAdam(ref.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(21)
+    for _ in range(2):
+        smp.random_batch(4, [0, 1], generator=g)
+    want = []
+    for e in range(2):
+        acc = []
+        for _ in range(5):
+            b = smp.random_batch(4, [0, 1], generator=g)
+            loss = masked_l1_loss(ref(b["input"]), b["target"], b["loss_mask"], b["dsm_mean"], b["dsm_std"])
+            loss.backward()
+            ropt.step()
+            for p in ref.parameters():
+                p.grad = None
+            acc.append(float(loss))
+        want.append(sum(acc) / len(acc))
+    assert meters == pytest.approx(want, rel=1e-12)
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(a, b), k
