@@ -15,11 +15,12 @@
 //  wgrad     dw[c][tap] = sum_q s[q][c] dout[q - tap]: same LDS tile of dout, four 16-byte loads of s in flight per lane,
 //            36 accumulators per lane, ONE block-level reduction at the end (LDS, two barriers) instead of 9 x 2.
 #include "rd_common.h"
+#include "rd_mfma_dev.h"
 
 namespace rd {
 
 // TUNE_EDGE_CONV: -1 all kernels of this file, else a bit mask (1 last fwd, 2 last dgrad, 4 last wgrad, 8 first fwd, 16 first wgrad,
-// 32 the composed tail kernels)
+// 32 the composed tail kernels); bit 64 (opt-in only, not implied by -1): the first convolution's forward on the matrix pipe)
 static bool edge_on(int bit) {
     const int v = tune(TUNE_EDGE_CONV);
     return v < 0 || (v & bit);
@@ -1320,6 +1321,179 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_seg_kernel(const floa
     }
 }
 
+// ---- first convolution on the matrix pipe, in exact fp32 (r05) ---------------------------------------------------------------
+// The segment kernels above are bound by vector-ALU issue: 27 fused multiply-adds per output element (CIN = 3), 0.91-0.97 of
+// the cycles of conv_first_fwd_seg / conv_first_fwd_act_seg are VALU instructions (profiles/r05_notes.md section 6), and the
+// packed form that would halve them is banned in this library.  `v_mfma_f32_32x32x2_f32` does the same arithmetic -- an fp32
+// fused multiply-add per k, accumulated in k order, bit for bit the chain `acc = fmaf(x, w, acc)` -- at twice the vector rate
+// and off the vector ALU.  As a GEMM: rows = the 32 pixels of one image row of the 16 x 32 tile, columns = output channels,
+// k = (ky, ci, kx) in the order the segment kernels add their products, so z is THE SAME BITS (asserted by
+// tests/test_ops_gpu.py::test_first_convolution_on_the_matrix_pipe_is_bit_identical).
+//   A: lane (x = lane % 32, khalf = lane / 32) reads X[ci][py + ky][x + kx] for k = 2 s + khalf -- one conflict-free ds_read_b32;
+//   B: w[co = lane % 32 + 32 j][k] sits in registers (2 s + khalf: NS values per 32-channel block, loaded once per block);
+//   C: lane = one output channel, sixteen pixels x = (r & 3) + 8 (r >> 2) + 4 khalf of the row: a store instruction writes the 128
+//      contiguous bytes of 32 channels of one pixel (lanes 0-31) and of the pixel four columns on (lanes 32-63); the BatchNorm
+//      statistics are sums over the lane's own registers; the 2 x 2 max-pool windows of the inference form are registers
+//      (r, r + 1) of the two rows of a row pair, which one wave owns.
+// A wave takes four image rows as two row pairs (4 x NB accumulators live at a time).
+template <int CIN, int NB, int MODE>      // NB = Cout / 32; MODE 0: z (+ per-tile BN statistics), 1: a = act(BN(z)) (+ 2 x 2 max-pool)
+__global__ __launch_bounds__(256, 2) void conv_first_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  float* __restrict__ out, float* __restrict__ aux,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float slope_val, const float* __restrict__ slope_dev, int N, int H,
+                                                                  int W, int tiles_x, int tiles_y) {
+    constexpr int Cout = NB * 32, K = 9 * CIN, NS = (K + 1) / 2;
+    __shared__ __attribute__((aligned(16))) float X[CIN * FH_PLANE + 2 * NS * Cout + 4 * 2 * Cout];
+    float* Wk = X + CIN * FH_PLANE;               // [k][co], k = (ky * CIN + ci) * 3 + kx, zero beyond K
+    float* red = Wk + 2 * NS * Cout;              // MODE 0: per-wave statistics [4][2][Cout]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, xl = lane & 31, khalf = lane >> 5;
+    const int tl = blockIdx.x;
+    const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+    const int y0 = ty * ET_H, x0 = tx * ET_W;
+    for (int e = t; e < 2 * NS * Cout; e += 256) {
+        const int k = e / Cout, co = e - k * Cout;
+        const int ky = k / (3 * CIN), ci = (k / 3) % CIN, kx = k % 3;
+        Wk[e] = k < K ? w[((long)co * CIN + ci) * 9 + ky * 3 + kx] : 0.f;
+    }
+    load_x_halo<CIN>(X, x, n, y0, x0, H, W, t);
+    __syncthreads();
+    float wb[NS][NB];
+    int aoff[NS];                                  // LDS word offset of this lane's A value of step s, relative to (row py, column xl)
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+        const int k = 2 * s_ + khalf;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) wb[s_][j] = Wk[k * Cout + j * 32 + xl];
+        const int kk = k < K ? k : 0;              // the padding k multiplies a zero weight: any finite A value will do
+        const int ky = kk / (3 * CIN), ci = (kk / 3) % CIN, kx = kk % 3;
+        aoff[s_] = ci * FH_PLANE + ky * FP + kx;
+    }
+    float sc[NB], sh[NB], slope = 0.f;
+    float st_s[NB], st_q[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        st_s[j] = st_q[j] = 0.f;
+        sc[j] = sh[j] = 0.f;
+        if (MODE == 1) {
+            const int co = j * 32 + xl;
+            sc[j] = invstd[co] * gamma[co];
+            sh[j] = beta[co] - mean[co] * sc[j];
+        }
+    }
+    if (MODE == 1) slope = slope_dev ? slope_dev[0] : slope_val;
+    const int H2 = H >> 1, W2 = W >> 1;
+#pragma unroll 1
+    for (int rp = 0; rp < 2; ++rp) {
+        const int py = wave * 4 + rp * 2;          // rows py, py + 1 of the tile
+        f32x16 acc[2][NB];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][j][r] = 0.f;
+        const float* xr = X + py * FP + xl;
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const float a0 = xr[aoff[s_]], a1 = xr[aoff[s_] + FP];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wb[s_][j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wb[s_][j], acc[1][j], 0, 0, 0);
+            }
+        }
+        // ---- epilogue of the row pair: buffer stores, the row / pixel part of the address in a scalar register, one per-lane offset
+        // (masked lanes carry an out-of-extent offset: no exec-mask branch per store)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int gy = y0 + py + q;
+            const bool rowok = gy < H;
+            const long rbase = (((long)n * H + (rowok ? gy : 0)) * W + x0) * Cout;
+            const int cols_left = W - x0;                  // pixels of this tile row inside the image
+            const __amdgpu_buffer_rsrc_t rsO = make_rsrc(out + rbase, (unsigned)((cols_left < ET_W ? cols_left : ET_W) * Cout * 4));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const unsigned lane_off = rowok ? (unsigned)((4 * khalf * Cout + j * 32 + xl) * 4) : kOOB;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int px = (r & 3) + 8 * (r >> 2);          // + 4 khalf in the lane offset
+                    float v = acc[q][j][r];
+                    if (MODE == 1) {
+                        const float y = fmaf(v, sc[j], sh[j]);
+                        v = y > 0.f ? y : y * slope;
+                        acc[q][j][r] = v;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rsO, lane_off, px * Cout * 4, 0);
+                    if (MODE == 0) {
+                        const bool in = rowok && px + 4 * khalf < cols_left;
+                        const float vm = in ? v : 0.f;
+                        st_s[j] += vm;
+                        st_q[j] = fmaf(vm, vm, st_q[j]);
+                    }
+                }
+            }
+        }
+        if (MODE == 1 && aux) {                    // 2 x 2 max-pool of the row pair: first maximum in window order, NaN wins
+            const int gy = y0 + py;
+            const bool rowok = gy < H;
+            const long pbase = (((long)n * H2 + ((rowok ? gy : 0) >> 1)) * W2 + (x0 >> 1)) * Cout;
+            const int pcols = (W - x0) >> 1;
+            const __amdgpu_buffer_rsrc_t rsP = make_rsrc(aux + pbase, (unsigned)((pcols < ET_W / 2 ? pcols : ET_W / 2) * Cout * 4));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const unsigned lane_off = rowok ? (unsigned)((2 * khalf * Cout + j * 32 + xl) * 4) : kOOB;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int px = (r & 3) + 8 * (r >> 2);
+                    float m = acc[0][j][r];
+                    const float c1 = acc[0][j][r + 1], c2 = acc[1][j][r], c3 = acc[1][j][r + 1];
+                    if (c1 > m || c1 != c1) m = c1;
+                    if (c2 > m || c2 != c2) m = c2;
+                    if (c3 > m || c3 != c3) m = c3;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(m), rsP, lane_off, (px >> 1) * Cout * 4, 0);
+                }
+            }
+        }
+    }
+    if (MODE == 0 && aux) {                        // BN statistics of the tile -> aux[tile][2][Cout], fixed order: halves, then waves
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float s2 = st_s[j] + __shfl_xor(st_s[j], 32), q2 = st_q[j] + __shfl_xor(st_q[j], 32);
+            if (khalf == 0) {
+                red[(wave * 2 + 0) * Cout + j * 32 + xl] = s2;
+                red[(wave * 2 + 1) * Cout + j * 32 + xl] = q2;
+            }
+        }
+        __syncthreads();
+        for (int e = t; e < 2 * Cout; e += 256) {
+            const int qq = e / Cout, c = e - qq * Cout;
+            aux[(long)tl * 2 * Cout + e] = ((red[(0 * 2 + qq) * Cout + c] + red[(1 * 2 + qq) * Cout + c]) + red[(2 * 2 + qq) * Cout + c]) +
+                                           red[(3 * 2 + qq) * Cout + c];
+        }
+    }
+}
+
+template <int CIN, int MODE>
+static void launch_first_mfma(const float* x, const float* wt, float* out, float* aux, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, float slope, const float* slope_dev, int n, int h, int w,
+                              int cout, hipStream_t s) {
+    const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H), nt = n * tx * ty;
+    if (cout == 64) hipLaunchKernelGGL((conv_first_fwd_mfma_kernel<CIN, 2, MODE>), dim3(nt), dim3(256), 0, s, x, wt, out, aux, mean, invstd, gamma, beta, slope, slope_dev, n, h, w, tx, ty);
+    else hipLaunchKernelGGL((conv_first_fwd_mfma_kernel<CIN, 1, MODE>), dim3(nt), dim3(256), 0, s, x, wt, out, aux, mean, invstd, gamma, beta, slope, slope_dev, n, h, w, tx, ty);
+}
+// (Cout = 128 would need 8 accumulators + 4 x NS weights per lane: it stays on the segment kernels)
+// OPT-IN (edge_conv >= 0 with bit 64 set), not part of "-1 = everything": measured SLOWER than the segment kernels although it takes
+// the 27 multiply-adds per element off the vector ALU (profiles/r05_notes.md section 11: cfg-S level 0 alone 192 vs 175 us; with the
+// stores removed 113 us -- of which the matrix pipe is busy 47 us --, with the MFMAs removed 144 us: one tile per block leaves the halo
+// load, the 3 us of MFMAs and 128 four-byte stores per lane of a tile in sequence, and the old kernel's 16-byte stores reach the HBM
+// write rate the 4-byte ones of the C layout do not).  Kept because it pins a fact the design leans on elsewhere: the fp32 MFMA is
+// the SAME BITS as the fmaf chain (tests/test_ops_gpu.py::test_first_convolution_on_the_matrix_pipe_is_bit_identical).
+static bool first_mfma_ok(int cout) {
+    const int v = tune(TUNE_EDGE_CONV);
+    return (cout == 32 || cout == 64) && v >= 0 && (v & 64);
+}
+
 // (5 and 6 input channels would need > 256 registers for the 216 weight-gradient accumulators: they stay on the generic kernel)
 static bool first_shape_ok(int cin, int cout) { return cin >= 1 && cin <= 4 && (cout == 32 || cout == 64 || cout == 128); }
 
@@ -1338,7 +1512,9 @@ template <int CIN>
 static int launch_first_seg(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
                             int w, int cout, hipStream_t s, const FirstBnBwd* bn) {
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H), nt = n * tx * ty;
-    if (!wgrad) {
+    if (!wgrad && first_mfma_ok(cout)) {
+        launch_first_mfma<CIN, 0>(x, wt, z, partial, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, n, h, w, cout, s);
+    } else if (!wgrad) {
         if (cout == 64) hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 16>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
         else if (cout == 32) hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 8>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
         else hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 32>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
@@ -1381,6 +1557,11 @@ static int launch_first_act(const float* x, const float* wt, const float* mean, 
                             const float* beta, float slope, const float* slope_dev, float* a, float* pooled, int n, int h, int w,
                             int cout, hipStream_t s) {
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H), nt = n * tx * ty;
+    if (first_mfma_ok(cout)) {
+        launch_first_mfma<CIN, 1>(x, wt, a, pooled, mean, invstd, gamma, beta, slope, slope_dev, n, h, w, cout, s);
+        RD_LAUNCH_CHECK("conv_first_fwd_act");
+        return RD_OK;
+    }
     if (cout == 64) hipLaunchKernelGGL((conv_first_fwd_act_seg_kernel<CIN, 16>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty);
     else if (cout == 32) hipLaunchKernelGGL((conv_first_fwd_act_seg_kernel<CIN, 8>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty);
     else hipLaunchKernelGGL((conv_first_fwd_act_seg_kernel<CIN, 32>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty);

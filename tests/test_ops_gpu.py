@@ -1026,3 +1026,48 @@ def test_first_convolution_with_bn_activation_and_pool_in_its_epilogue(n, cin, h
     a3, p3 = ops.conv3x3_first_fwd_act(xc.to(dev()), wt, mean, invstd, gamma, beta, slope, sdev, pool=True)
     close(nchw(a3), yt, tol=2e-6, name="a")
     close(nchw(p3), F.max_pool2d(yt, 2), tol=2e-6, name="pooled")
+
+
+@pytest.mark.parametrize("cin", [1, 2, 3, 4])
+@pytest.mark.parametrize("cout", [32, 64])
+def test_first_convolution_on_the_matrix_pipe_is_bit_identical(cin, cout):
+    """r05: `encoder.0.0.0` (lib/UNet.py:159) forward on `v_mfma_f32_32x32x2_f32` -- fp32 fused multiply-adds in the k order of the
+    vector kernels (opt-in, knob edge_conv = 127: measured slower, profiles/r05_notes.md section 11) -- against those kernels (the
+    default): z THE SAME BITS, on full and ragged tiles; the
+    BatchNorm statistics of its epilogue agree to rounding (another summation order); the inference form (eval BN + activation +
+    2 x 2 max-pool in the epilogue) gives the same activation and pooled BITS, NaN / tie rule included."""
+    from resdepth_amd import ops, _lib
+    _lib.load()
+    g = torch.Generator().manual_seed(100 * cin + cout)
+    for (n, h, w) in ((3, 64, 96), (2, 48, 40), (1, 16, 8)):
+        x = torch.randn(n, cin, h, w, generator=g)
+        x[0, 0, 3, 5] = float("nan") if h == 48 else x[0, 0, 3, 5]
+        x[-1, -1, 6:8, 6:8] = 0.25                                   # a constant patch: pool ties
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.3
+        mean, var = torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5
+        gamma, beta = torch.randn(cout, generator=g), torch.randn(cout, generator=g) * 0.2
+        xd, wd = x.to(DEV), wt.to(DEV)
+        invstd = (var + 1e-5).rsqrt().to(DEV)
+        res = {}
+        for knob in (127, -1):
+            _lib.tune_set("edge_conv", knob)
+            try:
+                z = ops.conv3x3_first_fwd(xd, wd)
+                z2, sums = ops.conv3x3_first_fwd_stats(xd, wd)
+                a, p = ops.conv3x3_first_fwd_act(xd, wd, mean.to(DEV), invstd, gamma.to(DEV), beta.to(DEV), 0.01, None, pool=True)
+                torch.cuda.synchronize()
+            finally:
+                _lib.tune_set("edge_conv", -1)
+            res[knob] = (z.cpu(), z2.cpu(), sums.cpu(), a.cpu(), p.cpu())
+        new, old = res[127], res[-1]
+        same = lambda u, v: torch.equal(u.view(torch.int32), v.view(torch.int32))
+        assert same(new[0], old[0]) and same(new[1], old[1]), (cin, cout, n, h, w)
+        assert same(new[3], old[3]) and same(new[4], old[4]), (cin, cout, n, h, w)
+        fin = torch.isfinite(old[2])
+        assert torch.equal(fin, torch.isfinite(new[2]))
+        if bool(fin.any()):
+            assert float(((new[2] - old[2])[fin]).abs().max() / (old[2][fin].abs().max() + 1e-30)) <= 1e-6
+        # and against torch on the CPU (what both have to be)
+        ref = F.conv2d(x, wt, None, 1, 1).permute(0, 2, 3, 1)
+        ok = torch.isfinite(ref)
+        assert float((new[0][ok] - ref[ok]).abs().max()) <= 2e-5 * float(ref[ok].abs().max())
