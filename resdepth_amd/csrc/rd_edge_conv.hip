@@ -20,7 +20,7 @@
 namespace rd {
 
 // TUNE_EDGE_CONV: -1 all kernels of this file, else a bit mask (1 last fwd, 2 last dgrad, 4 last wgrad, 8 first fwd, 16 first wgrad,
-// 32 the composed tail kernels); bit 64 (opt-in only, not implied by -1): the first convolution's forward on the matrix pipe)
+// 32 the composed tail kernels); bits 64 / 128 (opt-in only, not implied by -1): the first convolution's forward / fused weight gradient on the matrix pipe)
 static bool edge_on(int bit) {
     const int v = tune(TUNE_EDGE_CONV);
     return v < 0 || (v & bit);
@@ -1494,6 +1494,172 @@ static bool first_mfma_ok(int cout) {
     return (cout == 32 || cout == 64) && v >= 0 && (v & 64);
 }
 
+// ---- the first convolution's fused weight gradient on the matrix pipe, in exact fp32 (r05) -----------------------------------------
+// conv_first_wgrad_seg_kernel<.., true> is bound by vector-ALU issue (0.81 of its cycles; profiles/r05_notes.md section 6): 54 vector
+// instructions per dz element, 27 of them the products dW[co][k] += dz[p][co] * xpatch[p][k].  Here those products are a GEMM on
+// `v_mfma_f32_32x32x2_f32` with K = pixels:
+//   A[co][p]: the lane (co = lane % 32 + 32 j, khalf = lane / 32) EVALUATES dz of pixel (row, 2 xs + khalf) for its channel -- the
+//             BatchNorm / activation / un-pool / skip-add backward of the segment kernel, expression for expression -- from 4-byte
+//             loads (lanes 0-31 = 128 contiguous bytes of one pixel); the operand never exists anywhere but in that register;
+//   B[p][k]:  lane (k = lane % 32 -> (ky, kx, ci), khalf) reads X[ci][row + ky][2 xs + khalf + kx] from the LDS halo: one
+//             conflict-free ds_read_b32 (bank = 8 ci + 4 ky + kx + khalf);
+//   C[co][k]: NB accumulators of 16 registers instead of 27 x 4 per lane.
+// Per step (2 pixels x 32 NB channels): 2 NB x ~24 vector instructions + 9 shared LDS reads of the dout tile (composed tail) against
+// NB MFMAs of 64 cycles -- about 40 % of the segment kernel's vector work per element.  A wave walks four image rows of the 16 x 32 tile;
+// the four waves' accumulators are added in wave order through LDS at the end of the block's tile loop: partial[block][k][Cout], the
+// segment kernel's layout, reduced over blocks by first_wgrad_reduce_kernel as before.  Deterministic; not bit-identical to the segment
+// kernel (another summation order), same fp32 products.
+template <int CIN, int NB, bool GF>      // GF: the full-resolution gradient operand is a tensor (else: absent, or evaluated from dout)
+__global__ __launch_bounds__(256, 4) void conv_first_wgrad_mfma_kernel(const float* __restrict__ x, float* __restrict__ partial, int N,
+                                                                    int H, int W, int tiles_x, int tiles_y, int ntiles, FirstBnBwd bn,
+                                                                    unsigned z_bytes, unsigned p_bytes, unsigned i_bytes) {
+    constexpr int Cout = NB * 32, NT = 9 * CIN, GS = NB == 2 ? 2 : 4;       // GS steps (pixel pairs) x two rows per batch of loads
+    static_assert(NT <= 32, "one 32-column block of (tap, ci)");
+    extern __shared__ __attribute__((aligned(16))) float msm[];
+    float* X = msm;                               // halo planes
+    float* Dl = X + CIN * FH_PLANE;               // dout tile + halo (640)
+    float* red = msm;                             // after the tile loop: [4 waves][NB][16][64], over the halo planes
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, xl = lane & 31, khalf = lane >> 5;
+    const bool lazy_g = bn.dout != nullptr;
+    float sc[NB], sh[NB], mu[NB], is[NB], k1[NB], k2[NB], wl[NB][9];
+    const float slope = bn.slope_dev ? bn.slope_dev[0] : bn.slope;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int co = j * 32 + xl;
+        mu[j] = bn.mean[co];
+        is[j] = bn.invstd[co];
+        sc[j] = is[j] * bn.gamma[co];
+        sh[j] = bn.beta[co] - mu[j] * sc[j];
+        k1[j] = k2[j] = 0.f;
+        if (bn.training) {
+            k1[j] = (float)(bn.sums[co] / bn.count);
+            k2[j] = (float)(bn.sums[Cout + co] / bn.count);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wl[j][tap] = lazy_g ? bn.w_last[co * 9 + tap] : 0.f;
+    }
+    // B operand: column k = xl -> row j_ = (ky * 3 + kx) * CIN + ci of the partial layout; columns >= NT are never written out
+    int boff;
+    {
+        const int j_ = xl < NT ? xl : 0, tap = j_ / CIN, ci = j_ - tap * CIN;
+        boff = ci * FH_PLANE + (tap / 3) * FP + tap % 3 + khalf;
+    }
+    const __amdgpu_buffer_rsrc_t rsZ = make_rsrc(bn.z, z_bytes), rsG = make_rsrc(bn.g_full ? bn.g_full : bn.z, z_bytes);
+    const __amdgpu_buffer_rsrc_t rsP = make_rsrc(bn.g_pool ? bn.g_pool : bn.z, p_bytes), rsI = make_rsrc(bn.idx ? (const void*)bn.idx : (const void*)bn.z, i_bytes);
+    const bool has_gp = bn.g_pool != nullptr;
+    const unsigned zlane = (unsigned)((khalf * Cout + xl) * 4), plane = (unsigned)(xl * 4), ilane = (unsigned)xl;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+        const int y0 = ty * ET_H, x0 = tx * ET_W;
+        __syncthreads();
+        load_x_halo<CIN>(X, x, n, y0, x0, H, W, t);
+        if (lazy_g) load_dout_tile(Dl, bn.dout, n, y0, x0, H, W, t);
+        __syncthreads();
+        // a wave takes image rows 4 wave .. 4 wave + 3 as two ROW PAIRS: the four pixels of a 2 x 2 pooling window (two steps of two
+        // rows) share one load of the pooled gradient and of the arg-max byte
+#pragma unroll 1
+        for (int rp = 0; rp < 2; ++rp) {
+            const int py = wave * 4 + rp * 2, gy = y0 + py;                                  // gy even
+            const bool rok0 = gy < H, rok1 = gy + 1 < H;
+            // byte offsets of the tile rows (scalar); < 4 GB checked by the launcher
+            const unsigned zrow = (unsigned)__builtin_amdgcn_readfirstlane((int)((((long)n * H + gy) * W + x0) * Cout * 4));
+            const unsigned zrow1 = zrow + (unsigned)(W * Cout * 4);
+            const unsigned prow = (unsigned)__builtin_amdgcn_readfirstlane((int)((((long)n * (H >> 1) + (gy >> 1)) * (W >> 1) + (x0 >> 1)) * Cout));
+            const float* xb = X + py * FP + boff;
+            const float* db = Dl + (py + 2) * EH_W + khalf + 2;
+#pragma unroll 1
+            for (int x4 = 0; x4 < 16; x4 += GS) {
+                float zv[2][GS][NB], gf[2][GS][GF ? NB : 1], gp[GS][NB];
+                int pi[GS][NB];
+                bool ok[2][GS];
+                const unsigned zs = (unsigned)(2 * x4 * Cout * 4), ps = (unsigned)(x4 * Cout);
+#pragma unroll
+                for (int u = 0; u < GS; ++u) {         // the loads of GS steps x two rows go out together; masked lanes carry an
+                    const int px = 2 * (x4 + u) + khalf;                    // out-of-extent offset and read zeros (no branch, no wait)
+                    const bool cok = x0 + px < W;
+                    ok[0][u] = rok0 && cok;
+                    ok[1][u] = rok1 && cok;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const unsigned zi = (unsigned)((2 * u * Cout + j * 32) * 4), pq = (unsigned)(u * Cout + j * 32);
+                        const unsigned v0 = ok[0][u] ? zlane + zi : kOOB, v1 = ok[1][u] ? zlane + zi : kOOB;
+                        zv[0][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsZ, v0, zrow + zs, 0));
+                        zv[1][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsZ, v1, zrow1 + zs, 0));
+                        if (GF) {
+                            gf[0][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsG, v0, zrow + zs, 0));
+                            gf[1][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsG, v1, zrow1 + zs, 0));
+                        }
+                        const bool pok = ok[0][u] && has_gp;                  // H even: row gy + 1 exists whenever gy does
+                        gp[u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsP, pok ? plane + pq * 4 : kOOB, (prow + ps) * 4, 0));
+                        pi[u][j] = (int)__builtin_amdgcn_raw_buffer_load_b8(rsI, pok ? ilane + pq : kOOB, prow + ps, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int kwin = q << 1 | khalf;                                          // this pixel's place in its 2 x 2 window
+#pragma unroll
+                    for (int u = 0; u < GS; ++u) {
+                        const int pxe = 2 * (x4 + u);                                        // even pixel of the pair
+                        const float b = xb[q * FP + pxe];
+                        float dv[9];
+                        if (lazy_g) {
+#pragma unroll
+                            for (int tap = 0; tap < 9; ++tap) dv[tap] = db[q * EH_W + pxe - (tap / 3) * EH_W - tap % 3];
+                        }
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) {
+                            float g = GF ? gf[q][u][GF ? j : 0] : 0.f;
+                            if (lazy_g) {              // g[q][c] = sum_tap dout[q - off(tap)] w_last[c][tap], taps in order from zero
+                                float ga = 0.f;
+#pragma unroll
+                                for (int tap = 0; tap < 9; ++tap) ga = fmaf(dv[tap], wl[j][tap], ga);
+                                g = ga;
+                            }
+                            const float xz = zv[q][u][j];
+                            const float y = fmaf(xz, sc[j], sh[j]);
+                            if (pi[u][j] == kwin) g += gp[u][j];
+                            const float gm = g * (y > 0.f ? 1.f : slope);
+                            const float xh = (xz - mu[j]) * is[j];
+                            const float o = bn.training ? sc[j] * (gm - k1[j] - xh * k2[j]) : sc[j] * gm;
+                            const float dzv = ok[q][u] ? o : 0.f;
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dzv, b, acc[j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- the four waves' accumulators, added in wave order; rows = co (C layout), columns = k -> partial[block][k][Cout]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * NB + j) * 16 + r) * 64 + lane] = acc[j][r];
+    __syncthreads();
+    float* out = partial + (long)blockIdx.x * NT * Cout;
+    for (int e = t; e < NB * 16 * 64; e += 256) {
+        const int l = e & 63, r = (e >> 6) & 15, j = e >> 10;
+        const int k = l & 31, co = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (k < NT) {
+            const float v = ((red[((0 * NB + j) * 16 + r) * 64 + l] + red[((1 * NB + j) * 16 + r) * 64 + l]) +
+                             red[((2 * NB + j) * 16 + r) * 64 + l]) + red[((3 * NB + j) * 16 + r) * 64 + l];
+            out[(long)k * Cout + co] = v;
+        }
+    }
+}
+
+// OPT-IN while it is being measured: edge_conv >= 0 with bit 128 set
+static bool first_wgrad_mfma_ok(int cin, int cout, int n, int h, int w) {
+    const int v = tune(TUNE_EDGE_CONV);
+    return cin <= 3 && (cout == 32 || cout == 64) && v >= 0 && (v & 128) && 4.0 * n * h * (double)w * cout < 4294967040.0;
+}
+
 // (5 and 6 input channels would need > 256 registers for the 216 weight-gradient accumulators: they stay on the generic kernel)
 static bool first_shape_ok(int cin, int cout) { return cin >= 1 && cin <= 4 && (cout == 32 || cout == 64 || cout == 128); }
 
@@ -1524,6 +1690,20 @@ static int launch_first_seg(bool wgrad, const float* x, const float* wt, float* 
             return RD_ERR_ARG;
         } else {
         const int nb = nt < 1024 ? nt : 1024;
+        if (first_wgrad_mfma_ok(CIN, cout, n, h, w)) {
+            const unsigned zb = (unsigned)(4.0 * n * h * (double)w * cout), pb = zb / 4, ib = zb / 16;
+            const size_t halo = CIN * FH_PLANE + 640, redw = (size_t)4 * (cout / 32) * 16 * 64;
+            const size_t sm = (halo > redw ? halo : redw) * sizeof(float);
+            if (bn->g_full) {
+                if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_mfma_kernel<CIN, 2, true>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
+                else hipLaunchKernelGGL((conv_first_wgrad_mfma_kernel<CIN, 1, true>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
+            } else {
+                if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_mfma_kernel<CIN, 2, false>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
+                else hipLaunchKernelGGL((conv_first_wgrad_mfma_kernel<CIN, 1, false>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
+            }
+            RD_LAUNCH_CHECK("conv_first_wgrad_mfma");
+            return RD_OK;
+        }
         const size_t smem = (size_t)(CIN * FH_PLANE + 9 * 256 * 4 + 640 + 9 * cout) * sizeof(float);
         if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 16, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
         else if (cout == 32) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 8, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);

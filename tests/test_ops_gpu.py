@@ -726,12 +726,24 @@ def test_8x8_patch_kernel_does_not_depend_on_the_batch_size():
     close(nchw(big[:8]), F.conv2d(x[:8].double(), wt.double(), None, 1, 1).float(), name="8x8 patch kernel vs fp64")
 
 
+@pytest.fixture(params=["vector", "matrix"])
+def first_wgrad_pipe(request):
+    """The fused first weight gradient on the vector ALU (segment kernel) or on the exact-f32 matrix pipe (knob edge_conv bit 128)."""
+    from resdepth_amd import _lib
+    _lib.load()
+    _lib.tune_set("edge_conv", 63 | 128 if request.param == "matrix" else -1)
+    yield request.param
+    _lib.tune_set("edge_conv", -1)
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout,slope,training", [(2, 64, 64, 3, 64, 0.0, True), (3, 32, 96, 1, 32, 0.01, True),
-                                                           (1, 48, 34, 2, 128, 0.01, False), (2, 18, 30, 3, 64, 0.0, True)])
-def test_first_conv_weight_gradient_with_the_bn_backward_evaluated_on_the_fly(n, h, w, cin, cout, slope, training):
+                                                           (1, 48, 34, 2, 128, 0.01, False), (2, 18, 30, 3, 64, 0.0, True),
+                                                           (2, 32, 64, 2, 64, 0.01, False)])
+def test_first_conv_weight_gradient_with_the_bn_backward_evaluated_on_the_fly(n, h, w, cin, cout, slope, training, first_wgrad_pipe):
     """rd_conv3x3_first_bwd_weight_bn == rd_conv3x3_first_bwd_weight(x, rd_bn_act_bwd_apply(...)): the first block's dz (BN +
     activation + un-pool + skip add, lib/UNet.py:44-47,159-161 differentiated) has the weight gradient as its only reader and
-    is evaluated inside it; tiles that are not multiples of 16 x 32, PReLU slope on the device, eval-mode form."""
+    is evaluated inside it; tiles that are not multiples of 16 x 32, PReLU slope on the device, eval-mode form.  Both
+    implementations: the segment kernel (vector ALU) and the r05 matrix-pipe kernel (v_mfma_f32_32x32x2_f32, K = pixels)."""
     from resdepth_amd import ops
     g = torch.Generator().manual_seed(h * 7 + cout)
     x = torch.randn(n, cin, h, w, generator=g).to(dev())
