@@ -20,7 +20,7 @@
 namespace rd {
 
 // TUNE_EDGE_CONV: -1 all kernels of this file, else a bit mask (1 last fwd, 2 last dgrad, 4 last wgrad, 8 first fwd, 16 first wgrad,
-// 32 the composed tail kernels); bits 64 / 128 (opt-in only, not implied by -1): the first convolution's forward / fused weight gradient on the matrix pipe)
+// 32 the composed tail kernels); 128 the first convolution's fused weight gradient on the matrix pipe; bit 64 (opt-in only, NOT implied by -1): its forward there)
 static bool edge_on(int bit) {
     const int v = tune(TUNE_EDGE_CONV);
     return v < 0 || (v & bit);
@@ -1654,10 +1654,10 @@ __global__ __launch_bounds__(256, 4) void conv_first_wgrad_mfma_kernel(const flo
     }
 }
 
-// OPT-IN while it is being measured: edge_conv >= 0 with bit 128 set
+// Default since r05 (cfg-S level 0: 0.272 -> 0.217 ms in the step, +0.6 % end to end, profiles/r05_notes.md section 12); edge_conv
+// without bit 128 (e.g. 63) selects the segment kernel.
 static bool first_wgrad_mfma_ok(int cin, int cout, int n, int h, int w) {
-    const int v = tune(TUNE_EDGE_CONV);
-    return cin <= 3 && (cout == 32 || cout == 64) && v >= 0 && (v & 128) && 4.0 * n * h * (double)w * cout < 4294967040.0;
+    return cin <= 3 && (cout == 32 || cout == 64) && edge_on(128) && 4.0 * n * h * (double)w * cout < 4294967040.0;
 }
 
 // (5 and 6 input channels would need > 256 registers for the 216 weight-gradient accumulators: they stay on the generic kernel)

@@ -728,10 +728,11 @@ def test_8x8_patch_kernel_does_not_depend_on_the_batch_size():
 
 @pytest.fixture(params=["vector", "matrix"])
 def first_wgrad_pipe(request):
-    """The fused first weight gradient on the vector ALU (segment kernel) or on the exact-f32 matrix pipe (knob edge_conv bit 128)."""
+    """The fused first weight gradient on the exact-f32 matrix pipe (the default since r05) or on the vector ALU (segment kernel:
+    knob edge_conv without bit 128)."""
     from resdepth_amd import _lib
     _lib.load()
-    _lib.tune_set("edge_conv", 63 | 128 if request.param == "matrix" else -1)
+    _lib.tune_set("edge_conv", -1 if request.param == "matrix" else 63)
     yield request.param
     _lib.tune_set("edge_conv", -1)
 
