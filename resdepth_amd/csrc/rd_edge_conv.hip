@@ -20,7 +20,8 @@
 namespace rd {
 
 // TUNE_EDGE_CONV: -1 all kernels of this file, else a bit mask (1 last fwd, 2 last dgrad, 4 last wgrad, 8 first fwd, 16 first wgrad,
-// 32 the composed tail kernels); 128 the first convolution's fused weight gradient on the matrix pipe; bit 64 (opt-in only, NOT implied by -1): its forward there)
+// 32 the composed tail kernels); 128 the first convolution's fused weight gradient on the matrix pipe; bits 64 / 256 (opt-in only, NOT implied by -1): the first
+// convolution's forward / the fused head of the backward there)
 static bool edge_on(int bit) {
     const int v = tune(TUNE_EDGE_CONV);
     return v < 0 || (v & bit);
@@ -1803,9 +1804,173 @@ int conv_last_tail_blocks(int n, int h, int w) {
     return (int)(nt < 1024 ? nt : 1024);
 }
 
+// ---- the head of the backward on the matrix pipe, in exact fp32 (r05; cf. conv_first_wgrad_mfma_kernel) -------------------------------
+// conv_last_bwd_tail_fused_kernel spends 18 of its ~33 vector instructions per element on two sets of nine products: the gradient
+// g = conv_last^T(dout) it evaluates per element, and the last convolution's weight gradient dw[c][tap] += act(BN(z))[p][c] dout[p - off].
+// Both are small GEMMs on `v_mfma_f32_32x32x2_f32`, per 32-pixel image row of the 16 x 32 tile and 32-channel block:
+//   G[p][c]   = sum_tap D[p - off(tap)] w[c][tap]   K = 9 taps (+ one zero): 5 MFMAs; lands in the C layout -- lane = channel,
+//               sixteen pixels P(r) = (r & 3) + 8 (r >> 2) + 4 khalf;
+//   dW[c][tap] += sum_p a[p][c] D[p - off(tap)]      K = pixels, taken in exactly that order: step r pairs pixel P(r) (lanes 0-31) with
+//               P(r) + 4 (lanes 32-63), so the lane that holds g of a pixel also loads its z (128 contiguous bytes per half wave),
+//               forms a = act(BN(z)) as the A operand and the BatchNorm-backward statistics of that element; B = the dout value of
+//               (pixel, tap = lane % 32), one LDS read, whose masked sum over the steps IS S[tap] (the bias part).
+// Per block the same rows as the vector kernel: wpartial[block][9 C + 9] doubles, bn_part[block][4][C] floats; the four waves are added
+// in wave order.  Deterministic; another summation order than the vector kernel's, the same fp32 products.
+template <int NB>
+__global__ __launch_bounds__(256, 4) void conv_last_bwd_tail_mfma_kernel(TailSkip sk, const float* __restrict__ dout,
+                                                                      const float* __restrict__ w, double* __restrict__ wpartial,
+                                                                      float* __restrict__ bn_part, int N, int H, int W, int tiles_x,
+                                                                      int tiles_y, int ntiles, unsigned z_bytes) {
+    constexpr int C = NB * 32;
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
+    float* D = tsm;                                // dout tile + halo (640)
+    float* red = tsm;                              // after the tile loop: [4][NB][16][64] accumulators, then the small sums
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, xl = lane & 31, khalf = lane >> 5;
+    const float slope = sk.slope_dev ? sk.slope_dev[0] : sk.slope;
+    float sc[NB], sh[NB], mu[NB], is[NB], wr5[NB][5];
+    int goff[5];
+#pragma unroll
+    for (int s_ = 0; s_ < 5; ++s_) {
+        const int k = 2 * s_ + khalf, kk = k < 9 ? k : 8;
+        goff[s_] = (2 - kk / 3) * EH_W + 2 - kk % 3;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) wr5[j][s_] = k < 9 ? w[(j * 32 + xl) * 9 + k] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int c = j * 32 + xl;
+        mu[j] = sk.mean[c];
+        is[j] = sk.invstd[c];
+        sc[j] = is[j] * sk.gamma[c];
+        sh[j] = sk.beta[c] - mu[j] * sc[j];
+    }
+    const int tapl = xl < 9 ? xl : 0;
+    const int boff = (2 - tapl / 3) * EH_W + 2 - tapl % 3 + 4 * khalf;      // B operand of the weight gradient: (tap = xl, pixel half)
+    const __amdgpu_buffer_rsrc_t rsZ = make_rsrc(sk.z, z_bytes);
+    const unsigned zlane = (unsigned)((4 * khalf * C + xl) * 4);
+    f32x16 acc[NB];
+    float bacc[NB][4], accs = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bacc[j][k] = 0.f;
+    }
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tx = tl % tiles_x, ty = (tl / tiles_x) % tiles_y, n = tl / (tiles_x * tiles_y);
+        const int y0 = ty * ET_H, x0 = tx * ET_W;
+        __syncthreads();
+        load_dout_tile(D, dout, n, y0, x0, H, W, t);
+        __syncthreads();
+#pragma unroll 1
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int py = wave * 4 + r4, gy = y0 + py;
+            const bool rowok = gy < H;
+            const unsigned zrow = (unsigned)__builtin_amdgcn_readfirstlane((int)((((long)n * H + gy) * W + x0) * C * 4));
+            const float* dr = D + py * EH_W;
+            f32x16 gt[NB];                         // g of this image row: lane = channel, register r = pixel P(r) + 4 khalf
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gt[j][r] = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < 5; ++s_) {
+                const float a = dr[xl + goff[s_]];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) gt[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wr5[j][s_], gt[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 16; rb += 8) {
+                float zv[8][NB];
+                bool ok[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {          // masked lanes carry an out-of-extent offset and read zeros
+                    const int r = rb + u, p0 = (r & 3) + 8 * (r >> 2);
+                    ok[u] = rowok && x0 + p0 + 4 * khalf < W;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        zv[u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsZ, ok[u] ? zlane + (unsigned)((p0 * C + j * 32) * 4) : kOOB, zrow, 0));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = rb + u, p0 = (r & 3) + 8 * (r >> 2);
+                    const float b = dr[p0 + boff];
+                    accs += ok[u] ? b : 0.f;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const float zz = zv[u][j];
+                        const float yv = fmaf(zz, sc[j], sh[j]);
+                        const float av = yv > 0.f ? yv : yv * slope;
+                        const float g = ok[u] ? gt[j][r] : 0.f;
+                        const float gm = g * (yv > 0.f ? 1.f : slope);
+                        const float xh = (zz - mu[j]) * is[j];
+                        bacc[j][0] += gm;
+                        bacc[j][1] = fmaf(gm, xh, bacc[j][1]);
+                        bacc[j][2] += g;
+                        if (!(yv > 0.f)) bacc[j][3] = fmaf(g, yv, bacc[j][3]);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok[u] ? av : 0.f, b, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- block reduction, fixed order: waves 0..3 (and the two pixel halves of a lane pair for the per-channel sums)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * NB + j) * 16 + r) * 64 + lane] = acc[j][r];
+    __syncthreads();
+    double* out = wpartial + (long)blockIdx.x * (9 * C + 9);
+    for (int e = t; e < NB * 16 * 64; e += 256) {
+        const int l = e & 63, r = (e >> 6) & 15, j = e >> 10;
+        const int tap = l & 31, co = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (tap < 9)
+            out[tap * C + co] = (((double)red[((0 * NB + j) * 16 + r) * 64 + l] + (double)red[((1 * NB + j) * 16 + r) * 64 + l]) +
+                                 (double)red[((2 * NB + j) * 16 + r) * 64 + l]) + (double)red[((3 * NB + j) * 16 + r) * 64 + l];
+    }
+    __syncthreads();
+    // per-channel statistics [4][C] and S[tap]: [wave][half][..] in LDS
+    float* rs = red;                               // [4 waves][2 halves][NB * 4 * 32]
+    float* ra = red + 4 * 2 * NB * 128;            // [4 waves][64 lanes]
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rs[((wave * 2 + khalf) * NB + j) * 128 + k * 32 + xl] = bacc[j][k];
+    ra[wave * 64 + lane] = accs;
+    __syncthreads();
+    for (int o = t; o < 4 * C; o += 256) {
+        const int k = o / C, c = o - k * C, j = c >> 5, cl = c & 31;
+        float sum = 0.f;
+        for (int wv = 0; wv < 4; ++wv)
+            for (int hf = 0; hf < 2; ++hf) sum += rs[((wv * 2 + hf) * NB + j) * 128 + k * 32 + cl];
+        bn_part[((long)blockIdx.x * 4 + k) * C + c] = sum;
+    }
+    if (t < 9) {
+        double sum = 0.0;
+        for (int wv = 0; wv < 4; ++wv)
+            for (int hf = 0; hf < 2; ++hf) sum += (double)ra[wv * 64 + hf * 32 + t];
+        out[9 * C + t] = sum;
+    }
+}
+
 int conv_last_bwd_tail_fused_launch(const TailSkip& sk, const float* dout, const float* wl, double* wpartial, float* bn_part, int n,
                                     int h, int w, int c, hipStream_t s) {
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H), nb = conv_last_tail_blocks(n, h, w);
+    {
+        // matrix-pipe form (r05): OPT-IN (edge_conv >= 0 with bit 256) -- 0.181 -> 0.161 ms for the kernel, nothing end to end
+        // (profiles/r05_notes.md section 13)
+        const int v = tune(TUNE_EDGE_CONV);
+        const double zb = 4.0 * n * h * (double)w * c;
+        if ((c == 32 || c == 64) && v >= 0 && (v & 256) && zb < 4294967040.0) {
+            const size_t words = (size_t)4 * (c / 32) * 16 * 64;      // >= 640 + the small sums
+            if (c == 64) hipLaunchKernelGGL(conv_last_bwd_tail_mfma_kernel<2>, dim3(nb), dim3(256), words * sizeof(float), s, sk, dout, wl, wpartial, bn_part, n, h, w, tx, ty, n * tx * ty, (unsigned)zb);
+            else hipLaunchKernelGGL(conv_last_bwd_tail_mfma_kernel<1>, dim3(nb), dim3(256), words * sizeof(float), s, sk, dout, wl, wpartial, bn_part, n, h, w, tx, ty, n * tx * ty, (unsigned)zb);
+            RD_LAUNCH_CHECK("conv_last_bwd_tail_mfma");
+            return RD_OK;
+        }
+    }
     const size_t smem = (640 + (size_t)(256 / (c / 4)) * 9 * c) * sizeof(float);
     hipLaunchKernelGGL(conv_last_bwd_tail_fused_kernel, dim3(nb), dim3(256), smem, s, sk, dout, wl, wpartial, bn_part, n, h, w, c, c / 4,
                        tx, ty, n * tx * ty);

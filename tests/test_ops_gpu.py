@@ -837,9 +837,24 @@ def test_tail_weight_gradient_of_the_last_up_convolution_from_the_output_gradien
     close(got.cpu(), want2.cpu(), name="vs the two-kernel route")
 
 
+@pytest.fixture(params=["vector", "matrix"])
+def head_pipe(request):
+    """The fused head of the backward (rd_conv3x3_last_bwd_tail_fused) on the vector ALU or on the exact-f32 matrix pipe (knob
+    edge_conv bit 256)."""
+    from resdepth_amd import _lib
+    _lib.load()
+    _lib.tune_set("edge_conv", HEAD_KNOB[request.param])
+    yield request.param
+    _lib.tune_set("edge_conv", -1)
+
+
+HEAD_KNOB = {"vector": 255, "matrix": 255 | 256}
+
+
 @pytest.mark.parametrize("n,h,w,cin,c0,slope,res", [(2, 64, 64, 128, 64, 0.0, True), (3, 32, 96, 64, 32, 0.01, False),
-                                                    (1, 36, 20, 32, 16, 0.01, True), (2, 32, 32, 16, 16, 0.0, True)])
-def test_tail_forward_and_last_weight_gradient_without_the_up_convolution_output(n, h, w, cin, c0, slope, res):
+                                                    (1, 36, 20, 32, 16, 0.01, True), (2, 32, 32, 16, 16, 0.0, True),
+                                                    (2, 18, 44, 64, 64, 0.01, True)])
+def test_tail_forward_and_last_weight_gradient_without_the_up_convolution_output(n, h, w, cin, c0, slope, res, head_pipe):
     """rd_conv3x3_last_fwd_tail / rd_conv3x3_last_bwd_weight_tail: the last convolution applied to
     s = ConvTranspose2d(x_coarse) + act(BN(z)) (lib/UNet.py:218-227) without s ever being a tensor -- forward from z (BN +
     activation on load), T = x_coarse . V and the bias stencil; its weight / bias gradient from z, dout and the correlations C16.
