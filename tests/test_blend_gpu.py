@@ -176,3 +176,30 @@ def test_cfg_g_at_the_survey_size_properties():
     ident = predict_linear_blend(staged(ds, 32), model)
     dsm = ds.raster[0].double().numpy()
     assert float(np.abs(ident - dsm).max()) <= 2e-4 * 3.0 + 1e-3          # fp32 normalise / de-normalise of heights around 400 m
+
+
+def test_host_raster_fresh_by_default_and_reused_on_request():
+    """predict_linear_blend returns a FRESH host array per call (the reference's behaviour, lib/evaluation.py:510-513): a caller
+    holding the previous result must not see it change; `host="reuse"` (or a HostRaster handed in) delivers into the same
+    pinned memory every time, for callers that sweep many rasters of one shape."""
+    from resdepth_amd import UNet, SyntheticRasterTiles, predict_linear_blend
+    from resdepth_amd.inference import HostRaster
+    torch.manual_seed(0)
+    model = UNet(n_input_channels=3, start_kernel=8, depth=3, bias_conv_layer=True).to(DEV).eval()
+    ds = SyntheticRasterTiles(96, 160, 3, tile_size=32, seed=3)
+    ld = DataLoader(ds, batch_size=7, shuffle=False)
+    a = predict_linear_blend(ld, model)
+    keep = a.copy()
+    b = predict_linear_blend(ld, model)
+    assert not np.shares_memory(a, b) and np.array_equal(a, keep) and np.array_equal(a, b)
+    c = predict_linear_blend(ld, model, host="reuse")
+    d = predict_linear_blend(ld, model, host="reuse")
+    assert np.shares_memory(c, d) and np.array_equal(c, keep)
+    h = HostRaster(96, 160, shared=False)
+    e = predict_linear_blend(ld, model, host=h)
+    assert np.shares_memory(e, h.array) and np.array_equal(e, keep)
+    # a HostRaster of another shape is not used (and not written)
+    other = HostRaster(64, 64, shared=False)
+    other.array[:] = 7.0
+    f = predict_linear_blend(ld, model, host=other)
+    assert f.shape == (96, 160) and np.array_equal(f, keep) and float(other.array.min()) == 7.0
