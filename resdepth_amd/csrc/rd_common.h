@@ -206,3 +206,62 @@ inline PixDiv make_pixdiv(int h, int w) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Non-temporal (streaming) 16-byte accesses for tensors a kernel touches exactly once and nobody reads again soon: the loads /
+// stores carry the `nt` cache policy, so the lines do not displace what the NEXT kernel needs from the 32 MB of L2.  Measured r05
+// (profiles/r05_notes.md section 14): bn_act_pool_fwd 0.322 -> 0.270 ms per step (4.9 -> 5.9 TB/s of algorithmic bytes) with z read
+// this way.  -DRD_NO_NT builds the plain accesses for A/B runs.
+// buffer intrinsics: auxiliary cache-policy operand; bit 1 = nt on gfx940+
+#ifdef RD_NO_NT
+#define RD_AUX_NT 0
+#else
+#define RD_AUX_NT 2
+#endif
+typedef float rd_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned char rd_u8x4 __attribute__((ext_vector_type(4)));
+#if defined(__HIPCC__)
+__device__ __forceinline__ float4 ld_nt4(const float* p) {
+#ifdef RD_NO_NT
+    return *reinterpret_cast<const float4*>(p);
+#else
+    const rd_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const rd_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#endif
+}
+__device__ __forceinline__ void st_nt4(float* p, float4 v) {
+#ifdef RD_NO_NT
+    *reinterpret_cast<float4*>(p) = v;
+#else
+    __builtin_nontemporal_store(rd_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<rd_f32x4*>(p));
+#endif
+}
+__device__ __forceinline__ float ld_nt1(const float* p) {
+#ifdef RD_NO_NT
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+__device__ __forceinline__ void st_nt1(float* p, float v) {
+#ifdef RD_NO_NT
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+__device__ __forceinline__ uchar4 ld_nt_u8x4(const unsigned char* p) {
+#ifdef RD_NO_NT
+    return *reinterpret_cast<const uchar4*>(p);
+#else
+    const rd_u8x4 v = __builtin_nontemporal_load(reinterpret_cast<const rd_u8x4*>(p));
+    return make_uchar4(v.x, v.y, v.z, v.w);
+#endif
+}
+__device__ __forceinline__ void st_nt_u8x4(unsigned char* p, uchar4 v) {
+#ifdef RD_NO_NT
+    *reinterpret_cast<uchar4*>(p) = v;
+#else
+    __builtin_nontemporal_store(rd_u8x4{v.x, v.y, v.z, v.w}, reinterpret_cast<rd_u8x4*>(p));
+#endif
+}
+#endif

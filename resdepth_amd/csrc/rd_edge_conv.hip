@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void tail_t16_kernel(TailSkip sk, const float*
         float a[CPL];
 #pragma unroll
         for (int g = 0; g < CPL / 4; ++g) {
-            const float4 z4 = pix < P ? *reinterpret_cast<const float4*>(sk.z + pix * C + j * CPL + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 z4 = pix < P ? ld_nt4(sk.z + pix * C + j * CPL + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             a[g * 4 + 0] = z4.x; a[g * 4 + 1] = z4.y; a[g * 4 + 2] = z4.z; a[g * 4 + 3] = z4.w;
         }
 #pragma unroll
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void conv_last_wgrad_tail_kernel(TailSkip sk, 
                 py[u] = e / ET_W;
                 px[u] = e - py[u] * ET_W;
                 ok[u] = y0 + py[u] < H && x0 + px[u] < W;
-                s4[u] = ok[u] ? *reinterpret_cast<const float4*>(sk.z + (((long)n * H + y0 + py[u]) * W + x0 + px[u]) * C + q * 4)
+                s4[u] = ok[u] ? ld_nt4(sk.z + (((long)n * H + y0 + py[u]) * W + x0 + px[u]) * C + q * 4)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256) void conv_last_bwd_tail_fused_kernel(TailSkip 
                 py[u] = e / ET_W;
                 px[u] = e - py[u] * ET_W;
                 ok[u] = y0 + py[u] < H && x0 + px[u] < W;
-                z4[u] = ok[u] ? *reinterpret_cast<const float4*>(sk.z + (((long)n * H + y0 + py[u]) * W + x0 + px[u]) * C + q * 4)
+                z4[u] = ok[u] ? ld_nt4(sk.z + (((long)n * H + y0 + py[u]) * W + x0 + px[u]) * C + q * 4)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -1025,8 +1025,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_fwd_seg_kernel(const float*
         for (int i = 0; i < 8; ++i) {
             const int gx = x0 + c0 + i;
             if (gy < H && gx < W) {
-                *reinterpret_cast<float4*>(z + (((long)n * H + gy) * W + gx) * Cout + cq * 4) =
-                    make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                st_nt4(z + (((long)n * H + gy) * W + gx) * Cout + cq * 4, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     st_s[k] += acc[i][k];
@@ -1590,15 +1589,15 @@ __global__ __launch_bounds__(256, 4) void conv_first_wgrad_mfma_kernel(const flo
                     for (int j = 0; j < NB; ++j) {
                         const unsigned zi = (unsigned)((2 * u * Cout + j * 32) * 4), pq = (unsigned)(u * Cout + j * 32);
                         const unsigned v0 = ok[0][u] ? zlane + zi : kOOB, v1 = ok[1][u] ? zlane + zi : kOOB;
-                        zv[0][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsZ, v0, zrow + zs, 0));
-                        zv[1][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsZ, v1, zrow1 + zs, 0));
+                        zv[0][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsZ, v0, zrow + zs, RD_AUX_NT));
+                        zv[1][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsZ, v1, zrow1 + zs, RD_AUX_NT));
                         if (GF) {
-                            gf[0][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsG, v0, zrow + zs, 0));
-                            gf[1][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsG, v1, zrow1 + zs, 0));
+                            gf[0][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsG, v0, zrow + zs, RD_AUX_NT));
+                            gf[1][u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsG, v1, zrow1 + zs, RD_AUX_NT));
                         }
                         const bool pok = ok[0][u] && has_gp;                  // H even: row gy + 1 exists whenever gy does
-                        gp[u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsP, pok ? plane + pq * 4 : kOOB, (prow + ps) * 4, 0));
-                        pi[u][j] = (int)__builtin_amdgcn_raw_buffer_load_b8(rsI, pok ? ilane + pq : kOOB, prow + ps, 0);
+                        gp[u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsP, pok ? plane + pq * 4 : kOOB, (prow + ps) * 4, RD_AUX_NT));
+                        pi[u][j] = (int)__builtin_amdgcn_raw_buffer_load_b8(rsI, pok ? ilane + pq : kOOB, prow + ps, RD_AUX_NT);
                     }
                 }
 #pragma unroll

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
         const float sc[4] = {is.x * ga.x, is.y * ga.y, is.z * ga.z, is.w * ga.w};
         const float sh[4] = {be.x - mu.x * sc[0], be.y - mu.y * sc[1], be.z - mu.z * sc[2], be.w - mu.w * sc[3]};
         if (!POOL) {
-            const float4 x = *reinterpret_cast<const float4*>(z + row * C + cq * 4);
+            const float4 x = ld_nt4(z + row * C + cq * 4);
             float4 y;
             y.x = act_fn(fmaf(x.x, sc[0], sh[0]), slope);
             y.y = act_fn(fmaf(x.y, sc[1], sh[1]), slope);
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const long pix = base + (k >> 1) * W + (k & 1);
-                const float4 x = *reinterpret_cast<const float4*>(z + pix * C + cq * 4);
+                const float4 x = ld_nt4(z + pix * C + cq * 4);        // z: read once here, next in the backward
                 const float xv[4] = {x.x, x.y, x.z, x.w};
                 float y[4];
                 y[0] = act_fn(fmaf(x.x, sc[0], sh[0]), slope);
@@ -424,9 +424,9 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
                 }
             }
             *reinterpret_cast<float4*>(pooled + row * C + cq * 4) = make_float4(m[0], m[1], m[2], m[3]);
-            if (zpool) *reinterpret_cast<float4*>(zpool + row * C + cq * 4) = make_float4(zm[0], zm[1], zm[2], zm[3]);
-            *reinterpret_cast<uchar4*>(idx + row * C + cq * 4) =
-                make_uchar4((unsigned char)mi[0], (unsigned char)mi[1], (unsigned char)mi[2], (unsigned char)mi[3]);
+            if (zpool) st_nt4(zpool + row * C + cq * 4, make_float4(zm[0], zm[1], zm[2], zm[3]));      // read in the backward
+            st_nt_u8x4(idx + row * C + cq * 4,
+                       make_uchar4((unsigned char)mi[0], (unsigned char)mi[1], (unsigned char)mi[2], (unsigned char)mi[3]));
         }
     }
 }
@@ -487,8 +487,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
                 const long img = row / ((long)W2 * H2);
                 base = (img * H + 2 * i) * W + 2 * j;
                 if (g_pool) {
-                    const float4 g4 = *reinterpret_cast<const float4*>(g_pool + row * C + cq * 4);
-                    const uchar4 i4 = *reinterpret_cast<const uchar4*>(idx + row * C + cq * 4);
+                    // the apply pass is the last reader of z, of both gradient operands and of the arg-max bytes
+                    const float4 g4 = APPLY ? ld_nt4(g_pool + row * C + cq * 4) : *reinterpret_cast<const float4*>(g_pool + row * C + cq * 4);
+                    const uchar4 i4 = APPLY ? ld_nt_u8x4(idx + row * C + cq * 4) : *reinterpret_cast<const uchar4*>(idx + row * C + cq * 4);
                     gp[0] = g4.x; gp[1] = g4.y; gp[2] = g4.z; gp[3] = g4.w;
                     pi[0] = i4.x; pi[1] = i4.y; pi[2] = i4.z; pi[3] = i4.w;
                 }
@@ -497,9 +498,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
 #pragma unroll
             for (int k = 0; k < (POOL ? 4 : 1); ++k) {
                 const long pix = POOL ? base + (k >> 1) * W + (k & 1) : base;
-                const float4 x4 = *reinterpret_cast<const float4*>(z + pix * C + cq * 4);
+                const float4 x4 = APPLY ? ld_nt4(z + pix * C + cq * 4) : *reinterpret_cast<const float4*>(z + pix * C + cq * 4);
                 float4 f4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (g_full) f4 = *reinterpret_cast<const float4*>(g_full + pix * C + cq * 4);
+                if (g_full) f4 = APPLY ? ld_nt4(g_full + pix * C + cq * 4) : *reinterpret_cast<const float4*>(g_full + pix * C + cq * 4);
                 const float x[4] = {x4.x, x4.y, x4.z, x4.w}, gf[4] = {f4.x, f4.y, f4.z, f4.w};
                 float o[4];
 #pragma unroll
@@ -936,16 +937,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float b2, float w2, float eps, float wd, float step_size,
                                                    float bc2_sqrt, float gscale) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        // the gradient and the two moments stream through once per step (non-temporal); the parameter is read again by the pack
         const float pe = p[e];
-        float ge = g[e] * gscale;
+        float ge = ld_nt1(g + e) * gscale;
         ge = fmaf(wd, pe, ge);
-        float me = m[e], ve = v[e];
+        float me = ld_nt1(m + e), ve = ld_nt1(v + e);
         me = me + w1 * (ge - me);
         ve = fmaf(w2 * ge, ge, ve * b2);
         const float denom = sqrtf(ve) / bc2_sqrt + eps;
         p[e] = pe - step_size * (me / denom);
-        m[e] = me;
-        v[e] = ve;
+        st_nt1(m + e, me);
+        st_nt1(v + e, ve);
     }
 }
 

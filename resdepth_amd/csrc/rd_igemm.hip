@@ -1480,6 +1480,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int s = part;
         for (; s + 3 * SPT < splits; s += 4 * SPT) {
+            // (plain loads: the non-temporal form measured 4 % SLOWER here -- 0.265 -> 0.276 ms per step, profiles/r05_notes.md
+            // section 14 -- the slabs were written a moment ago by the strip kernel and part of them still sits in L2)
             const float4 v0 = src[(long)s * quads], v1 = src[(long)(s + SPT) * quads];
             const float4 v2 = src[(long)(s + 2 * SPT) * quads], v3 = src[(long)(s + 3 * SPT) * quads];
             a0 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
