@@ -1125,8 +1125,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_act_seg_kernel(const fl
             }
             const int gx = x0 + c0 + i;
             if (gy < H && gx < W)
-                *reinterpret_cast<float4*>(a + (((long)n * H + gy) * W + gx) * Cout + cq * 4) =
-                    make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+                st_nt4(a + (((long)n * H + gy) * W + gx) * Cout + cq * 4, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));   // next read: the tail
         }
         if ((sg & 1) == 0) {
 #pragma unroll
