@@ -19,6 +19,7 @@ launch stream over the timed region (rd_prof_*, include/resdepth_hip.h); `cpu_ba
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -50,6 +51,10 @@ ARITHMETIC = ("fp32 storage and accumulation; MFMA-class kernels multiply exactl
               "u = 2^-24, vs 16 u / 75 u for the exact-f32 MFMA chain; tests/test_split_numerics_gpu.py); +-Inf / NaN operands "
               "propagate exactly like fp32 in the forward / data-gradient kernels (weight gradients: same set of non-finite "
               "outputs, an Inf may surface as NaN); RD_MFMA=f32 selects the exact-f32 MFMA kernels")
+ARITHMETIC_SPLIT2 = ("RD_MFMA=split2 (libresdepth_hip_split2.so, OPT-IN, not the headline arithmetic): fp32 storage and accumulation; MFMA-class "
+                     "kernels multiply two-term operands (x ~ x1+x2, round-to-nearest bf16 terms, |x - x1 - x2| <= 2^-16 |x|) with three "
+                     "products per multiply (a1 b1, a1 b2, a2 b1): |error| <= 3 * 2^-16 |ab| per product, ~17 significant bits; whole net "
+                     "on cfg-S: forward 7e-6, gradients <= 4e-5 rel-L2 against the fp64 oracle (tests/test_split2_gpu.py)")
 MFMA_RANDOM_OPERAND_TFLOPS = 1850.0     # measured, scripts/ubench/mfma_order.hip: register-only MFMA loop on split terms (hi/mid/lo) of N(0,1) floats
 MFMA_CLASSES = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "convt2x2_fwd", "convt2x2_dgrad", "convt2x2_wgrad")
 
@@ -282,7 +287,8 @@ def infer_main(args, world, rank, dev):
             "metric": "DSM tiles/sec forward-only tiled inference + linear blend (256x256, 3-ch, depth-5 U-Net)",
             "value": round(tiles_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic raster",
+            "vs_baseline": None, "dtype": "f32" if _lib.mfma_mode() != "split2" else "f32 storage / bf16x2 multiplies (RD_MFMA=split2)",
+            "data": "synthetic raster",
             "config": {"workload": f"cfg-G: {args.raster}x{args.raster} raster, {n_tiles_global} tiles of 256x256 at stride 128, "
                                    f"eval-mode BN, batch {args.batch}",
                        "parallelism": f"tiles sharded over {world} GPU(s)" + (" (ranks SHARE one GPU: code-path check)" if args.share_gpu else "")},
@@ -549,6 +555,23 @@ def eval_stats_measurement(dev, side=8192):
                     "(f64) + ground truth (f32) + mask (u8) per call"}
 
 
+def split2_measurement():
+    """RD_MFMA=split2 in a child process (train step of cfg-S and the cfg-G sweep), never `value`."""
+    env = {k: v for k, v in os.environ.items() if k != "RESDEPTH_HIP_LIB"}
+    env["RD_MFMA"] = "split2"
+    base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-secondary", "--no-prof"]
+    r = subprocess.run(base + ["--steps", "20", "--warmup", "5"], env=env, capture_output=True, text=True, timeout=600)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    out = {"tiles_per_s": d["value"], "step_ms_median": d["step_ms_median"], "arithmetic": d["arithmetic"],
+           "note": "python bench.py under RD_MFMA=split2 in a child process, 20 timed steps of the same cfg-S workload; an opt-in "
+                   "precision mode, NOT the headline arithmetic"}
+    r = subprocess.run(base + ["--infer", "--raster", "8192", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    g = json.loads(r.stdout.strip().splitlines()[-1])
+    out["cfg_G_tiles_per_s"] = g["value"]
+    return out
+
+
 def secondary_measurements(args, dev, tb):
     """Numbers DESIGN.md quotes beside the headline, measured in the same invocation (few steps each; never `value`)."""
     from resdepth_amd import _lib
@@ -579,6 +602,10 @@ def secondary_measurements(args, dev, tb):
         _lib.tune_set("mfma_f32", 0)
         tb.model.invalidate_packed()
         _lib.prof_enable(0)
+    try:        # the opt-in two-term / three-product build on the same workload (its library is chosen per process: child run)
+        out["split2"] = split2_measurement()
+    except Exception as e:      # noqa: BLE001
+        out["split2"] = {"error": repr(e)[:300]}
     try:        # the drop-in loop: Trainer.inference_one_epoch over host-resident pinned batches, H2D prefetch on / off
         on = trainer_loop_measurement(dev, tb.wl, tb.n, prefetch=1)
         off = trainer_loop_measurement(dev, tb.wl, tb.n, iters=12, prefetch=0)
@@ -966,13 +993,15 @@ def main():
                               f"HIP events, serialized pass of {prof_steps} steps right after the timed region "
                               "(timed region itself: un-instrumented, wgrad kernels overlapped on a 2nd stream)")
         per_gpu = tiles_s / world
+        from resdepth_amd import _lib as _l
+        mode = _l.mfma_mode()
         out = {
             "metric": "DSM tiles/sec fwd+bwd (256x256, 3-ch, depth-5 U-Net)" if args.workload == "S" else
                       "DSM tiles/sec fwd+bwd (512x512, 2-ch, depth-6 U-Net)", "value": round(tiles_s, 2),
             "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32",
-            "arithmetic": ARITHMETIC,
+            "dtype": "f32" if mode != "split2" else "f32 storage / bf16x2 multiplies (RD_MFMA=split2)",
+            "arithmetic": ARITHMETIC if mode != "split2" else ARITHMETIC_SPLIT2,
             "data": ("synthetic rasters resident in HBM, a fresh augmented batch assembled on the GPU every step"
                      if args.from_rasters else "synthetic (randn tiles resident in HBM, default-initialised weights)"),
             "config": {"workload": wl["name"] + ", fwd+loss+bwd+Adam",
@@ -987,7 +1016,7 @@ def main():
                            "pair per step on the launch stream (rank 0)",
             "e2e": {"tflops": round(per_gpu * wl["flop"] / 1e12, 2),
                     "frac_f32_peak": round(per_gpu * wl["flop"] / 1e12 / PEAK_F32_TFLOPS, 4),
-                    "frac_split_mfma_bound": round(per_gpu * wl["flop"] / 1e12 / PEAK_SPLIT_TFLOPS, 4),
+                    "frac_split_mfma_bound": round(per_gpu * wl["flop"] / 1e12 / (PEAK_SPLIT_TFLOPS * (2 if mode == "split2" else 1)), 4),
                     "hbm_frac": round(per_gpu * wl["bytes_a"] / (PEAK_HBM_GBS * 1e9), 4),
                     "hbm_frac_note": "tiles/s/GPU x op-level compulsory bytes per tile (SURVEY 8d model A) / 8 TB/s"},
             "roofline": roof,

@@ -40,7 +40,16 @@ typedef void* rd_stream_t; /* hipStream_t */
 #define RD_ERR_WS 2
 #define RD_ERR_HIP 3
 
-int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream); 102: rd_host_register & co */
+int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream); 102: rd_host_register & co; 103: rd_mfma_products */
+/* Arithmetic of the split-bf16 MFMA kernels in THIS build of the library (one source tree, two shared objects):
+ *   6  libresdepth_hip.so         x = x1 + x2 + x3 (three bf16 terms, exact), six products per multiply: fp32-class results,
+ *                                 the default and the only build the headline numbers / parity bars are quoted on;
+ *   3  libresdepth_hip_split2.so  x ~ x1 + x2 (two round-to-nearest bf16 terms, |error| <= 2^-18 |x|), three products
+ *                                 (a1 b1, a1 b2, a2 b1): ~17 significant bits per product, half the matrix-pipe work.  An
+ *                                 OPT-IN precision mode (RD_MFMA=split2 in the Python host), in kind what cuDNN's TF32 default
+ *                                 is to the reference on an NVIDIA GPU (lib/UNet.py:196-246 run through torch.backends.cudnn
+ *                                 with allow_tf32 = True: 10 mantissa bits), at 128 x its precision.  DESIGN.md section 3.1h. */
+int rd_mfma_products(void);
 const char* rd_last_error_string(void);
 
 /* ---- weight (re)packing: torch layouts -> GEMM operand layouts ------------------- */

@@ -15,7 +15,13 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RESDEPTH_HIP_LIB: alternative build of the same library (kernel diagnosis builds)
-LIB_PATH = os.environ.get("RESDEPTH_HIP_LIB") or os.path.join(_HERE, "libresdepth_hip.so")
+# RD_MFMA=split2: the two-term / three-product build of the same sources (include/resdepth_hip.h: rd_mfma_products) -- an
+# opt-in precision mode, chosen once per process like RD_MFMA=f32 (which is a switch inside the default library)
+MFMA_MODE = os.environ.get("RD_MFMA", "")
+if MFMA_MODE not in ("", "f32", "split3", "split2"):
+    raise RuntimeError(f"RD_MFMA={MFMA_MODE!r}: expected f32, split3 (default) or split2")
+LIB_NAME = "libresdepth_hip_split2.so" if MFMA_MODE == "split2" else "libresdepth_hip.so"
+LIB_PATH = os.environ.get("RESDEPTH_HIP_LIB") or os.path.join(_HERE, LIB_NAME)
 
 _lib = None
 _lock = threading.Lock()
@@ -30,6 +36,7 @@ SZ = C.c_size_t
 # name -> (restype, argtypes); mirrors include/resdepth_hip.h one to one
 SIGNATURES = {
     "rd_version": (I, []),
+    "rd_mfma_products": (I, []),
     "rd_last_error_string": (C.c_char_p, []),
     "rd_pack_conv3x3_weight": (I, [P, P, P, I, I, P]),
     "rd_pack_item_pieces": (LL, [I, I, I, I]),
@@ -146,8 +153,20 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        want = 3 if MFMA_MODE == "split2" else 6
+        if "RESDEPTH_HIP_LIB" not in os.environ and lib.rd_mfma_products() != want:
+            raise RuntimeError(f"resdepth_amd: {LIB_PATH} computes {lib.rd_mfma_products()} products per multiply, RD_MFMA={MFMA_MODE or 'split3'} "
+                               f"needs {want}: stale build -- run resdepth_amd/csrc/build.sh")
         _lib = lib
     return _lib
+
+
+def mfma_mode() -> str:
+    """Arithmetic of the matrix-pipe convolution kernels in this process: "split3" (default: six bf16 products per multiply,
+    fp32-class), "split2" (RD_MFMA=split2: three products, ~17 bits) or "f32" (RD_MFMA=f32 / tune knob mfma_f32: exact)."""
+    if tune_get("mfma_f32"):
+        return "f32"
+    return "split2" if load().rd_mfma_products() == 3 else "split3"
 
 
 def check(rc: int, what: str = ""):

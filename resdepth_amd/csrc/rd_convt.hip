@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
 #pragma unroll
         for (int g = 0; g < TM; g += GP) {
 #pragma unroll
-            for (int t6 = 0; t6 < 5; ++t6)
+            for (int t6 = LO0; t6 < 5; ++t6)
 #pragma unroll
                 for (int i = g; i < g + GP; ++i)
                     lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
 #pragma unroll
         for (int g = 0; g < TM; g += GP) {
 #pragma unroll
-            for (int t6 = 0; t6 < 5; ++t6)
+            for (int t6 = LO0; t6 < 5; ++t6)
 #pragma unroll
                 for (int i = g; i < g + GP; ++i)
                     lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_kernel(CtwParams p) {
                 for (int q = 0; q < 3; ++q) bf[(j + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(cur + b_rd[j + 1][q]);
             }
 #pragma unroll
-            for (int t6 = 0; t6 < 6; ++t6) {
+            for (int t6 = LO0; t6 < 6; ++t6) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[j & 1][PB6[t6]], acc[i][j], 0, 0, 0);

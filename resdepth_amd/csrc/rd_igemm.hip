@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 #pragma unroll
         for (int g = 0; g < TM; g += GP) {
 #pragma unroll
-            for (int t6 = 0; t6 < 5; ++t6)
+            for (int t6 = LO0; t6 < 5; ++t6)
 #pragma unroll
                 for (int i = g; i < g + GP; ++i)
                     lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
@@ -495,6 +495,21 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const bf16x8*>(nstage + a_rd[i] + NEXT + q * 8);
         };
+#if RD_NPROD == 3
+        // three products (a2 b1, a1 b2, a1 b1): term 2 is never read
+#pragma unroll
+        for (int i = 0; i < TM; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], lo[i], 0, 0, 0);
+        rd(1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], lo[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][0], 0, 0, 0);
+        rd(0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#else
 #pragma unroll
         for (int i = 0; i < TM; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], lo[i], 0, 0, 0);
         rd(2);
@@ -515,6 +530,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#endif
         __builtin_amdgcn_s_setprio(0);
     };
     // W8: K is accumulated in RANGES of eight chunks (128 channels), each merged into `tot` in turn -- whether the ranges of a
@@ -1335,7 +1351,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) bf[j][q] = *reinterpret_cast<const bf16x8*>(stage + b_rd[j][q]);
 #pragma unroll
-        for (int t6 = 0; t6 < 5; ++t6)
+        for (int t6 = LO0; t6 < 5; ++t6)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1620,6 +1636,11 @@ static int check_conv_args(int n, int h, int w, int cin, int cout) {
 using namespace rd;
 
 extern "C" {
+
+// 6: every fp32 product as six bf16 products (three-term split, fp32-class results -- libresdepth_hip.so) | 3: the
+// libresdepth_hip_split2.so build of the same sources (-DRD_NPROD=3: two-term split, three products; rd_mfma_dev.h)
+int rd_mfma_products(void) { return RD_NPROD; }
+
 
 size_t rd_packed_weight_bytes(int rows, int taps, int cin) {
     if (rows <= 0 || taps <= 0 || cin <= 0) return 0;

@@ -42,6 +42,10 @@ constexpr int SROWB = 96;   // bytes of one (row, K-step) in the packed split-B 
 // u = 2^-24; scripts/split_numerics.py) -- whereas `lo` only ever holds terms of its own size.  `hi` then behaves like an
 // fp32 dot product with one rounding per 16 products.
 constexpr int PA6[6] = {2, 1, 0, 1, 0, 0}, PB6[6] = {0, 1, 2, 0, 1, 0};
+#ifndef RD_NPROD
+#define RD_NPROD 6
+#endif
+constexpr int LO0 = RD_NPROD == 3 ? 3 : 0;      // first kept entry of PA6 / PB6
 // hi + lo.  An infinite operand lives in its first term only (split3), so hi = Inf * b1 carries the correct +-Inf (or NaN
 // for Inf * 0 / Inf - Inf, as in fp32) while lo may have picked up Inf * 0 = NaN from a ZERO lower term of the other
 // operand: an infinite hi therefore wins.  (Only difference to an fp32 product left: Inf * b with 0 < |b| < 2^-133.)
@@ -57,11 +61,19 @@ __device__ __forceinline__ float merge_hi_lo(float hi, float lo) { return __buil
 // keep an Inf apart from Inf * 0 anyway -- there a non-finite operand yields NaN in every output it touches.
 template <bool GUARD = true>
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+#if RD_NPROD == 3
+    h = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) << 16;
+    float r = x - __uint_as_float(h);
+    if (GUARD) r = (r == r) ? r : 0.f;
+    m = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)r) << 16;
+    l = 0u;
+#else
     h = __float_as_uint(x) & 0xffff0000u;
     float r = x - __uint_as_float(h);
     if (GUARD) r = (r == r) ? r : 0.f;
     m = __float_as_uint(r) & 0xffff0000u;
     l = __float_as_uint(r - __uint_as_float(m));
+#endif
 }
 // float4 (4 consecutive k) -> three 8-byte groups of 4 bf16 (one per term); v_perm_b32 -> {hi16(odd), hi16(even)}
 __device__ __forceinline__ void split_pack4(const float4 v, uint2& ph, uint2& pm, uint2& pl) {

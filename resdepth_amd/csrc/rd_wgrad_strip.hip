@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_kernel(WsParams p) {
         for (int dy = 0; dy < 3; ++dy) {
             if (dy < 2) read_b(dy + 1, bf[(dy + 1) & 1]);
 #pragma unroll
-            for (int t6 = 0; t6 < 6; ++t6)
+            for (int t6 = LO0; t6 < 6; ++t6)
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
                     acc[dy * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t6]], bf[dy & 1][d][PB[t6]], acc[dy * 3 + d], 0, 0, 0);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
         for (int dy = 0; dy < 3; ++dy) {
             if (dy < 2) read_b(dy + 1, bf[(dy + 1) & 1]);
 #pragma unroll
-            for (int t6 = 0; t6 < 6; ++t6)
+            for (int t6 = LO0; t6 < 6; ++t6)
 #pragma unroll
                 for (int d = 0; d < 3; ++d)
                     acc[dy * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t6]], bf[dy & 1][d][PB[t6]], acc[dy * 3 + d], 0, 0, 0);

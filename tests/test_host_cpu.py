@@ -20,6 +20,31 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.rd_version() >= 100
+    assert lib.rd_mfma_products() == 6 and _lib.MFMA_MODE in ("", "split3", "f32")
+
+
+def test_split2_build_exports_the_same_abi_and_is_only_reached_by_its_switch():
+    """libresdepth_hip_split2.so (-DRD_NPROD=3: two-term split, three products) is the same C ABI; the Python host loads it
+    only under RD_MFMA=split2, refuses unknown modes, and refuses a library whose product count is not the mode's."""
+    import ctypes
+    import subprocess
+    import sys
+    from resdepth_amd import _lib
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libresdepth_hip_split2.so")
+    lib = ctypes.CDLL(path)
+    for name in _lib.SIGNATURES:
+        assert hasattr(lib, name), name
+    assert lib.rd_mfma_products() == 3 and lib.rd_version() == _lib.load().rd_version()
+    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "check_isa.sh"), path], capture_output=True, text=True)
+    assert r.returncode == 0 and "packed-f32 VALU 0, scratch 0" in r.stdout, r.stdout + r.stderr
+    code = "from resdepth_amd import _lib; l = _lib.load(); print(_lib.LIB_PATH.rsplit('/', 1)[1], l.rd_mfma_products())"
+    env = {k: v for k, v in os.environ.items() if k not in ("RESDEPTH_HIP_LIB", "RD_MFMA")}
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, RD_MFMA="split2"), capture_output=True, text=True)
+    assert out.stdout.split() == ["libresdepth_hip_split2.so", "3"], out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, RD_MFMA="split3"), capture_output=True, text=True)
+    assert out.stdout.split() == ["libresdepth_hip.so", "6"], out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, RD_MFMA="tf32"), capture_output=True, text=True)
+    assert out.returncode != 0 and "RD_MFMA" in out.stderr
 
 
 @pytest.mark.parametrize("c,sk,d,bias", [(3, 64, 5, True), (1, 8, 3, False), (2, 16, 4, True)])
