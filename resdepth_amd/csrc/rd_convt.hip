@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
             float* row = stage + s_lds[k];
             *reinterpret_cast<uint2*>(row) = ph;
             *reinterpret_cast<uint2*>(row + 8) = pm;
-            *reinterpret_cast<uint2*>(row + 16) = pl;
+            if (kTerm3) *reinterpret_cast<uint2*>(row + 16) = pl;
         }
     };
     auto load_b = [&](int kt, uint4 (&rb)[3]) {
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
             float* row = stage + s_lds[k];
             *reinterpret_cast<uint2*>(row) = ph;
             *reinterpret_cast<uint2*>(row + 8) = pm;
-            *reinterpret_cast<uint2*>(row + 16) = pl;
+            if (kTerm3) *reinterpret_cast<uint2*>(row + 16) = pl;
         }
     };
     // weight fragments: K-step kt = (tap, chunk) in tap-outer order lives at kt' = chunk * 4 + tap of the packed operand
@@ -576,21 +576,15 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_kernel(CtwParams p) {
     // interleaved with MFMAs is nearly free up to ~1 instruction per MFMA (profiles/r02_notes.md section 1)
     auto store_piece = [&](float* stage, const float4 (&v)[4], int c) {
         if (!active) return;
-        const unsigned sel = 0x07060302u;
-        unsigned h[4], m[4], l[4];          // the 4 pixels of channel c
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float xv = c == 0 ? v[j].x : c == 1 ? v[j].y : c == 2 ? v[j].z : v[j].w;
-            split3<false>(xv, h[j], m[j], l[j]);
-        }
+        uint2 ph, pm, pl;                   // the 4 pixels of channel c
+        split_pack4v<false>(c == 0 ? v[0].x : c == 1 ? v[0].y : c == 2 ? v[0].z : v[0].w, c == 0 ? v[1].x : c == 1 ? v[1].y : c == 2 ? v[1].z : v[1].w,
+                            c == 0 ? v[2].x : c == 1 ? v[2].y : c == 2 ? v[2].z : v[2].w, c == 0 ? v[3].x : c == 1 ? v[3].y : c == 2 ? v[3].z : v[3].w,
+                            ph, pm, pl);
         const int flip = (c >> 1) * 4;      // rows lds_row0 + 2, + 3 carry the next swizzle value (chunk index ^ 1)
         float* rowp = stage + c * 32;
-        *reinterpret_cast<uint2*>(rowp + (wr_e[0] ^ flip)) =
-            make_uint2(__builtin_amdgcn_perm(h[1], h[0], sel), __builtin_amdgcn_perm(h[3], h[2], sel));
-        *reinterpret_cast<uint2*>(rowp + (wr_e[1] ^ flip)) =
-            make_uint2(__builtin_amdgcn_perm(m[1], m[0], sel), __builtin_amdgcn_perm(m[3], m[2], sel));
-        *reinterpret_cast<uint2*>(rowp + (wr_e[2] ^ flip)) =
-            make_uint2(__builtin_amdgcn_perm(l[1], l[0], sel), __builtin_amdgcn_perm(l[3], l[2], sel));
+        *reinterpret_cast<uint2*>(rowp + (wr_e[0] ^ flip)) = ph;
+        *reinterpret_cast<uint2*>(rowp + (wr_e[1] ^ flip)) = pm;
+        if (kTerm3) *reinterpret_cast<uint2*>(rowp + (wr_e[2] ^ flip)) = pl;
     };
     auto store_task = [&](float* stage, const float4 (&v)[4]) {
 #pragma unroll

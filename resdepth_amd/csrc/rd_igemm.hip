@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
             split_pack4(ra[i], ph, pm, pl);
             *reinterpret_cast<uint2*>(stage + a_wr[i] + ((0 + hi) ^ sw) * 4) = ph;
             *reinterpret_cast<uint2*>(stage + a_wr[i] + ((2 + hi) ^ sw) * 4) = pm;
-            *reinterpret_cast<uint2*>(stage + a_wr[i] + ((4 + hi) ^ sw) * 4) = pl;
+            if (kTerm3) *reinterpret_cast<uint2*>(stage + a_wr[i] + ((4 + hi) ^ sw) * 4) = pl;
         }
     };
 
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
             float* row = stage + s_lds[k];
             *reinterpret_cast<uint2*>(row) = ph;
             *reinterpret_cast<uint2*>(row + 8) = pm;
-            *reinterpret_cast<uint2*>(row + 16) = pl;
+            if (kTerm3) *reinterpret_cast<uint2*>(row + 16) = pl;
         }
     };
     auto load_b = [&](int kt, uint4 (&rb)[3]) {
@@ -1303,26 +1303,19 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
     };
     auto store_task = [&](float* stage, const float4 (&x)[4]) {
         if (!active) return;
-        unsigned h[4][4], m[4][4], l[4][4];     // [pixel j][channel c]
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            split3<false>(x[j].x, h[j][0], m[j][0], l[j][0]);
-            split3<false>(x[j].y, h[j][1], m[j][1], l[j][1]);
-            split3<false>(x[j].z, h[j][2], m[j][2], l[j][2]);
-            split3<false>(x[j].w, h[j][3], m[j][3], l[j][3]);
-        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+            uint2 ph, pm, pl;               // the 4 pixels of channel c
+            split_pack4v<false>(c == 0 ? x[0].x : c == 1 ? x[0].y : c == 2 ? x[0].z : x[0].w, c == 0 ? x[1].x : c == 1 ? x[1].y : c == 2 ? x[1].z : x[1].w,
+                                c == 0 ? x[2].x : c == 1 ? x[2].y : c == 2 ? x[2].z : x[2].w, c == 0 ? x[3].x : c == 1 ? x[3].y : c == 2 ? x[3].z : x[3].w,
+                                ph, pm, pl);
             const int row = lds_row0 + c;
             const int sw = (row >> 1) & 7;
             float* base = stage + row * 32 + (kq & 1) * 2;
             const int hi = kq >> 1;
-            *reinterpret_cast<uint2*>(base + ((0 + hi) ^ sw) * 4) =
-                make_uint2(__builtin_amdgcn_perm(h[1][c], h[0][c], 0x07060302u), __builtin_amdgcn_perm(h[3][c], h[2][c], 0x07060302u));
-            *reinterpret_cast<uint2*>(base + ((2 + hi) ^ sw) * 4) =
-                make_uint2(__builtin_amdgcn_perm(m[1][c], m[0][c], 0x07060302u), __builtin_amdgcn_perm(m[3][c], m[2][c], 0x07060302u));
-            *reinterpret_cast<uint2*>(base + ((4 + hi) ^ sw) * 4) =
-                make_uint2(__builtin_amdgcn_perm(l[1][c], l[0][c], 0x07060302u), __builtin_amdgcn_perm(l[3][c], l[2][c], 0x07060302u));
+            *reinterpret_cast<uint2*>(base + ((0 + hi) ^ sw) * 4) = ph;
+            *reinterpret_cast<uint2*>(base + ((2 + hi) ^ sw) * 4) = pm;
+            if (kTerm3) *reinterpret_cast<uint2*>(base + ((4 + hi) ^ sw) * 4) = pl;
         }
     };
 

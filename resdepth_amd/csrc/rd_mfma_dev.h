@@ -75,17 +75,44 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
     l = __float_as_uint(r - __uint_as_float(m));
 #endif
 }
-// float4 (4 consecutive k) -> three 8-byte groups of 4 bf16 (one per term); v_perm_b32 -> {hi16(odd), hi16(even)}
-__device__ __forceinline__ void split_pack4(const float4 v, uint2& ph, uint2& pm, uint2& pl) {
+// four values (consecutive k) -> 8-byte groups of 4 bf16, one per term; v_perm_b32 -> {hi16(odd), hi16(even)}.
+// kTerm3: the third term exists (six-product build); the three-product build writes / reads two terms only.
+constexpr bool kTerm3 = RD_NPROD != 3;
+#if RD_NPROD == 3
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two values -> {rn_bf16(x1) : rn_bf16(x0)} and the same of the remainders: v_cvt_pk_bf16_f32, 2 unpack, 2 sub, v_cvt_pk_bf16_f32
+template <bool GUARD>
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& ph, unsigned& pm) {
+    const f32x2_t v = {x0, x1};
+    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+    float r0 = x0 - __uint_as_float(ph << 16), r1 = x1 - __uint_as_float(ph & 0xffff0000u);
+    if (GUARD) {
+        r0 = (r0 == r0) ? r0 : 0.f;
+        r1 = (r1 == r1) ? r1 : 0.f;
+    }
+    const f32x2_t r = {r0, r1};
+    pm = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+}
+#endif
+template <bool GUARD = true>
+__device__ __forceinline__ void split_pack4v(float x0, float x1, float x2, float x3, uint2& ph, uint2& pm, uint2& pl) {
+#if RD_NPROD == 3
+    split2_pair<GUARD>(x0, x1, ph.x, pm.x);
+    split2_pair<GUARD>(x2, x3, ph.y, pm.y);
+    pl = make_uint2(0u, 0u);
+#else
     unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-    split3(v.x, h0, m0, l0);
-    split3(v.y, h1, m1, l1);
-    split3(v.z, h2, m2, l2);
-    split3(v.w, h3, m3, l3);
+    split3<GUARD>(x0, h0, m0, l0);
+    split3<GUARD>(x1, h1, m1, l1);
+    split3<GUARD>(x2, h2, m2, l2);
+    split3<GUARD>(x3, h3, m3, l3);
     ph = make_uint2(__builtin_amdgcn_perm(h1, h0, 0x07060302u), __builtin_amdgcn_perm(h3, h2, 0x07060302u));
     pm = make_uint2(__builtin_amdgcn_perm(m1, m0, 0x07060302u), __builtin_amdgcn_perm(m3, m2, 0x07060302u));
     pl = make_uint2(__builtin_amdgcn_perm(l1, l0, 0x07060302u), __builtin_amdgcn_perm(l3, l2, 0x07060302u));
+#endif
 }
+__device__ __forceinline__ void split_pack4(const float4 v, uint2& ph, uint2& pm, uint2& pl) { split_pack4v<true>(v.x, v.y, v.z, v.w, ph, pm, pl); }
 __device__ __forceinline__ uint4 buf_load4u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);

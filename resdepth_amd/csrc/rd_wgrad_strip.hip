@@ -103,23 +103,17 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_kernel(WsParams p) {
     auto store_task = [&](int yy, const float4 (&v)[4]) {
         if (!active) return;
         float* region = isA ? smem + ((yy + 1) & 1) * (A_ROWS * 32) : smem + RING0 + ((yy + 3) & 3) * (B_ROWS * 32);
-        const unsigned sel = 0x07060302u;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            unsigned h[4], m[4], l[4];      // the 4 pixels of channel c
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xv = c == 0 ? v[j].x : c == 1 ? v[j].y : c == 2 ? v[j].z : v[j].w;
-                split3<false>(xv, h[j], m[j], l[j]);
-            }
+            uint2 ph, pm, pl;               // the 4 pixels of channel c
+            split_pack4v<false>(c == 0 ? v[0].x : c == 1 ? v[0].y : c == 2 ? v[0].z : v[0].w, c == 0 ? v[1].x : c == 1 ? v[1].y : c == 2 ? v[1].z : v[1].w,
+                                c == 0 ? v[2].x : c == 1 ? v[2].y : c == 2 ? v[2].z : v[2].w, c == 0 ? v[3].x : c == 1 ? v[3].y : c == 2 ? v[3].z : v[3].w,
+                                ph, pm, pl);
             const int flip = (c >> 1) * 4;  // next swizzle value = chunk index ^ 1 = word offset ^ 4
             float* rowp = region + c * 32;
-            *reinterpret_cast<uint2*>(rowp + (wr_e[0] ^ flip)) =
-                make_uint2(__builtin_amdgcn_perm(h[1], h[0], sel), __builtin_amdgcn_perm(h[3], h[2], sel));
-            *reinterpret_cast<uint2*>(rowp + (wr_e[1] ^ flip)) =
-                make_uint2(__builtin_amdgcn_perm(m[1], m[0], sel), __builtin_amdgcn_perm(m[3], m[2], sel));
-            *reinterpret_cast<uint2*>(rowp + (wr_e[2] ^ flip)) =
-                make_uint2(__builtin_amdgcn_perm(l[1], l[0], sel), __builtin_amdgcn_perm(l[3], l[2], sel));
+            *reinterpret_cast<uint2*>(rowp + (wr_e[0] ^ flip)) = ph;
+            *reinterpret_cast<uint2*>(rowp + (wr_e[1] ^ flip)) = pm;
+            if (kTerm3) *reinterpret_cast<uint2*>(rowp + (wr_e[2] ^ flip)) = pl;
         }
     };
 
@@ -334,15 +328,11 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
     };
     // float4 (4 channels of a pixel) -> three 8-byte pieces (one per term) at dst, dst + term stride, dst + 2 term strides
     auto put = [&](char* dst, int tstride, const float4 x) {
-        unsigned h0, m0_, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-        split3<false>(x.x, h0, m0_, l0);
-        split3<false>(x.y, h1, m1, l1);
-        split3<false>(x.z, h2, m2, l2);
-        split3<false>(x.w, h3, m3, l3);
-        const unsigned sel = 0x07060302u;
-        *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_amdgcn_perm(h1, h0, sel), __builtin_amdgcn_perm(h3, h2, sel));
-        *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(__builtin_amdgcn_perm(m1, m0_, sel), __builtin_amdgcn_perm(m3, m2, sel));
-        *reinterpret_cast<uint2*>(dst + 2 * tstride) = make_uint2(__builtin_amdgcn_perm(l1, l0, sel), __builtin_amdgcn_perm(l3, l2, sel));
+        uint2 ph, pm, pl;
+        split_pack4v<false>(x.x, x.y, x.z, x.w, ph, pm, pl);
+        *reinterpret_cast<uint2*>(dst) = ph;
+        *reinterpret_cast<uint2*>(dst + tstride) = pm;
+        if (kTerm3) *reinterpret_cast<uint2*>(dst + 2 * tstride) = pl;
     };
     auto store_task = [&](int yy, const float4 (&v)[AI + BI]) {
         char* sa = reinterpret_cast<char*>(smem) + ((yy + 1) & 1) * ASTAGE;
