@@ -569,6 +569,8 @@ def split2_measurement():
                        timeout=600)
     g = json.loads(r.stdout.strip().splitlines()[-1])
     out["cfg_G_tiles_per_s"] = g["value"]
+    r = subprocess.run(base + ["--workload", "M", "--steps", "3", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=600)
+    out["cfg_M_tiles_per_s"] = json.loads(r.stdout.strip().splitlines()[-1])["value"]
     return out
 
 
