@@ -31,6 +31,8 @@ def test_split2_build_exports_the_same_abi_and_is_only_reached_by_its_switch():
     import sys
     from resdepth_amd import _lib
     path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libresdepth_hip_split2.so")
+    if not os.path.exists(path):         # a tree built before the second library existed: csrc/build.sh makes both
+        subprocess.run(["bash", os.path.join(ROOT, "resdepth_amd", "csrc", "build.sh")], check=True, capture_output=True)
     lib = ctypes.CDLL(path)
     for name in _lib.SIGNATURES:
         assert hasattr(lib, name), name
