@@ -315,6 +315,7 @@ class TrainBench:
     def __init__(self, wl, n, dev, rank=0, gs=None, from_rasters=False):
         from resdepth_amd import UNet, FusedAdam, synthetic_batch
         self.wl, self.n, self.gs = wl, n, gs
+        self.graph, self.use_graph = None, False      # resdepth_amd.graph.GraphedTrainStep (attach_optimizer); on for the headline only
         torch.manual_seed(0)
         self.model = UNet(n_input_channels=wl["c"], start_kernel=64, depth=wl["depth"], bias_conv_layer=True).to(dev).train()
         b = synthetic_batch(n, wl["c"], wl["t"], seed=1234 + rank)
@@ -338,6 +339,8 @@ class TrainBench:
         from resdepth_amd import FusedAdam
         self.opt = FusedAdam(self.model.parameters(), lr=2e-4, weight_decay=1e-5)
         self.params = list(self.model.parameters())
+        from resdepth_amd.graph import GraphedTrainStep
+        self.graph = GraphedTrainStep(self.model, self.opt, warmup=2)
 
     def step(self):
         from resdepth_amd import masked_l1_loss
@@ -346,6 +349,10 @@ class TrainBench:
             xx, yy, mm, me, sd_ = bb["input"], bb["target"], bb["loss_mask"], bb["dsm_mean"], bb["dsm_std"]
         else:
             xx, yy, mm, me, sd_ = self.x, self.y, self.mask, self.mean, self.std
+        if self.use_graph and self.gs is None:
+            loss = self.graph(xx, yy, mm, me, sd_)        # one hipGraph launch once captured (eager while it warms up)
+            self.losses.append(loss.clone() if self.graph.why_eager is None else loss)
+            return
         y_pred = self.model(xx)
         loss = masked_l1_loss(y_pred, yy, mm, me, sd_, grad_sync=self.gs)
         loss.backward()
@@ -574,6 +581,26 @@ def split2_measurement():
     return out
 
 
+def graph_small_batch_measurement(dev, wl, n=4, steps=40):
+    res = {}
+    for mode in ("eager", "graph"):
+        t = TrainBench(wl, n, dev)
+        t.attach_optimizer()
+        t.use_graph = mode == "graph"
+        for _ in range(4):
+            t.step()
+        dt, ev = t.timed(steps, 4)
+        res[mode] = {"tiles_per_s": round(n * steps / dt, 1), "step_ms_median": round(_median(ev), 3)}
+        if mode == "graph":
+            res[mode]["replays"] = t.graph.replays
+        del t
+    res["note"] = (f"cfg-S at batch {n}, fwd+loss+bwd+Adam, {steps} timed steps: the eager iteration is bound by its ~110 launches "
+                   "(~3.5 ms of host time per step), resdepth_amd.graph.GraphedTrainStep replays it as one HIP graph (0.35 ms of host "
+                   "time, bit-identical results); at batch >= 8 the eager iteration wins (no longer launch-bound, and its two-stream "
+                   "backward overlaps better than the replayed branches)")
+    return res
+
+
 def secondary_measurements(args, dev, tb):
     """Numbers DESIGN.md quotes beside the headline, measured in the same invocation (few steps each; never `value`)."""
     from resdepth_amd import _lib
@@ -608,6 +635,10 @@ def secondary_measurements(args, dev, tb):
         out["split2"] = split2_measurement()
     except Exception as e:      # noqa: BLE001
         out["split2"] = {"error": repr(e)[:300]}
+    try:        # the launch-bound regime: the same iteration at batch 4, eager (~110 launches) vs one captured HIP graph per step
+        out["hip_graph_small_batch"] = graph_small_batch_measurement(dev, tb.wl)
+    except Exception as e:      # noqa: BLE001
+        out["hip_graph_small_batch"] = {"error": repr(e)[:300]}
     try:        # the drop-in loop: Trainer.inference_one_epoch over host-resident pinned batches, H2D prefetch on / off
         on = trainer_loop_measurement(dev, tb.wl, tb.n, prefetch=1)
         off = trainer_loop_measurement(dev, tb.wl, tb.n, iters=12, prefetch=0)
@@ -848,6 +879,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the exact-f32 / cfg-M / cfg-G secondary measurements")
     ap.add_argument("--no-prof", action="store_true", help="disable the per-kernel HIP-event timing")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the iteration as one captured HIP graph (resdepth_amd.graph) instead of ~110 eager launches: pays when the "
+                         "step is launch-bound (batch <= 6 at cfg-S), costs the two-stream overlap at the benchmark batch")
     ap.add_argument("--separate-bn-stats", action="store_true",
                     help="A/B: BN-backward sums from the stand-alone reduction pass instead of the data-gradient epilogues")
     ap.add_argument("--serial-backward", action="store_true",
@@ -948,11 +982,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    tb.use_graph = args.graph and not use_dist
+    if tb.use_graph:
+        for _ in range(4):                       # two eager warm-up iterations, capture preparation, capture: outside the timed region
+            tb.step()
+        torch.cuda.synchronize()
     dt, step_ms = tb.timed(args.steps, args.warmup, barrier)
     timed_losses = list(tb.losses)
+    graph_info = {"enabled": bool(tb.use_graph), "replays": tb.graph.replays, "last_eager_reason": tb.graph.why_eager,
+                  "note": "the whole iteration (weight packing, forward, loss, two-stream backward, Adam) replayed as one captured HIP "
+                          "graph per step: the same kernels and arguments as the eager iteration, bit-identical results "
+                          "(tests/test_graph_gpu.py).  Off by default: at this batch the eager iteration is not launch-bound and its "
+                          "two-stream backward overlaps better than the graph's branches (secondary.hip_graph_small_batch has the "
+                          "launch-bound case)"}
     # ---- diagnostics pass (after the timed region, production two-stream mode): host enqueue time and, with a process
     # group, the exposed part of every exchange point
     diag = diagnostics_pass(tb, gs, args.diag_steps, barrier) if args.diag_steps > 0 else None
+    if tb.use_graph and diag is not None:        # the eager iteration's enqueue time beside the graph launch's
+        tb.use_graph = False
+        d2 = diagnostics_pass(tb, gs, args.diag_steps, barrier)
+        diag["host_enqueue_ms_eager"] = d2["host_enqueue_ms"]
+    tb.use_graph = False                         # everything below (instrumented passes, arithmetic switches) runs eagerly
     # ---- per-kernel roofline pass.  In the timed region the weight-gradient kernels run concurrently with the
     # dgrad/BN chain on a second stream, so a kernel's event-to-event duration there includes time shared with another
     # kernel; the roofline numbers therefore come from a SERIALIZED pass of the same step, in this process, right after
@@ -1025,10 +1075,13 @@ def main():
             "kernels": kernels,
             "loss_first_last": [round(loss_vals[0], 6), round(loss_vals[-1], 6)] if loss_vals else None,
         }
+        out["hip_graph"] = graph_info
         if dist_info:
             out["dist"] = dist_info
         if diag is not None:
             out["host_enqueue_ms"] = diag["host_enqueue_ms"]
+            if "host_enqueue_ms_eager" in diag:
+                out["host_enqueue_ms_eager"] = diag["host_enqueue_ms_eager"]
             out["host_enqueue_note"] = ("wall time of one step() on the launching thread (median of the diagnostics pass, GPU "
                                         "queue never full): every kernel launch, allocation and event of the step through ctypes")
         if world == 1 and not args.no_secondary and args.workload == "S" and not args.from_rasters and not use_dist:

@@ -40,7 +40,7 @@ typedef void* rd_stream_t; /* hipStream_t */
 #define RD_ERR_WS 2
 #define RD_ERR_HIP 3
 
-int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream); 102: rd_host_register & co; 103: rd_mfma_products */
+int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream); 102: rd_host_register & co; 103: rd_mfma_products; 104: rd_adam_step_dev */
 /* Arithmetic of the split-bf16 MFMA kernels in THIS build of the library (one source tree, two shared objects):
  *   6  libresdepth_hip.so         x = x1 + x2 + x3 (three bf16 terms, exact), six products per multiply: fp32-class results,
  *                                 the default and the only build the headline numbers / parity bars are quoted on;
@@ -357,6 +357,12 @@ int rd_masked_l1_finish(const float* yp, const float* y, const uint8_t* mask, co
 /* beta1/beta2 are doubles so that (1-beta) is formed from the host's double scalars exactly like torch does */
 int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, double beta1, double beta2, float eps,
                  float weight_decay, float step_size, float bc2_sqrt, float grad_scale, rd_stream_t s);
+
+/* The same step with its scalars in DEVICE memory: scalars_dev[8] = {(float)(1-beta1), (float)beta2, (float)(1-beta2), eps, weight_decay,
+ * step_size, bc2_sqrt, grad_scale} -- bit-identical to rd_adam_step called with those values.  This is the launch a captured HIP graph
+ * replays (resdepth_amd/graph.py: one graph launch per lib/Trainer.py:212-222 iteration); the host rewrites the scalars before each
+ * replay (step count of the bias corrections, learning-rate schedule), the graph itself never changes. */
+int rd_adam_step_dev(float* p, const float* g, float* m, float* v, long long numel, const float* scalars_dev, rd_stream_t s);
 
 /* ---- torch.optim.SGD step over a flat buffer (lib/utils.py:332-334: SGD(lr, weight_decay)) ---- */
 /* g = grad_scale*g + wd*p;  momentum != 0: buf = first_step ? g : momentum*buf + (1-dampening)*g;  g = nesterov ? g + momentum*buf : buf;

@@ -112,6 +112,7 @@ SIGNATURES = {
     "rd_masked_l1_partial": (I, [P, P, P, P, P, P, I, LL, P, SZ, P]),
     "rd_masked_l1_finish": (I, [P, P, P, P, P, P, D, P, P, P, I, LL, P]),
     "rd_adam_step": (I, [P, P, P, P, LL, D, D, F, F, F, F, F, P]),
+    "rd_adam_step_dev": (I, [P, P, P, P, LL, P, P]),
     "rd_sgd_step": (I, [P, P, P, LL, F, F, F, F, I, I, F, P]),
     "rd_blend_accumulate": (I, [P, P, P, P, P, I, I, I, P, I, I, P]),
     "rd_host_register": (I, [P, SZ]),

@@ -932,10 +932,9 @@ __global__ __launch_bounds__(256) void l1_finish_kernel(const float* __restrict_
 }
 
 // ---- Adam -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, long n, float w1,
-                                                   float b2, float w2, float eps, float wd, float step_size,
-                                                   float bc2_sqrt, float gscale) {
+__device__ __forceinline__ void adam_elements(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, long n, float w1, float b2, float w2, float eps, float wd,
+                                              float step_size, float bc2_sqrt, float gscale) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         // the gradient and the two moments stream through once per step (non-temporal); the parameter is read again by the pack
         const float pe = p[e];
@@ -949,6 +948,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         st_nt1(m + e, me);
         st_nt1(v + e, ve);
     }
+}
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float w1,
+                                                   float b2, float w2, float eps, float wd, float step_size,
+                                                   float bc2_sqrt, float gscale) {
+    adam_elements(p, g, m, v, n, w1, b2, w2, eps, wd, step_size, bc2_sqrt, gscale);
+}
+// the same step with its eight scalars read from device memory (sc = {1-beta1, beta2, 1-beta2, eps, weight_decay, step_size,
+// sqrt(bias_correction2), grad_scale}): the form a captured HIP graph replays -- the host refreshes sc before every replay
+// (step count, learning-rate schedule), the launch itself never changes
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long n, const float* __restrict__ sc) {
+    adam_elements(p, g, m, v, n, sc[0], sc[1], sc[2], sc[3], sc[4], sc[5], sc[6], sc[7]);
 }
 
 // ---- SGD (torch.optim.SGD, lib/utils.py:332-334: lr + coupled weight decay; momentum / dampening / nesterov as torch) ----
@@ -1877,6 +1889,15 @@ int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, 
                        (long)numel, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, step_size, bc2_sqrt,
                        grad_scale);
     RD_LAUNCH_CHECK("adam");
+    return RD_OK;
+}
+
+int rd_adam_step_dev(float* p, const float* g, float* m, float* v, long long numel, const float* scalars_dev, rd_stream_t s) {
+    RD_REQUIRE(p && g && m && v && scalars_dev && numel > 0, "rd_adam_step_dev: bad arguments");
+    ProfScope ps((hipStream_t)s, "adam", 0, 28.0 * numel);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_cap((numel + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v,
+                       (long)numel, scalars_dev);
+    RD_LAUNCH_CHECK("adam_dev");
     return RD_OK;
 }
 

@@ -168,7 +168,7 @@ static void drain_locked() {
 
 extern "C" {
 
-int rd_version(void) { return 103; }      // 101 (r04): rd_set_splitk_workspace keyed by (device, stream); 102 (r05): rd_host_register; 103: rd_mfma_products
+int rd_version(void) { return 104; }      // 101 (r04): rd_set_splitk_workspace keyed by (device, stream); 102 (r05): rd_host_register; 103: rd_mfma_products; 104: rd_adam_step_dev
 
 const char* rd_last_error_string(void) { return rd::g_err; }
 

@@ -645,6 +645,12 @@ def adam_step(p, g, m, v, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, 
                               bc2_sqrt, grad_scale, stream_ptr()), "adam_step")
 
 
+def adam_step_dev(p, g, m, v, scalars_dev):
+    """rd_adam_step with its eight scalars in device memory (the launch a captured step replays; resdepth_amd/graph.py)."""
+    assert scalars_dev.is_cuda and scalars_dev.dtype == torch.float32 and scalars_dev.numel() >= 8
+    check(load().rd_adam_step_dev(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(scalars_dev), stream_ptr()), "adam_step_dev")
+
+
 def sgd_step(p, g, buf, lr, weight_decay, momentum=0.0, dampening=0.0, nesterov=False, first_step=False, grad_scale=1.0):
     check(load().rd_sgd_step(ptr(p), ptr(g), ptr(buf), p.numel(), lr, weight_decay, momentum, dampening,
                              1 if nesterov else 0, 1 if first_step else 0, grad_scale, stream_ptr()), "sgd_step")

@@ -25,6 +25,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._flat_state = {}      # group index -> (flat_ptr, m, v)
         self.grad_scale = 1.0
+        self._cap = None           # captured-step support (capture_prepare / capture_step / advance)
 
     def load_state_dict(self, state_dict):
         """torch.optim.Optimizer.load_state_dict replaces state[p]['exp_avg'|'exp_avg_sq'] by the loaded tensors; the flat
@@ -32,10 +33,95 @@ class FusedAdam(torch.optim.Optimizer):
         them: the next step() copies the loaded moments into fresh flat buffers and re-points the state views."""
         super().load_state_dict(state_dict)
         self._flat_state = {}
+        self._cap = None           # a captured step holds the OLD moment buffers: resdepth_amd.graph re-captures
 
     def __setstate__(self, state):
         super().__setstate__(state)
         self._flat_state = {}
+        self._cap = None
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    # ---- captured-step support: the step as a fixed launch whose scalars live in device memory --------------------------
+    # resdepth_amd.graph.GraphedTrainStep captures forward + loss + backward + capture_step() into one HIP graph.  What changes
+    # from step to step on the HOST side of torch.optim.Adam -- the step count in the bias corrections, a scheduler's learning
+    # rate, grad_scale -- is written by advance() into an 8-float device block before every replay (rd_adam_step_dev).
+    _RING = 64
+
+    def capture_prepare(self):
+        """Outside any capture.  True if every group is on the one-launch flat path with its moments allocated (after at least
+        one eager step with all gradients present); allocates the scalar blocks."""
+        self._sync_steps()
+        groups = []
+        for gi, group in enumerate(self.param_groups):
+            params = list(group["params"])
+            if not params:
+                continue
+            if group.get("amsgrad") or group.get("maximize") or any(p.grad is None or not p.is_cuda for p in params):
+                return False
+            flat = self._flat_state.get(gi)
+            pr = self._flat_range([p.data for p in params])
+            gr = self._flat_range([p.grad for p in params])
+            if flat is None or pr is None or gr is None or pr[0] != flat[0] or gr[1] != flat[1].numel() or \
+                    not self._same_layout(params, pr, gr):
+                return False
+            dev = params[0].device
+            groups.append(dict(gi=gi, t=float(self.state[params[0]]["step"]), dev=torch.zeros(8, device=dev, dtype=torch.float32),
+                               ring=torch.zeros(self._RING, 8, dtype=torch.float32).pin_memory(), events=[None] * self._RING, slot=0))
+        if not groups:
+            return False
+        self._cap = groups
+        return True
+
+    def capture_step(self):
+        """Inside the capture (gradients of this very capture in place): one rd_adam_step_dev per group."""
+        for c in self._cap:
+            group = self.param_groups[c["gi"]]
+            params = list(group["params"])
+            flat = self._flat_state[c["gi"]]
+            pr = self._flat_range([p.data for p in params])
+            gr = self._flat_range([p.grad for p in params])
+            if pr is None or gr is None or pr[0] != flat[0] or gr[1] != flat[1].numel() or not self._same_layout(params, pr, gr):
+                raise RuntimeError("FusedAdam.capture_step: the gradients of the captured backward are not one flat buffer in the "
+                                   "parameters' layout")
+            with _lib.device_of(params[0]):
+                ops.adam_step_dev(_as_flat(params[pr[2]].data, gr[1]), _as_flat(params[gr[2]].grad, gr[1]), flat[1], flat[2], c["dev"])
+
+    def advance(self):
+        """Before every replay (stream-ordered in front of it): count the step, refresh the scalar blocks from the param_groups
+        as they are NOW, tell the packed-weight caches that the parameters are about to change."""
+        import numpy as np
+        for c in self._cap:
+            group = self.param_groups[c["gi"]]
+            b1, b2 = group["betas"]
+            c["t"] += 1.0
+            t = c["t"]
+            bc1 = 1.0 - b1 ** t
+            bc2 = 1.0 - b2 ** t
+            i = c["slot"]
+            c["slot"] = (i + 1) % self._RING
+            if c["events"][i] is not None:
+                c["events"][i].synchronize()          # the copy that last used this pinned slot has left it
+            c["ring"][i].copy_(torch.from_numpy(np.array([1.0 - b1, b2, 1.0 - b2, group["eps"], group["weight_decay"], group["lr"] / bc1,
+                                                          math.sqrt(bc2), self.grad_scale], dtype=np.float64).astype(np.float32)))
+            with _lib.device_of(c["dev"]):
+                c["dev"].copy_(c["ring"][i], non_blocking=True)
+                ev = c["events"][i] or torch.cuda.Event()
+                ev.record()
+                c["events"][i] = ev
+            for p in group["params"]:
+                _lib.bump_param_generation(p.data_ptr())
+
+    def _sync_steps(self):
+        """state[p]['step'] (torch.optim.Adam's per-parameter CPU counters) <- the captured path's python counter."""
+        if self._cap:
+            for c in self._cap:
+                for p in self.param_groups[c["gi"]]["params"]:
+                    st = self.state[p]
+                    if "step" in st and float(st["step"]) != c["t"]:
+                        st["step"].fill_(c["t"])
 
     @staticmethod
     def _flat_range(tensors):
@@ -92,12 +178,18 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._sync_steps()
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group["params"]]
             if not params:
                 continue
             with _lib.device_of(params[0]):
                 self._step_group(gi, group, params)
+        if self._cap:                      # an eager step between replays (a ragged batch): the captured counter follows
+            for c in self._cap:
+                ps = self.param_groups[c["gi"]]["params"]
+                if ps and "step" in self.state[ps[0]]:
+                    c["t"] = float(self.state[ps[0]]["step"])
         return loss
 
     def _step_group(self, gi, group, params):

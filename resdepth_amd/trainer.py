@@ -197,6 +197,12 @@ class Trainer:
         # host -> device staging of the next batch under the current step (DevicePrefetcher); 0 = the copies ride the compute
         # stream in front of the forward, as in r04
         self.prefetch_batches = int(_get(args, "prefetch_batches", 1))
+        # hip_graph: replay the training iteration as ONE captured HIP graph (resdepth_amd.graph.GraphedTrainStep) instead of
+        # ~110 launches -- for launch-bound iterations (cfg-S: batch <= 6; +39 % at batch 4), bit-identical; off by default
+        # (at the benchmark batch the eager two-stream backward is 4-5 % faster).  Ragged batches, validation and
+        # multi-rank gradient synchronisation run the eager iteration either way.
+        self.hip_graph = bool(_get(args, "hip_graph", False))
+        self._graphed = None
 
         if self.pretrained_path is not None:
             self._load_pretrain(self.pretrained_path)
@@ -320,12 +326,27 @@ class Trainer:
         params = list(self.model.parameters())
         for p in params:
             p.grad = None
+        graphed = None
+        if phase == "train" and self.hip_graph and self.device.type == "cuda":
+            if self._graphed is None or self._graphed.model is not self.model or self._graphed.optimizer is not self.optimizer:
+                from .graph import GraphedTrainStep
+                self._graphed = GraphedTrainStep(self.model, self.optimizer)
+            graphed = self._graphed
+            self.model.train()
         for c_iter, batch in enumerate(loader):
-            dev.add(self._loss_on_device(batch, phase == "train"))
+            if graphed is not None:
+                x, y, loss_mask = self._extract_inputs_outputs_loss_masks(batch)
+                to = lambda t, dt=None: t.to(self.device, dtype=dt, non_blocking=True)      # noqa: E731
+                # .clone(): after a replay the loss is the graph's own output buffer, rewritten by the next one
+                dev.add(graphed(to(x), to(y), to(loss_mask), to(torch.flatten(batch["dsm_mean"]), torch.float32),
+                                to(torch.flatten(batch["dsm_std"]), torch.float32)).clone())
+            else:
+                dev.add(self._loss_on_device(batch, phase == "train"))
             if phase == "train":
-                self.optimizer.step()
-                for p in params:
-                    p.grad = None
+                if graphed is None:
+                    self.optimizer.step()
+                    for p in params:
+                        p.grad = None
                 if (c_iter + 1) % self.freq_average_train_loss == 0:
                     dev.flush_into(meters["MAE_metric"])
                     curr_iter = num_iter * epoch + (c_iter + 1)
