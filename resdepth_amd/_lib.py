@@ -244,9 +244,10 @@ def ensure_splitk_workspace(device, nbytes: int = SPLITK_BYTES) -> None:
     with _ws_lock:
         _splitk_clock += 1
         if key in _splitk:
-            _splitk[key][1] = _splitk_clock
+            if _splitk[key][1] != _PINNED:
+                _splitk[key][1] = _splitk_clock
             return
-        mine = [k for k in _splitk if k[0] == index]
+        mine = [k for k in _splitk if k[0] == index and _splitk[k][1] != _PINNED]
         buf = None
         if len(mine) >= SPLITK_MAX_STREAMS:
             # evict the least recently used registration of this device and hand its scratch to the new stream: a process that
@@ -263,6 +264,35 @@ def ensure_splitk_workspace(device, nbytes: int = SPLITK_BYTES) -> None:
         with torch.cuda.device(index):
             check(load().rd_set_splitk_workspace(buf.data_ptr(), buf.numel(), stream), "set_splitk_workspace")
         _splitk[key] = [buf, _splitk_clock]     # kept alive while registered (the library holds the raw pointer)
+
+
+_PINNED = float("inf")
+
+
+def pin_splitk_workspace(stream: "torch.cuda.Stream", nbytes: int = SPLITK_BYTES):
+    """A split-K scratch of its own for `stream`, outside the least-recently-used turnover of ensure_splitk_workspace: what a
+    captured HIP graph needs (resdepth_amd/graph.py) -- its kernels keep the raw pointer for as long as the graph is replayed, and
+    registering inside a capture could need the eviction's device synchronisation, which a capture forbids.  Call outside any
+    capture; returns the buffer (the caller keeps it alive); unpin_splitk_workspace(stream) gives the registration up."""
+    index = stream.device.index
+    key = (index, stream.cuda_stream)
+    with _ws_lock:
+        old = _splitk.pop(key, None)
+        buf = old[0] if old is not None and old[0].numel() >= int(nbytes) else \
+            torch.empty(int(nbytes), dtype=torch.uint8, device=torch.device("cuda", index))
+        with torch.cuda.device(index):
+            check(load().rd_set_splitk_workspace(buf.data_ptr(), buf.numel(), stream.cuda_stream), "set_splitk_workspace")
+        _splitk[key] = [buf, _PINNED]
+    return buf
+
+
+def unpin_splitk_workspace(stream: "torch.cuda.Stream") -> None:
+    key = (stream.device.index, stream.cuda_stream)
+    with _ws_lock:
+        if key in _splitk and _splitk[key][1] == _PINNED:
+            with torch.cuda.device(key[0]):
+                check(load().rd_set_splitk_workspace(None, 0, key[1]), "set_splitk_workspace")
+            _splitk.pop(key)
 
 
 # ---- parameter generation counter (bumped by in-place updates done through raw pointers) -------

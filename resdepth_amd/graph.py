@@ -41,6 +41,8 @@ class GraphedTrainStep:
         self._loss = None
         self._grads = None
         self._cap_token = None
+        self._stream = None                      # the capture stream, with a split-K scratch of its own (_lib.pin_splitk_workspace)
+        self._scratch = None
         self.why_eager = None                    # reason the last call ran eagerly (None: it was a replay)
         self.replays = 0
 
@@ -74,6 +76,13 @@ class GraphedTrainStep:
         """Drop the captured graph (the next eligible call captures again)."""
         self._graph = self._static = self._loss = self._grads = self._key = self._cap_token = None
 
+    def __del__(self):
+        try:
+            if self._stream is not None:
+                _lib.unpin_splitk_workspace(self._stream)
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass
+
     def _capture(self, batch):
         dev = batch[0].device
         for p in self.params:
@@ -84,9 +93,14 @@ class GraphedTrainStep:
         for s, t in zip(static, batch):
             s.copy_(t)
         self.model.invalidate_packed()           # the capture must contain the weight packing: every replay follows an update
+        if self._stream is None:
+            # the engine registers a split-K scratch per stream on first use and evicts the least recently used one beyond eight
+            # streams (with a device synchronisation): neither may happen inside a capture, nor to a buffer a graph points into
+            self._stream = torch.cuda.Stream(device=dev)
+            self._scratch = _lib.pin_splitk_workspace(self._stream)
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with torch.cuda.graph(g, stream=self._stream, capture_error_mode="thread_local"):
             out = self.model(static[0])
             loss = masked_l1_loss(out, static[1], static[2], static[3], static[4])
             loss.backward()

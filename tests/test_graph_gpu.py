@@ -45,7 +45,13 @@ def _same_state(ma, oa, mb, ob):
 def test_replayed_iterations_leave_the_bits_of_eager_ones():
     """12 iterations over 4 batches, the learning rate halved in the middle (what a scheduler does), one ragged batch on the way
     (eager fallback between replays): weights, BN buffers, moments, step counts and every loss bit-identical."""
-    from resdepth_amd import UNet, GraphedTrainStep
+    from resdepth_amd import UNet, GraphedTrainStep, _lib
+    # a process that has used many streams already: the split-K scratch registry is full, a new stream evicts the least recently
+    # used registration WITH a device synchronisation -- the capture stream must not go through that (it owns a pinned scratch)
+    streams = [torch.cuda.Stream() for _ in range(_lib.SPLITK_MAX_STREAMS + 1)]
+    for st in streams:
+        with torch.cuda.stream(st):
+            _lib.ensure_splitk_workspace(DEV)
     torch.manual_seed(0)
     sd0 = copy.deepcopy(UNet(**KW).state_dict())
     full, ragged = _batches(4, 4), _batches(3, 1, seed=40)
