@@ -40,24 +40,42 @@ typedef void* rd_stream_t; /* hipStream_t */
 #define RD_ERR_WS 2
 #define RD_ERR_HIP 3
 
-int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream); 102: rd_host_register & co; 103: rd_mfma_products; 104: rd_adam_step_dev */
-/* Arithmetic of the split-bf16 MFMA kernels in THIS build of the library (one source tree, two shared objects):
- *   6  libresdepth_hip.so         x = x1 + x2 + x3 (three bf16 terms, exact), six products per multiply: fp32-class results,
- *                                 the default and the only build the headline numbers / parity bars are quoted on;
- *   3  libresdepth_hip_split2.so  x ~ x1 + x2 (two round-to-nearest bf16 terms, |error| <= 2^-18 |x|), three products
- *                                 (a1 b1, a1 b2, a2 b1): ~17 significant bits per product, half the matrix-pipe work.  An
- *                                 OPT-IN precision mode (RD_MFMA=split2 in the Python host), in kind what cuDNN's TF32 default
- *                                 is to the reference on an NVIDIA GPU (lib/UNet.py:196-246 run through torch.backends.cudnn
- *                                 with allow_tf32 = True: 10 mantissa bits), at 128 x its precision.  DESIGN.md section 3.1h. */
+int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream); 102: rd_host_register & co; 103: rd_mfma_products; 104: rd_adam_step_dev; 105 (r06): rd_quant_next / rd_amax, packed operands hold both split forms */
+/* Arithmetic of the split MFMA kernels -- ONE library, chosen per launch (csrc/rd_mfma_dev.h):
+ *   6  "split3"   x = x1 + x2 + x3 (three bf16 terms, exact), six products per multiply on v_mfma_f32_32x32x16_bf16.  No
+ *                 assumption about the operands; what every launch falls back to.
+ *   3  "split2h"  x ~ (x1 + x2) / s: two FP16 terms of s x (11 bits each, |error| <= 2^-22 |s x|), s = a power of two per
+ *                 operand tensor that maps the tensor's largest magnitude into [2^14, 2^15); three products (a1 b1, a1 b2,
+ *                 a2 b1) on v_mfma_f32_32x32x16_f16, scaled back exactly: <= 3 * 2^-22 relative error per product, half the
+ *                 matrix instructions.  Needs the operands' magnitudes: see rd_quant_next.
+ * rd_mfma_products() returns the mode of the process: the knob `mfma_products` (rd_tune_set, RD_TUNE, RD_MFMA=split2h | split3).
+ * In mode 3 a launch still runs the six-product body when an operand comes without a magnitude slot or its maximum is +-Inf
+ * (decided on the device at kernel start, no host round trip) -- fp32's non-finite semantics are those of mode 6. */
 int rd_mfma_products(void);
+/* Magnitude slots.  A slot is 16 consecutive 32-bit words of device memory, zeroed by the caller before its producer runs; the
+ * producer max-accumulates the IEEE bit patterns of |x| into it (atomic integer max: order-independent, so run-to-run
+ * identical) and a consumer takes the largest of the 16 words as the tensor's maximum.
+ *   rd_quant_next(a, b, out, out2): the slots the NEXT rd_* call of this host thread takes (any may be NULL); that call clears
+ *     them again, whether it uses them or not.  Consumers (rd_conv3x3_fwd*, rd_conv3x3_bwd_data*, rd_convt2x2_fwd*,
+ *     rd_convt2x2_bwd_data*, rd_conv1x1_*): a = slot of the activation / gradient operand, b = slot of the packed weight;
+ *     weight gradients (rd_*_bwd_weight): a = slot of the gradient operand (dz / dout / dy), b = slot of x.  Producers: out =
+ *     slot that receives max |primary output| (z is not an operand and gets none: rd_conv3x3_fwd_act -> a, rd_conv3x3_bwd_data*
+ *     -> dx, rd_convt2x2_fwd* -> out, rd_bn_act_pool_fwd -> a (un-pooled form), rd_bn_act_bwd_apply -> dz), out2 = slot of
+ *     the pooled output (rd_conv3x3_fwd_act, rd_bn_act_pool_fwd, rd_conv3x3_first_fwd_act); rd_pack_*: out2 = the weight's
+ *     slot, which the call fills itself before it writes the three-product form of the operand.
+ *   rd_amax(x, n, slot): max |x[0..n)| into a (zeroed) slot: operands that no producer of this library wrote. */
+int rd_quant_next(const unsigned* a_amax, const unsigned* b_amax, unsigned* out_amax, unsigned* out2_amax);
+int rd_amax(const float* x, long long n, unsigned* slot, rd_stream_t s);
+#define RD_AMAX_WORDS 16
 const char* rd_last_error_string(void);
 
 /* ---- weight (re)packing: torch layouts -> GEMM operand layouts ------------------- */
 /* Every packed operand B[rows][K = taps*Cin] is ONE opaque caller-owned buffer of
  * rd_packed_weight_bytes(rows, taps, Cin) bytes: the fp32 GEMM layout (rows*K floats, described
- * below) followed by the same matrix pre-split into three bf16 terms per element in the LDS row
- * layout of the split-bf16 MFMA kernels.  The conv entry points take the buffer's
- * base pointer.  (rows, taps, Cin) per operand:
+ * below) followed by the same matrix pre-split in the fragment order of the split MFMA kernels, in BOTH
+ * forms: three bf16 terms per element (96 bytes per row and 16-k step), then two fp16 terms of the
+ * scaled element (64 bytes; written only when the pack call was given the weight's magnitude slot:
+ * rd_quant_next(..., out2) in mode 3).  The conv entry points take the buffer's base pointer.  (rows, taps, Cin) per operand:
  *   conv3x3  wf: (Cout, 9, Cin)   wd: (Cin, 9, Cout)
  *   convT2x2 wtf: (4*Cout, 1, Cin)  wtd: (Cin, 4, Cout)
  *   conv1x1  wf: (Cout, 1, Cin)   wt: (Cin, 1, Cout) */
@@ -81,7 +99,8 @@ int rd_pack_conv3x3_weight(const float* w_oihw, float* wf, float* wd, int cout, 
  * 10 int64:
  *   { w (device pointer, torch layout), forward-operand buffer, data-gradient-operand buffer, kind (0 = conv3x3 [Cout][Cin][3][3],
  *     1 = ConvTranspose2d [Cin][Cout][2][2]), Cout, Cin, first piece index, fp32 forward-operand pointer (convT only: the buffer
- *     base again when the fp32 layout wtf is wanted, else 0), first tile index, 0 }
+ *     base again when the fp32 layout wtf is wanted, else 0), first tile index, magnitude slot of w (device pointer to 16 zeroed
+ *     words; 0 = six-product form only) }
  * A layer whose channel counts are both multiples of 32 is packed by the TILE kernel (rd_pack_item_tiles() > 0 tiles, coalesced
  * loads through LDS; it then owns no pieces: its `first piece index` is the running piece count), every other layer piece by
  * piece (rd_pack_item_pieces() pieces, gathered loads; it owns no tiles).  The buffers are the opaque packed buffers of

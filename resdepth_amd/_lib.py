@@ -15,13 +15,16 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RESDEPTH_HIP_LIB: alternative build of the same library (kernel diagnosis builds)
-# RD_MFMA=split2: the two-term / three-product build of the same sources (include/resdepth_hip.h: rd_mfma_products) -- an
-# opt-in precision mode, chosen once per process like RD_MFMA=f32 (which is a switch inside the default library)
+# RD_MFMA: arithmetic of the matrix-pipe kernels, read by the LIBRARY at load time (csrc/rd_runtime.hip) -- one shared object:
+#   split2h  two fp16 terms / three products where the operands carry magnitude slots (include/resdepth_hip.h: rd_quant_next)
+#   split3   three bf16 terms / six products everywhere
+#   f32      v_mfma_f32_32x32x2_f32 (exact)
+# and switchable in-process: tune_set("mfma_products", 3 | 6), tune_set("mfma_f32", 0 | 1).
 MFMA_MODE = os.environ.get("RD_MFMA", "")
-if MFMA_MODE not in ("", "f32", "split3", "split2"):
-    raise RuntimeError(f"RD_MFMA={MFMA_MODE!r}: expected f32, split3 (default) or split2")
-LIB_NAME = "libresdepth_hip_split2.so" if MFMA_MODE == "split2" else "libresdepth_hip.so"
-LIB_PATH = os.environ.get("RESDEPTH_HIP_LIB") or os.path.join(_HERE, LIB_NAME)
+if MFMA_MODE not in ("", "f32", "split3", "split2h"):
+    raise RuntimeError(f"RD_MFMA={MFMA_MODE!r}: expected f32, split3 or split2h")
+LIB_PATH = os.environ.get("RESDEPTH_HIP_LIB") or os.path.join(_HERE, "libresdepth_hip.so")
+AMAX_WORDS = 16      # RD_AMAX_WORDS: 32-bit words of one magnitude slot
 
 _lib = None
 _lock = threading.Lock()
@@ -37,6 +40,8 @@ SZ = C.c_size_t
 SIGNATURES = {
     "rd_version": (I, []),
     "rd_mfma_products": (I, []),
+    "rd_quant_next": (I, [P, P, P, P]),
+    "rd_amax": (I, [P, LL, P, P]),
     "rd_last_error_string": (C.c_char_p, []),
     "rd_pack_conv3x3_weight": (I, [P, P, P, I, I, P]),
     "rd_pack_item_pieces": (LL, [I, I, I, I]),
@@ -154,20 +159,87 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        want = 3 if MFMA_MODE == "split2" else 6
-        if "RESDEPTH_HIP_LIB" not in os.environ and lib.rd_mfma_products() != want:
-            raise RuntimeError(f"resdepth_amd: {LIB_PATH} computes {lib.rd_mfma_products()} products per multiply, RD_MFMA={MFMA_MODE or 'split3'} "
-                               f"needs {want}: stale build -- run resdepth_amd/csrc/build.sh")
+        if lib.rd_version() < 105:
+            raise RuntimeError(f"resdepth_amd: {LIB_PATH} is version {lib.rd_version()} (< 105): stale build -- run "
+                               "resdepth_amd/csrc/build.sh")
         _lib = lib
     return _lib
 
 
 def mfma_mode() -> str:
-    """Arithmetic of the matrix-pipe convolution kernels in this process: "split3" (default: six bf16 products per multiply,
-    fp32-class), "split2" (RD_MFMA=split2: three products, ~17 bits) or "f32" (RD_MFMA=f32 / tune knob mfma_f32: exact)."""
+    """Arithmetic of the matrix-pipe convolution kernels in this process: "split2h" (two fp16 terms, three products per multiply
+    on operands with magnitude slots), "split3" (three bf16 terms, six products) or "f32" (exact)."""
     if tune_get("mfma_f32"):
         return "f32"
-    return "split2" if load().rd_mfma_products() == 3 else "split3"
+    return "split2h" if load().rd_mfma_products() == 3 else "split3"
+
+
+_products = None
+
+
+def products() -> int:
+    """3 when GEMM operands should carry magnitude slots (split2h mode, split kernels active), else 6.  Cached; tune_set drops
+    the cache."""
+    global _products
+    if _products is None:
+        _products = 3 if (load().rd_mfma_products() == 3 and not tune_get("mfma_f32")) else 6
+    return _products
+
+
+# ---- magnitude slots (include/resdepth_hip.h: rd_quant_next) ----------------------------------------------------------------
+# A tensor that is an operand of a three-product GEMM carries its slot as the attribute `_rd_amax` (a 16-word int32 view of a
+# pool); producers draw the slot from the pool that is ACTIVE on the calling thread (`with AmaxPool(...)`: the engine's forward
+# and backward), consumers read the attribute -- a tensor without one (any torch op's result, a view, .contiguous()) simply
+# runs the six-product body.
+_tls = threading.local()
+
+
+class AmaxPool:
+    """A zeroed block of magnitude slots for one pass (forward or backward) of one model: one torch.zeros per pass."""
+
+    def __init__(self, device, slots: int = 96):
+        self.buf = torch.zeros(slots * AMAX_WORDS, dtype=torch.int32, device=device)
+        self.n, self.cap = 0, slots
+
+    def take(self):
+        if self.n >= self.cap:
+            return None                      # more producers than planned: the tensor goes without (six-product consumer)
+        v = self.buf[self.n * AMAX_WORDS:(self.n + 1) * AMAX_WORDS]
+        self.n += 1
+        return v
+
+    def __enter__(self):
+        self._prev = getattr(_tls, "pool", None)
+        _tls.pool = self
+        return self
+
+    def __exit__(self, *exc):
+        _tls.pool = self._prev
+        return False
+
+
+def amax_slot():
+    """A fresh slot from the active pool, or None (no pool / six-product mode)."""
+    pool = getattr(_tls, "pool", None)
+    return pool.take() if pool is not None else None
+
+
+def slot_of(t):
+    return getattr(t, "_rd_amax", None) if t is not None else None
+
+
+def tag(t, slot):
+    if t is not None and slot is not None:
+        t._rd_amax = slot
+    return t
+
+
+def quant_next(a=None, b=None, out=None, out2=None):
+    """rd_quant_next with tensors (None -> NULL): only worth a call when something is set."""
+    if a is None and b is None and out is None and out2 is None:
+        return
+    load().rd_quant_next(a.data_ptr() if a is not None else None, b.data_ptr() if b is not None else None,
+                         out.data_ptr() if out is not None else None, out2.data_ptr() if out2 is not None else None)
 
 
 def check(rc: int, what: str = ""):
@@ -334,7 +406,9 @@ def global_generation() -> int:
 
 # ---- diagnosis knobs ----------------------------------------------------------------------------
 def tune_set(name: str, value: int):
+    global _products
     check(load().rd_tune_set(name.encode(), int(value)), "tune_set")
+    _products = None
 
 
 def tune_get(name: str) -> int:

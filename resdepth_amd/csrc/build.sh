@@ -35,19 +35,3 @@ for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/rd_runtime.o "$OBJ"/rd_igemm.o "$OBJ"/rd_convt.o "$OBJ"/rd_wgrad_strip.o "$OBJ"/rd_elementwise.o "$OBJ"/rd_edge_conv.o "$OBJ"/rd_stats.o
 [ -n "$RD_SKIP_ISA_CHECK" ] || bash "$HERE/../../scripts/check_isa.sh" "$OUT"
 echo "built $OUT"
-# The two-term / three-product build (include/resdepth_hip.h: rd_mfma_products; RD_MFMA=split2): the three translation units
-# that hold split-bf16 kernels compiled again with -DRD_NPROD=3, linked with the other four objects as they are.
-if [ -z "$RD_OUT" ] && [ -z "$RD_NO_SPLIT2" ]; then
-  OUT2="$HERE/../libresdepth_hip_split2.so"; OBJ2="$OBJ/split2"; mkdir -p "$OBJ2"; pids=()
-  for f in rd_igemm rd_convt rd_wgrad_strip; do
-    if [ ! -f "$OBJ2/$f.o" ] || [ "$OBJ/$f.o" -nt "$OBJ2/$f.o" ]; then
-      F="$FLAGS"; [ $f = rd_wgrad_strip ] && F="$BASE"
-      $HIPCC $F -DRD_NPROD=3 -c "$HERE/$f.hip" -o "$OBJ2/$f.o" &
-      pids+=($!)
-    fi
-  done
-  for p in "${pids[@]}"; do wait $p; done
-  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT2" "$OBJ"/rd_runtime.o "$OBJ2"/rd_igemm.o "$OBJ2"/rd_convt.o "$OBJ2"/rd_wgrad_strip.o "$OBJ"/rd_elementwise.o "$OBJ"/rd_edge_conv.o "$OBJ"/rd_stats.o
-  [ -n "$RD_SKIP_ISA_CHECK" ] || bash "$HERE/../../scripts/check_isa.sh" "$OUT2"
-  echo "built $OUT2"
-fi

@@ -11,6 +11,7 @@ void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
 // ---- profiling (rd_prof_*) -----------------------------------------------------------
+struct QuantArgs;
 int prof_level();   // 0 off, 1 = MFMA (roofline) kernel classes only, 2 = every kernel class
 void prof_begin(hipStream_t s, const char* cls, double flops, double bytes);
 void prof_end(hipStream_t s);
@@ -53,28 +54,40 @@ enum TuneKey {
     TUNE_LAST_BLOCKS,      // first-stage blocks of the last-conv gradient kernels
     TUNE_NT_SPLITK,        // -1 auto | 0: never use the split-K patch kernel for 8 x 8 images (needs rd_set_splitk_workspace)
     TUNE_NT_EPI,           // -1 auto | 0: patch kernels keep the LDS-staged epilogue (r03) instead of the register-direct one
+    TUNE_MFMA_PRODUCTS,    // 3: two-term fp16 split, three products, where the operands carry magnitude slots (rd_quant_next; RD_MFMA=split2h) | 6: three-term bf16 split everywhere (RD_MFMA=split3)
     TUNE_D2H_BLOCKS,       // rd_copy_to_host_async: 0 (default) = hipMemcpyAsync (the runtime's blit kernel) | n > 0: own copy kernel with n workgroups (r05 experiment: slower)
     TUNE_COUNT
 };
 int tune(int key);
-// split-bf16 MFMA arithmetic enabled (default) or exact f32 (TUNE_MFMA_F32)
+// split MFMA arithmetic enabled (default) or exact f32 (TUNE_MFMA_F32)
 inline int mfma_split() { return !tune(TUNE_MFMA_F32); }
+// products per fp32 multiply of the split kernels: 3 (operands with magnitude slots) or 6
+inline int mfma_products() { return tune(TUNE_MFMA_PRODUCTS) == 3 ? 3 : 6; }
+// rd_quant_next(): the magnitude slots the NEXT entry point of this host thread takes (cleared by the take)
+struct QuantArgs {
+    const unsigned* a;     // operand A (activations / gradients), 16 words
+    const unsigned* b;     // operand B (packed weights; the second activation operand of a weight gradient)
+    unsigned* out;         // receives max |output|
+    unsigned* out2;        // second output of the call (pooled tensor), or the weight slot a pack call fills
+};
+QuantArgs quant_take();
 // conv3x3 weight-gradient strip kernel (rd_wgrad_strip.hip): number of split-K slabs it will write for this shape
 // (0 = shape not handled, use the TN kernel), and its launcher (*splits_out = 0 when it did not run; *swapped_out = 1
 // when the slab is the mirrored transpose [Cin][(8 - tap) * Cout + co], see plan_strip)
 int wgrad_strip_splits(int n, int h, int w, int cin, int cout);
 int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int h, int w, int cin, int cout, hipStream_t s,
-                       int* splits_out, int* swapped_out);
+                       int* splits_out, int* swapped_out, const unsigned* x_amax = nullptr, const unsigned* dz_amax = nullptr);
 
 // transposed-convolution patch kernels (rd_convt.hip); *launched = 0 when the shape is left to the generic NT kernel
 int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, const float* bias, const float* skip,
                      const float* sk_mean, const float* sk_invstd, const float* sk_gamma, const float* sk_beta, float sk_slope,
-                     const float* sk_slope_dev, float* out, int n, int h, int w, int cin, int cout, hipStream_t s, int* launched);
+                     const float* sk_slope_dev, float* out, int n, int h, int w, int cin, int cout, hipStream_t s, int* launched,
+                     const QuantArgs& qa);
 
 // transposed-convolution weight gradient (rd_convt.hip): workspace of its split-K slabs (0: shape left to the generic TN kernel)
 size_t convt_wgrad_ws_bytes(int n, int h, int w, int cin, int cout);
 int convt_wgrad_launch(const float* x, const float* dout, float* slab, int n, int h, int w, int cin, int cout, hipStream_t s,
-                       int* splits_out);
+                       int* splits_out, const unsigned* x_amax = nullptr, const unsigned* dout_amax = nullptr);
 
 // last convolution, tile kernels (rd_edge_conv.hip); *launched = 0 / blocks = 0 when the shape stays on the generic kernels
 int conv_last_fwd_launch(const float* s_in, const float* wt, const float* bias, const float* x_nchw, int xc, float* out, int n,
@@ -141,7 +154,7 @@ struct FirstBnBwd {
 };
 int conv_first_fwd_act_launch(const float* x, const float* wt, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, float slope, const float* slope_dev, float* a, float* pooled, int n, int h, int w,
-                              int cin, int cout, hipStream_t s);
+                              int cin, int cout, hipStream_t s, unsigned* p_amax = nullptr);
 int conv_first_seg_launch(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
                           int w, int cin, int cout, hipStream_t s, const FirstBnBwd* bn = nullptr);
 int conv_last_wgrad_launch(const float* s_in, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s);

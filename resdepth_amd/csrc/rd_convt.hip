@@ -39,6 +39,13 @@ struct CtParams {
     int tiles_x, ngroups, nk;
     unsigned x_bytes, w_bytes;
     int direct;              // register-direct epilogue (r04) instead of the LDS-staged one (tune nt_epi = 0)
+    // three-product arithmetic (rd_mfma_dev.h): magnitude slots of x / of the weights (both non-null: NP = 3 body unless a
+    // maximum is infinite), the two-term fp16 fragments of the weights, and the slot that receives max |out|
+    const unsigned* a_amax;
+    const unsigned* b_amax;
+    const void* wsplit3;
+    unsigned w_bytes3;
+    unsigned* out_amax;
 };
 
 __device__ __forceinline__ float ct_act(float y, float slope) { return y > 0.f ? y : y * slope; }
@@ -52,15 +59,14 @@ __device__ __forceinline__ float ct_act(float y, float slope) { return y > 0.f ?
 // Which pixel a 4-lane cluster loads does not matter to the global loads (64 contiguous bytes per cluster either way).
 __device__ __forceinline__ int stage_row(int idx) { return (idx & ~7) | ((idx & 3) << 1) | ((idx >> 2) & 1); }
 
-template <int TM>
-__global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
+template <int NP, int TM>
+__device__ __forceinline__ void convt_fwd_body(const CtParams& p, float* smem, const Quant qz) {
+    typedef typename frag_of<NP>::type FR;
+    constexpr int NT = NP == 3 ? 2 : 3;
     constexpr int BM = 32 * TM, RS = 28;                  // LDS row = 3 terms x 16 bf16 + 16 B pad (conflict-free b128 reads)
     constexpr int STAGE = BM * RS;
     constexpr int NLD = (BM * 4 + 255) / 256;             // staging float4 per thread and K-step
     constexpr int CS = 128 + 4;
-    constexpr int EPI_WORDS = 32 * CS;
-    constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int cg = lb % p.ngroups, tile_m = lb / p.ngroups;     // the column groups of one patch run back to back (A from L2)
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = lo[i][r] = 0.f;
 
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.x, p.x_bytes), rsB = make_rsrc(p.wsplit, p.w_bytes);
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.x, p.x_bytes), rsB = make_rsrc(NP == 3 ? p.wsplit3 : p.wsplit, NP == 3 ? p.w_bytes3 : p.w_bytes);
     unsigned s_off[NLD];
     int s_lds[NLD];
     const int c4 = t & 3;
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
         s_lds[k] = row < BM ? row * RS + c4 * 2 : -1;
     }
     const int nb = cg * 4 + wave;                         // 32-column block of this wave
-    const unsigned b_off = (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16);
+    const unsigned b_off = (unsigned)(((long)nb * p.nk * NT) * 1024 + lane * 16);
 
     auto load_a = [&](int kt, float4 (&ra)[NLD]) {
         const bool cok = kt < p.nk;
@@ -100,26 +106,26 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
         for (int k = 0; k < NLD; ++k) {
             if (s_lds[k] < 0) continue;
             uint2 ph, pm, pl;
-            split_pack4(ra[k], ph, pm, pl);
+            split_pack4<NP>(ra[k], qz.sa, ph, pm, pl);
             float* row = stage + s_lds[k];
             *reinterpret_cast<uint2*>(row) = ph;
             *reinterpret_cast<uint2*>(row + 8) = pm;
-            if (kTerm3) *reinterpret_cast<uint2*>(row + 16) = pl;
+            if (kterm3<NP>()) *reinterpret_cast<uint2*>(row + 16) = pl;
         }
     };
     auto load_b = [&](int kt, uint4 (&rb)[3]) {
         const unsigned voff = kt < p.nk ? b_off : kOOB;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((kt * 3 + q) * 1024));
+        for (int q = 0; q < NT; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((kt * NT + q) * 1024));
     };
     const int lrow = lane & 31, half = lane >> 5;
-    bf16x8 af[TM][3];
+    FR af[TM][3];
     auto read_a = [&](const float* stage) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                af[i][q] = *reinterpret_cast<const bf16x8*>(stage + (i * 32 + lrow) * RS + half * 4 + q * 8);
+            for (int q = 0; q < NT; ++q)
+                af[i][q] = *reinterpret_cast<const FR*>(stage + (i * 32 + lrow) * RS + half * 4 + q * 8);
     };
     constexpr int GP = TM >= 2 ? 2 : 1;
     constexpr int NB_ = TM >= 4 ? 3 : 4;
@@ -129,19 +135,17 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
         store_a(stage_next, ra);          // tile kt+1 (this stage was last read before the previous barrier)
         load_a(kt + 3, ra);
         load_b(kt + NB_ - 1, bnew);        // into the register set of tile kt-1
-        bf16x8 bf[3];
+        FR bf[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bf[q] = __builtin_bit_cast(bf16x8, bcur[q]);
+        for (int q = 0; q < NT; ++q) bf[q] = __builtin_bit_cast(FR, bcur[q]);
 #pragma unroll
         for (int g = 0; g < TM; g += GP) {
 #pragma unroll
-            for (int t6 = LO0; t6 < 5; ++t6)
+            for (int t6 = lo0<NP>(); t6 < 5; ++t6)
 #pragma unroll
-                for (int i = g; i < g + GP; ++i)
-                    lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
+                for (int i = g; i < g + GP; ++i) lo[i] = mfma16<NP>(af[i][PA6[t6]], bf[PB6[t6]], lo[i]);
 #pragma unroll
-            for (int i = g; i < g + GP; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i], 0, 0, 0);
+            for (int i = g; i < g + GP; ++i) acc[i] = mfma16<NP>(af[i][0], bf[0], acc[i]);
         }
         __syncthreads();
         read_a(stage_next);               // tile kt+1, consumed by the next step
@@ -221,14 +225,18 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     skv[i][r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsS, voff_s(i, r), soffd(i, r), 0));
+            float omax = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = merge_hi_lo(acc[i][r], lo[i][r]) + bias1;
+                    const float v = merge_q<NP>(acc[i][r], lo[i][r], qz.dexp) + bias1;
                     const float s1 = BNSKIP ? ct_act(fmaf(skv[i][r], sc1, sh1), slope1) : skv[i][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(s1 + v), rsO, voff(i, r), soffd(i, r), 0);
+                    const float o = s1 + v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(o), rsO, voff(i, r), soffd(i, r), 0);
+                    if (FULL || rowok(i, r)) omax = amax_acc(omax, o);
                 }
+            if (p.out_amax) amax_commit(p.out_amax, omax);
         };
         if (p.sk_mean) {
             if (rows_left >= p.TR) emit(std::true_type(), std::true_type());
@@ -259,6 +267,7 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
         slope = p.sk_slope_dev ? p.sk_slope_dev[0] : p.sk_slope;
     }
     float* Cs = smem;
+    float omax = 0.f;
     // all skip loads of the tile go out first (the fragment / weight registers of the main loop are dead by now): the
     // HBM latency is paid once per block instead of once per 32-row pass
     long off[TM][4];
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            Cs[((r & 3) + 8 * (r >> 2) + 4 * half) * CS + wave * 32 + lrow] = merge_hi_lo(acc[i][r], lo[i][r]);
+            Cs[((r & 3) + 8 * (r >> 2) + 4 * half) * CS + wave * 32 + lrow] = merge_q<NP>(acc[i][r], lo[i][r], qz.dexp);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -297,9 +306,21 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
                 v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w;
             }
             *reinterpret_cast<float4*>(p.out + off[i][k]) = v;
+            omax = amax_acc(amax_acc(amax_acc(amax_acc(omax, v.x), v.y), v.z), v.w);
         }
         __syncthreads();
     }
+    if (p.out_amax) amax_commit(p.out_amax, omax);
+}
+
+template <int TM>
+__global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
+    constexpr int STAGE = 32 * TM * 28, EPI_WORDS = 32 * (128 + 4);
+    constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    const Quant qz = quant_select(p.a_amax, p.b_amax);
+    if (qz.use3) convt_fwd_body<3, TM>(p, smem, qz);
+    else convt_fwd_body<6, TM>(p, smem, qz);
 }
 
 // ---- data gradient:  dx[p][ci] = sum_{a,b,co} dout[2g+a][2x+b][co] * W[ci][co][a][b]   (p = (g, x), g = n*H + y) --------
@@ -314,15 +335,16 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
 // 16-byte row-contiguous stores through LDS + the BatchNorm-backward statistics hook).
 //   <TM=4, WM=1, WN=4>: 128 pixels x 128 channels (Cin >= 128, big grids)     <TM=2, WM=1, WN=4>: 64 x 128 (small grids)
 //   <TM=2, WM=2, WN=2>: 128 pixels x 64 channels (Cin = 64: the 128^2 -> 256^2 level, HBM-bound)
-template <int TM, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
+template <int NP, int TM, int WM, int WN>
+__device__ __forceinline__ void convt_dgrad_body(const NtParams& p, float* smem, const Quant qz) {
+    typedef typename frag_of<NP>::type FR;
+    constexpr int NT = NP == 3 ? 2 : 3;
     constexpr int BM = 32 * TM * WM, BN = 32 * WN, RS = 28;
     constexpr int STAGE = BM * RS;
     constexpr int NLD = (BM * 4 + 255) / 256;
     constexpr int EPI_WORDS = 32 * (BN + 4) + 512;
     constexpr int SM0 = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
     constexpr int SMEM = SM0 > 4096 ? SM0 : 4096;           // BN-backward statistics scratch of the epilogue
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;    // the column groups of one pixel tile run back to back
@@ -337,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = lo[i][r] = 0.f;
 
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.Bsplit, p.b_bytes);
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(NP == 3 ? p.Bsplit3 : p.Bsplit, NP == 3 ? p.b_bytes3 : p.b_bytes);
     unsigned s_off[NLD];
     int s_lds[NLD];
     const int c4 = t & 3;
@@ -351,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
         s_lds[k] = row < BM ? row * RS + c4 * 2 : -1;
     }
     const int nb = (n0 >> 5) + wn;                          // 32-column block of this wave
-    const unsigned b_off = (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16);
+    const unsigned b_off = (unsigned)(((long)nb * p.nk * NT) * 1024 + lane * 16);
     const int cpt = p.chunks;                               // 16-channel chunks per tap
     const int half_nk = 2 * cpt;
     const unsigned arow = (unsigned)__builtin_amdgcn_readfirstlane(2 * W * Cd * 4);     // bytes from fine row 2g to fine row 2g+1
@@ -371,11 +393,11 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
         for (int k = 0; k < NLD; ++k) {
             if (s_lds[k] < 0) continue;
             uint2 ph, pm, pl;
-            split_pack4(ra[k], ph, pm, pl);
+            split_pack4<NP>(ra[k], qz.sa, ph, pm, pl);
             float* row = stage + s_lds[k];
             *reinterpret_cast<uint2*>(row) = ph;
             *reinterpret_cast<uint2*>(row + 8) = pm;
-            if (kTerm3) *reinterpret_cast<uint2*>(row + 16) = pl;
+            if (kterm3<NP>()) *reinterpret_cast<uint2*>(row + 16) = pl;
         }
     };
     // weight fragments: K-step kt = (tap, chunk) in tap-outer order lives at kt' = chunk * 4 + tap of the packed operand
@@ -384,17 +406,17 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
         const unsigned voff = kt < p.nk ? b_off : kOOB;
         const int ktp = __builtin_amdgcn_readfirstlane(kt < p.nk ? b_chunk * 4 + b_tap : 0);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((ktp * 3 + q) * 1024));
+        for (int q = 0; q < NT; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((ktp * NT + q) * 1024));
         if (++b_chunk == cpt) { b_chunk = 0; ++b_tap; }
     };
     const int lrow = lane & 31, half = lane >> 5;
-    bf16x8 af[TM][3];
+    FR af[TM][3];
     auto read_a = [&](const float* stage) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                af[i][q] = *reinterpret_cast<const bf16x8*>(stage + ((wm * TM + i) * 32 + lrow) * RS + half * 4 + q * 8);
+            for (int q = 0; q < NT; ++q)
+                af[i][q] = *reinterpret_cast<const FR*>(stage + ((wm * TM + i) * 32 + lrow) * RS + half * 4 + q * 8);
     };
     constexpr int GP = TM >= 2 ? 2 : 1;
 
@@ -419,19 +441,17 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
         store_a(stage_next, ra_);         // tile kt+1 (this stage was last read before the previous barrier)
         load_a(kt + 3, ra_);
         load_b(kt + NB - 1, bnew);
-        bf16x8 bf[3];
+        FR bf[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bf[q] = __builtin_bit_cast(bf16x8, bcur[q]);
+        for (int q = 0; q < NT; ++q) bf[q] = __builtin_bit_cast(FR, bcur[q]);
 #pragma unroll
         for (int g = 0; g < TM; g += GP) {
 #pragma unroll
-            for (int t6 = LO0; t6 < 5; ++t6)
+            for (int t6 = lo0<NP>(); t6 < 5; ++t6)
 #pragma unroll
-                for (int i = g; i < g + GP; ++i)
-                    lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
+                for (int i = g; i < g + GP; ++i) lo[i] = mfma16<NP>(af[i][PA6[t6]], bf[PB6[t6]], lo[i]);
 #pragma unroll
-            for (int i = g; i < g + GP; ++i)
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][0], 0, 0, 0);
+            for (int i = g; i < g + GP; ++i) acc[i][0] = mfma16<NP>(af[i][0], bf[0], acc[i][0]);
         }
         __syncthreads();
         read_a(stage_next);               // tile kt+1, consumed by the next step
@@ -448,8 +468,19 @@ __global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = merge_hi_lo(acc[i][0][r], lo[i][r]);
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = merge_q<NP>(acc[i][0][r], lo[i][r], qz.dexp);
     nt_epilogue<BM, BN, WM, WN, EPI_STORE, SMEM, 1>(acc, smem, p, m0, n0, tile_m);
+}
+
+template <int TM, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void convt_dgrad_kernel(NtParams p) {
+    constexpr int STAGE = 32 * TM * WM * 28, EPI_WORDS = 32 * (32 * WN + 4) + 512;
+    constexpr int SM0 = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
+    constexpr int SMEM = SM0 > 4096 ? SM0 : 4096;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    const Quant qz = quant_select(p.a_amax, p.b_amax);
+    if (qz.use3) convt_dgrad_body<3, TM, WM, WN>(p, smem, qz);
+    else convt_dgrad_body<6, TM, WM, WN>(p, smem, qz);
 }
 
 // p: A = dout, Bsplit / b_bytes = the split operand of wtd[ci][(ab, co)], C = dx, M = coarse pixels, N = Cin, Cin = Cd (channels
@@ -468,6 +499,7 @@ int convt_dgrad_launch(NtParams p, hipStream_t s, int* launched, int* tiles_m_ou
     p.vec = 1;
     p.patch = 0;
     p.a_bytes = (unsigned)ab;
+    if (mfma_products() != 3 || !p.a_amax || !p.b_amax) p.a_amax = p.b_amax = nullptr;    // six products
     // 64-row tiles (152 VGPRs: three waves per SIMD) beat 128-row tiles at every cfg-S level (r03: 176 vs 165 TFLOP/s at
     // 32^2 x 256, equal at 64^2 x 128; profiles/r03_notes.md); convt_patch = 3 forces the 128-row variant for A/B runs
     int cfg = p.N < 128 ? 2 : 1;
@@ -512,13 +544,16 @@ struct CtwParams {
     int total_ks, kps;       // K-steps in all / per split
     int tiles_n, tiles_mn;
     unsigned a_bytes, b_bytes;
+    const unsigned* a_amax;  // magnitude slots of dout / x (both non-null: three-product body, rd_mfma_dev.h)
+    const unsigned* b_amax;
 };
 
-template <int TN>
-__global__ __launch_bounds__(512, 2) void convt_wgrad_kernel(CtwParams p) {
+template <int NP, int TN>
+__device__ __forceinline__ void convt_wgrad_body(const CtwParams& p, float* smem, const Quant qz) {
+    typedef typename frag_of<NP>::type FR;
+    constexpr int NT = NP == 3 ? 2 : 3;
     constexpr int BM = 256, BN = 64 * TN, ROWS = BM + BN;
     constexpr int STAGE = ROWS * 32;                         // words
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int gb = xcd_remap(blockIdx.x, gridDim.x);
     const int split = gb / p.tiles_mn;
@@ -574,17 +609,18 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_kernel(CtwParams p) {
     // of a task are issued BETWEEN the MFMA groups of a K-step (mma_tile): all eight waves leave the barrier together, so a
     // store phase in front of the MFMAs would idle the matrix pipe of every SIMD at the same time, while VALU work
     // interleaved with MFMAs is nearly free up to ~1 instruction per MFMA (profiles/r02_notes.md section 1)
+    const float qs = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(isA ? qz.sa : qz.sb)));
     auto store_piece = [&](float* stage, const float4 (&v)[4], int c) {
         if (!active) return;
         uint2 ph, pm, pl;                   // the 4 pixels of channel c
-        split_pack4v<false>(c == 0 ? v[0].x : c == 1 ? v[0].y : c == 2 ? v[0].z : v[0].w, c == 0 ? v[1].x : c == 1 ? v[1].y : c == 2 ? v[1].z : v[1].w,
+        split_pack4v<NP, false>(c == 0 ? v[0].x : c == 1 ? v[0].y : c == 2 ? v[0].z : v[0].w, c == 0 ? v[1].x : c == 1 ? v[1].y : c == 2 ? v[1].z : v[1].w,
                             c == 0 ? v[2].x : c == 1 ? v[2].y : c == 2 ? v[2].z : v[2].w, c == 0 ? v[3].x : c == 1 ? v[3].y : c == 2 ? v[3].z : v[3].w,
-                            ph, pm, pl);
+                            qs, ph, pm, pl);
         const int flip = (c >> 1) * 4;      // rows lds_row0 + 2, + 3 carry the next swizzle value (chunk index ^ 1)
         float* rowp = stage + c * 32;
         *reinterpret_cast<uint2*>(rowp + (wr_e[0] ^ flip)) = ph;
         *reinterpret_cast<uint2*>(rowp + (wr_e[1] ^ flip)) = pm;
-        if (kTerm3) *reinterpret_cast<uint2*>(rowp + (wr_e[2] ^ flip)) = pl;
+        if (kterm3<NP>()) *reinterpret_cast<uint2*>(rowp + (wr_e[2] ^ flip)) = pl;
     };
     auto store_task = [&](float* stage, const float4 (&v)[4]) {
 #pragma unroll
@@ -618,24 +654,23 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_kernel(CtwParams p) {
     auto mma_tile = [&](const float* cur, float* nxt, const float4 (&v)[4]) {
         // (TN < 4: 12 / 24 MFMAs per wave and K-step -- interleaving measured slower there: 133 vs 154 and 89 vs 98 TFLOP/s
         // at the 64^2 x 128 / 128^2 x 64 levels, where it gains 165 -> 175 at 16^2 x 512; the whole task goes first)
-        bf16x8 af[2][3], bf[2][3];
+        FR af[2][3], bf[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(cur + a_rd[i][q]);
+            for (int q = 0; q < NT; ++q) af[i][q] = *reinterpret_cast<const FR*>(cur + a_rd[i][q]);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bf[0][q] = *reinterpret_cast<const bf16x8*>(cur + b_rd[0][q]);
+        for (int q = 0; q < NT; ++q) bf[0][q] = *reinterpret_cast<const FR*>(cur + b_rd[0][q]);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (j + 1 < TN) {                                // next column block's fragments while this one multiplies
 #pragma unroll
-                for (int q = 0; q < 3; ++q) bf[(j + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(cur + b_rd[j + 1][q]);
+                for (int q = 0; q < NT; ++q) bf[(j + 1) & 1][q] = *reinterpret_cast<const FR*>(cur + b_rd[j + 1][q]);
             }
 #pragma unroll
-            for (int t6 = LO0; t6 < 6; ++t6) {
+            for (int t6 = lo0<NP>(); t6 < 6; ++t6) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[j & 1][PB6[t6]], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) acc[i][j] = mfma16<NP>(af[i][PA6[t6]], bf[j & 1][PB6[t6]], acc[i][j]);
             }
             if (TN == 4) store_piece(nxt, v, j);
         }
@@ -682,9 +717,17 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_kernel(CtwParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = wm * Cd + co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                out[(long)m * Cin + n] = acc[i][j][r];
+                out[(long)m * Cin + n] = scale_q<NP>(acc[i][j][r], qz.dexp);
             }
         }
+}
+
+template <int TN>
+__global__ __launch_bounds__(512, 2) void convt_wgrad_kernel(CtwParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (256 + 64 * TN) * 32];
+    const Quant qz = quant_select(p.a_amax, p.b_amax);
+    if (qz.use3) convt_wgrad_body<3, TN>(p, smem, qz);
+    else convt_wgrad_body<6, TN>(p, smem, qz);
 }
 
 struct CtwPlan {
@@ -721,7 +764,7 @@ size_t convt_wgrad_ws_bytes(int n, int h, int w, int cin, int cout) {
 
 // *splits_out = 0: shape left to the generic TN kernel; else the slab [splits][4 * cout][cin] was written
 int convt_wgrad_launch(const float* x, const float* dout, float* slab, int n, int h, int w, int cin, int cout, hipStream_t s,
-                       int* splits_out) {
+                       int* splits_out, const unsigned* x_amax, const unsigned* dout_amax) {
     *splits_out = 0;
     const CtwPlan pl = plan_convt_wgrad(n, h, w, cin, cout);
     if (!pl.ok) return RD_OK;
@@ -732,6 +775,7 @@ int convt_wgrad_launch(const float* x, const float* dout, float* slab, int n, in
     q.tiles_n = pl.tiles_n; q.tiles_mn = pl.tiles_m * pl.tiles_n;
     q.a_bytes = (unsigned)(16.0 * n * h * (double)w * cout);
     q.b_bytes = (unsigned)(4.0 * n * h * (double)w * cin);
+    if (mfma_products() == 3 && x_amax && dout_amax) { q.a_amax = dout_amax; q.b_amax = x_amax; }
     const double px = (double)n * h * w;
     char pcls[64];
     snprintf(pcls, sizeof(pcls), "convt2x2_wgrad|convt_wgrad<%d>", pl.tn);
@@ -749,7 +793,8 @@ int convt_wgrad_launch(const float* x, const float* dout, float* slab, int n, in
 // kernel (rd_igemm.hip).  Returns 0 when it did not launch.
 int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, const float* bias, const float* skip,
                      const float* sk_mean, const float* sk_invstd, const float* sk_gamma, const float* sk_beta, float sk_slope,
-                     const float* sk_slope_dev, float* out, int n, int h, int w, int cin, int cout, hipStream_t s, int* launched) {
+                     const float* sk_slope_dev, float* out, int n, int h, int w, int cin, int cout, hipStream_t s, int* launched,
+                     const QuantArgs& qa) {
     *launched = 0;
     if (!mfma_split() || tune(TUNE_CONVT_PATCH) == 0) return RD_OK;
     if (cin % 32 != 0 || cout % 64 != 0 || (w != 8 && w % 16 != 0)) return RD_OK;     // nk = Cin/16 even; 16- (or 8-) pixel patch rows
@@ -775,6 +820,10 @@ int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, co
     p.nk = cin / 16;
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wsplit_bytes;
+    p.wsplit3 = (const char*)wsplit + wsplit_bytes;                  // the two-term form follows the three-term form
+    p.w_bytes3 = (unsigned)(wsplit_bytes / SROWB * SROWB3);
+    p.out_amax = qa.out;
+    if (mfma_products() == 3 && qa.a && qa.b) { p.a_amax = qa.a; p.b_amax = qa.b; }
     const long tiles_y = (G + p.TR - 1) / p.TR;
     const long grid = tiles_y * p.tiles_x * p.ngroups;
     if (grid >= (1L << 31)) return RD_OK;

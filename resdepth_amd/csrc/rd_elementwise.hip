@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "rd_common.h"
+#include "rd_mfma_dev.h"
 
 namespace rd {
 
@@ -372,11 +373,12 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
                                                               const float* __restrict__ slope_dev,
                                                               float* __restrict__ a, float* __restrict__ pooled,
                                                               uint8_t* __restrict__ idx, float* __restrict__ zpool, long rows,
-                                                              int H, int W, int C, int CQ) {
+                                                              int H, int W, int C, int CQ, unsigned* a_amax, unsigned* p_amax) {
     // rows = pooled pixels (POOL) or pixels; one thread per (row, cq).  zpool (nullable): z at the arg-max position -- the
     // pooled part of the BN-backward statistics is then a pass over quarter-size tensors (rd_conv3x3_bwd_data_bnstats)
     const float slope = slope_dev ? slope_dev[0] : slope_val;   // PReLU: learnable slope read on the device
     const long total = rows * CQ;
+    float amx = 0.f, pmx = 0.f;     // a_amax / p_amax (nullable): magnitude slots of a / pooled (operands of three-product GEMMs)
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int cq = (int)(e % CQ);
         const long row = e / CQ;
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
             y.z = act_fn(fmaf(x.z, sc[2], sh[2]), slope);
             y.w = act_fn(fmaf(x.w, sc[3], sh[3]), slope);
             *reinterpret_cast<float4*>(a + row * C + cq * 4) = y;
+            amx = amax_acc(amax_acc(amax_acc(amax_acc(amx, y.x), y.y), y.z), y.w);
         } else {
             const int W2 = W >> 1, H2 = H >> 1;
             const int j = (int)(row % W2);
@@ -424,11 +427,16 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(const float* __res
                 }
             }
             *reinterpret_cast<float4*>(pooled + row * C + cq * 4) = make_float4(m[0], m[1], m[2], m[3]);
+            pmx = amax_acc(amax_acc(amax_acc(amax_acc(pmx, m[0]), m[1]), m[2]), m[3]);
             if (zpool) st_nt4(zpool + row * C + cq * 4, make_float4(zm[0], zm[1], zm[2], zm[3]));      // read in the backward
             st_nt_u8x4(idx + row * C + cq * 4,
                        make_uchar4((unsigned char)mi[0], (unsigned char)mi[1], (unsigned char)mi[2], (unsigned char)mi[3]));
         }
     }
+    // (with pooling, max |a| = max |pooled| whenever a maximum exists: the pooled value IS the window's largest, and the slot of
+    // `a` is only asked for without pooling)
+    if (a_amax) amax_commit(a_amax, POOL ? pmx : amx);
+    if (p_amax) amax_commit(p_amax, pmx);
 }
 
 // ---- BN + activation (+ pool) backward ---------------------------------------------------------
@@ -444,8 +452,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
                                                          const uint8_t* __restrict__ idx, double* __restrict__ partial,
                                                          const double* __restrict__ sums, double count, int training,
                                                          float* __restrict__ dz, long rows, int H, int W, int C, int CQ,
-                                                         int RP, long rows_per_block) {
+                                                         int RP, long rows_per_block, unsigned* dz_amax) {
     __shared__ double red[APPLY ? 1 : 16 * 256];
+    float dmx = 0.f;                // dz_amax (APPLY, nullable): magnitude slot of dz
     const int t = threadIdx.x, cq = t % CQ, pr = t / CQ;
     const bool active = pr < RP;
     const float slope = slope_dev ? slope_dev[0] : slope_val;
@@ -519,7 +528,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
                         o[q] = training ? sc[q] * (gm - k1[q] - xh * k2[q]) : sc[q] * gm;
                     }
                 }
-                if (APPLY) *reinterpret_cast<float4*>(dz + pix * C + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                if (APPLY) {
+                    *reinterpret_cast<float4*>(dz + pix * C + cq * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                    dmx = amax_acc(amax_acc(amax_acc(amax_acc(dmx, o[0]), o[1]), o[2]), o[3]);
+                }
             }
             if (!APPLY) {
 #pragma unroll
@@ -527,6 +539,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict
             }
         }
     }
+    if (APPLY && dz_amax) amax_commit(dz_amax, dmx);
     if (!APPLY) {
         reduce_rows<16>(acc, red, t, CQ, RP, active);
         if (t < CQ) {
@@ -1340,6 +1353,7 @@ int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, c
                        int w, int c, rd_stream_t s) {
     RD_REQUIRE(z && mean && invstd && gamma && beta && (a || pooled), "rd_bn_act_pool_fwd: null pointer");
     RD_REQUIRE(c % 4 == 0 && c > 0, "rd_bn_act_pool_fwd: C must be a multiple of 4 (got %d)", c);
+    const QuantArgs qa = quant_take();      // out: magnitude slot of a (un-pooled form), out2: of pooled
     const int CQ = c / 4;
     const long pixels = (long)n * h * w;
     if (pooled) {
@@ -1347,14 +1361,14 @@ int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, c
         const long rows = pixels / 4;
         ProfScope ps((hipStream_t)s, "bn_act_pool_fwd", 0,
                      4.0 * pixels * c * (a ? 2.25 : 1.25) + 0.25 * pixels * c + (zpool ? 1.0 * pixels * c : 0.0));
-        hipLaunchKernelGGL((bn_act_pool_fwd_kernel<true>), dim3(grid_cap((rows * CQ + 255) / 256, 8192)), dim3(256), 0,
+        hipLaunchKernelGGL((bn_act_pool_fwd_kernel<true>), dim3(grid_cap((rows * CQ + 255) / 256, qa.out2 ? 2048 : 8192)), dim3(256), 0,
                            (hipStream_t)s, z, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, idx, zpool, rows, h, w, c,
-                           CQ);
+                           CQ, (unsigned*)nullptr, qa.out2);
     } else {
         ProfScope ps((hipStream_t)s, "bn_act_fwd", 0, 8.0 * pixels * c);
-        hipLaunchKernelGGL((bn_act_pool_fwd_kernel<false>), dim3(grid_cap((pixels * CQ + 255) / 256, 8192)), dim3(256),
+        hipLaunchKernelGGL((bn_act_pool_fwd_kernel<false>), dim3(grid_cap((pixels * CQ + 255) / 256, qa.out ? 2048 : 8192)), dim3(256),
                            0, (hipStream_t)s, z, mean, invstd, gamma, beta, slope, slope_dev, a, (float*)nullptr,
-                           (uint8_t*)nullptr, (float*)nullptr, pixels, h, w, c, CQ);
+                           (uint8_t*)nullptr, (float*)nullptr, pixels, h, w, c, CQ, qa.out, (unsigned*)nullptr);
     }
     RD_LAUNCH_CHECK("bn_act_pool_fwd");
     return RD_OK;
@@ -1387,11 +1401,11 @@ int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd,
     if (pool)
         hipLaunchKernelGGL((bn_act_bwd_kernel<true, false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean, invstd,
                            gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
-                           (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
+                           (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block, (unsigned*)nullptr);
     else
         hipLaunchKernelGGL((bn_act_bwd_kernel<false, false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
                            invstd, gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
-                           (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
+                           (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block, (unsigned*)nullptr);
     hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(4 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
                        sums, pl.nb, 4 * c, c, dbeta, dgamma, dextra);
     RD_LAUNCH_CHECK("bn_act_bwd_reduce");
@@ -1417,6 +1431,7 @@ int rd_bn_act_bwd_apply(const float* z, const float* mean, const float* invstd, 
     RD_REQUIRE(g_full || g_pool, "rd_bn_act_bwd_apply: no gradient source");
     RD_REQUIRE(!g_pool || idx, "rd_bn_act_bwd_apply: g_pool needs idx");
     RD_REQUIRE(count > 0, "rd_bn_act_bwd_apply: count must be positive");
+    const QuantArgs qa = quant_take();      // out: magnitude slot of dz
     const bool pool = g_pool != nullptr;
     const long pixels = (long)n * h * w;
     const long rows = pool ? pixels / 4 : pixels;
@@ -1428,11 +1443,11 @@ int rd_bn_act_bwd_apply(const float* z, const float* mean, const float* invstd, 
         if (pool)
             hipLaunchKernelGGL((bn_act_bwd_kernel<true, true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
                                invstd, gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)nullptr, sums, count,
-                               training, dz, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
+                               training, dz, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block, qa.out);
         else
             hipLaunchKernelGGL((bn_act_bwd_kernel<false, true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
                                invstd, gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)nullptr, sums, count, training,
-                               dz, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
+                               dz, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block, qa.out);
     }
     if (dgamma || dbeta)
         hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, dgamma, dbeta,
@@ -1494,7 +1509,8 @@ int rd_conv3x3_first_fwd_act(const float* x, const float* wt, const float* mean,
                "rd_conv3x3_first_fwd_act: shape not covered (1-4 input channels, 32 / 64 / 128 output channels, even H and W)");
     ProfScope ps((hipStream_t)s, "conv_first_fwd", 2.0 * n * h * w * cout * 9.0 * cin,
                  4.0 * n * h * w * (double)(cin + cout * (pooled ? 1.25 : 1.0)));
-    return conv_first_fwd_act_launch(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cin, cout, (hipStream_t)s);
+    return conv_first_fwd_act_launch(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cin, cout, (hipStream_t)s,
+                                     quant_take().out2);
 }
 
 size_t rd_conv3x3_first_fwd_stats_ws_bytes(int n, int h, int w, int cin, int cout) {

@@ -182,15 +182,16 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(NtParams p) {
 // 32-byte spans: no LDS bank conflicts on either side.
 __device__ __forceinline__ int swz(int r) { return (r ^ (r >> 3)) & 7; }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
-__global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
+template <int NP, int BM, int BN, int WM, int WN, int AMODE, int EPI>
+__device__ __forceinline__ void igemm_nt_split_body(const NtParams& p, float* smem, const Quant qz) {
+    typedef typename frag_of<NP>::type FR;
+    constexpr int NT = NP == 3 ? 2 : 3;               // split terms per operand
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(TN == 1, "each wave owns one 32-column block: its B fragments come straight from global memory");
     constexpr int AI = BM / 64;                       // A: 4 float4 per 16-k row, 64 rows per pass
     constexpr int STAGE = BM * 32;                    // words per LDS stage (A only)
     constexpr int EPI_WORDS = 32 * (BN + 4) + 512;    // epilogue staging: one 32-row block per pass
     constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = lb % p.tiles_n, tile_m = lb / p.tiles_n;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
         for (int r = 0; r < 16; ++r) acc[i][0][r] = lo[i][r] = 0.f;
 
     const int H = p.H, W = p.W;
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.Bsplit, p.b_bytes);
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(NP == 3 ? p.Bsplit3 : p.Bsplit, NP == 3 ? p.b_bytes3 : p.b_bytes);
     unsigned a_off[AI], a_val[AI];
     int a_wr[AI];       // LDS word address of this thread's 8 bytes of term 0 (terms 1, 2: chunk +2, +4 before the swizzle)
 #pragma unroll
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
     // B fragments: packed layout [row-block of 32][kt][term][lane][16 B] (split_pack_kernel): one fully coalesced
     // 1 KB load per (wave, term, K-step)
     const int nb = (n0 >> 5) + wn;
-    const unsigned b_off = (nb * 32 < p.N) ? (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16) : kOOB;
+    const unsigned b_off = (nb * 32 < p.N) ? (unsigned)(((long)nb * p.nk * NT) * 1024 + lane * 16) : kOOB;
 
     auto load_a = [&](int kt, float4 (&ra)[AI]) {
         // K order = channel-chunk outer, tap inner (see the f32 kernel).  kt >= nk (prefetch running past the end):
@@ -263,17 +264,17 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
     auto load_b = [&](int kt, uint4 (&rb)[3]) {
         const unsigned voff = kt < p.nk ? b_off : kOOB;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((kt * 3 + q) * 1024));
+        for (int q = 0; q < NT; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((kt * NT + q) * 1024));
     };
     auto store_a = [&](float* stage, const float4 (&ra)[AI]) {
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int sw = swz(r0 + 64 * i), hi = c4 >> 1;
             uint2 ph, pm, pl;
-            split_pack4(ra[i], ph, pm, pl);
+            split_pack4<NP>(ra[i], qz.sa, ph, pm, pl);
             *reinterpret_cast<uint2*>(stage + a_wr[i] + ((0 + hi) ^ sw) * 4) = ph;
             *reinterpret_cast<uint2*>(stage + a_wr[i] + ((2 + hi) ^ sw) * 4) = pm;
-            if (kTerm3) *reinterpret_cast<uint2*>(stage + a_wr[i] + ((4 + hi) ^ sw) * 4) = pl;
+            if (kterm3<NP>()) *reinterpret_cast<uint2*>(stage + a_wr[i] + ((4 + hi) ^ sw) * 4) = pl;
         }
     };
 
@@ -285,10 +286,10 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) a_rd[i][q] = row * 32 + ((2 * q + half) ^ swz(row)) * 4;
     }
-    bf16x8 af[TM][3];
+    FR af[TM][3];
     auto read_a = [&](const float* stage, int i) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(stage + a_rd[i][q]);
+        for (int q = 0; q < NT; ++q) af[i][q] = *reinterpret_cast<const FR*>(stage + a_rd[i][q]);
     };
     // six products per (a, b) pair, smallest terms first; lane half g owns k = 8g .. 8g+7 (the same 8 k for A and B)
     // One K-step.  Software pipeline per tile j:  global load (step j-4) -> split + LDS write (step j-2) -> fragment
@@ -298,20 +299,18 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
         store_a(wstage, ra);          // tile kt+2
         load_a(kt + 4, ra);
         load_b(kt + 3, bnew);
-        bf16x8 bf[3];
+        FR bf[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bf[q] = __builtin_bit_cast(bf16x8, bcur[q]);
+        for (int q = 0; q < NT; ++q) bf[q] = __builtin_bit_cast(FR, bcur[q]);
         constexpr int GP = TM >= 2 ? 2 : 1;       // row blocks interleaved per group (independent accumulators)
 #pragma unroll
         for (int g = 0; g < TM; g += GP) {
 #pragma unroll
-            for (int t6 = LO0; t6 < 5; ++t6)
+            for (int t6 = lo0<NP>(); t6 < 5; ++t6)
 #pragma unroll
-                for (int i = g; i < g + GP; ++i)
-                    lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
+                for (int i = g; i < g + GP; ++i) lo[i] = mfma16<NP>(af[i][PA6[t6]], bf[PB6[t6]], lo[i]);
 #pragma unroll
-            for (int i = g; i < g + GP; ++i)
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][0], 0, 0, 0);
+            for (int i = g; i < g + GP; ++i) acc[i][0] = mfma16<NP>(af[i][0], bf[0], acc[i][0]);
 #pragma unroll
             for (int i = g; i < g + GP; ++i) read_a(rstage, i);      // tile kt+1, consumed one step later
         }
@@ -344,8 +343,18 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = merge_hi_lo(acc[i][0][r], lo[i][r]);
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = merge_q<NP>(acc[i][0][r], lo[i][r], qz.dexp);
     nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m);
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
+    constexpr int STAGE = BM * 32, EPI_WORDS = 32 * (BN + 4) + 512;
+    constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    const Quant qz = quant_select(p.a_amax, p.b_amax);
+    if (qz.use3) igemm_nt_split_body<3, BM, BN, WM, WN, AMODE, EPI>(p, smem, qz);
+    else igemm_nt_split_body<6, BM, BN, WM, WN, AMODE, EPI>(p, smem, qz);
 }
 
 // ---- conv3x3 forward / data gradient with halo reuse (split-bf16) ----------------------------------------------------
@@ -362,8 +371,10 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 // turn.  16 patches x 8 column tiles are too few blocks, so small grids give every range its own block (p.ksplit = number of
 // ranges, p.chunks_per = 8): the blocks park their range in a scratch slab and draw a ticket, the last one adds the ranges in
 // the same order and runs the epilogue (statistics, BN-backward hook) on the finished tile -- the same bits as the unsplit form.
-template <int BN, int WM, int WN, int EPI, int SKEW = 8, int W8 = 0>
-__global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
+template <int NP, int BN, int WM, int WN, int EPI, int SKEW, int W8>
+__device__ __forceinline__ void conv3_halo_split_body(const NtParams& p, float* smem, int& sk_last, const Quant qz) {
+    typedef typename frag_of<NP>::type FR;
+    constexpr int NT = NP == 3 ? 2 : 3;               // split terms per operand
     constexpr int BM = 128, PH = 8, PW = 16, HW_ = W8 ? 20 : PW + 2, HROWS = (PH + 2) * HW_;   // 180 (200) halo pixels
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(TN == 1, "one 32-column block per wave");
@@ -376,9 +387,6 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     constexpr int NLD = (HROWS * 4 + 255) / 256;      // staging float4 per thread and chunk
     constexpr int EPI_WORDS = 32 * (BN + 4) + 512;
     constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
-
-    __shared__ int sk_last;
     const int lb0 = xcd_remap(blockIdx.x, gridDim.x);
     const int ksp = W8 && p.ksplit > 1 ? p.ksplit : 1;
     const int ksplit_id = lb0 % ksp, lb = lb0 / ksp;           // the K ranges of one tile are neighbours (same XCD / L2)
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = lo[i][r] = 0.f;
 
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(p.Bsplit, p.b_bytes);
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes), rsB = make_rsrc(NP == 3 ? p.Bsplit3 : p.Bsplit, NP == 3 ? p.b_bytes3 : p.b_bytes);
     // staging tasks: element e = t + 256 k -> halo pixel e >> 2, 16-byte quarter e & 3 of its 64-byte channel chunk
     unsigned s_off[NLD];
     int s_lds[NLD];
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         s_lds[k] = hr < HROWS ? hy * HP + hx * RS + c4 * 2 : -1;
     }
     const int nb = (n0 >> 5) + wn;
-    const unsigned b_off = (nb * 32 < p.N) ? (unsigned)(((long)nb * p.nk * 3) * 1024 + lane * 16) : kOOB;
+    const unsigned b_off = (nb * 32 < p.N) ? (unsigned)(((long)nb * p.nk * NT) * 1024 + lane * 16) : kOOB;
 
     auto load_halo = [&](int chunk, float4 (&rh)[NLD]) {
         const bool cok = chunk < cend && chunk * SK + c4 * 4 < p.Cin;
@@ -433,17 +441,17 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         for (int k = 0; k < NLD; ++k) {
             if (s_lds[k] < 0) continue;
             uint2 ph, pm, pl;
-            split_pack4(rh[k], ph, pm, pl);
+            split_pack4<NP>(rh[k], qz.sa, ph, pm, pl);
             float* row = stage + s_lds[k];
             *reinterpret_cast<uint2*>(row) = ph;
             *reinterpret_cast<uint2*>(row + 8) = pm;
-            if (kTerm3) *reinterpret_cast<uint2*>(row + 16) = pl;
+            if (kterm3<NP>()) *reinterpret_cast<uint2*>(row + 16) = pl;
         }
     };
     auto load_b = [&](int kt, uint4 (&rb)[3]) {
         const unsigned voff = kt < cend * 9 ? b_off : kOOB;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((kt * 3 + q) * 1024));
+        for (int q = 0; q < NT; ++q) rb[q] = buf_load4u(rsB, voff, (unsigned)((kt * NT + q) * 1024));
     };
 
     const int lrow = lane & 31, half = lane >> 5;
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         const int row = (wm * TM + i) * 32 + lrow;            // tile row -> patch pixel (row >> 4, row & 15)
         a_rd[i] = (row >> 4) * HP + ((row & 15) + (W8 ? 2 * ((row & 15) >> 3) : 0)) * RS + half * 4;
     }
-    bf16x8 af[TM][3];
+    FR af[TM][3];
 
     float* stage_cur = smem;
     float* stage_nxt = smem + STAGE;
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(stage_cur + a_rd[i] + q * 8);
+        for (int q = 0; q < NT; ++q) af[i][q] = *reinterpret_cast<const FR*>(stage_cur + a_rd[i] + q * 8);
 
     // tap step: MFMAs of (chunk, TAP) with the fragments in af / bcur; prefetch the weights two steps ahead; reload af
     // for the next step right after its last use (next tap of this chunk, or tap 0 of the next chunk's stage)
@@ -475,9 +483,9 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         constexpr int TAP = decltype(tap_c)::value;
         constexpr int NEXT = TAP == 8 ? 0 : (TAP + 1) / 3 * HP + (TAP + 1) % 3 * RS;
         load_b(kt + 2, bnew);
-        bf16x8 bf[3];
+        FR bf[3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bf[q] = __builtin_bit_cast(bf16x8, bcur[q]);
+        for (int q = 0; q < NT; ++q) bf[q] = __builtin_bit_cast(FR, bcur[q]);
         const float* nstage = TAP == 8 ? stage_nxt : stage_cur;
         // Raised wave priority over the MFMA cluster of a tap: with two blocks per CU there are two waves per SIMD, and the
         // sibling's staging VALU / LDS instructions otherwise win issue slots between this wave's MFMAs.  r03, interleaved:
@@ -493,44 +501,43 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         // 3 * TM fragment reads behind the ~19th MFMA and the next tap starts with four lgkmcnt waits
         auto rd = [&](int q) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const bf16x8*>(nstage + a_rd[i] + NEXT + q * 8);
+            for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const FR*>(nstage + a_rd[i] + NEXT + q * 8);
         };
-#if RD_NPROD == 3
-        // three products (a2 b1, a1 b2, a1 b1): term 2 is never read
+        if constexpr (NP == 3) {
+            // three products (a2 b1, a1 b2, a1 b1): term 2 does not exist
 #pragma unroll
-        for (int i = 0; i < TM; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[0], lo[i], 0, 0, 0);
-        rd(1);
+            for (int i = 0; i < TM; ++i) lo[i] = mfma16<NP>(af[i][1], bf[0], lo[i]);
+            rd(1);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], lo[i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) lo[i] = mfma16<NP>(af[i][0], bf[1], lo[i]);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][0], 0, 0, 0);
-        rd(0);
-        __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-#else
+            for (int i = 0; i < TM; ++i) acc[i][0] = mfma16<NP>(af[i][0], bf[0], acc[i][0]);
+            rd(0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[0], lo[i], 0, 0, 0);
-        rd(2);
+            for (int i = 0; i < TM; ++i) lo[i] = mfma16<NP>(af[i][2], bf[0], lo[i]);
+            rd(2);
 #pragma unroll
-        for (int t6 = 1; t6 < 4; ++t6)
+            for (int t6 = 1; t6 < 4; ++t6)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[PB6[t6]], lo[i], 0, 0, 0);
-        rd(1);
+                for (int i = 0; i < TM; ++i) lo[i] = mfma16<NP>(af[i][PA6[t6]], bf[PB6[t6]], lo[i]);
+            rd(1);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[1], lo[i], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) lo[i] = mfma16<NP>(af[i][0], bf[1], lo[i]);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[0], acc[i][0], 0, 0, 0);
-        rd(0);
-        __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-#endif
+            for (int i = 0; i < TM; ++i) acc[i][0] = mfma16<NP>(af[i][0], bf[0], acc[i][0]);
+            rd(0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     // W8: K is accumulated in RANGES of eight chunks (128 channels), each merged into `tot` in turn -- whether the ranges of a
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                tot[i][r] += merge_hi_lo(acc[i][0][r], lo[i][r]);
+                tot[i][r] += merge_q<NP>(acc[i][0][r], lo[i][r], qz.dexp);
                 acc[i][0][r] = lo[i][r] = 0.f;
             }
     }
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = W8 ? tot[i][r] : merge_hi_lo(acc[i][0][r], lo[i][r]);
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = W8 ? tot[i][r] : merge_q<NP>(acc[i][0][r], lo[i][r], qz.dexp);
     if (ksp > 1) {
         // All traffic through the slab is agent-scope (sc1) relaxed atomics -- coherent across the XCDs' L2s by themselves --
         // ordered by completion: the partial stores are acknowledged (vmcnt = 0) before the block's ticket is drawn.  (The
@@ -614,14 +621,70 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m, pool_base);
 }
 
+template <int BN, int WM, int WN, int EPI, int SKEW = 8, int W8 = 0>
+__global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
+    constexpr int HW_ = W8 ? 20 : 18, HP = HW_ * 28 + SKEW, STAGE = 10 * HP, EPI_WORDS = 32 * (BN + 4) + 512;
+    constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    __shared__ int sk_last;
+    const Quant qz = quant_select(p.a_amax, p.b_amax);
+    if (qz.use3) conv3_halo_split_body<3, BN, WM, WN, EPI, SKEW, W8>(p, smem, sk_last, qz);
+    else conv3_halo_split_body<6, BN, WM, WN, EPI, SKEW, W8>(p, smem, sk_last, qz);
+}
+
+// one 16-byte fragment piece per term of row n, K-step kt, k-half g: the six-product form (three bf16 terms) at `out`, and --
+// out3 != nullptr -- the three-product form (two fp16 terms of s3 * v, rd_mfma_dev.h) at `out3`
+__device__ __forceinline__ void write_split_piece(uint4* out, long n, int nk, int kt, int g, const float (&v)[8], uint4* out3 = nullptr,
+                                                  float s3 = 1.f) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
+    const long blk = ((n >> 5) * nk + kt) * 3;
+    const int lane = g * 32 + (int)(n & 31);
+    const unsigned sel = 0x07060302u;
+    out[blk * 64 + lane] = make_uint4(__builtin_amdgcn_perm(h[1], h[0], sel), __builtin_amdgcn_perm(h[3], h[2], sel),
+                                      __builtin_amdgcn_perm(h[5], h[4], sel), __builtin_amdgcn_perm(h[7], h[6], sel));
+    out[(blk + 1) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(m[1], m[0], sel), __builtin_amdgcn_perm(m[3], m[2], sel),
+                                            __builtin_amdgcn_perm(m[5], m[4], sel), __builtin_amdgcn_perm(m[7], m[6], sel));
+    out[(blk + 2) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(l[1], l[0], sel), __builtin_amdgcn_perm(l[3], l[2], sel),
+                                            __builtin_amdgcn_perm(l[5], l[4], sel), __builtin_amdgcn_perm(l[7], l[6], sel));
+    if (out3) {
+        uint4 ph, pm;
+        split2h_pair_v(v[0], v[1], s3, ph.x, pm.x);
+        split2h_pair_v(v[2], v[3], s3, ph.y, pm.y);
+        split2h_pair_v(v[4], v[5], s3, ph.z, pm.z);
+        split2h_pair_v(v[6], v[7], s3, ph.w, pm.w);
+        const long blk3 = ((n >> 5) * nk + kt) * 2;
+        out3[blk3 * 64 + lane] = ph;
+        out3[(blk3 + 1) * 64 + lane] = pm;
+    }
+}
+// three-product form of a packed operand: follows the six-product form (rows32 * nk * 96 bytes = rows32 * nk * 6 uint4)
+__device__ __forceinline__ uint4* form3_of(uint4* out6, long rows, int nk) { return out6 + rows32_of_dev(rows) * nk * 6; }
+// scale of a weight tensor's three-product form from its magnitude slot (the kernel that filled it ran just before)
+__device__ __forceinline__ float pack_scale(const unsigned* amax) {
+    return __uint_as_float((unsigned)scale_bexp(amax_read(amax)) << 23);
+}
+
+// max |w| of weight tensors into their magnitude slots: block b of an item strides over the item's elements
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ w, long n, unsigned* slot, const float* __restrict__ row_scale,
+                                                   long row_len) {
+    float m = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        m = amax_acc(m, row_scale ? w[e] * row_scale[e / row_len] : w[e]);
+    amax_commit(slot, m);
+}
+
 // fp32 GEMM-layout B[N][K] (K = taps*Cin, tap-major) -> split-bf16 fragment layout
 //   [row block nb = n/32][kt][term q][lane = 32*(j/8) + n%32][8 bf16: k = 8*(j/8) .. +7]      (16 bytes per lane)
 // kt = chunk*taps + tap, j = channel within the 16-channel chunk; rows beyond N and channels beyond Cin are zero.
 __global__ void split_pack_kernel(const float* __restrict__ B, uint4* __restrict__ out, int N, int K, int Cin,
-                                  int taps, int nk) {
+                                  int taps, int nk, const unsigned* amax) {
     // one thread per (row n, K-step kt, k-half g): 8 consecutive channels -> one 16-byte fragment piece per term
     const long rows32 = (long)((N + 31) / 32) * 32;
     const long total = rows32 * nk * 2;
+    uint4* out3 = amax ? form3_of(out, N, nk) : nullptr;
+    const float s3 = amax ? pack_scale(amax) : 1.f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int g = (int)(e & 1);
         const int kt = (int)((e >> 1) % nk);
@@ -636,18 +699,7 @@ __global__ void split_pack_kernel(const float* __restrict__ B, uint4* __restrict
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (n < N && ci0 + j < Cin) ? src[j] : 0.f;
         }
-        unsigned h[8], m[8], l[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
-        const long blk = ((n >> 5) * nk + kt) * 3;
-        const int lane = g * 32 + (int)(n & 31);
-        const unsigned sel = 0x07060302u;
-        out[blk * 64 + lane] = make_uint4(__builtin_amdgcn_perm(h[1], h[0], sel), __builtin_amdgcn_perm(h[3], h[2], sel),
-                                          __builtin_amdgcn_perm(h[5], h[4], sel), __builtin_amdgcn_perm(h[7], h[6], sel));
-        out[(blk + 1) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(m[1], m[0], sel), __builtin_amdgcn_perm(m[3], m[2], sel),
-                                                __builtin_amdgcn_perm(m[5], m[4], sel), __builtin_amdgcn_perm(m[7], m[6], sel));
-        out[(blk + 2) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(l[1], l[0], sel), __builtin_amdgcn_perm(l[3], l[2], sel),
-                                                __builtin_amdgcn_perm(l[5], l[4], sel), __builtin_amdgcn_perm(l[7], l[6], sel));
+        write_split_piece(out, n, nk, kt, g, v, out3, s3);
     }
 }
 
@@ -657,10 +709,11 @@ __global__ void split_pack_kernel(const float* __restrict__ B, uint4* __restrict
 //   pieces [Tf, Tf+Td)  data-gradient operand rows n = ci, k = (tap', co):   w[co0+j][ci][8-tap']
 // one thread per 16-byte fragment piece (row n, K-step kt = chunk*9 + tap, k-half g); gathered, cached loads.
 __global__ void split_pack_conv3x3_kernel(const float* __restrict__ w, uint4* __restrict__ outf, uint4* __restrict__ outd,
-                                          int cout, int cin, const float* __restrict__ row_scale) {
+                                          int cout, int cin, const float* __restrict__ row_scale, const unsigned* amax) {
     const int nkf = 9 * ((cin + SK - 1) / SK), nkd = 9 * ((cout + SK - 1) / SK);
     const long rf = (long)((cout + 31) / 32) * 32, rd_ = (long)((cin + 31) / 32) * 32;
     const long Tf = rf * nkf * 2, Td = outd ? rd_ * nkd * 2 : 0;
+    const float s3 = amax ? pack_scale(amax) : 1.f;
     for (long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x; e0 < Tf + Td; e0 += (long)gridDim.x * blockDim.x) {
         const bool fwd = e0 < Tf;
         const long e = fwd ? e0 : e0 - Tf;
@@ -678,19 +731,8 @@ __global__ void split_pack_conv3x3_kernel(const float* __restrict__ w, uint4* __
             if (fwd && row_scale && n < N) x *= row_scale[n];       // eval-mode BatchNorm folded into the forward operand
             v[j] = x;
         }
-        unsigned h[8], m[8], l[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
-        const long blk = ((n >> 5) * nk + kt) * 3;
-        const int lane = g * 32 + (int)(n & 31);
-        const unsigned sel = 0x07060302u;
         uint4* out = fwd ? outf : outd;
-        out[blk * 64 + lane] = make_uint4(__builtin_amdgcn_perm(h[1], h[0], sel), __builtin_amdgcn_perm(h[3], h[2], sel),
-                                          __builtin_amdgcn_perm(h[5], h[4], sel), __builtin_amdgcn_perm(h[7], h[6], sel));
-        out[(blk + 1) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(m[1], m[0], sel), __builtin_amdgcn_perm(m[3], m[2], sel),
-                                                __builtin_amdgcn_perm(m[5], m[4], sel), __builtin_amdgcn_perm(m[7], m[6], sel));
-        out[(blk + 2) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(l[1], l[0], sel), __builtin_amdgcn_perm(l[3], l[2], sel),
-                                                __builtin_amdgcn_perm(l[5], l[4], sel), __builtin_amdgcn_perm(l[7], l[6], sel));
+        write_split_piece(out, n, nk, kt, g, v, amax ? form3_of(out, N, nk) : nullptr, s3);
     }
 }
 
@@ -701,23 +743,8 @@ __global__ void split_pack_conv3x3_kernel(const float* __restrict__ w, uint4* __
 // layouts, splits them and writes the three fragment pieces.  Items (8 x int64 each): w pointer, forward-operand buffer,
 // data-gradient-operand buffer, kind (0 conv3x3, 1 convT2x2), Cout, Cin, first piece, write-f32-layout flag.
 struct PackItem {
-    long long w, outf, outd, kind, cout, cin, begin, f32, tile_begin, reserved;
+    long long w, outf, outd, kind, cout, cin, begin, f32, tile_begin, amax;   // amax: magnitude slot of w (0: six-product form only)
 };
-
-__device__ __forceinline__ void write_split_piece(uint4* out, long n, int nk, int kt, int g, const float (&v)[8]) {
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
-    const long blk = ((n >> 5) * nk + kt) * 3;
-    const int lane = g * 32 + (int)(n & 31);
-    const unsigned sel = 0x07060302u;
-    out[blk * 64 + lane] = make_uint4(__builtin_amdgcn_perm(h[1], h[0], sel), __builtin_amdgcn_perm(h[3], h[2], sel),
-                                      __builtin_amdgcn_perm(h[5], h[4], sel), __builtin_amdgcn_perm(h[7], h[6], sel));
-    out[(blk + 1) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(m[1], m[0], sel), __builtin_amdgcn_perm(m[3], m[2], sel),
-                                            __builtin_amdgcn_perm(m[5], m[4], sel), __builtin_amdgcn_perm(m[7], m[6], sel));
-    out[(blk + 2) * 64 + lane] = make_uint4(__builtin_amdgcn_perm(l[1], l[0], sel), __builtin_amdgcn_perm(l[3], l[2], sel),
-                                            __builtin_amdgcn_perm(l[5], l[4], sel), __builtin_amdgcn_perm(l[7], l[6], sel));
-}
 
 __global__ __launch_bounds__(256) void pack_all_kernel(const PackItem* __restrict__ items, int n_items, long total) {
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
@@ -728,6 +755,12 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackItem* __restric
         const int cout = (int)I.cout, cin = (int)I.cin;
         long e = p - I.begin;
         float v[8];
+        const unsigned* am = reinterpret_cast<const unsigned*>(I.amax);
+        const float s3 = am ? pack_scale(am) : 1.f;
+        auto put = [&](long long outp, long rows, long n, int nk, int kt, int g) {
+            uint4* out = reinterpret_cast<uint4*>(outp);
+            write_split_piece(out, n, nk, kt, g, v, am ? form3_of(out, rows, nk) : nullptr, s3);
+        };
         if (I.kind == 0) {
             // conv3x3 w[co][ci][3][3]: forward rows n = co, k = (tap, ci); data gradient rows n = ci, k = (8 - tap, co)
             const int nkf = 9 * ((cin + SK - 1) / SK), nkd = 9 * ((cout + SK - 1) / SK);
@@ -743,7 +776,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackItem* __restric
                 const int c = c0 + j;
                 v[j] = (n < N && c < Kc) ? (fwd ? w[((long)n * cin + c) * 9 + tap] : w[((long)c * cin + n) * 9 + (8 - tap)]) : 0.f;
             }
-            write_split_piece(reinterpret_cast<uint4*>(fwd ? I.outf : I.outd), n, nk, kt, g, v);
+            put(fwd ? I.outf : I.outd, N, n, nk, kt, g);
         } else {
             // convT2x2 w[ci][co][2][2]: forward rows n = (ab, co), k = ci; data gradient rows n = ci, k = (ab, co);
             // optional third segment: the fp32 forward operand wtf[(ab, co)][ci] (exact-f32 kernel of the short-K levels)
@@ -755,7 +788,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackItem* __restric
                 const int ab = (int)(n / cout), co = (int)(n - (long)ab * cout), c0 = kt * SK + g * 8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (n < 4L * cout && c0 + j < cin) ? w[((long)(c0 + j) * cout + co) * 4 + ab] : 0.f;
-                write_split_piece(reinterpret_cast<uint4*>(I.outf), n, nkf, kt, g, v);
+                put(I.outf, 4L * cout, n, nkf, kt, g);
             } else if (e < Tf + Td) {
                 e -= Tf;
                 const int g = (int)(e & 1), kt = (int)((e >> 1) % nkd);
@@ -763,7 +796,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackItem* __restric
                 const int chunk = kt / 4, ab = kt - chunk * 4, c0 = chunk * SK + g * 8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (n < cin && c0 + j < cout) ? w[((long)n * cout + c0 + j) * 4 + ab] : 0.f;
-                write_split_piece(reinterpret_cast<uint4*>(I.outd), n, nkd, kt, g, v);
+                put(I.outd, cin, n, nkd, kt, g);
             } else {
                 e -= Tf + Td;                    // 8 consecutive elements of wtf[(ab*Cout + co)][ci]
                 float* wtf = reinterpret_cast<float*>(I.f32);
@@ -781,6 +814,18 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackItem* __restric
     }
 }
 
+
+// magnitude slots of every item of a fused pack (first pass of rd_pack_weights_fused in three-product mode): 32 blocks per item
+__global__ __launch_bounds__(256) void pack_items_amax_kernel(const PackItem* __restrict__ items, int n_items) {
+    const int it = blockIdx.x >> 5, part = blockIdx.x & 31;
+    const PackItem I = items[it];
+    if (!I.amax) return;
+    const float* __restrict__ w = reinterpret_cast<const float*>(I.w);
+    const long n = (long)I.cout * I.cin * (I.kind == 0 ? 9 : 4);
+    float m = 0.f;
+    for (long e = (long)part * 256 + threadIdx.x; e < n; e += 32 * 256) m = amax_acc(m, w[e]);
+    amax_commit(reinterpret_cast<unsigned*>(I.amax), m);
+}
 
 // ---- tile packer: layers whose channel counts are multiples of 32 (every MFMA layer of cfg-S / cfg-M) -----------------------
 // pack_all_kernel gathers every 16-byte fragment piece straight from the torch layouts: 4-byte loads 36 B (conv3x3) or 16 B
@@ -803,6 +848,12 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const PackItem* __restr
         const int cout = (int)I.cout, cin = (int)I.cin;
         const int lt = (int)(T - I.tile_begin);
         float v[8];
+        const unsigned* am = reinterpret_cast<const unsigned*>(I.amax);
+        const float s3 = am ? pack_scale(am) : 1.f;
+        auto put = [&](long long outp, long rows, long n, int nk, int kt) {
+            uint4* out = reinterpret_cast<uint4*>(outp);
+            write_split_piece(out, n, nk, kt, g, v, am ? form3_of(out, rows, nk) : nullptr, s3);
+        };
         if (I.kind == 0) {
             const int tiles_ci = cin >> 5, co0 = (lt / tiles_ci) * 32, ci0 = (lt % tiles_ci) * 32;
             // (a parameter is a view into the flat buffer at an arbitrary float offset -- e.g. behind a 1-element PReLU slope:
@@ -826,11 +877,11 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const PackItem* __restr
                 if (dg == 0) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = tile[nl * 289 + (chunk_l * 16 + g * 8 + j) * 9 + tap];
-                    write_split_piece(reinterpret_cast<uint4*>(I.outf), co0 + nl, nkf, ((ci0 >> 4) + chunk_l) * 9 + tap, g, v);
+                    put(I.outf, cout, co0 + nl, nkf, ((ci0 >> 4) + chunk_l) * 9 + tap);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = tile[(chunk_l * 16 + g * 8 + j) * 289 + nl * 9 + (8 - tap)];
-                    write_split_piece(reinterpret_cast<uint4*>(I.outd), ci0 + nl, nkd, ((co0 >> 4) + chunk_l) * 9 + tap, g, v);
+                    put(I.outd, cin, ci0 + nl, nkd, ((co0 >> 4) + chunk_l) * 9 + tap);
                 }
             }
         } else {
@@ -855,11 +906,11 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const PackItem* __restr
                 if (dg == 0) {          // forward rows n = (ab, co), k = ci
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = pl[(chunk_l * 16 + g * 8 + j) * 33 + nl];
-                    write_split_piece(reinterpret_cast<uint4*>(I.outf), (long)ab * cout + co0 + nl, nkf, (ci0 >> 4) + chunk_l, g, v);
+                    put(I.outf, 4L * cout, (long)ab * cout + co0 + nl, nkf, (ci0 >> 4) + chunk_l);
                 } else {                // data gradient rows n = ci, k = (co chunk, ab)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = pl[nl * 33 + chunk_l * 16 + g * 8 + j];
-                    write_split_piece(reinterpret_cast<uint4*>(I.outd), ci0 + nl, nkd, ((co0 >> 4) + chunk_l) * 4 + ab, g, v);
+                    put(I.outd, cin, ci0 + nl, nkd, ((co0 >> 4) + chunk_l) * 4 + ab);
                 }
             }
             if (I.f32) {                // fp32 forward operand wtf[(ab, co)][ci] of the short-K levels (exact-f32 NT kernel)
@@ -882,18 +933,28 @@ static inline int nk16_of(int taps, int cin) { return taps * cdiv(cin, SK); }
 static inline size_t packed_f32_bytes(long rows, int taps, int cin) { return align16((size_t)rows * taps * cin * 4); }
 static inline long rows32_of(long rows) { return (rows + 31) / 32 * 32; }
 static inline size_t packed_bytes(long rows, int taps, int cin) {
-    return packed_f32_bytes(rows, taps, cin) + (size_t)rows32_of(rows) * nk16_of(taps, cin) * SROWB;
+    return packed_f32_bytes(rows, taps, cin) + (size_t)rows32_of(rows) * nk16_of(taps, cin) * (SROWB + SROWB3);
 }
 
-static int split_pack(const float* b_f32, long rows, int taps, int cin, hipStream_t s) {
+static int grid_for(long total, int block, int cap);
+// max |w| of a weight tensor -> its magnitude slot (zeroed by the caller); row_scale: the folded operand's rows
+static void launch_amax(const float* w, long n, unsigned* slot, const float* row_scale, long row_len, hipStream_t s) {
+    hipLaunchKernelGGL(amax_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, s, w, n, slot, row_scale, row_len);
+}
+
+static int split_pack(const float* b_f32, long rows, int taps, int cin, hipStream_t s, const unsigned* amax = nullptr) {
     uint4* out = (uint4*)((char*)b_f32 + packed_f32_bytes(rows, taps, cin));
     const int nk = nk16_of(taps, cin);
     const long total = rows32_of(rows) * nk * 2;
     long g = (total + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(split_pack_kernel, dim3((int)g), dim3(256), 0, s, b_f32, out, (int)rows, taps * cin, cin, taps, nk);
+    hipLaunchKernelGGL(split_pack_kernel, dim3((int)g), dim3(256), 0, s, b_f32, out, (int)rows, taps * cin, cin, taps, nk, amax);
     RD_LAUNCH_CHECK("split_pack");
     return RD_OK;
+}
+
+static inline void set_quant(NtParams& p, const QuantArgs& q) {
+    p.a_amax = q.a; p.b_amax = q.b; p.out_amax = q.out; p.pool_amax = q.out2;
 }
 
 template <int AMODE, int EPI>
@@ -916,6 +977,9 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     p.a_bytes = (unsigned)a_bytes;
     p.b_bytes = (unsigned)b_bytes;
     p.Bsplit = (const char*)p.B + packed_f32_bytes(p.N, taps, p.Cin);
+    p.Bsplit3 = (const char*)p.Bsplit + (size_t)rows32_of(p.N) * p.nk * SROWB;
+    p.b_bytes3 = (unsigned)((double)rows32_of(p.N) * p.nk * SROWB3);
+    if (!split || mfma_products() != 3 || !p.a_amax || !p.b_amax) p.a_amax = p.b_amax = nullptr;    // six products
     const int force = tune(TUNE_NT_TILE);
     const int tiles_128x64 = cdiv(p.M, 128) * cdiv(p.N, 64);
     int cfg;
@@ -1053,6 +1117,8 @@ struct TnParams {
     int kchunk;  // pixels per split, multiple of 32
     int tiles_n, tiles_mn;
     unsigned a_bytes, b_bytes;
+    const unsigned* a_amax;   // magnitude slots of A / B (both non-null: three-product body, rd_mfma_dev.h); split kernel only
+    const unsigned* b_amax;
 };
 
 template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
@@ -1209,11 +1275,12 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnParams p) {   // (256,3
 // (128-byte rows: chunk = 2*term + khalf, XOR-swizzled by (row >> 1) & 7 -- conflict-free b64 writes and b128 reads).
 // Threads [0, BM) stage A, [BM, BM+BN) stage B (wave-uniform roles).  K-step = 16 pixels, LDS double-buffered, two
 // K-steps of global loads in flight.
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
+template <int NP, int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+__device__ __forceinline__ void wgrad_tn_split_body(const TnParams& p, float* smem, const Quant qz) {
+    typedef typename frag_of<NP>::type FR;
+    constexpr int NT = NP == 3 ? 2 : 3;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int STAGE = (BM + BN) * 32;            // words
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int nb_mn = p.tiles_mn;
     const int gb = xcd_remap(blockIdx.x, gridDim.x);
@@ -1301,21 +1368,22 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
             }
         }
     };
+    const float qs = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(isA ? qz.sa : qz.sb)));   // wave-uniform role
     auto store_task = [&](float* stage, const float4 (&x)[4]) {
         if (!active) return;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             uint2 ph, pm, pl;               // the 4 pixels of channel c
-            split_pack4v<false>(c == 0 ? x[0].x : c == 1 ? x[0].y : c == 2 ? x[0].z : x[0].w, c == 0 ? x[1].x : c == 1 ? x[1].y : c == 2 ? x[1].z : x[1].w,
+            split_pack4v<NP, false>(c == 0 ? x[0].x : c == 1 ? x[0].y : c == 2 ? x[0].z : x[0].w, c == 0 ? x[1].x : c == 1 ? x[1].y : c == 2 ? x[1].z : x[1].w,
                                 c == 0 ? x[2].x : c == 1 ? x[2].y : c == 2 ? x[2].z : x[2].w, c == 0 ? x[3].x : c == 1 ? x[3].y : c == 2 ? x[3].z : x[3].w,
-                                ph, pm, pl);
+                                qs, ph, pm, pl);
             const int row = lds_row0 + c;
             const int sw = (row >> 1) & 7;
             float* base = stage + row * 32 + (kq & 1) * 2;
             const int hi = kq >> 1;
             *reinterpret_cast<uint2*>(base + ((0 + hi) ^ sw) * 4) = ph;
             *reinterpret_cast<uint2*>(base + ((2 + hi) ^ sw) * 4) = pm;
-            if (kTerm3) *reinterpret_cast<uint2*>(base + ((4 + hi) ^ sw) * 4) = pl;
+            if (kterm3<NP>()) *reinterpret_cast<uint2*>(base + ((4 + hi) ^ sw) * 4) = pl;
         }
     };
 
@@ -1334,27 +1402,25 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
         for (int q = 0; q < 3; ++q) b_rd[j][q] = row * 32 + ((2 * q + half) ^ ((row >> 1) & 7)) * 4;
     }
     auto mma_tile = [&](const float* stage) {
-        bf16x8 af[TM][3], bf[TN][3];
+        FR af[TM][3], bf[TN][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(stage + a_rd[i][q]);
+            for (int q = 0; q < NT; ++q) af[i][q] = *reinterpret_cast<const FR*>(stage + a_rd[i][q]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) bf[j][q] = *reinterpret_cast<const bf16x8*>(stage + b_rd[j][q]);
+            for (int q = 0; q < NT; ++q) bf[j][q] = *reinterpret_cast<const FR*>(stage + b_rd[j][q]);
 #pragma unroll
-        for (int t6 = LO0; t6 < 5; ++t6)
+        for (int t6 = lo0<NP>(); t6 < 5; ++t6)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA6[t6]], bf[j][PB6[t6]], lo[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) lo[i][j] = mfma16<NP>(af[i][PA6[t6]], bf[j][PB6[t6]], lo[i][j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<NP>(af[i][0], bf[j][0], acc[i][j]);
     };
 
     if (k_begin < k_end) {
@@ -1387,9 +1453,17 @@ __global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.M) out[(long)m * p.N + n] = merge_hi_lo(acc[i][j][r], lo[i][j][r]);
+                if (m < p.M) out[(long)m * p.N + n] = merge_q<NP>(acc[i][j][r], lo[i][j][r], qz.dexp);
             }
         }
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void wgrad_tn_split_kernel(TnParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * 32];
+    const Quant qz = quant_select(p.a_amax, p.b_amax);
+    if (qz.use3) wgrad_tn_split_body<3, BM, BN, WM, WN, AMODE, BMODE>(p, smem, qz);
+    else wgrad_tn_split_body<6, BM, BN, WM, WN, AMODE, BMODE>(p, smem, qz);
 }
 
 struct TnPlan {
@@ -1441,6 +1515,7 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cl
     p.kchunk = pl.kchunk;
     p.tiles_n = pl.tiles_n;
     p.tiles_mn = pl.tiles_m * pl.tiles_n;
+    if (!split || mfma_products() != 3 || !p.a_amax || !p.b_amax) p.a_amax = p.b_amax = nullptr;    // six products
     const int grid = p.tiles_mn * pl.splits;
     if (split) {
         if (pl.bm == 128 && pl.bn == 128)
@@ -1530,8 +1605,6 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         }
     }
 }
-
-static int grid_for(long total, int block, int cap);
 
 static void launch_slab_reduce(const float* slab, float* dw, int M, int N, int splits, int mode, int Cin, int Cout, hipStream_t s) {
     const long quads = (long)M * N / 4;
@@ -1630,9 +1703,16 @@ using namespace rd;
 
 extern "C" {
 
-// 6: every fp32 product as six bf16 products (three-term split, fp32-class results -- libresdepth_hip.so) | 3: the
-// libresdepth_hip_split2.so build of the same sources (-DRD_NPROD=3: two-term split, three products; rd_mfma_dev.h)
-int rd_mfma_products(void) { return RD_NPROD; }
+// 3: operands that carry magnitude slots (rd_quant_next) are multiplied as two fp16 terms / three products (rd_mfma_dev.h);
+// 6: three bf16 terms / six products everywhere.  The knob `mfma_products` (RD_MFMA=split2h | split3) of ONE library.
+int rd_mfma_products(void) { return mfma_products(); }
+
+int rd_amax(const float* x, long long n, unsigned* slot, rd_stream_t s) {
+    RD_REQUIRE(x && slot && n > 0, "rd_amax: bad arguments");
+    launch_amax(x, (long)n, slot, nullptr, 1, (hipStream_t)s);
+    RD_LAUNCH_CHECK("rd_amax");
+    return RD_OK;
+}
 
 
 size_t rd_packed_weight_bytes(int rows, int taps, int cin) {
@@ -1643,6 +1723,8 @@ size_t rd_packed_weight_bytes(int rows, int taps, int cin) {
 int rd_pack_conv3x3_weight(const float* w, float* wf, float* wd, int cout, int cin, rd_stream_t s) {
     RD_REQUIRE(w && wf && cout > 0 && cin > 0, "rd_pack_conv3x3_weight: bad arguments");
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 12.0 * cout * cin * 9);
+    unsigned* amax = mfma_products() == 3 ? quant_take().out2 : (quant_take(), nullptr);   // the weight's magnitude slot (zeroed)
+    if (amax) launch_amax(w, (long)cout * cin * 9, amax, nullptr, 1, (hipStream_t)s);
     if (mfma_split()) {     // split kernels only: both fragment tensors in one launch, fp32 GEMM layouts left unwritten
         uint4* of = (uint4*)((char*)wf + packed_f32_bytes(cout, 9, cin));
         uint4* od = wd ? (uint4*)((char*)wd + packed_f32_bytes(cin, 9, cout)) : nullptr;
@@ -1650,7 +1732,7 @@ int rd_pack_conv3x3_weight(const float* w, float* wf, float* wd, int cout, int c
         long g = (pieces + 255) / 256;
         if (g > 8192) g = 8192;
         hipLaunchKernelGGL(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, od, cout, cin,
-                           (const float*)nullptr);
+                           (const float*)nullptr, (const unsigned*)amax);
         RD_LAUNCH_CHECK("pack_conv3x3");
         return RD_OK;
     }
@@ -1662,8 +1744,8 @@ int rd_pack_conv3x3_weight(const float* w, float* wf, float* wd, int cout, int c
                            (const float*)wf, wd, cout, 9, cin, 1);
     }
     RD_LAUNCH_CHECK("pack_conv3x3");
-    if (int e = split_pack(wf, cout, 9, cin, (hipStream_t)s)) return e;
-    if (wd) return split_pack(wd, cin, 9, cout, (hipStream_t)s);
+    if (int e = split_pack(wf, cout, 9, cin, (hipStream_t)s, amax)) return e;
+    if (wd) return split_pack(wd, cin, 9, cout, (hipStream_t)s, amax);
     return RD_OK;
 }
 
@@ -1671,12 +1753,14 @@ int rd_pack_conv3x3_weight_folded(const float* w, const float* row_scale, float*
     RD_REQUIRE(w && wf && row_scale && cout > 0 && cin > 0, "rd_pack_conv3x3_weight_folded: bad arguments");
     RD_REQUIRE(mfma_split(), "rd_pack_conv3x3_weight_folded: only the split-bf16 kernels implement the folded inference path");
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 10.0 * cout * cin * 9);
+    unsigned* amax = mfma_products() == 3 ? quant_take().out2 : (quant_take(), nullptr);   // magnitude slot of the SCALED rows
+    if (amax) launch_amax(w, (long)cout * cin * 9, amax, row_scale, (long)cin * 9, (hipStream_t)s);
     uint4* of = (uint4*)((char*)wf + packed_f32_bytes(cout, 9, cin));
     const long pieces = rows32_of(cout) * nk16_of(9, cin) * 2;
     long g = (pieces + 255) / 256;
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, (uint4*)nullptr, cout, cin,
-                       row_scale);
+                       row_scale, (const unsigned*)amax);
     RD_LAUNCH_CHECK("pack_conv3x3_folded");
     return RD_OK;
 }
@@ -1697,6 +1781,9 @@ int rd_pack_weights_fused(const void* items_dev, int n_items, long long total_pi
                "rd_pack_weights_fused: bad arguments");
     RD_REQUIRE(mfma_split(), "rd_pack_weights_fused: the fused packer writes the split-bf16 operands only");
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 10.0 * 8.0 * (double)total_pieces + 14.0 * 9216.0 * (double)total_tiles);
+    // items with a magnitude slot (column 9 of the table; zeroed by the caller) get the three-product form too: first their maxima
+    if (mfma_products() == 3)
+        hipLaunchKernelGGL(pack_items_amax_kernel, dim3(32 * n_items), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items);
     if (total_tiles > 0) {
         const long gt = total_tiles < 4096 ? total_tiles : 4096;
         hipLaunchKernelGGL(pack_tiles_kernel, dim3((int)gt), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items,
@@ -1715,6 +1802,8 @@ int rd_pack_weights_fused(const void* items_dev, int n_items, long long total_pi
 int rd_pack_convt2x2_weight(const float* w, float* wtf, float* wtd, int cin, int cout, rd_stream_t s) {
     RD_REQUIRE(w && wtf && cout > 0 && cin > 0, "rd_pack_convt2x2_weight: bad arguments");
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 12.0 * cout * cin * 4);
+    unsigned* amax = mfma_products() == 3 ? quant_take().out2 : (quant_take(), nullptr);
+    if (amax) launch_amax(w, (long)cout * cin * 4, amax, nullptr, 1, (hipStream_t)s);
     hipLaunchKernelGGL(pack_convt_kernel, dim3(grid_for((long)cout * cin * 4)), dim3(256), 0, (hipStream_t)s, w, wtf,
                        (float*)nullptr, cin, cout);
     if (wtd) {
@@ -1723,8 +1812,8 @@ int rd_pack_convt2x2_weight(const float* w, float* wtf, float* wtd, int cin, int
                            (const float*)wtf, wtd, 4 * cout, 1, cin, 0);
     }
     RD_LAUNCH_CHECK("pack_convt");
-    if (int e = split_pack(wtf, 4L * cout, 1, cin, (hipStream_t)s)) return e;
-    if (wtd) return split_pack(wtd, cin, 4, cout, (hipStream_t)s);
+    if (int e = split_pack(wtf, 4L * cout, 1, cin, (hipStream_t)s, amax)) return e;
+    if (wtd) return split_pack(wtd, cin, 4, cout, (hipStream_t)s, amax);
     return RD_OK;
 }
 
@@ -1747,6 +1836,7 @@ int rd_conv3x3_fwd_stats(const float* x, const float* wf, float* z, double* sums
         return RD_ERR_WS;
     }
     NtParams p = {};
+    set_quant(p, quant_take());
     p.A = x; p.B = wf; p.C = z;
     p.M = n * h * w; p.N = cout; p.K = 9 * cin; p.Cin = cin;
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
@@ -1768,6 +1858,7 @@ int rd_conv3x3_fwd_bn(const float* x, const float* wf, float* z, double count, f
         return RD_ERR_WS;
     }
     NtParams p = {};
+    set_quant(p, quant_take());
     p.A = x; p.B = wf; p.C = z;
     p.M = n * h * w; p.N = cout; p.K = 9 * cin; p.Cin = cin;
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
@@ -1787,6 +1878,7 @@ int rd_conv3x3_fwd_act(const float* x, const float* wf_folded, const float* shif
     RD_REQUIRE(!pooled || (w % 16 == 0 && h % 8 == 0),
                "rd_conv3x3_fwd_act: the pooling epilogue needs W a multiple of 16 and H a multiple of 8 (got %dx%d)", h, w);
     NtParams p = {};
+    set_quant(p, quant_take());
     p.A = x; p.B = wf_folded; p.C = a;
     p.M = n * h * w; p.N = cout; p.K = 9 * cin; p.Cin = cin;
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
@@ -1800,6 +1892,7 @@ int rd_conv3x3_bwd_data(const float* dz, const float* wd, float* dx, int n, int 
     RD_REQUIRE(dz && wd && dx, "rd_conv3x3_bwd_data: null pointer");
     RD_REQUIRE(cout % 4 == 0, "rd_conv3x3_bwd_data: Cout must be a multiple of 4 (got %d)", cout);
     NtParams p = {};
+    set_quant(p, quant_take());
     p.A = dz; p.B = wd; p.C = dx;
     p.M = n * h * w; p.N = cin; p.K = 9 * cout; p.Cin = cout;
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
@@ -1828,6 +1921,7 @@ int rd_conv3x3_bwd_data_bnstats(const float* dz, const float* wd, float* dx, int
     RD_REQUIRE(dz && wd && dx && rows_out, "rd_conv3x3_bwd_data_bnstats: null pointer");
     RD_REQUIRE(cout % 4 == 0, "rd_conv3x3_bwd_data_bnstats: Cout must be a multiple of 4 (got %d)", cout);
     NtParams p = {};
+    set_quant(p, quant_take());
     p.A = dz; p.B = wd; p.C = dx;
     p.M = n * h * w; p.N = cin; p.K = 9 * cout; p.Cin = cout;
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
@@ -1849,13 +1943,14 @@ int rd_conv3x3_bwd_weight(const float* x, const float* dz, float* dw, int n, int
     RD_REQUIRE(x && dz && dw, "rd_conv3x3_bwd_weight: null pointer");
     RD_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "rd_conv3x3_bwd_weight: channels must be multiples of 4 (%d, %d)", cin,
                cout);
+    const QuantArgs wq = quant_take();       // a: slot of dz, b: slot of x
     const size_t need = rd_conv3x3_bwd_weight_ws_bytes(n, h, w, cin, cout);
     if (ws_bytes < need || !ws) {
         set_error("rd_conv3x3_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
         return RD_ERR_WS;
     }
     int strip_splits = 0, strip_swapped = 0;
-    if (int e = wgrad_strip_launch(x, dz, (float*)ws, n, h, w, cin, cout, (hipStream_t)s, &strip_splits, &strip_swapped)) return e;
+    if (int e = wgrad_strip_launch(x, dz, (float*)ws, n, h, w, cin, cout, (hipStream_t)s, &strip_splits, &strip_swapped, wq.b, wq.a)) return e;
     if (strip_splits > 0) {
         ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (strip_splits + 1) * (double)cout * 9 * cin);
         if (strip_swapped)
@@ -1867,6 +1962,7 @@ int rd_conv3x3_bwd_weight(const float* x, const float* dz, float* dw, int n, int
     }
     TnPlan pl = plan_tn(cout, 9 * cin, (long)n * h * w);
     TnParams p = {};
+    p.a_amax = wq.a; p.b_amax = wq.b;
     p.A = dz; p.B = x; p.slab = (float*)ws;
     p.M = cout; p.N = 9 * cin; p.Kp = (long)n * h * w;
     p.lda = cout; p.ldb = cin; p.Cin = cin; p.Cout = cout;
@@ -1883,15 +1979,17 @@ int rd_convt2x2_fwd(const float* x, const float* wtf, const float* bias, const f
     if (int e = check_conv_args(n, h, w, cin, cout)) return e;
     RD_REQUIRE(x && wtf && out, "rd_convt2x2_fwd: null pointer");
     RD_REQUIRE(cin % 4 == 0, "rd_convt2x2_fwd: Cin must be a multiple of 4 (got %d)", cin);
+    const QuantArgs qa = quant_take();
     {
         int launched = 0;
         const size_t sb = (size_t)rows32_of(4L * cout) * nk16_of(1, cin) * SROWB;
         if (int e = convt_fwd_launch(x, (const char*)wtf + packed_f32_bytes(4L * cout, 1, cin), sb, bias, skip, nullptr, nullptr,
-                                     nullptr, nullptr, 0.f, nullptr, out, n, h, w, cin, cout, (hipStream_t)s, &launched))
+                                     nullptr, nullptr, 0.f, nullptr, out, n, h, w, cin, cout, (hipStream_t)s, &launched, qa))
             return e;
         if (launched) return RD_OK;
     }
     NtParams p = {};
+    set_quant(p, qa);
     p.A = x; p.B = wtf; p.C = out; p.bias = bias; p.skip = skip;
     p.M = n * h * w; p.N = 4 * cout; p.K = cin; p.Cin = cin; p.Cout = cout;
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
@@ -1904,15 +2002,17 @@ int rd_convt2x2_fwd_bnskip(const float* x, const float* wtf, const float* bias, 
     if (int e = check_conv_args(n, h, w, cin, cout)) return e;
     RD_REQUIRE(x && wtf && out && z_skip && mean && invstd && gamma && beta, "rd_convt2x2_fwd_bnskip: null pointer");
     RD_REQUIRE(cin % 4 == 0, "rd_convt2x2_fwd_bnskip: Cin must be a multiple of 4 (got %d)", cin);
+    const QuantArgs qa = quant_take();
     {
         int launched = 0;
         const size_t sb = (size_t)rows32_of(4L * cout) * nk16_of(1, cin) * SROWB;
         if (int e = convt_fwd_launch(x, (const char*)wtf + packed_f32_bytes(4L * cout, 1, cin), sb, bias, z_skip, mean, invstd,
-                                     gamma, beta, slope, slope_dev, out, n, h, w, cin, cout, (hipStream_t)s, &launched))
+                                     gamma, beta, slope, slope_dev, out, n, h, w, cin, cout, (hipStream_t)s, &launched, qa))
             return e;
         if (launched) return RD_OK;
     }
     NtParams p = {};
+    set_quant(p, qa);
     p.A = x; p.B = wtf; p.C = out; p.bias = bias; p.skip = z_skip;
     p.sk_mean = mean; p.sk_invstd = invstd; p.sk_gamma = gamma; p.sk_beta = beta; p.sk_slope = slope; p.sk_slope_dev = slope_dev;
     p.M = n * h * w; p.N = 4 * cout; p.K = cin; p.Cin = cin; p.Cout = cout;
@@ -1927,6 +2027,8 @@ static int convt_dgrad_try(NtParams p, hipStream_t s, int* rows_out) {
     if (b_bytes >= 4294967040.0) return 0;
     p.b_bytes = (unsigned)b_bytes;
     p.Bsplit = (const char*)p.B + packed_f32_bytes(p.N, taps, p.Cin);
+    p.Bsplit3 = (const char*)p.Bsplit + (size_t)b_bytes;
+    p.b_bytes3 = (unsigned)((double)rows32_of(p.N) * (taps * cdiv(p.Cin, SK)) * SROWB3);
     int launched = 0;
     if (int e = convt_dgrad_launch(p, s, &launched, rows_out)) return e;
     return launched ? -1 : 0;
@@ -1938,6 +2040,7 @@ int rd_convt2x2_bwd_data(const float* dout, const float* wtd, float* dx, int n, 
     RD_REQUIRE(dout && wtd && dx, "rd_convt2x2_bwd_data: null pointer");
     RD_REQUIRE(cout % 4 == 0, "rd_convt2x2_bwd_data: Cout must be a multiple of 4 (got %d)", cout);
     NtParams p = {};
+    set_quant(p, quant_take());
     p.A = dout; p.B = wtd; p.C = dx;
     p.M = n * h * w; p.N = cin; p.K = 4 * cout; p.Cin = cout;
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
@@ -1953,6 +2056,7 @@ int rd_convt2x2_bwd_data_bnstats(const float* dout, const float* wtd, float* dx,
     RD_REQUIRE(dout && wtd && dx && rows_out, "rd_convt2x2_bwd_data_bnstats: null pointer");
     RD_REQUIRE(cout % 4 == 0, "rd_convt2x2_bwd_data_bnstats: Cout must be a multiple of 4 (got %d)", cout);
     NtParams p = {};
+    set_quant(p, quant_take());
     p.A = dout; p.B = wtd; p.C = dx;
     p.M = n * h * w; p.N = cin; p.K = 4 * cout; p.Cin = cout;
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
@@ -1975,6 +2079,7 @@ int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw, int n, 
     RD_REQUIRE(x && dout && dw, "rd_convt2x2_bwd_weight: null pointer");
     RD_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "rd_convt2x2_bwd_weight: channels must be multiples of 4 (%d, %d)", cin,
                cout);
+    const QuantArgs wq = quant_take();       // a: slot of dout, b: slot of x
     const size_t need = rd_convt2x2_bwd_weight_ws_bytes(n, h, w, cin, cout);
     if (ws_bytes < need || !ws) {
         set_error("rd_convt2x2_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -1982,7 +2087,7 @@ int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw, int n, 
     }
     {
         int splits = 0;
-        if (int e = convt_wgrad_launch(x, dout, (float*)ws, n, h, w, cin, cout, (hipStream_t)s, &splits)) return e;
+        if (int e = convt_wgrad_launch(x, dout, (float*)ws, n, h, w, cin, cout, (hipStream_t)s, &splits, wq.b, wq.a)) return e;
         if (splits > 0) {
             ProfScope ps((hipStream_t)s, "wgrad_reduce", 0, 4.0 * (splits + 1) * 4.0 * cout * cin);
             launch_slab_reduce((const float*)ws, dw, 4 * cout, cin, splits, 1, cin, cout, (hipStream_t)s);
@@ -1992,6 +2097,7 @@ int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw, int n, 
     }
     TnPlan pl = plan_tn(4 * cout, cin, (long)n * h * w);
     TnParams p = {};
+    p.a_amax = wq.a; p.b_amax = wq.b;
     p.A = dout; p.B = x; p.slab = (float*)ws;
     p.M = 4 * cout; p.N = cin; p.Kp = (long)n * h * w;
     p.lda = cout; p.ldb = cin; p.Cin = cin; p.Cout = cout;
@@ -2009,10 +2115,12 @@ int rd_convt2x2_bwd_weight(const float* x, const float* dout, float* dw, int n, 
 int rd_pack_conv1x1_weight(const float* w, float* wf, float* wt, int cout, int cin, rd_stream_t s) {
     RD_REQUIRE(w && wf && cout > 0 && cin > 0, "rd_pack_conv1x1_weight: bad arguments");
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 16.0 * cout * cin);
+    unsigned* amax = mfma_products() == 3 ? quant_take().out2 : (quant_take(), nullptr);
+    if (amax) launch_amax(w, (long)cout * cin, amax, nullptr, 1, (hipStream_t)s);
     if (int e = check_hip(hipMemcpyAsync(wf, w, (size_t)cout * cin * 4, hipMemcpyDeviceToDevice, (hipStream_t)s),
                           "pack_conv1x1 copy"))
         return e;
-    if (int e = split_pack(wf, cout, 1, cin, (hipStream_t)s)) return e;
+    if (int e = split_pack(wf, cout, 1, cin, (hipStream_t)s, amax)) return e;
     if (!wt) return RD_OK;
     {
         const long tiles = (long)cdiv(cout, 32) * cdiv(cin, 32);
@@ -2020,7 +2128,7 @@ int rd_pack_conv1x1_weight(const float* w, float* wf, float* wt, int cout, int c
                            cout, 1, cin, 0);
     }
     RD_LAUNCH_CHECK("pack_conv1x1");
-    return split_pack(wt, cin, 1, cout, (hipStream_t)s);
+    return split_pack(wt, cin, 1, cout, (hipStream_t)s, amax);
 }
 
 int rd_conv1x1_fwd(const float* x, const float* w, float* out, long long pixels, int cin, int cout, rd_stream_t s) {
@@ -2028,6 +2136,7 @@ int rd_conv1x1_fwd(const float* x, const float* w, float* out, long long pixels,
     RD_REQUIRE(cin % 4 == 0, "rd_conv1x1_fwd: Cin must be a multiple of 4 (got %d)", cin);
     RD_REQUIRE(pixels * 4LL < (1LL << 31), "rd_conv1x1_fwd: pixel count too large for 32-bit tile indices");
     NtParams p = {};
+    set_quant(p, quant_take());
     p.A = x; p.B = w; p.C = out;
     p.M = (int)pixels; p.N = cout; p.K = cin; p.Cin = cin;
     p.H = 1; p.W = 1; p.pd = make_pixdiv(1, 1);
@@ -2039,6 +2148,7 @@ int rd_conv1x1_bwd_data(const float* dy, const float* wt, float* dx, long long p
     RD_REQUIRE(cout % 4 == 0, "rd_conv1x1_bwd_data: Cout must be a multiple of 4 (got %d)", cout);
     RD_REQUIRE(pixels * 4LL < (1LL << 31), "rd_conv1x1_bwd_data: pixel count too large for 32-bit tile indices");
     NtParams p = {};
+    set_quant(p, quant_take());
     p.A = dy; p.B = wt; p.C = dx;
     p.M = (int)pixels; p.N = cin; p.K = cout; p.Cin = cout;
     p.H = 1; p.W = 1; p.pd = make_pixdiv(1, 1);
@@ -2055,6 +2165,7 @@ int rd_conv1x1_bwd_weight(const float* x, const float* dy, float* dw, long long 
     RD_REQUIRE(x && dy && dw && pixels > 0, "rd_conv1x1_bwd_weight: bad arguments");
     RD_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "rd_conv1x1_bwd_weight: channels must be multiples of 4 (%d, %d)", cin,
                cout);
+    const QuantArgs wq = quant_take();       // a: slot of dy, b: slot of x
     const size_t need = rd_conv1x1_bwd_weight_ws_bytes(pixels, cin, cout);
     if (ws_bytes < need || !ws) {
         set_error("rd_conv1x1_bwd_weight: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -2062,6 +2173,7 @@ int rd_conv1x1_bwd_weight(const float* x, const float* dy, float* dw, long long 
     }
     TnPlan pl = plan_tn(cout, cin, (long)pixels);
     TnParams p = {};
+    p.a_amax = wq.a; p.b_amax = wq.b;
     p.A = dy; p.B = x; p.slab = (float*)ws;
     p.M = cout; p.N = cin; p.Kp = (long)pixels;
     p.lda = cout; p.ldb = cin; p.Cin = cin; p.Cout = cout;

@@ -32,24 +32,122 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int SK = 16;      // k-values per K-step
-constexpr int SROWB = 96;   // bytes of one (row, K-step) in the packed split-B tensor
+constexpr int SROWB = 96;   // bytes of one (row, K-step) in the packed split-B tensor, six-product form (3 bf16 terms)
+constexpr int SROWB3 = 64;  // ... three-product form (2 fp16 terms), which follows the six-product form in the packed buffer
 
-// ---- the six products of a*b = (a1+a2+a3)(b1+b2+b3) that are kept, smallest first.  The five products of weight <= 2^-8
+// =====================================================================================================================
+//  Two arithmetic forms of the same fp32 GEMM, chosen PER LAUNCH ON THE DEVICE (one library, template parameter NP):
+//
+//  NP = 6  "split3": x = x1 + x2 + x3 exactly (three bf16 terms by truncation), six products on v_mfma_f32_32x32x16_bf16.
+//          No assumption about the operands: the form every kernel falls back to.
+//  NP = 3  "split2h" (r06): x ~ (x1 + x2) / s with x1 = rn16(s x), x2 = rn16(s x - x1) two FP16 terms (11 significant bits
+//          each: |s x - x1 - x2| <= 2^-22 |s x|, and <= 2^-25 absolute once x2 is an fp16 subnormal), s = a power of two per
+//          operand TENSOR that puts the tensor's largest magnitude into [2^14, 2^15); three products a1 b1 (hi), a1 b2,
+//          a2 b1 (lo) on v_mfma_f32_32x32x16_f16 -- half the matrix instructions -- and the result scaled back by
+//          2^-(ea + eb) (v_ldexp: exact).  Per product: |ab - (a1 b1 + a1 b2 + a2 b1)/(sa sb)| <= 3 * 2^-22 |ab| for
+//          elements within 2^-18 of their tensor's maximum (64 x tighter than two bf16 terms), and <= 2^-39 amax(a) |b| below.
+//          It needs the tensor maxima: producers max-accumulate |x| into a 16-word device slot from their epilogues
+//          (amax_commit; an integer max of IEEE bit patterns is order-independent, so results stay run-to-run identical) and
+//          the consumer reads them at kernel start (quant_select).  An operand without a slot, or whose maximum is Inf (NaN
+//          elements are fine: they stay NaN in both terms), sends the launch to the NP = 6 body -- which therefore keeps
+//          fp32's non-finite semantics.
+// =====================================================================================================================
+constexpr int AMAX_WORDS = 16;      // one slot = 16 words: a wave commits to word (its id & 15), spreading same-address atomics
+
+template <int NP> struct frag_of { typedef bf16x8 type; };
+template <> struct frag_of<3> { typedef f16x8 type; };
+template <int NP>
+__device__ __forceinline__ f32x16 mfma16(typename frag_of<NP>::type a, typename frag_of<NP>::type b, f32x16 c) {
+    if constexpr (NP == 3) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// what a launch was given / decided about its operands (wave-uniform, scalar registers)
+struct Quant {
+    int use3;       // 1: NP = 3 body
+    float sa, sb;   // operand scales 2^ea, 2^eb (sb only where B is split on the fly: the weight-gradient kernels)
+    int dexp;       // -(ea + eb): exponent of the result's scale-back
+};
+__device__ __forceinline__ unsigned amax_read(const unsigned* __restrict__ slot) {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < AMAX_WORDS; ++i) {
+        const unsigned v = slot[i];
+        m = v > m ? v : m;
+    }
+    return m;
+}
+// biased exponent of the scale that maps a tensor maximum with bits `am` into [2^14, 2^15) (clamped to a finite float)
+__device__ __forceinline__ int scale_bexp(unsigned am) {
+    const int b = 268 - (int)(am >> 23);
+    return b > 254 ? 254 : b;
+}
+__device__ __forceinline__ Quant quant_select(const unsigned* a_amax, const unsigned* b_amax) {
+    Quant q = {0, 1.f, 1.f, 0};
+    if (a_amax == nullptr || b_amax == nullptr) return q;
+    const unsigned am = (unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(a_amax));
+    const unsigned bm = (unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(b_amax));
+    if (am >= 0x7f800000u || bm >= 0x7f800000u) return q;        // an infinite element: exact non-finite semantics live in NP = 6
+    const int ea = scale_bexp(am), eb = scale_bexp(bm);
+    q.use3 = 1;
+    q.sa = __uint_as_float((unsigned)ea << 23);
+    q.sb = __uint_as_float((unsigned)eb << 23);
+    q.dexp = 254 - ea - eb;
+    return q;
+}
+// producer side: m = max |v| over what this lane wrote (>= 0; a NaN element is ignored by v_max, see above) -> slot
+__device__ __forceinline__ float amax_acc(float m, float v) {
+    float r;
+    asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(m), "v"(v));
+    return r;
+}
+// EVERY thread of the block calls this (block-uniform control flow): wave maximum by cross-lane exchange, block maximum through
+// 8 words of LDS, then ONE agent-scope atomic per block.  Measured r06: device-scope atomics on one 128-byte line retire at
+// ~11 ns each whatever word they hit (MI355X_MICROARCH.md "fanin"), so one per WAVE of an 8192-block element-wise kernel cost
+// 0.23 ms per launch (bn_act_pool_fwd 0.27 -> 1.44 ms per step) -- hence one per block, and the element-wise producers cap
+// their grid at 2048 blocks when a slot is asked for (amax_grid_cap).
+__device__ __forceinline__ void amax_commit(unsigned* slot, float m) {
+    __shared__ unsigned amax_red[16];
+    unsigned b = __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)b, o);
+        b = other > b ? other : b;
+    }
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) b = amax_red[w] > b ? amax_red[w] : b;
+        __hip_atomic_fetch_max(slot + (blockIdx.x & (AMAX_WORDS - 1)), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- NP = 6: the six products of a*b = (a1+a2+a3)(b1+b2+b3) that are kept, smallest first.  The five products of weight <= 2^-8
 // go into a SEPARATE accumulator (lo) and only a1*b1 into the main one (hi); the two are added once in the epilogue.
 // With a single accumulator a 2^-16-class group sum (8 products) that is below half an ulp of a large running sum is
 // rounded away EVERY time -- a one-sided loss of up to 2^-15 |ab| on same-sign data (measured 163 u rms at K = 4608,
 // u = 2^-24; scripts/split_numerics.py) -- whereas `lo` only ever holds terms of its own size.  `hi` then behaves like an
-// fp32 dot product with one rounding per 16 products.
+// fp32 dot product with one rounding per 16 products.  NP = 3 keeps entries 3..5 of the table: a2 b1, a1 b2 (lo), a1 b1 (hi).
 constexpr int PA6[6] = {2, 1, 0, 1, 0, 0}, PB6[6] = {0, 1, 2, 0, 1, 0};
-#ifndef RD_NPROD
-#define RD_NPROD 6
-#endif
-constexpr int LO0 = RD_NPROD == 3 ? 3 : 0;      // first kept entry of PA6 / PB6
-// hi + lo.  An infinite operand lives in its first term only (split3), so hi = Inf * b1 carries the correct +-Inf (or NaN
-// for Inf * 0 / Inf - Inf, as in fp32) while lo may have picked up Inf * 0 = NaN from a ZERO lower term of the other
+template <int NP> constexpr int lo0() { return NP == 3 ? 3 : 0; }      // first kept entry of PA6 / PB6
+// hi + lo.  NP = 6: an infinite operand lives in its first term only (split3), so hi = Inf * b1 carries the correct +-Inf (or
+// NaN for Inf * 0 / Inf - Inf, as in fp32) while lo may have picked up Inf * 0 = NaN from a ZERO lower term of the other
 // operand: an infinite hi therefore wins.  (Only difference to an fp32 product left: Inf * b with 0 < |b| < 2^-133.)
+// NP = 3: no infinite operand reaches this form (quant_select); the sum is scaled back by 2^dexp.
 __device__ __forceinline__ float merge_hi_lo(float hi, float lo) { return __builtin_fabsf(hi) == __builtin_inff() ? hi : hi + lo; }
+template <int NP>
+__device__ __forceinline__ float merge_q(float hi, float lo, int dexp) {
+    if constexpr (NP == 3) return __builtin_amdgcn_ldexpf(hi + lo, dexp);
+    else return merge_hi_lo(hi, lo);
+}
+template <int NP>
+__device__ __forceinline__ float scale_q(float v, int dexp) {       // single-accumulator kernels (weight gradients)
+    if constexpr (NP == 3) return __builtin_amdgcn_ldexpf(v, dexp);
+    else return v;
+}
 
 // x = h + m + l exactly (|x| >= 2^-110; below that the third term is a bf16 subnormal and absorbs an absolute error
 // <= 2^-133); h, m, l have <= 8 significant bits (bf16-representable), returned as fp32 bit patterns.  Split by
@@ -61,58 +159,53 @@ __device__ __forceinline__ float merge_hi_lo(float hi, float lo) { return __buil
 // keep an Inf apart from Inf * 0 anyway -- there a non-finite operand yields NaN in every output it touches.
 template <bool GUARD = true>
 __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-#if RD_NPROD == 3
-    h = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) << 16;
-    float r = x - __uint_as_float(h);
-    if (GUARD) r = (r == r) ? r : 0.f;
-    m = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)r) << 16;
-    l = 0u;
-#else
     h = __float_as_uint(x) & 0xffff0000u;
     float r = x - __uint_as_float(h);
     if (GUARD) r = (r == r) ? r : 0.f;
     m = __float_as_uint(r) & 0xffff0000u;
     l = __float_as_uint(r - __uint_as_float(m));
-#endif
 }
-// four values (consecutive k) -> 8-byte groups of 4 bf16, one per term; v_perm_b32 -> {hi16(odd), hi16(even)}.
-// kTerm3: the third term exists (six-product build); the three-product build writes / reads two terms only.
-constexpr bool kTerm3 = RD_NPROD != 3;
-#if RD_NPROD == 3
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-// two values -> {rn_bf16(x1) : rn_bf16(x0)} and the same of the remainders: v_cvt_pk_bf16_f32, 2 unpack, 2 sub, v_cvt_pk_bf16_f32
-template <bool GUARD>
-__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& ph, unsigned& pm) {
-    const f32x2_t v = {x0, x1};
-    ph = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-    float r0 = x0 - __uint_as_float(ph << 16), r1 = x1 - __uint_as_float(ph & 0xffff0000u);
-    if (GUARD) {
-        r0 = (r0 == r0) ? r0 : 0.f;
-        r1 = (r1 == r1) ? r1 : 0.f;
+// NP = 3: two values -> {rn16(s x1) : rn16(s x0)} and the fp16 of the two remainders, 2 VALU per element: v_fma_mixlo/hi_f16
+// evaluate fma(x, s, -h) with ONE rounding, to fp16 (s x is exact, so is s x - h: the remainder of an 11-bit rounding of a
+// 24-bit value has <= 13 significant bits), and write one half of the destination each -- scale, convert, subtract and pack in
+// four instructions (the compiler's own lowering of the C expression takes seven).
+__device__ __forceinline__ void split2h_pair(float x0, float x1, float s, unsigned& ph, unsigned& pm) {
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(ph) : "v"(x0), "v"(x1), "s"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(pm)
+        : "v"(x0), "v"(x1), "s"(s), "v"(ph));
+}
+// the same with the scale in a vector register (pack kernels: threads of one wave may serve different tensors)
+__device__ __forceinline__ void split2h_pair_v(float x0, float x1, float s, unsigned& ph, unsigned& pm) {
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0\n\tv_fma_mixhi_f16 %0, %2, %3, 0" : "=&v"(ph) : "v"(x0), "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(pm)
+        : "v"(x0), "v"(x1), "v"(s), "v"(ph));
+}
+// four values (consecutive k) -> 8-byte groups of 4 x 16 bit, one per term; NP = 6: v_perm_b32 -> {hi16(odd), hi16(even)}.
+// `s`: the operand's scale (NP = 3 only).  kterm3<NP>: the third term exists.
+template <int NP> constexpr bool kterm3() { return NP != 3; }
+template <int NP, bool GUARD = true>
+__device__ __forceinline__ void split_pack4v(float x0, float x1, float x2, float x3, float s, uint2& ph, uint2& pm, uint2& pl) {
+    if constexpr (NP == 3) {
+        split2h_pair(x0, x1, s, ph.x, pm.x);
+        split2h_pair(x2, x3, s, ph.y, pm.y);
+        pl = make_uint2(0u, 0u);
+    } else {
+        unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+        split3<GUARD>(x0, h0, m0, l0);
+        split3<GUARD>(x1, h1, m1, l1);
+        split3<GUARD>(x2, h2, m2, l2);
+        split3<GUARD>(x3, h3, m3, l3);
+        ph = make_uint2(__builtin_amdgcn_perm(h1, h0, 0x07060302u), __builtin_amdgcn_perm(h3, h2, 0x07060302u));
+        pm = make_uint2(__builtin_amdgcn_perm(m1, m0, 0x07060302u), __builtin_amdgcn_perm(m3, m2, 0x07060302u));
+        pl = make_uint2(__builtin_amdgcn_perm(l1, l0, 0x07060302u), __builtin_amdgcn_perm(l3, l2, 0x07060302u));
     }
-    const f32x2_t r = {r0, r1};
-    pm = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
-#endif
-template <bool GUARD = true>
-__device__ __forceinline__ void split_pack4v(float x0, float x1, float x2, float x3, uint2& ph, uint2& pm, uint2& pl) {
-#if RD_NPROD == 3
-    split2_pair<GUARD>(x0, x1, ph.x, pm.x);
-    split2_pair<GUARD>(x2, x3, ph.y, pm.y);
-    pl = make_uint2(0u, 0u);
-#else
-    unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-    split3<GUARD>(x0, h0, m0, l0);
-    split3<GUARD>(x1, h1, m1, l1);
-    split3<GUARD>(x2, h2, m2, l2);
-    split3<GUARD>(x3, h3, m3, l3);
-    ph = make_uint2(__builtin_amdgcn_perm(h1, h0, 0x07060302u), __builtin_amdgcn_perm(h3, h2, 0x07060302u));
-    pm = make_uint2(__builtin_amdgcn_perm(m1, m0, 0x07060302u), __builtin_amdgcn_perm(m3, m2, 0x07060302u));
-    pl = make_uint2(__builtin_amdgcn_perm(l1, l0, 0x07060302u), __builtin_amdgcn_perm(l3, l2, 0x07060302u));
-#endif
+template <int NP>
+__device__ __forceinline__ void split_pack4(const float4 v, float s, uint2& ph, uint2& pm, uint2& pl) {
+    split_pack4v<NP, true>(v.x, v.y, v.z, v.w, s, ph, pm, pl);
 }
-__device__ __forceinline__ void split_pack4(const float4 v, uint2& ph, uint2& pm, uint2& pl) { split_pack4v<true>(v.x, v.y, v.z, v.w, ph, pm, pl); }
 __device__ __forceinline__ uint4 buf_load4u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);

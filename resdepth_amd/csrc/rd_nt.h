@@ -70,6 +70,16 @@ struct NtParams {
     // training-mode EPI_STORE (no shift / pooling epilogue), N % 32 == 0, patch kernels or plain row tiles with M a multiple
     // of the tile height: the register-direct epilogue (nt_epilogue_direct) instead of the LDS-staged one
     int direct;
+    // ---- NP = 3 arithmetic (rd_mfma_dev.h).  a_amax / b_amax: 16-word magnitude slots of the A / B operand tensors, both
+    // non-null asks for the three-product body (the kernel still takes the six-product one when a maximum is infinite);
+    // Bsplit3 / b_bytes3: the two-term fp16 fragments of B, scaled by the scale of *b_amax (they follow Bsplit in the packed
+    // buffer).  out_amax / pool_amax (nullable): slots that receive max |C| / max |pool_out| from the epilogue.
+    const unsigned* a_amax;
+    const unsigned* b_amax;
+    const void* Bsplit3;
+    unsigned b_bytes3;
+    unsigned* out_amax;
+    unsigned* pool_amax;
 };
 
 // transposed-convolution data gradient (rd_convt.hip); *launched = 0 when the shape is left to the generic NT kernel
@@ -159,6 +169,7 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][B
         }
         if (p.pool_out && pool_base >= 0) {
             const int Wp = p.W >> 1;
+            float pmax = 0.f;
             const __amdgpu_buffer_rsrc_t rsP = make_rsrc(p.pool_out + pool_base * N, (unsigned)((3 * Wp + 8) * N * 4));
             const unsigned lane_off_p = (unsigned)(((2 * half) * N + ncol0 + lrow) * 4);
             const int prow0 = __builtin_amdgcn_readfirstlane(wm * TM * Wp);
@@ -176,7 +187,9 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][B
                         }
                         const unsigned so = (unsigned)((prow0 + i * Wp + ((r >> 1) & 1) + 4 * ((r >> 2) & 1)) * rowN);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(mx), rsP, ncol0 + j * 32 < N ? lane_off_p + j * 128 : kOOB, so, 0);
+                        pmax = amax_acc(pmax, mx);
                     }
+            if (p.pool_amax) amax_commit(p.pool_amax, pmax);
         }
     }
     // ---- C
@@ -187,6 +200,17 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][B
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[i][j][r]), rsC, ((r >> 2) & 1) ? vo2[j] : vo1[j], soff(i, r), 0);
+    if (p.out_amax) {                                           // magnitude of C for the GEMM that takes it as an operand
+        float cmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (img2_ok || !((r >> 2) & 1)) cmax = amax_acc(cmax, acc[i][j][r]);
+        amax_commit(p.out_amax, cmax);
+    }
     // ---- forward BatchNorm statistics: per-(tile_m) column sums / sums of squares [tiles_m][2][N]
     if (st_on) {
         float* red = smem;                                      // WM > 1: [wm][2][BN]
@@ -339,6 +363,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
 #pragma unroll
     for (int k = 0; k < 16; ++k) bacc[k] = 0.f;
     float bslope = 0.f;
+    float cmax = 0.f, pmax = 0.f;           // max |stored value| of this thread (p.out_amax / p.pool_amax)
     if (bn_on) {
         bslope = p.bn_slope_dev ? p.bn_slope_dev[0] : p.bn_slope;
         const int n = n0 + (t % Q) * 4;
@@ -423,6 +448,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                         v.z = skip_act(v.z + sh4.z, p.act_slope); v.w = skip_act(v.w + sh4.w, p.act_slope);
                     }
                     *reinterpret_cast<float4*>(p.C + (long)m * p.N + n) = v;
+                    cmax = amax_acc(amax_acc(amax_acc(amax_acc(cmax, v.x), v.y), v.z), v.w);
                     if (bn_on) {
                         const float4 z4 = zpre[kk];
                         const float zz[4] = {z4.x, z4.y, z4.z, z4.w}, gv[4] = {v.x, v.y, v.z, v.w};
@@ -464,6 +490,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                         v.x = s4.x + v.x; v.y = s4.y + v.y; v.z = s4.z + v.z; v.w = s4.w + v.w;
                     }
                     *reinterpret_cast<float4*>(p.C + o) = v;
+                    cmax = amax_acc(amax_acc(amax_acc(amax_acc(cmax, v.x), v.y), v.z), v.w);
                 }
             }
             if (EPI == EPI_STORE && p.pool_out && pool_base >= 0) {
@@ -485,6 +512,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                     // pooled pixel: patch origin + (pass, j); rowbase / 32 = pass index = pooled row inside the patch
                     const long pp = pool_base + (long)(rowbase >> 5) * (p.W >> 1) + j;
                     *reinterpret_cast<float4*>(p.pool_out + pp * p.N + n) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+                    pmax = amax_acc(amax_acc(amax_acc(amax_acc(pmax, mx[0]), mx[1]), mx[2]), mx[3]);
                 }
             }
         } else {
@@ -496,6 +524,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                 if (EPI == EPI_STORE) {
                     if (p.shift) v = skip_act(v + p.shift[n], p.act_slope);
                     p.C[(long)m * p.N + n] = v;
+                    cmax = amax_acc(cmax, v);
                 } else {
                     const int ab = n / p.Cout, co = n - ab * p.Cout;
                     int jj, ii, img;
@@ -513,10 +542,13 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                         v = sv + v;
                     }
                     p.C[o] = v;
+                    cmax = amax_acc(cmax, v);
                 }
             }
         }
     }
+    if (p.out_amax) amax_commit(p.out_amax, cmax);
+    if (EPI == EPI_STORE && p.pool_amax && p.pool_out) amax_commit(p.pool_amax, pmax);
     if (EPI == EPI_STORE && p.stats && t < BN && n0 + t < p.N) {
         float* out = p.stats + (long)tile_m * 2 * p.N;
         out[n0 + t] = tot_s;

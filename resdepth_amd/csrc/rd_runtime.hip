@@ -34,7 +34,7 @@ struct TuneEntry {
 static TuneEntry g_tune[TUNE_COUNT] = {
     {"mfma_f32", 0},   {"nt_tile", -1},      {"nt_halo", -1},    {"nt_skew", 1},     {"tn_tile", -1},     {"tn_blocks", 512}, {"tn_split", -1},
     {"wg_strip", -1},  {"wg_minblocks", 768}, {"wg_blocks", 512}, {"wg_occ", 2}, {"convt_patch", -1}, {"edge_conv", -1}, {"rows_blocks", 512}, {"last_blocks", 2048},
-    {"nt_splitk", -1}, {"nt_epi", -1}, {"d2h_blocks", 0},
+    {"nt_splitk", -1}, {"nt_epi", -1}, {"mfma_products", 6}, {"d2h_blocks", 0},
 };
 static int tune_index(const char* name, size_t len) {
     for (int i = 0; i < TUNE_COUNT; ++i)
@@ -43,7 +43,11 @@ static int tune_index(const char* name, size_t len) {
 }
 static const int g_tune_env = [] {      // RD_TUNE="name=value,..." and the RD_MFMA=f32 mode switch, read once at load time
     if (const char* m = getenv("RD_MFMA"))
+    {
         if (!strcmp(m, "f32")) g_tune[TUNE_MFMA_F32].value = 1;
+        if (!strcmp(m, "split2h")) g_tune[TUNE_MFMA_PRODUCTS].value = 3;
+        if (!strcmp(m, "split3")) g_tune[TUNE_MFMA_PRODUCTS].value = 6;
+    }
     const char* e = getenv("RD_TUNE");
     while (e && *e) {
         const char* eq = strchr(e, '=');
@@ -56,6 +60,14 @@ static const int g_tune_env = [] {      // RD_TUNE="name=value,..." and the RD_M
     return 0;
 }();
 int tune(int key) { return g_tune[key].value; }
+
+// ---- magnitude slots of the next call (rd_quant_next) ---------------------------------------------------------------
+static thread_local QuantArgs t_quant = {nullptr, nullptr, nullptr, nullptr};
+QuantArgs quant_take() {
+    const QuantArgs q = t_quant;
+    t_quant = {nullptr, nullptr, nullptr, nullptr};
+    return q;
+}
 
 // ---- split-K scratch (rd_set_splitk_workspace) --------------------------------------------------------------------
 // One registration per (device, HIP stream): [64 KB of tile tickets, zeroed here once; the kernels leave them zero]
@@ -168,9 +180,14 @@ static void drain_locked() {
 
 extern "C" {
 
-int rd_version(void) { return 104; }      // 101 (r04): rd_set_splitk_workspace keyed by (device, stream); 102 (r05): rd_host_register; 103: rd_mfma_products; 104: rd_adam_step_dev
+int rd_version(void) { return 105; }      // 101 (r04): rd_set_splitk_workspace keyed by (device, stream); 102 (r05): rd_host_register; 103: rd_mfma_products; 104: rd_adam_step_dev; 105 (r06): rd_quant_next, rd_amax, packed operands carry both split forms
 
 const char* rd_last_error_string(void) { return rd::g_err; }
+
+int rd_quant_next(const unsigned* a_amax, const unsigned* b_amax, unsigned* out_amax, unsigned* out2_amax) {
+    rd::t_quant = {a_amax, b_amax, out_amax, out2_amax};
+    return RD_OK;
+}
 
 int rd_tune_set(const char* name, int value) {
     const int i = name ? rd::tune_index(name, strlen(name)) : -1;

@@ -27,181 +27,10 @@ struct WsParams {
     int strips_x, chunks_y, rows_per_chunk, reps;
     int tiles_ci, tiles_mn;
     unsigned a_bytes, b_bytes;
+    const unsigned* a_amax;   // magnitude slots of dz / x (both non-null: three-product body, rd_mfma_dev.h)
+    const unsigned* b_amax;
     int n_img;          // W8 form: images in the batch (a strip is a PAIR of 8 x 8 images; the last pair may lack its second one)
 };
-
-template <int OCC>
-__global__ __launch_bounds__(256, OCC) void wgrad_strip_kernel(WsParams p) {
-    constexpr int A_ROWS = 128, B_ROWS = 96;                   // LDS rows per A stage / per ring slot
-    constexpr int RING0 = 2 * A_ROWS * 32;                     // word offset of the halo ring
-    __shared__ __attribute__((aligned(16))) float smem[(2 * A_ROWS + 4 * B_ROWS) * 32];
-
-    const int gb = xcd_remap(blockIdx.x, gridDim.x);           // blocks of one strip share an XCD's L2
-    const int split = gb / p.tiles_mn;
-    const int lb = gb - split * p.tiles_mn;
-    const int tile_ci = lb % p.tiles_ci, tile_m = lb / p.tiles_ci;
-    const int m0 = tile_m * 128, ci0 = tile_ci * 32;
-    // this block accumulates p.reps consecutive strips (strip id -> x strip, row chunk, image); set per strip below
-    int img = 0, x0 = 0, ya = 0, yb = 0;
-    const int H = p.H, W = p.W;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-
-    // staging role: threads [0,128) dz row (32 channel quads x 4 pixel quarters), [128,224) x halo row (3 dx x 8 x 4)
-    const bool isA = __builtin_amdgcn_readfirstlane(t) < 128;   // wave-uniform role: waves 0,1 stage dz, waves 2,3 stage x
-    const bool active = t < 224;
-    const int idx = isA ? t : t - 128;
-    const int kq = idx & 3;
-    const int quad = isA ? (idx >> 2) : ((idx >> 2) & 7);
-    const int dxi = isA ? 0 : (idx >> 5);
-    const int ch = isA ? m0 + quad * 4 : ci0 + quad * 4;
-    const bool ch_ok = active && ch < (isA ? p.Cout : p.Cin);
-    const int pxr = kq * 4 + (isA ? 0 : dxi - 1);              // first of this task's 4 pixels, relative to the strip's x0
-    const int lds_row0 = isA ? quad * 4 : dxi * 32 + quad * 4;
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.dz, p.a_bytes), rsB = make_rsrc(p.x, p.b_bytes);
-
-    // virtual step yy stages T(yy) = { dz row yy+1, x halo row yy+2 } and multiplies row yy.
-    // Addressing is split into a per-thread part (fixed for the whole strip: pixel column, channel, validity) and a
-    // per-row scalar part, so a K-step costs a handful of SALU/VALU instructions besides the split arithmetic.
-    const int C = isA ? p.Cout : p.Cin;
-    unsigned voff[4];                       // byte offset of pixel j's 16 bytes within an image row; kOOB when masked
-    const unsigned row_bytes = (unsigned)W * C * 4;
-    unsigned img_base = 0;                  // operands are < 4 GiB (checked by the launcher)
-    auto set_strip = [&](int sid) {
-        const int sx = sid % p.strips_x;
-        const int cy = (sid / p.strips_x) % p.chunks_y;
-        img = sid / (p.strips_x * p.chunks_y);
-        x0 = sx * 16;
-        ya = cy * p.rows_per_chunk;
-        yb = ya + p.rows_per_chunk;
-        img_base = (unsigned)img * H * row_bytes;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int px = x0 + pxr + j;
-            voff[j] = (ch_ok && (unsigned)px < (unsigned)W) ? (unsigned)((px * C + ch) * 4) : kOOB;
-        }
-    };
-    auto load_task = [&](int yy, float4 (&v)[4]) {
-        const int r = isA ? yy + 1 : yy + 2;
-        const bool ok = isA ? (r >= ya && r < yb) : (r >= 0 && r < H && r <= yb);
-        const unsigned soff = ok ? img_base + (unsigned)r * row_bytes : 0u;
-        if (isA) {      // (a descriptor chosen per lane would make the compiler emit waterfall loops)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = buf_load4(rsA, ok ? voff[j] : kOOB, soff);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = buf_load4(rsB, ok ? voff[j] : kOOB, soff);
-        }
-    };
-    // LDS word offsets of this task's channel rows: rows lds_row0 + c, swizzle (row >> 1) & 7 -> c in {0,1} share one
-    // swizzle value, c in {2,3} the next one (lds_row0 is a multiple of 4)
-    int wr_e[3];
-    {
-        const int sw = (lds_row0 >> 1) & 7, hi = kq >> 1;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) wr_e[q] = lds_row0 * 32 + (kq & 1) * 2 + ((2 * q + hi) ^ sw) * 4;
-    }
-    auto store_task = [&](int yy, const float4 (&v)[4]) {
-        if (!active) return;
-        float* region = isA ? smem + ((yy + 1) & 1) * (A_ROWS * 32) : smem + RING0 + ((yy + 3) & 3) * (B_ROWS * 32);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            uint2 ph, pm, pl;               // the 4 pixels of channel c
-            split_pack4v<false>(c == 0 ? v[0].x : c == 1 ? v[0].y : c == 2 ? v[0].z : v[0].w, c == 0 ? v[1].x : c == 1 ? v[1].y : c == 2 ? v[1].z : v[1].w,
-                                c == 0 ? v[2].x : c == 1 ? v[2].y : c == 2 ? v[2].z : v[2].w, c == 0 ? v[3].x : c == 1 ? v[3].y : c == 2 ? v[3].z : v[3].w,
-                                ph, pm, pl);
-            const int flip = (c >> 1) * 4;  // next swizzle value = chunk index ^ 1 = word offset ^ 4
-            float* rowp = region + c * 32;
-            *reinterpret_cast<uint2*>(rowp + (wr_e[0] ^ flip)) = ph;
-            *reinterpret_cast<uint2*>(rowp + (wr_e[1] ^ flip)) = pm;
-            if (kTerm3) *reinterpret_cast<uint2*>(rowp + (wr_e[2] ^ flip)) = pl;
-        }
-    };
-
-    const int lrow = lane & 31, half = lane >> 5;
-    int a_rd[3], b_rd[3][3];
-    {
-        const int row = wave * 32 + lrow;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) a_rd[q] = row * 32 + ((2 * q + half) ^ ((row >> 1) & 7)) * 4;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int rb = d * 32 + lrow;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) b_rd[d][q] = rb * 32 + ((2 * q + half) ^ ((rb >> 1) & 7)) * 4;
-        }
-    }
-    f32x16 acc[9];
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
-
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-    auto mma_row = [&](int y) {
-        // one block per CU (80 KB LDS): latency is hidden inside the wave -- the B fragments of the next vertical tap
-        // are fetched while the 18 MFMAs of the current one run (two fragment register sets)
-        const float* a_stage = smem + (y & 1) * (A_ROWS * 32);
-        bf16x8 af[3], bf[2][3][3];
-        auto read_b = [&](int dy, bf16x8 (&dst)[3][3]) {
-            const float* slot = smem + RING0 + ((y + dy) & 3) * (B_ROWS * 32);      // image row y+dy-1 lives in slot (row+1)&3
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) dst[d][q] = *reinterpret_cast<const bf16x8*>(slot + b_rd[d][q]);
-        };
-#pragma unroll
-        for (int q = 0; q < 3; ++q) af[q] = *reinterpret_cast<const bf16x8*>(a_stage + a_rd[q]);
-        read_b(0, bf[0]);
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            if (dy < 2) read_b(dy + 1, bf[(dy + 1) & 1]);
-#pragma unroll
-            for (int t6 = LO0; t6 < 6; ++t6)
-#pragma unroll
-                for (int d = 0; d < 3; ++d)
-                    acc[dy * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t6]], bf[dy & 1][d][PB[t6]], acc[dy * 3 + d], 0, 0, 0);
-        }
-    };
-
-    float4 v0[4], v1[4];
-    for (int rep = 0; rep < p.reps; ++rep) {
-        set_strip(split * p.reps + rep);
-        const int ys = ya - 3;                   // three warm-up steps fill the halo ring and the first dz row
-        load_task(ys, v0);
-        load_task(ys + 1, v1);
-        store_task(ys, v0);
-        load_task(ys + 2, v0);
-        __syncthreads();
-        store_task(ys + 1, v1);
-        load_task(ys + 3, v1);
-        __syncthreads();
-        store_task(ys + 2, v0);
-        load_task(ys + 4, v0);
-        __syncthreads();
-        for (int yy = ya; yy < yb; yy += 2) {    // rows_per_chunk is even; no branches around the MFMAs (accumulators
-            store_task(yy, v1);                  // stay in AGPRs across the loops)
-            load_task(yy + 2, v1);
-            mma_row(yy);
-            __syncthreads();
-            store_task(yy + 1, v0);
-            load_task(yy + 3, v0);
-            mma_row(yy + 1);
-            __syncthreads();
-        }
-    }
-
-    float* out = p.slab + (long)split * p.M * p.N;
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-        const int n = tp * p.Cin + ci0 + lrow;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < p.M) out[(long)m * p.N + n] = acc[tp][r];
-        }
-    }
-}
-
 
 // ---- the same strip schedule with the gfx950 transpose read (ds_read_b64_tr_b16) ------------------------------------------
 // wgrad_strip_kernel transposes pixel-major data into k-contiguous LDS rows in registers, which forces the x halo row to be
@@ -215,7 +44,8 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_kernel(WsParams p) {
 //   * LDS: pixel strides of 832 B (dz, 64 B pad) and 192 B (x) put the four pixel rows of a transpose read 16 banks apart --
 //     the two 16-lane groups of a 32-lane half then cover all 64 banks; 40 KB per block instead of 80.
 typedef short v4s16 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 lds_tr2(const float* smem_base, int byte_off, int second) {
+template <typename FR>
+__device__ __forceinline__ FR lds_tr2(const float* smem_base, int byte_off, int second) {
     // two transpose reads (k = 0..3 and 4..7 of the lane's octet) -> one 8 x bf16 MFMA operand
     typedef __attribute__((address_space(3))) v4s16* lds_p;
     const char* b = reinterpret_cast<const char*>(smem_base) + byte_off;
@@ -223,7 +53,7 @@ __device__ __forceinline__ bf16x8 lds_tr2(const float* smem_base, int byte_off, 
     const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(b + second));
     typedef short v8s16 __attribute__((ext_vector_type(8)));
     const v8s16 r = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    return __builtin_bit_cast(bf16x8, r);
+    return __builtin_bit_cast(FR, r);
 }
 
 // NCO x NCI = 4 waves: wave (cw, cb) owns output channels [32 cw, +32) x input channels [32 cb, +32) of the block tile.
@@ -235,8 +65,10 @@ __device__ __forceinline__ bf16x8 lds_tr2(const float* smem_base, int byte_off, 
 // has 2 x 10 pixels, and the fragment reads of the second image's pixels start two halo pixels later (a per-lane constant, as in
 // the W8 form of conv3_halo_split_kernel) -- the tap shifts stay compile-time row offsets.  Replaces the generic TN kernel for this
 // level (two register transposes per operand, 7 VALU per MFMA: 99 TFLOP/s).
-template <int OCC, int NCO, int NCI, bool W8 = false>
-__global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
+template <int NP, int NCO, int NCI, bool W8>
+__device__ __forceinline__ void wgrad_strip_tr_body(const WsParams& p, float* smem, const Quant qz) {
+    typedef typename frag_of<NP>::type FR;
+    constexpr int NT = NP == 3 ? 2 : 3;
     static_assert(NCO * NCI == 4, "four waves");
     constexpr int TA = 64 * NCO, TB = 64 * NCI;                // bytes of one term of one pixel (32 channels x 2 B per wave column)
     // pixel strides: 3 terms + padding so that (stride / 4) mod 64 is 16 or 48 -- the four pixel rows of a transpose read then
@@ -249,7 +81,6 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
     constexpr int RINGB = 2 * ASTAGE;                          // byte offset of the halo ring
     constexpr int AQ = 8 * NCO, BQ = 8 * NCI;                  // channel quads per pixel
     constexpr int AI = 16 * AQ / 256, BI = (HPX * BQ + 255) / 256;     // staging items (float4) per thread
-    __shared__ __attribute__((aligned(16))) float smem[(2 * ASTAGE + 4 * BSLOT) / 4];
 
     const int gb = xcd_remap(blockIdx.x, gridDim.x);
     const int split = gb / p.tiles_mn;
@@ -327,21 +158,21 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
         for (int k = 0; k < BI; ++k) v[AI + k] = buf_load4(rsB, okb ? voffB[k] : kOOB, sb);
     };
     // float4 (4 channels of a pixel) -> three 8-byte pieces (one per term) at dst, dst + term stride, dst + 2 term strides
-    auto put = [&](char* dst, int tstride, const float4 x) {
+    auto put = [&](char* dst, int tstride, const float4 x, float qs) {
         uint2 ph, pm, pl;
-        split_pack4v<false>(x.x, x.y, x.z, x.w, ph, pm, pl);
+        split_pack4v<NP, false>(x.x, x.y, x.z, x.w, qs, ph, pm, pl);
         *reinterpret_cast<uint2*>(dst) = ph;
         *reinterpret_cast<uint2*>(dst + tstride) = pm;
-        if (kTerm3) *reinterpret_cast<uint2*>(dst + 2 * tstride) = pl;
+        if (kterm3<NP>()) *reinterpret_cast<uint2*>(dst + 2 * tstride) = pl;
     };
     auto store_task = [&](int yy, const float4 (&v)[AI + BI]) {
         char* sa = reinterpret_cast<char*>(smem) + ((yy + 1) & 1) * ASTAGE;
 #pragma unroll
-        for (int k = 0; k < AI; ++k) put(sa + a_wr[k], TA, v[k]);
+        for (int k = 0; k < AI; ++k) put(sa + a_wr[k], TA, v[k], qz.sa);
         char* sb = reinterpret_cast<char*>(smem) + RINGB + ((yy + 3) & 3) * BSLOT;
 #pragma unroll
         for (int k = 0; k < BI; ++k)
-            if (b_act[k]) put(sb + b_wr[k], TB, v[AI + k]);
+            if (b_act[k]) put(sb + b_wr[k], TB, v[AI + k], qz.sb);
     };
 
     // fragment addressing: lane -> 16-lane group g (n-block nb = g & 1, k-octet h = g >> 1), i = lane & 15
@@ -359,25 +190,24 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
     auto mma_row = [&](int y) {
         const int a_stage = (y & 1) * ASTAGE;
-        bf16x8 af[3], bf[2][3][3];
-        auto read_b = [&](int dy, bf16x8 (&dst)[3][3]) {
+        FR af[3], bf[2][3][3];
+        auto read_b = [&](int dy, FR (&dst)[3][3]) {
             const int slot = RINGB + ((y + dy) & 3) * BSLOT;    // image row y+dy-1 lives in slot (row+1)&3
 #pragma unroll
             for (int d = 0; d < 3; ++d)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) dst[d][q] = lds_tr2(smem, slot + b_rd + d * BPX + q * TB, 4 * BPX);
+                for (int q = 0; q < NT; ++q) dst[d][q] = lds_tr2<FR>(smem, slot + b_rd + d * BPX + q * TB, 4 * BPX);
         };
 #pragma unroll
-        for (int q = 0; q < 3; ++q) af[q] = lds_tr2(smem, a_stage + a_rd + q * TA, 4 * APX);
+        for (int q = 0; q < NT; ++q) af[q] = lds_tr2<FR>(smem, a_stage + a_rd + q * TA, 4 * APX);
         read_b(0, bf[0]);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             if (dy < 2) read_b(dy + 1, bf[(dy + 1) & 1]);
 #pragma unroll
-            for (int t6 = LO0; t6 < 6; ++t6)
+            for (int t6 = lo0<NP>(); t6 < 6; ++t6)
 #pragma unroll
-                for (int d = 0; d < 3; ++d)
-                    acc[dy * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t6]], bf[dy & 1][d][PB[t6]], acc[dy * 3 + d], 0, 0, 0);
+                for (int d = 0; d < 3; ++d) acc[dy * 3 + d] = mfma16<NP>(af[PA[t6]], bf[dy & 1][d][PB[t6]], acc[dy * 3 + d]);
         }
     };
 
@@ -423,7 +253,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
             const int tapo = base + tp * p.Cin * 4;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[tp][r]), rsO, lane_off, (unsigned)(tapo + ((r & 3) + 8 * (r >> 2)) * rowN), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(scale_q<NP>(acc[tp][r], qz.dexp)), rsO, lane_off, (unsigned)(tapo + ((r & 3) + 8 * (r >> 2)) * rowN), 0);
         }
         return;
     }
@@ -433,9 +263,20 @@ __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < p.M) out[(long)m * p.N + n] = acc[tp][r];
+            if (m < p.M) out[(long)m * p.N + n] = scale_q<NP>(acc[tp][r], qz.dexp);
         }
     }
+}
+
+template <int OCC, int NCO, int NCI, bool W8 = false>
+__global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
+    constexpr int TA = 64 * NCO, TB = 64 * NCI;
+    constexpr int APX = 3 * TA + (NCO == 4 ? 64 : NCO == 2 ? 64 : 0), BPX = 3 * TB + (NCI == 2 ? 64 : 0);
+    constexpr int HPX = W8 ? 20 : 18, ASTAGE = 16 * APX, BSLOT = HPX * BPX;
+    __shared__ __attribute__((aligned(16))) float smem[(2 * ASTAGE + 4 * BSLOT) / 4];
+    const Quant qz = quant_select(p.a_amax, p.b_amax);
+    if (qz.use3) wgrad_strip_tr_body<3, NCO, NCI, W8>(p, smem, qz);
+    else wgrad_strip_tr_body<6, NCO, NCI, W8>(p, smem, qz);
 }
 
 struct WsPlan {
@@ -499,7 +340,7 @@ int wgrad_strip_splits(int n, int h, int w, int cin, int cout) {
 }
 
 int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int h, int w, int cin, int cout, hipStream_t s,
-                       int* splits_out, int* swapped_out) {
+                       int* splits_out, int* swapped_out, const unsigned* x_amax, const unsigned* dz_amax) {
     const WsPlan wp = plan_strip(n, h, w, cin, cout);
     *splits_out = 0;
     *swapped_out = 0;
@@ -507,6 +348,7 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     if (wp.swapped) {
         const float* tp = x; x = dz; dz = tp;
         const int tc = cin; cin = cout; cout = tc;
+        const unsigned* ta = x_amax; x_amax = dz_amax; dz_amax = ta;
     }
     WsParams q = {};
     q.dz = dz; q.x = x; q.slab = slab;
@@ -515,6 +357,7 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     q.strips_x = wp.strips_x; q.chunks_y = wp.chunks_y; q.rows_per_chunk = wp.rows_per_chunk; q.reps = wp.reps;
     q.tiles_ci = wp.tiles_ci; q.tiles_mn = wp.tiles_m * wp.tiles_ci;
     q.n_img = n;
+    if (mfma_products() == 3 && x_amax && dz_amax) { q.a_amax = dz_amax; q.b_amax = x_amax; }
     const double ab = 4.0 * n * h * w * (double)cout, bb = 4.0 * n * h * w * (double)cin;
     RD_REQUIRE(ab < 4294967040.0 && bb < 4294967040.0, "rd_conv3x3_bwd_weight: operand beyond the 4 GiB descriptor range");
     q.a_bytes = (unsigned)ab; q.b_bytes = (unsigned)bb;
@@ -522,22 +365,18 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     char pcls[64];      // "<operation>|<kernel symbol as rocprofv3 prints it, summarize_prof.py form>"
     if (wp.w8) snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip_tr<%d,2,2,w8>", occ_);
     else if (wp.sq) snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip_tr<%d,2,2>", occ_);
-    else if (tune(TUNE_WG_STRIP) != 1) snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip_tr<%d,4,1>", occ_);
-    else snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip<%d>", occ_);
+    else snprintf(pcls, sizeof(pcls), "conv3x3_wgrad|wgrad_strip_tr<%d,4,1>", occ_);
     ProfScope ps(s, pcls, 2.0 * cout * 9.0 * cin * (double)n * h * w, ab + bb + 4.0 * cout * 9.0 * cin, true);
-    // transpose-read variant by default (r03: 2.80 -> 2.69 ms over the nine layers alone, +0.8 % end to end, VALU per MFMA
-    // 2.9 -> see profiles/r03_summary.json); wg_strip = 1 selects the register-transpose kernel for A/B runs
-    const bool tr = tune(TUNE_WG_STRIP) != 1;
+    // (the r02 register-transpose kernel this replaced -- 2.80 -> 2.69 ms over the nine layers, profiles/r03_notes.md -- left the
+    // library in r06)
     const dim3 grid(q.tiles_mn * wp.splits);
     const int occ = tune(TUNE_WG_OCC);
     if (wp.w8 && occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 2, 2, true>), grid, dim3(256), 0, s, q);
     else if (wp.w8) hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 2, 2, true>), grid, dim3(256), 0, s, q);
     else if (wp.sq && occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 2, 2>), grid, dim3(256), 0, s, q);
     else if (wp.sq) hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 2, 2>), grid, dim3(256), 0, s, q);
-    else if (tr && occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 4, 1>), grid, dim3(256), 0, s, q);
-    else if (tr) hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 4, 1>), grid, dim3(256), 0, s, q);
-    else if (occ == 2) hipLaunchKernelGGL(wgrad_strip_kernel<2>, grid, dim3(256), 0, s, q);
-    else hipLaunchKernelGGL(wgrad_strip_kernel<1>, grid, dim3(256), 0, s, q);
+    else if (occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 4, 1>), grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 4, 1>), grid, dim3(256), 0, s, q);
     RD_LAUNCH_CHECK("wgrad_strip");
     *splits_out = wp.splits;
     *swapped_out = wp.swapped;

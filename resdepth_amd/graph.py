@@ -48,6 +48,10 @@ class GraphedTrainStep:
 
     # ---- the eager iteration (lib/Trainer.py:212-222) -------------------------------------------------------------------
     def _eager(self, x, y, mask, mean, std):
+        # gradients a previous call left in place (keep_grads, or a replay's graph-owned buffers) must not be ACCUMULATED into:
+        # every iteration starts from "no gradient", like lib/Trainer.py:221-222; keep_grads only decides what is left afterwards
+        for p in self.params:
+            p.grad = None
         out = self.model(x)
         loss = masked_l1_loss(out, y, mask, mean, std, grad_sync=getattr(self.model, "grad_sync", None))
         loss.backward()
@@ -68,9 +72,14 @@ class GraphedTrainStep:
             return f"{type(self.optimizer).__name__} has no captured form"
         return None
 
-    @staticmethod
-    def _shape_key(ts):
-        return tuple((tuple(t.shape), t.dtype, t.device) for t in ts)
+    def _shape_key(self, ts):
+        """What a capture is valid for: the batch's shapes AND the device pointers the captured kernels were given -- the flat
+        parameter / gradient buffers and every parameter view.  model.to() / .float() / flatten_parameters() or a `p.data`
+        reassignment re-home them; a replay would then keep training the old memory."""
+        m = self.model
+        fp, fg = getattr(m, "_flat_param", None), getattr(m, "_flat_grad", None)
+        ptrs = (fp.data_ptr() if fp is not None else 0, fg.data_ptr() if fg is not None else 0) + tuple(p.data_ptr() for p in self.params)
+        return tuple((tuple(t.shape), t.dtype, t.device) for t in ts), ptrs
 
     def invalidate(self):
         """Drop the captured graph (the next eligible call captures again)."""
@@ -123,8 +132,12 @@ class GraphedTrainStep:
             why = "warm-up"
         if why is None and self._graph is not None and self.optimizer._cap is not self._cap_token:
             self.invalidate()                    # optimizer.load_state_dict / a new optimizer state: capture again
-        if why is None and self._graph is not None and self._shape_key(batch) != self._key:
-            why = "batch shape differs from the captured one"
+        if why is None and self._graph is not None:
+            key = self._shape_key(batch)
+            if key[1] != self._key[1]:
+                self.invalidate()                # parameters re-homed since the capture: capture again (below)
+            elif key[0] != self._key[0]:
+                why = "batch shape differs from the captured one"
         if why is not None:
             self.why_eager = why
             return self._eager(*batch)

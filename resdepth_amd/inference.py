@@ -145,15 +145,48 @@ def _frontiers(pos_y, tile_size, rows):
     return out
 
 
-def _local_tile_rows(ds, n_expected=None):
-    """Row (y) of every tile of this loader's dataset in sweep order, from host-side metadata (no device read-back), or None."""
+def _local_tile_rows(dataloader):
+    """Row (y) of every tile this loader will yield, IN THE ORDER it yields them, from host-side metadata (no device read-back)
+    -- or None, which turns the streamed read-back off (everything is copied at the end).  The order is only known when the
+    loader walks `dataset.pos` front to back: a SequentialSampler (or no sampler machinery at all) over a dataset with one
+    `pos` entry per item.  A shuffled loader, a custom (batch) sampler or a `pos` that means something else would let rows
+    leave for the host before every tile that overlaps them has been blended."""
+    ds = dataloader.dataset
     pos = getattr(ds, "pos", None)
     if pos is None:
         return None
+    sampler = getattr(dataloader, "sampler", None)
+    if sampler is not None and not isinstance(sampler, torch.utils.data.SequentialSampler):
+        return None
+    bs = getattr(dataloader, "batch_sampler", None)
+    if bs is not None and not isinstance(bs, torch.utils.data.BatchSampler):
+        return None
     try:
+        if len(pos) != len(ds):
+            return None
         return [int(p[0]) for p in pos]
     except Exception:       # noqa: BLE001
         return None
+
+
+def _group_on_one_node() -> bool:
+    """Do all ranks of the default process group share rank 0's node AND its PID namespace (what HostRaster(shared=True) needs)?
+    Every rank reports (boot id, pid-namespace inode); the answer is the same on every rank (an all-gather)."""
+    import torch.distributed as dist
+
+    def ident():
+        try:
+            boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+        except OSError:
+            boot = os.uname().nodename
+        try:
+            ns = os.readlink("/proc/self/ns/pid")
+        except OSError:
+            ns = "?"
+        return boot + "|" + ns
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, ident())
+    return all(o == out[0] for o in out)
 
 
 def _exchange_overlaps(raster, me, plan, cols, device):
@@ -219,6 +252,11 @@ def predict_linear_blend(dataloader, model, reduce_to_rank0: bool = True, host=N
     plan = getattr(ds, "shard_plan", None) if exchange else None
     banded = bool(plan) and len(plan) == torch.distributed.get_world_size() and plan[0]["monotonic"] \
         and getattr(ds, "shard", (0, 1))[0] == torch.distributed.get_rank()
+    if exchange and banded and torch.distributed.get_world_size() > 1 and not _group_on_one_node():
+        # the band plan delivers through ONE host array that every rank maps from rank 0's /proc/<pid>/fd/<n> (HostRaster): that
+        # path only exists inside rank 0's node and PID namespace.  A group that spans nodes (or containers) takes the dense route
+        # (each rank its own raster, one reduce to rank 0)
+        banded = False
     if exchange:
         # every rank must take the same route (the dense one ends in a collective)
         flag = torch.tensor([1 if banded else 0], dtype=torch.int32, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
@@ -237,7 +275,7 @@ def predict_linear_blend(dataloader, model, reduce_to_rank0: bool = True, host=N
             _host_cache[(rows, cols, banded)], own_host = host, False
     dense_reduce = exchange and not banded
     copier = None
-    tile_rows = _local_tile_rows(ds)
+    tile_rows = _local_tile_rows(dataloader)
     if not dense_reduce:
         # rows that may leave early: the rows this rank delivers, minus the ones other ranks still add to
         early = [(me["c0"], me["c1"])]

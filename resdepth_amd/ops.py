@@ -12,7 +12,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import check, load, ptr, stream_ptr, workspace
+from ._lib import amax_slot, check, load, ptr, quant_next, slot_of, stream_ptr, tag, workspace
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -22,6 +22,35 @@ def _f32(t, name):
     if t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32, got {t.dtype}")
     return t
+
+
+def _gemm_slots(x, w, out=None, out2=None):
+    """rd_quant_next for a GEMM launch: the magnitude slots of its two operands (both or neither: an operand without a slot
+    sends the launch to the six-product body) and of its outputs."""
+    a, b = slot_of(x), slot_of(w)
+    if a is None or b is None or _lib.products() != 3:
+        a = b = None
+    quant_next(a, b, out, out2)
+
+
+def _out_slot():
+    """slot for a tensor this launch produces, when a pool is active (the engine's forward / backward in split2h mode)"""
+    return amax_slot() if _lib.products() == 3 else None
+
+
+def _weight_slot(device):
+    """a zeroed slot of its own for a packed weight (the per-layer pack calls; the fused pack has one array for the model)"""
+    return torch.zeros(_lib.AMAX_WORDS, dtype=torch.int32, device=device) if _lib.products() == 3 else None
+
+
+def amax_of(x):
+    """Tag `x` with a freshly computed magnitude slot (rd_amax: one extra pass over x) -- for operands no kernel of this library
+    produced (tests, inputs of the generic first-convolution path).  No-op outside split2h mode."""
+    if _lib.products() != 3 or slot_of(x) is not None:
+        return x
+    slot = torch.zeros(_lib.AMAX_WORDS, dtype=torch.int32, device=x.device)
+    check(load().rd_amax(ptr(x), x.numel(), slot.data_ptr(), stream_ptr()), "amax")
+    return tag(x, slot)
 
 
 def _packed_buffer(rows, taps, cin, device):
@@ -35,31 +64,38 @@ def pack_conv3x3_weight(w, need_dgrad=True):
     cout, cin = w.shape[0], w.shape[1]
     wf = _packed_buffer(cout, 9, cin, w.device)
     wd = _packed_buffer(cin, 9, cout, w.device) if need_dgrad else None
+    slot = _weight_slot(w.device)
+    quant_next(out2=slot)
     check(load().rd_pack_conv3x3_weight(ptr(w.detach()), ptr(wf), ptr(wd), cout, cin, stream_ptr()), "pack_conv3x3")
-    return wf, wd
+    return tag(wf, slot), tag(wd, slot)
 
 
 def pack_conv3x3_weight_folded(w, row_scale):
     """Forward operand with eval-mode BatchNorm folded in: rows scaled by gamma / sqrt(running_var + eps)."""
     cout, cin = w.shape[0], w.shape[1]
     wf = _packed_buffer(cout, 9, cin, w.device)
+    slot = _weight_slot(w.device)
+    quant_next(out2=slot)
     check(load().rd_pack_conv3x3_weight_folded(ptr(w.detach()), ptr(_f32(row_scale, "row_scale")), ptr(wf), cout, cin,
                                                stream_ptr()), "pack_conv3x3_folded")
-    return wf
+    return tag(wf, slot)
 
 
 def pack_convt2x2_weight(w, need_dgrad=True):
     cin, cout = w.shape[0], w.shape[1]
     wtf = _packed_buffer(4 * cout, 1, cin, w.device)
     wtd = _packed_buffer(cin, 4, cout, w.device) if need_dgrad else None
+    slot = _weight_slot(w.device)
+    quant_next(out2=slot)
     check(load().rd_pack_convt2x2_weight(ptr(w.detach()), ptr(wtf), ptr(wtd), cin, cout, stream_ptr()), "pack_convt")
-    return wtf, wtd
+    return tag(wtf, slot), tag(wtd, slot)
 
 
 def conv3x3_fwd(x, wf):
     n, h, w, cin = x.shape
     cout = wf.shape[0]
     z = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
+    _gemm_slots(x, wf)
     check(load().rd_conv3x3_fwd(ptr(_f32(x, "x")), ptr(wf), ptr(z), n, h, w, cin, cout, stream_ptr()), "conv3x3_fwd")
     return z
 
@@ -71,6 +107,7 @@ def conv3x3_fwd_stats(x, wf):
     z = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
     sums = torch.empty(2 * cout, device=x.device, dtype=torch.float64)
     ws = workspace(load().rd_conv3x3_fwd_stats_ws_bytes(n, h, w, cin, cout), x.device)
+    _gemm_slots(x, wf)
     check(load().rd_conv3x3_fwd_stats(ptr(_f32(x, "x")), ptr(wf), ptr(z), ptr(sums), n, h, w, cin, cout, ws.data_ptr(),
                                       ws.numel(), stream_ptr()), "conv3x3_fwd_stats")
     return z, sums
@@ -82,9 +119,11 @@ def conv3x3_fwd_act(x, wf_folded, shift, slope, pool=False):
     cout = wf_folded.shape[0]
     a = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
     pooled = torch.empty(n, h // 2, w // 2, cout, device=x.device, dtype=torch.float32) if pool else None
+    sa, sp = _out_slot(), (_out_slot() if pool else None)
+    _gemm_slots(x, wf_folded, sa, sp)
     check(load().rd_conv3x3_fwd_act(ptr(_f32(x, "x")), ptr(wf_folded), ptr(shift), float(slope), ptr(a), ptr(pooled), n, h, w,
                                     cin, cout, stream_ptr()), "conv3x3_fwd_act")
-    return a, pooled
+    return tag(a, sa), tag(pooled, sp)
 
 
 def conv3x3_fwd_bn(x, wf, running_mean, running_var, num_batches_tracked, eps=BN_EPS, momentum=BN_MOMENTUM):
@@ -96,6 +135,7 @@ def conv3x3_fwd_bn(x, wf, running_mean, running_var, num_batches_tracked, eps=BN
     mean = torch.empty(cout, device=x.device, dtype=torch.float32)
     invstd = torch.empty(cout, device=x.device, dtype=torch.float32)
     ws = workspace(load().rd_conv3x3_fwd_stats_ws_bytes(n, h, w, cin, cout), x.device)
+    _gemm_slots(x, wf)
     check(load().rd_conv3x3_fwd_bn(ptr(_f32(x, "x")), ptr(wf), ptr(z), float(n * h * w), eps, momentum, ptr(mean), ptr(invstd),
                                    ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), n, h, w, cin, cout,
                                    ws.data_ptr(), ws.numel(), stream_ptr()), "conv3x3_fwd_bn")
@@ -125,6 +165,9 @@ def conv3x3_bwd_data(dz, wd, bn=None):
     n, h, w, cout = dz.shape
     cin = wd.shape[0]
     dx = torch.empty(n, h, w, cin, device=dz.device, dtype=torch.float32)
+    so = _out_slot()
+    tag(dx, so)
+    _gemm_slots(dz, wd, so)
     if bn is None:
         check(load().rd_conv3x3_bwd_data(ptr(dz), ptr(wd), ptr(dx), n, h, w, cin, cout, stream_ptr()), "conv3x3_bwd_data")
         return dx
@@ -150,6 +193,7 @@ def conv3x3_bwd_weight(x, dz, out=None, ws_slot=0):
         out = torch.empty(cout, cin, 3, 3, device=x.device, dtype=torch.float32)
     nb = load().rd_conv3x3_bwd_weight_ws_bytes(n, h, w, cin, cout)
     ws = workspace(nb, x.device, ws_slot)
+    _gemm_slots(dz, x)
     check(load().rd_conv3x3_bwd_weight(ptr(x), ptr(dz), ptr(out), n, h, w, cin, cout, ws.data_ptr(), ws.numel(),
                                        stream_ptr()), "conv3x3_bwd_weight")
     return out
@@ -200,6 +244,9 @@ def conv3x3_first_fwd_act(x_nchw, w, mean, invstd, gamma, beta, slope, slope_dev
     cout = w.shape[0]
     a = torch.empty(n, h, wd, cout, device=x_nchw.device, dtype=torch.float32)
     pooled = torch.empty(n, h // 2, wd // 2, cout, device=x_nchw.device, dtype=torch.float32) if pool else None
+    sp = _out_slot() if pool else None
+    quant_next(out2=sp)
+    tag(pooled, sp)
     check(load().rd_conv3x3_first_fwd_act(ptr(_f32(x_nchw, "x")), ptr(w.detach()), ptr(mean), ptr(invstd), ptr(gamma.detach()),
                                           ptr(beta.detach()), float(slope), ptr(slope_dev), ptr(a), ptr(pooled), n, h, wd, cin, cout,
                                           stream_ptr()), "conv3x3_first_fwd_act")
@@ -428,9 +475,11 @@ def convt2x2_fwd(x, wtf, bias, skip):
     n, h, w, cin = x.shape
     cout = wtf.shape[0] // 4
     out = torch.empty(n, 2 * h, 2 * w, cout, device=x.device, dtype=torch.float32)
+    so = _out_slot()
+    _gemm_slots(x, wtf, so)
     check(load().rd_convt2x2_fwd(ptr(x), ptr(wtf), ptr(bias.detach() if bias is not None else None), ptr(skip),
                                  ptr(out), n, h, w, cin, cout, stream_ptr()), "convt2x2_fwd")
-    return out
+    return tag(out, so)
 
 
 def convt2x2_fwd_bnskip(x, wtf, bias, z_skip, mean, invstd, gamma, beta, slope, slope_dev=None):
@@ -439,6 +488,9 @@ def convt2x2_fwd_bnskip(x, wtf, bias, z_skip, mean, invstd, gamma, beta, slope, 
     n, h, w, cin = x.shape
     cout = wtf.shape[0] // 4
     out = torch.empty(n, 2 * h, 2 * w, cout, device=x.device, dtype=torch.float32)
+    so = _out_slot()
+    tag(out, so)
+    _gemm_slots(x, wtf, so)
     check(load().rd_convt2x2_fwd_bnskip(ptr(x), ptr(wtf), ptr(bias.detach() if bias is not None else None), ptr(z_skip),
                                         ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()), float(slope),
                                         ptr(slope_dev), ptr(out), n, h, w, cin, cout, stream_ptr()), "convt2x2_fwd_bnskip")
@@ -449,6 +501,7 @@ def convt2x2_bwd_data(dout, wtd, bn=None):
     n, h2, w2, cout = dout.shape
     cin = wtd.shape[0]
     dx = torch.empty(n, h2 // 2, w2 // 2, cin, device=dout.device, dtype=torch.float32)
+    _gemm_slots(dout, wtd)
     if bn is None:
         check(load().rd_convt2x2_bwd_data(ptr(dout), ptr(wtd), ptr(dx), n, h2 // 2, w2 // 2, cin, cout, stream_ptr()),
               "convt2x2_bwd_data")
@@ -467,6 +520,7 @@ def convt2x2_bwd_weight(x, dout, out=None, ws_slot=0):
         out = torch.empty(cin, cout, 2, 2, device=x.device, dtype=torch.float32)
     nb = load().rd_convt2x2_bwd_weight_ws_bytes(n, h, w, cin, cout)
     ws = workspace(nb, x.device, ws_slot)
+    _gemm_slots(dout, x)
     check(load().rd_convt2x2_bwd_weight(ptr(x), ptr(dout), ptr(out), n, h, w, cin, cout, ws.data_ptr(), ws.numel(),
                                         stream_ptr()), "convt2x2_bwd_weight")
     return out
@@ -478,14 +532,17 @@ def pack_conv1x1_weight(w):
     cout, cin = w.shape[0], w.shape[1]
     wf = _packed_buffer(cout, 1, cin, w.device)
     wt = _packed_buffer(cin, 1, cout, w.device)
+    slot = _weight_slot(w.device)
+    quant_next(out2=slot)
     check(load().rd_pack_conv1x1_weight(ptr(w.detach()), ptr(wf), ptr(wt), cout, cin, stream_ptr()), "pack_conv1x1")
-    return wf, wt
+    return tag(wf, slot), tag(wt, slot)
 
 
 def conv1x1_fwd(x, w2d):
     n, h, w, cin = x.shape
     cout = w2d.shape[0]
     out = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
+    _gemm_slots(x, w2d)
     check(load().rd_conv1x1_fwd(ptr(_f32(x, "x")), ptr(w2d), ptr(out), n * h * w, cin, cout, stream_ptr()), "conv1x1_fwd")
     return out
 
@@ -494,6 +551,7 @@ def conv1x1_bwd_data(dy, wt):
     n, h, w, cout = dy.shape
     cin = wt.shape[0]
     dx = torch.empty(n, h, w, cin, device=dy.device, dtype=torch.float32)
+    _gemm_slots(dy, wt)
     check(load().rd_conv1x1_bwd_data(ptr(dy), ptr(wt), ptr(dx), n * h * w, cin, cout, stream_ptr()), "conv1x1_bwd_data")
     return dx
 
@@ -505,6 +563,7 @@ def conv1x1_bwd_weight(x, dy, out=None, ws_slot=0):
         out = torch.empty(cout, cin, 1, 1, device=x.device, dtype=torch.float32)
     nb = load().rd_conv1x1_bwd_weight_ws_bytes(n * h * w, cin, cout)
     ws = workspace(nb, x.device, ws_slot)
+    _gemm_slots(dy, x)
     check(load().rd_conv1x1_bwd_weight(ptr(x), ptr(dy), ptr(out), n * h * w, cin, cout, ws.data_ptr(), ws.numel(),
                                        stream_ptr()), "conv1x1_bwd_weight")
     return out
@@ -579,6 +638,10 @@ def bn_act_pool_fwd(z, mean, invstd, gamma, beta, slope, pool, slope_dev=None, w
         idx = torch.empty(n, h // 2, w // 2, c, device=z.device, dtype=torch.uint8)
         if want_zpool:
             zpool = torch.empty_like(pooled)
+    sa, sp = (None, _out_slot()) if pool else (_out_slot(), None)       # the tensor the next GEMM takes as an operand
+    quant_next(out=sa, out2=sp)
+    tag(a, sa)
+    tag(pooled, sp)
     check(load().rd_bn_act_pool_fwd(ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
                                     float(slope), ptr(slope_dev), ptr(a), ptr(pooled), ptr(idx), ptr(zpool), n, h, w, c,
                                     stream_ptr()),
@@ -609,6 +672,9 @@ def bn_act_bwd_apply(z, mean, invstd, gamma, beta, slope, g_full, g_pool, idx, s
                      dgamma=None, dbeta=None, slope_dev=None):
     n, h, w, c = z.shape
     dz = torch.empty_like(z)
+    so = _out_slot()
+    quant_next(out=so)
+    tag(dz, so)
     check(load().rd_bn_act_bwd_apply(ptr(z), ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()),
                                      float(slope), ptr(slope_dev), ptr(g_full), ptr(g_pool), ptr(idx), ptr(sums),
                                      float(count),

@@ -339,6 +339,8 @@ class UNet(nn.Module):
             # split-bf16 mode: every operand of the network in ONE launch into persistent buffers (device item table)
             plan = self._pack_plan()
             with torch.cuda.stream(side):
+                if _lib.products() == 3:
+                    plan["wamax"].zero_()        # the layers' magnitude slots: the pack fills them, then writes the fp16 forms
                 _lib.check(_lib.load().rd_pack_weights_fused(plan["items"].data_ptr(), plan["n"], plan["total"], plan["tiles"],
                                                              _lib.stream_ptr()), "pack_weights_fused")
                 if self._tail_expected(True):
@@ -383,7 +385,7 @@ class UNet(nn.Module):
         """Identity of the parameter values the packed operands were built from: flat buffer, its raw-pointer generation
         (FusedAdam / broadcast write through `.data`), the autograd versions, and the arithmetic mode (the split-bf16 and the
         exact-f32 kernels read different layouts of the packed buffers; only the active one is written)."""
-        return (self._own_param_key(), _lib.global_generation(), _lib.tune_get("mfma_f32"))
+        return (self._own_param_key(), _lib.global_generation(), _lib.tune_get("mfma_f32"), _lib.products())
 
     def _own_param_key(self):
         """The part of the pack key that only THIS model's parameters move: flat buffer, autograd versions, and the raw-pointer
@@ -401,6 +403,11 @@ class UNet(nn.Module):
             return plan
         lib, dev, d = _lib.load(), self._flat_param.device, self.depth
         rows, buffers, begin, tbegin = [], {}, 0, 0
+        n_layers = 3 * d - 1 + (1 if self._first_generic() else 0)      # d - 1 encoder convs + bottleneck + d up-convs + d - 1 decoder convs
+        wamax = torch.zeros(n_layers * _lib.AMAX_WORDS, dtype=torch.int32, device=dev)    # one magnitude slot per layer
+
+        def slot(i):
+            return wamax[i * _lib.AMAX_WORDS:(i + 1) * _lib.AMAX_WORDS]
 
         def count(kind, cout, cin, f32):
             """-> (first piece, first tile) of this item; tile-packed layers own no pieces and vice versa"""
@@ -420,19 +427,22 @@ class UNet(nn.Module):
             nonlocal begin
             cout, cin = w.shape[0], w.shape[1]
             wf, wd = ops._packed_buffer(cout, 9, cin, dev), ops._packed_buffer(cin, 9, cout, dev)
-            buffers[key] = (wf, wd)
+            sl = slot(len(rows))
+            buffers[key] = (_lib.tag(wf, sl), _lib.tag(wd, sl))
             b0, t0 = count(0, cout, cin, 0)
-            rows.append([w.data_ptr(), split_ptr(wf, cout, 9, cin), split_ptr(wd, cin, 9, cout), 0, cout, cin, b0, 0, t0, 0])
+            rows.append([w.data_ptr(), split_ptr(wf, cout, 9, cin), split_ptr(wd, cin, 9, cout), 0, cout, cin, b0, 0, t0,
+                         sl.data_ptr()])
 
         def convt(key, w):
             nonlocal begin
             cin, cout = w.shape[0], w.shape[1]
             wtf, wtd = ops._packed_buffer(4 * cout, 1, cin, dev), ops._packed_buffer(cin, 4, cout, dev)
-            buffers[key] = (wtf, wtd)
+            sl = slot(len(rows))
+            buffers[key] = (_lib.tag(wtf, sl), _lib.tag(wtd, sl))
             f32 = 1 if cin <= 128 else 0       # short-K levels may run on the exact-f32 NT kernel (fp32 operand layout)
             b0, t0 = count(1, cout, cin, f32)
             rows.append([w.data_ptr(), split_ptr(wtf, 4 * cout, 1, cin), split_ptr(wtd, cin, 4, cout), 1, cout, cin, b0,
-                         wtf.data_ptr() if f32 else 0, t0, 0])
+                         wtf.data_ptr() if f32 else 0, t0, sl.data_ptr()])
 
         if self._first_generic():
             conv("enc_first", self.encoder[0][0][0].weight)
@@ -444,8 +454,9 @@ class UNet(nn.Module):
             if i < d - 1:
                 conv(("dec_c", i), self.decoder[i][1][0].weight)
         items = torch.tensor(rows, dtype=torch.int64).to(dev)
+        assert len(rows) == n_layers
         plan = {"flat": self._flat_param.data_ptr(), "items": items, "n": len(rows), "total": begin, "tiles": tbegin,
-                "buffers": buffers}
+                "buffers": buffers, "wamax": wamax}
         self.__dict__["_pack_plan_cache"] = plan
         return plan
 
@@ -642,6 +653,20 @@ class UNet(nn.Module):
         return ops.conv3x3_last_fwd(cur, self.last_layer.weight, self.last_layer.bias, x_res)
 
     def _engine_forward(self, x, training: bool, save: bool, keep_skips: bool = False):
+        """split2h mode: the pass runs under a pool of magnitude slots (_lib.AmaxPool, one torch.zeros): every kernel that writes
+        a GEMM operand max-accumulates |x| into a slot of it, the tensor carries the slot as `_rd_amax`, and the GEMM that takes
+        the tensor reads it -- see ops._gemm_slots.  The pool is kept with the saved activations (the weight gradients of the
+        backward read the forward's slots)."""
+        if _lib.products() != 3:
+            return self._engine_forward_impl(x, training, save, keep_skips)
+        pool = _lib.AmaxPool(x.device)
+        with pool:
+            out, S = self._engine_forward_impl(x, training, save, keep_skips)
+        if S is not None:
+            S["amax_pool"] = pool
+        return out, S
+
+    def _engine_forward_impl(self, x, training: bool, save: bool, keep_skips: bool = False):
         if not training and not save and self._can_fold():
             return self._engine_forward_folded(x), None
         d = self.depth
@@ -796,6 +821,12 @@ class UNet(nn.Module):
         return dx
 
     def _engine_backward(self, S, dout, want_dx=False):
+        if _lib.products() != 3:
+            return self._engine_backward_impl(S, dout, want_dx)
+        with _lib.AmaxPool(dout.device):         # the gradient operands' magnitude slots (a fresh block per backward)
+            return self._engine_backward_impl(S, dout, want_dx)
+
+    def _engine_backward_impl(self, S, dout, want_dx=False):
         """Writes every parameter gradient into a flat gradient buffer; returns the list of views
         (state_dict / parameters() order).  Order of production: head, decoder levels d-1..0 + bottleneck,
         encoder levels d-1..0 -- i.e. from the END of the flat buffer towards its start, which is what the
