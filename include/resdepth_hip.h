@@ -40,7 +40,7 @@ typedef void* rd_stream_t; /* hipStream_t */
 #define RD_ERR_WS 2
 #define RD_ERR_HIP 3
 
-int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream); 102: rd_host_register & co; 103: rd_mfma_products; 104: rd_adam_step_dev; 105 (r06): rd_quant_next / rd_amax, packed operands hold both split forms */
+int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream); 102: rd_host_register & co; 103: rd_mfma_products; 104: rd_adam_step_dev; 105 (r06): rd_quant_next / rd_amax, packed operands hold both split forms; 106: rd_plan_* */
 /* Arithmetic of the split MFMA kernels -- ONE library, chosen per launch (csrc/rd_mfma_dev.h):
  *   6  "split3"   x = x1 + x2 + x3 (three bf16 terms, exact), six products per multiply on v_mfma_f32_32x32x16_bf16.  No
  *                 assumption about the operands; what every launch falls back to.
@@ -52,9 +52,10 @@ int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registration
  * In mode 3 a launch still runs the six-product body when an operand comes without a magnitude slot or its maximum is +-Inf
  * (decided on the device at kernel start, no host round trip) -- fp32's non-finite semantics are those of mode 6. */
 int rd_mfma_products(void);
-/* Magnitude slots.  A slot is 16 consecutive 32-bit words of device memory, zeroed by the caller before its producer runs; the
- * producer max-accumulates the IEEE bit patterns of |x| into it (atomic integer max: order-independent, so run-to-run
- * identical) and a consumer takes the largest of the 16 words as the tensor's maximum.
+/* Magnitude slots.  A slot is RD_AMAX_SLOT_BYTES (2 KB) of device memory, 128-byte aligned, zeroed by the caller before its
+ * producer runs: sixteen 32-bit words, one at the start of each 128-byte line (same-line device atomics serialise; sixteen
+ * lines take them in parallel).  The producer max-accumulates the IEEE bit patterns of |x| into them (atomic integer max:
+ * order-independent, so run-to-run identical) and a consumer takes the largest of the 16 words as the tensor's maximum.
  *   rd_quant_next(a, b, out, out2): the slots the NEXT rd_* call of this host thread takes (any may be NULL); that call clears
  *     them again, whether it uses them or not.  Consumers (rd_conv3x3_fwd*, rd_conv3x3_bwd_data*, rd_convt2x2_fwd*,
  *     rd_convt2x2_bwd_data*, rd_conv1x1_*): a = slot of the activation / gradient operand, b = slot of the packed weight;
@@ -66,8 +67,38 @@ int rd_mfma_products(void);
  *   rd_amax(x, n, slot): max |x[0..n)| into a (zeroed) slot: operands that no producer of this library wrote. */
 int rd_quant_next(const unsigned* a_amax, const unsigned* b_amax, unsigned* out_amax, unsigned* out2_amax);
 int rd_amax(const float* x, long long n, unsigned* slot, rd_stream_t s);
-#define RD_AMAX_WORDS 16
+/* zero `bytes` (a multiple of 16, 16-byte aligned) with a kernel launch -- which a launch plan records, unlike a memset node */
+int rd_zero(void* p, size_t bytes, rd_stream_t s);
+#define RD_AMAX_SLOT_BYTES 2048
 const char* rd_last_error_string(void);
+
+/* ---- launch plans: the iteration's launch list recorded once, replayed from C (r06) ------------------------------------------
+ * A training iteration (lib/Trainer.py:212-222) is ~110 kernel launches on two HIP streams, enqueued through Python + ctypes at
+ * ~30-50 us each: 3-6 ms of host time per step against 7 ms of GPU time.  A plan holds that list -- for every launch of THIS
+ * library on one of two streams: the kernel, its grid / block / dynamic LDS and a copy of its argument values; the event
+ * records / waits that order the two streams; and segment ends, where the host does something between replays (a collective of
+ * torch.distributed, which stays in Python).  rd_plan_replay enqueues one segment with one hipLaunchKernel per entry (~4 us).
+ * The pointers inside the arguments are the ones of the recorded iteration: the caller records while the iteration's memory
+ * comes from a pool that stays reserved (torch: under a CUDA-graph capture, whose private pool outlives it) and feeds the batch
+ * through fixed input tensors.  What a plan cannot hold (a hipMemcpyAsync / hipMemsetAsync of the library on a plan stream)
+ * marks the recording unusable: rd_plan_end then returns NULL with the reason in rd_last_error_string().
+ *   rd_plan_begin(main, side)        start recording launches on these two streams (one recording per process at a time; launches
+ *                                    on other streams are ignored)
+ *   rd_plan_event_record(stream)     -> event index >= 0 (-1: not recording / not a plan stream)
+ *   rd_plan_event_wait(stream, ev)   the stream waits for that event (ev < 0 on a plan stream marks the recording unusable)
+ *   rd_plan_segment()                ends the current segment -> its index
+ *   rd_plan_poison(why)              mark the recording unusable (host logic that knows the iteration cannot be replayed)
+ *   rd_plan_end(&launches, &segs)    -> plan handle | NULL
+ *   rd_plan_replay(plan, seg, main, side)   enqueue segment `seg` on the given streams (they need not be the recorded ones)
+ *   rd_plan_free(plan) */
+int rd_plan_begin(rd_stream_t main_stream, rd_stream_t side_stream);
+int rd_plan_event_record(rd_stream_t stream);
+int rd_plan_event_wait(rd_stream_t stream, int ev);
+int rd_plan_segment(void);
+int rd_plan_poison(const char* why);
+void* rd_plan_end(int* n_launches, int* n_segments);
+int rd_plan_replay(void* plan, int segment, rd_stream_t main_stream, rd_stream_t side_stream);
+int rd_plan_free(void* plan);
 
 /* ---- weight (re)packing: torch layouts -> GEMM operand layouts ------------------- */
 /* Every packed operand B[rows][K = taps*Cin] is ONE opaque caller-owned buffer of
@@ -99,8 +130,8 @@ int rd_pack_conv3x3_weight(const float* w_oihw, float* wf, float* wd, int cout, 
  * 10 int64:
  *   { w (device pointer, torch layout), forward-operand buffer, data-gradient-operand buffer, kind (0 = conv3x3 [Cout][Cin][3][3],
  *     1 = ConvTranspose2d [Cin][Cout][2][2]), Cout, Cin, first piece index, fp32 forward-operand pointer (convT only: the buffer
- *     base again when the fp32 layout wtf is wanted, else 0), first tile index, magnitude slot of w (device pointer to 16 zeroed
- *     words; 0 = six-product form only) }
+ *     base again when the fp32 layout wtf is wanted, else 0), first tile index, magnitude slot of w (device pointer to a zeroed
+ *     RD_AMAX_SLOT_BYTES block; 0 = six-product form only) }
  * A layer whose channel counts are both multiples of 32 is packed by the TILE kernel (rd_pack_item_tiles() > 0 tiles, coalesced
  * loads through LDS; it then owns no pieces: its `first piece index` is the running piece count), every other layer piece by
  * piece (rd_pack_item_pieces() pieces, gathered loads; it owns no tiles).  The buffers are the opaque packed buffers of

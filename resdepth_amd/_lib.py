@@ -24,7 +24,7 @@ MFMA_MODE = os.environ.get("RD_MFMA", "")
 if MFMA_MODE not in ("", "f32", "split3", "split2h"):
     raise RuntimeError(f"RD_MFMA={MFMA_MODE!r}: expected f32, split3 or split2h")
 LIB_PATH = os.environ.get("RESDEPTH_HIP_LIB") or os.path.join(_HERE, "libresdepth_hip.so")
-AMAX_WORDS = 16      # RD_AMAX_WORDS: 32-bit words of one magnitude slot
+AMAX_WORDS = 512     # RD_AMAX_SLOT_BYTES / 4: int32 elements of one magnitude slot (sixteen words on sixteen 128-byte lines)
 
 _lib = None
 _lock = threading.Lock()
@@ -40,8 +40,17 @@ SZ = C.c_size_t
 SIGNATURES = {
     "rd_version": (I, []),
     "rd_mfma_products": (I, []),
+    "rd_plan_begin": (I, [P, P]),
+    "rd_plan_event_record": (I, [P]),
+    "rd_plan_event_wait": (I, [P, I]),
+    "rd_plan_segment": (I, []),
+    "rd_plan_poison": (I, [C.c_char_p]),
+    "rd_plan_end": (P, [P, P]),
+    "rd_plan_replay": (I, [P, I, P, P]),
+    "rd_plan_free": (I, [P]),
     "rd_quant_next": (I, [P, P, P, P]),
     "rd_amax": (I, [P, LL, P, P]),
+    "rd_zero": (I, [P, SZ, P]),
     "rd_last_error_string": (C.c_char_p, []),
     "rd_pack_conv3x3_weight": (I, [P, P, P, I, I, P]),
     "rd_pack_item_pieces": (LL, [I, I, I, I]),
@@ -159,8 +168,8 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.rd_version() < 105:
-            raise RuntimeError(f"resdepth_amd: {LIB_PATH} is version {lib.rd_version()} (< 105): stale build -- run "
+        if lib.rd_version() < 106:
+            raise RuntimeError(f"resdepth_amd: {LIB_PATH} is version {lib.rd_version()} (< 106): stale build -- run "
                                "resdepth_amd/csrc/build.sh")
         _lib = lib
     return _lib
@@ -187,7 +196,7 @@ def products() -> int:
 
 
 # ---- magnitude slots (include/resdepth_hip.h: rd_quant_next) ----------------------------------------------------------------
-# A tensor that is an operand of a three-product GEMM carries its slot as the attribute `_rd_amax` (a 16-word int32 view of a
+# A tensor that is an operand of a three-product GEMM carries its slot as the attribute `_rd_amax` (a 2 KB int32 view of a
 # pool); producers draw the slot from the pool that is ACTIVE on the calling thread (`with AmaxPool(...)`: the engine's forward
 # and backward), consumers read the attribute -- a tensor without one (any torch op's result, a view, .contiguous()) simply
 # runs the six-product body.
@@ -197,8 +206,8 @@ _tls = threading.local()
 class AmaxPool:
     """A zeroed block of magnitude slots for one pass (forward or backward) of one model: one torch.zeros per pass."""
 
-    def __init__(self, device, slots: int = 96):
-        self.buf = torch.zeros(slots * AMAX_WORDS, dtype=torch.int32, device=device)
+    def __init__(self, device, slots: int = 64):
+        self.buf = zeros_i32(slots * AMAX_WORDS, device)
         self.n, self.cap = 0, slots
 
     def take(self):
@@ -216,6 +225,54 @@ class AmaxPool:
     def __exit__(self, *exc):
         _tls.pool = self._prev
         return False
+
+
+def zeros_i32(n: int, device) -> torch.Tensor:
+    """torch.zeros(n, int32) with the zeroing done by a kernel of the library (rd_zero: a launch plan records it)."""
+    t = torch.empty(n, dtype=torch.int32, device=device)
+    zero_(t)
+    return t
+
+
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    with device_of(t):
+        check(load().rd_zero(t.data_ptr(), t.numel() * t.element_size(), stream_ptr()), "zero")
+    return t
+
+
+# ---- stream ordering through the library, so that a launch plan can record it (include/resdepth_hip.h: rd_plan_*) -----------
+_plan_rec = None          # the PlanRecorder of the recording in progress (resdepth_amd/plan.py), else None
+
+
+class Ev:
+    """A recorded position of a stream: torch.cuda.Event + its index in the plan being recorded (-1: none)."""
+    __slots__ = ("e", "idx")
+
+    def __init__(self, stream):
+        self.e = torch.cuda.Event()
+        self.e.record(stream)
+        self.idx = load().rd_plan_event_record(stream.cuda_stream) if _plan_rec is not None else -1
+
+
+def ev_wait(stream, ev: "Ev") -> None:
+    stream.wait_event(ev.e)
+    if _plan_rec is not None:
+        load().rd_plan_event_wait(stream.cuda_stream, ev.idx)
+
+
+def wait_stream(dst, src) -> None:
+    """dst waits for everything enqueued on src so far (torch's Stream.wait_stream, visible to a plan recording)."""
+    ev_wait(dst, Ev(src))
+
+
+def host_action(fn) -> None:
+    """Something the HOST does between kernels of an iteration -- a collective of torch.distributed.  Eager: runs now.  While a
+    plan is recorded: the current segment ends here and `fn` becomes what the replay loop calls after it; it is NOT run now (the
+    recording executes nothing: it happens under a graph capture, whose results are discarded)."""
+    if _plan_rec is None:
+        fn()
+    else:
+        _plan_rec.add_action(fn)
 
 
 def amax_slot():
@@ -418,11 +475,20 @@ def tune_get(name: str) -> int:
 
 
 # ---- profiler -----------------------------------------------------------------------------------
+_prof_level = 0
+
+
 def prof_enable(level):
     """0/False off; 1 = MFMA (roofline) kernel classes only; 2/True = every kernel class."""
+    global _prof_level
     if level is True:
         level = 2
     check(load().rd_prof_enable(int(level)))
+    _prof_level = int(level)
+
+
+def prof_level_py() -> int:
+    return _prof_level
 
 
 def prof_reset():

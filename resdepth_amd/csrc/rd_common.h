@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+
+#include <tuple>
+#include <utility>
+
 #include "../../include/resdepth_hip.h"
 
 namespace rd {
@@ -65,7 +69,7 @@ inline int mfma_split() { return !tune(TUNE_MFMA_F32); }
 inline int mfma_products() { return tune(TUNE_MFMA_PRODUCTS) == 3 ? 3 : 6; }
 // rd_quant_next(): the magnitude slots the NEXT entry point of this host thread takes (cleared by the take)
 struct QuantArgs {
-    const unsigned* a;     // operand A (activations / gradients), 16 words
+    const unsigned* a;     // operand A (activations / gradients); a slot = RD_AMAX_SLOT_BYTES
     const unsigned* b;     // operand B (packed weights; the second activation operand of a weight gradient)
     unsigned* out;         // receives max |output|
     unsigned* out2;        // second output of the call (pooled tensor), or the weight slot a pack call fills
@@ -200,6 +204,35 @@ inline PixDiv make_pixdiv(int h, int w) {
     d.HW = h * w;
     return d;
 }
+
+// ---- launch plans (include/resdepth_hip.h: rd_plan_*) -------------------------------------------------------------------
+// Every kernel of the library is launched through rd::launch (RD_LAUNCH): while a plan is being recorded, a launch on one of
+// the plan's two streams is appended to it -- kernel function, grid, block, dynamic LDS and a COPY of the argument values --
+// and a recorded plan is replayed by rd_plan_replay with one hipLaunchKernel per entry, no Python, no argument marshalling.
+bool plan_recording();
+void plan_note_launch(const void* fn, dim3 grid, dim3 block, size_t shmem, hipStream_t s, void** args, const size_t* sizes,
+                      const size_t* aligns, int nargs);
+// a stream operation of the library that a plan cannot hold (memcpy / memset nodes): the recording is marked unusable
+void plan_poison(hipStream_t s, const char* why);
+
+template <typename... KArgs, size_t... I>
+inline void launch_impl(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t s, std::tuple<KArgs...>& vals,
+                        std::index_sequence<I...>) {
+    void* ptrs[sizeof...(KArgs) > 0 ? sizeof...(KArgs) : 1] = {(void*)&std::get<I>(vals)...};
+    if (plan_recording()) {
+        const size_t sizes[sizeof...(KArgs) > 0 ? sizeof...(KArgs) : 1] = {sizeof(KArgs)...};
+        const size_t aligns[sizeof...(KArgs) > 0 ? sizeof...(KArgs) : 1] = {alignof(KArgs)...};
+        plan_note_launch((const void*)kern, grid, block, shmem, s, ptrs, sizes, aligns, (int)sizeof...(KArgs));
+    }
+    (void)hipLaunchKernel((const void*)kern, grid, block, ptrs, shmem, s);
+}
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t s, Args&&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+    std::tuple<KArgs...> vals(static_cast<KArgs>(std::forward<Args>(args))...);      // the kernel's own parameter types
+    launch_impl(kern, grid, block, shmem, s, vals, std::index_sequence_for<KArgs...>());
+}
+#define RD_LAUNCH(kernel, grid, block, shmem, stream, ...) rd::launch(kernel, grid, block, shmem, stream, ##__VA_ARGS__)
 
 #define RD_REQUIRE(cond, ...)              \
     do {                                   \

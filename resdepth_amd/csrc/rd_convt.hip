@@ -514,9 +514,9 @@ int convt_dgrad_launch(NtParams p, hipStream_t s, int* launched, int* tiles_m_ou
     char pcls[64];
     snprintf(pcls, sizeof(pcls), "convt2x2_dgrad|convt_dgrad<%s>", cfg == 0 ? "4,1,4" : cfg == 1 ? "2,1,4" : "2,2,2");
     ProfScope ps(s, pcls, 2.0 * p.M * (double)p.N * p.K, 4.0 * (4.0 * p.M * Cd + (double)p.N * p.K + (double)p.M * p.N * (p.bn_part ? 2 : 1)), true);
-    if (cfg == 0) hipLaunchKernelGGL((convt_dgrad_kernel<4, 1, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
-    else if (cfg == 1) hipLaunchKernelGGL((convt_dgrad_kernel<2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((convt_dgrad_kernel<2, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    if (cfg == 0) RD_LAUNCH((convt_dgrad_kernel<4, 1, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    else if (cfg == 1) RD_LAUNCH((convt_dgrad_kernel<2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    else RD_LAUNCH((convt_dgrad_kernel<2, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, p);
     RD_LAUNCH_CHECK("convt_dgrad");
     *launched = 1;
     return RD_OK;
@@ -781,9 +781,9 @@ int convt_wgrad_launch(const float* x, const float* dout, float* slab, int n, in
     snprintf(pcls, sizeof(pcls), "convt2x2_wgrad|convt_wgrad<%d>", pl.tn);
     ProfScope ps(s, pcls, 2.0 * 4.0 * cout * cin * px, 4.0 * px * (4.0 * cout + cin) + 4.0 * pl.splits * 4.0 * cout * cin, true);
     const dim3 grid((unsigned)(q.tiles_mn * pl.splits));
-    if (pl.tn == 4) hipLaunchKernelGGL(convt_wgrad_kernel<4>, grid, dim3(512), 0, s, q);
-    else if (pl.tn == 2) hipLaunchKernelGGL(convt_wgrad_kernel<2>, grid, dim3(512), 0, s, q);
-    else hipLaunchKernelGGL(convt_wgrad_kernel<1>, grid, dim3(512), 0, s, q);
+    if (pl.tn == 4) RD_LAUNCH(convt_wgrad_kernel<4>, grid, dim3(512), 0, s, q);
+    else if (pl.tn == 2) RD_LAUNCH(convt_wgrad_kernel<2>, grid, dim3(512), 0, s, q);
+    else RD_LAUNCH(convt_wgrad_kernel<1>, grid, dim3(512), 0, s, q);
     RD_LAUNCH_CHECK("convt_wgrad");
     *splits_out = pl.splits;
     return RD_OK;
@@ -832,8 +832,8 @@ int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, co
     ProfScope ps(s, pcls, 2.0 * M * 4.0 * cout * cin,
                  4.0 * ((double)M * cin + 4.0 * cout * cin + (skip ? 2.0 : 1.0) * 4.0 * M * cout), true);
     p.direct = tune(TUNE_NT_EPI) != 0;
-    if (tm == 2) hipLaunchKernelGGL(convt_fwd_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(convt_fwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, p);
+    if (tm == 2) RD_LAUNCH(convt_fwd_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, p);
+    else RD_LAUNCH(convt_fwd_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, p);
     RD_LAUNCH_CHECK("convt_fwd");
     *launched = 1;
     return RD_OK;

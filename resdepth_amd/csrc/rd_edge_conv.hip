@@ -1482,8 +1482,8 @@ static void launch_first_mfma(const float* x, const float* wt, float* out, float
                               const float* gamma, const float* beta, float slope, const float* slope_dev, int n, int h, int w,
                               int cout, hipStream_t s) {
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H), nt = n * tx * ty;
-    if (cout == 64) hipLaunchKernelGGL((conv_first_fwd_mfma_kernel<CIN, 2, MODE>), dim3(nt), dim3(256), 0, s, x, wt, out, aux, mean, invstd, gamma, beta, slope, slope_dev, n, h, w, tx, ty);
-    else hipLaunchKernelGGL((conv_first_fwd_mfma_kernel<CIN, 1, MODE>), dim3(nt), dim3(256), 0, s, x, wt, out, aux, mean, invstd, gamma, beta, slope, slope_dev, n, h, w, tx, ty);
+    if (cout == 64) RD_LAUNCH((conv_first_fwd_mfma_kernel<CIN, 2, MODE>), dim3(nt), dim3(256), 0, s, x, wt, out, aux, mean, invstd, gamma, beta, slope, slope_dev, n, h, w, tx, ty);
+    else RD_LAUNCH((conv_first_fwd_mfma_kernel<CIN, 1, MODE>), dim3(nt), dim3(256), 0, s, x, wt, out, aux, mean, invstd, gamma, beta, slope, slope_dev, n, h, w, tx, ty);
 }
 // (Cout = 128 would need 8 accumulators + 4 x NS weights per lane: it stays on the segment kernels)
 // OPT-IN (edge_conv >= 0 with bit 64 set), not part of "-1 = everything": measured SLOWER than the segment kernels although it takes
@@ -1684,9 +1684,9 @@ static int launch_first_seg(bool wgrad, const float* x, const float* wt, float* 
     if (!wgrad && first_mfma_ok(cout)) {
         launch_first_mfma<CIN, 0>(x, wt, z, partial, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, n, h, w, cout, s);
     } else if (!wgrad) {
-        if (cout == 64) hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 16>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
-        else if (cout == 32) hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 8>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
-        else hipLaunchKernelGGL((conv_first_fwd_seg_kernel<CIN, 32>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
+        if (cout == 64) RD_LAUNCH((conv_first_fwd_seg_kernel<CIN, 16>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
+        else if (cout == 32) RD_LAUNCH((conv_first_fwd_seg_kernel<CIN, 8>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
+        else RD_LAUNCH((conv_first_fwd_seg_kernel<CIN, 32>), dim3(nt), dim3(256), 0, s, x, wt, z, partial, n, h, w, tx, ty);
     } else if (bn) {
         if constexpr (CIN > 3) {      // 144 accumulators + the fused operands do not fit 256 registers
             set_error("conv_first_wgrad (fused BN backward): Cin <= 3 only");
@@ -1698,27 +1698,27 @@ static int launch_first_seg(bool wgrad, const float* x, const float* wt, float* 
             const size_t halo = CIN * FH_PLANE + 640, redw = (size_t)4 * (cout / 32) * 16 * 64;
             const size_t sm = (halo > redw ? halo : redw) * sizeof(float);
             if (bn->g_full) {
-                if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_mfma_kernel<CIN, 2, true>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
-                else hipLaunchKernelGGL((conv_first_wgrad_mfma_kernel<CIN, 1, true>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
+                if (cout == 64) RD_LAUNCH((conv_first_wgrad_mfma_kernel<CIN, 2, true>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
+                else RD_LAUNCH((conv_first_wgrad_mfma_kernel<CIN, 1, true>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
             } else {
-                if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_mfma_kernel<CIN, 2, false>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
-                else hipLaunchKernelGGL((conv_first_wgrad_mfma_kernel<CIN, 1, false>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
+                if (cout == 64) RD_LAUNCH((conv_first_wgrad_mfma_kernel<CIN, 2, false>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
+                else RD_LAUNCH((conv_first_wgrad_mfma_kernel<CIN, 1, false>), dim3(nb), dim3(256), sm, s, x, partial, n, h, w, tx, ty, nt, *bn, zb, pb, ib);
             }
             RD_LAUNCH_CHECK("conv_first_wgrad_mfma");
             return RD_OK;
         }
         const size_t smem = (size_t)(CIN * FH_PLANE + 9 * 256 * 4 + 640 + 9 * cout) * sizeof(float);
-        if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 16, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
-        else if (cout == 32) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 8, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
-        else hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 32, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
+        if (cout == 64) RD_LAUNCH((conv_first_wgrad_seg_kernel<CIN, 16, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
+        else if (cout == 32) RD_LAUNCH((conv_first_wgrad_seg_kernel<CIN, 8, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
+        else RD_LAUNCH((conv_first_wgrad_seg_kernel<CIN, 32, true>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, *bn);
         }
     } else {
         const int nb = nt < 1024 ? nt : 1024;
         const size_t smem = (size_t)(CIN * FH_PLANE + 9 * 256 * 4) * sizeof(float);
         const FirstBnBwd none = {};
-        if (cout == 64) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 16, false>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, none);
-        else if (cout == 32) hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 8, false>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, none);
-        else hipLaunchKernelGGL((conv_first_wgrad_seg_kernel<CIN, 32, false>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, none);
+        if (cout == 64) RD_LAUNCH((conv_first_wgrad_seg_kernel<CIN, 16, false>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, none);
+        else if (cout == 32) RD_LAUNCH((conv_first_wgrad_seg_kernel<CIN, 8, false>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, none);
+        else RD_LAUNCH((conv_first_wgrad_seg_kernel<CIN, 32, false>), dim3(nb), dim3(256), smem, s, x, dz, partial, n, h, w, tx, ty, nt, none);
     }
     RD_LAUNCH_CHECK("conv_first_seg");
     return RD_OK;
@@ -1745,9 +1745,9 @@ static int launch_first_act(const float* x, const float* wt, const float* mean, 
         RD_LAUNCH_CHECK("conv_first_fwd_act");
         return RD_OK;
     }
-    if (cout == 64) hipLaunchKernelGGL((conv_first_fwd_act_seg_kernel<CIN, 16>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax);
-    else if (cout == 32) hipLaunchKernelGGL((conv_first_fwd_act_seg_kernel<CIN, 8>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax);
-    else hipLaunchKernelGGL((conv_first_fwd_act_seg_kernel<CIN, 32>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax);
+    if (cout == 64) RD_LAUNCH((conv_first_fwd_act_seg_kernel<CIN, 16>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax);
+    else if (cout == 32) RD_LAUNCH((conv_first_fwd_act_seg_kernel<CIN, 8>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax);
+    else RD_LAUNCH((conv_first_fwd_act_seg_kernel<CIN, 32>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax);
     RD_LAUNCH_CHECK("conv_first_fwd_act");
     return RD_OK;
 }
@@ -1772,9 +1772,9 @@ int conv_last_fwd_launch(const float* s_in, const float* wt, const float* bias, 
     if (!edge_shape_ok(c) || !edge_on(1)) return RD_OK;
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
     const dim3 grid(n * tx * ty);
-    if (c == 64) hipLaunchKernelGGL(conv_last_fwd_dpp_kernel<8>, grid, dim3(256), 0, s, s_in, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
-    else if (c == 32) hipLaunchKernelGGL(conv_last_fwd_dpp_kernel<4>, grid, dim3(256), 0, s, s_in, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
-    else hipLaunchKernelGGL(conv_last_fwd_dpp_kernel<2>, grid, dim3(256), 0, s, s_in, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    if (c == 64) RD_LAUNCH(conv_last_fwd_dpp_kernel<8>, grid, dim3(256), 0, s, s_in, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    else if (c == 32) RD_LAUNCH(conv_last_fwd_dpp_kernel<4>, grid, dim3(256), 0, s, s_in, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    else RD_LAUNCH(conv_last_fwd_dpp_kernel<2>, grid, dim3(256), 0, s, s_in, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
     RD_LAUNCH_CHECK("conv_last_fwd");
     *launched = 1;
     return RD_OK;
@@ -1784,9 +1784,9 @@ int conv_last_fwd_tail_launch(const TailSkip& sk, const float* t16, const float*
                               const float* x_nchw, int xc, float* out, int n, int h, int w, int c, hipStream_t s) {
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
     const dim3 grid(n * tx * ty);
-    if (c == 64) hipLaunchKernelGGL(conv_last_fwd_tail_kernel<8>, grid, dim3(256), 0, s, sk, t16, b9, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
-    else if (c == 32) hipLaunchKernelGGL(conv_last_fwd_tail_kernel<4>, grid, dim3(256), 0, s, sk, t16, b9, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
-    else hipLaunchKernelGGL(conv_last_fwd_tail_kernel<2>, grid, dim3(256), 0, s, sk, t16, b9, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    if (c == 64) RD_LAUNCH(conv_last_fwd_tail_kernel<8>, grid, dim3(256), 0, s, sk, t16, b9, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    else if (c == 32) RD_LAUNCH(conv_last_fwd_tail_kernel<4>, grid, dim3(256), 0, s, sk, t16, b9, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
+    else RD_LAUNCH(conv_last_fwd_tail_kernel<2>, grid, dim3(256), 0, s, sk, t16, b9, wt, bias, x_nchw, xc, out, n, h, w, tx, ty);
     RD_LAUNCH_CHECK("conv_last_fwd_tail");
     return RD_OK;
 }
@@ -1796,7 +1796,7 @@ int conv_last_wgrad_tail_launch(const TailSkip& sk, const float* dout, double* p
     const long nt = (long)n * tx * ty;
     const int nb = (int)(nt < 1024 ? nt : 1024);
     const size_t smem = (640 + (size_t)(256 / (c / 4)) * 9 * c) * sizeof(float);
-    hipLaunchKernelGGL(conv_last_wgrad_tail_kernel, dim3(nb), dim3(256), smem, s, sk, dout, partial, n, h, w, c, c / 4, tx, ty, (int)nt);
+    RD_LAUNCH(conv_last_wgrad_tail_kernel, dim3(nb), dim3(256), smem, s, sk, dout, partial, n, h, w, c, c / 4, tx, ty, (int)nt);
     RD_LAUNCH_CHECK("conv_last_wgrad_tail");
     return RD_OK;
 }
@@ -1967,14 +1967,14 @@ int conv_last_bwd_tail_fused_launch(const TailSkip& sk, const float* dout, const
         const double zb = 4.0 * n * h * (double)w * c;
         if ((c == 32 || c == 64) && v >= 0 && (v & 256) && zb < 4294967040.0) {
             const size_t words = (size_t)4 * (c / 32) * 16 * 64;      // >= 640 + the small sums
-            if (c == 64) hipLaunchKernelGGL(conv_last_bwd_tail_mfma_kernel<2>, dim3(nb), dim3(256), words * sizeof(float), s, sk, dout, wl, wpartial, bn_part, n, h, w, tx, ty, n * tx * ty, (unsigned)zb);
-            else hipLaunchKernelGGL(conv_last_bwd_tail_mfma_kernel<1>, dim3(nb), dim3(256), words * sizeof(float), s, sk, dout, wl, wpartial, bn_part, n, h, w, tx, ty, n * tx * ty, (unsigned)zb);
+            if (c == 64) RD_LAUNCH(conv_last_bwd_tail_mfma_kernel<2>, dim3(nb), dim3(256), words * sizeof(float), s, sk, dout, wl, wpartial, bn_part, n, h, w, tx, ty, n * tx * ty, (unsigned)zb);
+            else RD_LAUNCH(conv_last_bwd_tail_mfma_kernel<1>, dim3(nb), dim3(256), words * sizeof(float), s, sk, dout, wl, wpartial, bn_part, n, h, w, tx, ty, n * tx * ty, (unsigned)zb);
             RD_LAUNCH_CHECK("conv_last_bwd_tail_mfma");
             return RD_OK;
         }
     }
     const size_t smem = (640 + (size_t)(256 / (c / 4)) * 9 * c) * sizeof(float);
-    hipLaunchKernelGGL(conv_last_bwd_tail_fused_kernel, dim3(nb), dim3(256), smem, s, sk, dout, wl, wpartial, bn_part, n, h, w, c, c / 4,
+    RD_LAUNCH(conv_last_bwd_tail_fused_kernel, dim3(nb), dim3(256), smem, s, sk, dout, wl, wpartial, bn_part, n, h, w, c, c / 4,
                        tx, ty, n * tx * ty);
     RD_LAUNCH_CHECK("conv_last_bwd_tail_fused");
     return RD_OK;
@@ -1982,7 +1982,7 @@ int conv_last_bwd_tail_fused_launch(const TailSkip& sk, const float* dout, const
 
 int tail_wl_finish_launch(const double* partial, int nb, const double* c16, const float* wt, const float* bt, float* dw, float* dbias,
                           int cin, int c0, hipStream_t s) {
-    hipLaunchKernelGGL(tail_wl_finish_kernel, dim3(c0), dim3(256), 0, s, partial, nb, c16, wt, bt, dw, dbias, cin, c0);
+    RD_LAUNCH(tail_wl_finish_kernel, dim3(c0), dim3(256), 0, s, partial, nb, c16, wt, bt, dw, dbias, cin, c0);
     RD_LAUNCH_CHECK("tail_wl_finish");
     return RD_OK;
 }
@@ -1992,7 +1992,7 @@ int conv_last_dgrad_launch(const float* dout, const float* wt, float* ds, int n,
     if (!edge_shape_ok(c) || !edge_on(2)) return RD_OK;
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
     const BnHook none = {};
-    hipLaunchKernelGGL(conv_last_dgrad_tile_kernel<false>, dim3(n * tx * ty), dim3(256), 0, s, dout, wt, ds, n, h, w, c, c / 4, tx,
+    RD_LAUNCH(conv_last_dgrad_tile_kernel<false>, dim3(n * tx * ty), dim3(256), 0, s, dout, wt, ds, n, h, w, c, c / 4, tx,
                        ty, none);
     RD_LAUNCH_CHECK("conv_last_dgrad");
     *launched = 1;
@@ -2007,7 +2007,7 @@ int conv_last_dgrad_bn_launch(const float* dout, const float* wt, float* ds, int
     if (!edge_shape_ok(c) || !edge_on(2)) return RD_OK;
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
     const BnHook bn = {bn_z, mean, invstd, gamma, beta, slope_dev, slope, part};
-    hipLaunchKernelGGL(conv_last_dgrad_tile_kernel<true>, dim3(n * tx * ty), dim3(256), 0, s, dout, wt, ds, n, h, w, c, c / 4, tx,
+    RD_LAUNCH(conv_last_dgrad_tile_kernel<true>, dim3(n * tx * ty), dim3(256), 0, s, dout, wt, ds, n, h, w, c, c / 4, tx,
                        ty, bn);
     RD_LAUNCH_CHECK("conv_last_dgrad");
     *rows = n * tx * ty;
@@ -2016,7 +2016,7 @@ int conv_last_dgrad_bn_launch(const float* dout, const float* wt, float* ds, int
 
 int tail_compose_launch(const float* wt, const float* bt, const float* wl, float* M, float* V, float* VT, float* B9, int cin, int c0,
                         hipStream_t s) {
-    hipLaunchKernelGGL(tail_compose_kernel, dim3(cin), dim3(64), 0, s, wt, bt, wl, M, V, VT, B9, cin, c0);
+    RD_LAUNCH(tail_compose_kernel, dim3(cin), dim3(64), 0, s, wt, bt, wl, M, V, VT, B9, cin, c0);
     RD_LAUNCH_CHECK("tail_compose");
     return RD_OK;
 }
@@ -2032,12 +2032,12 @@ int convt_last_dgrad_launch(const float* dout, const float* V, float* dprev, int
     *rows = 0;
     if (bn_z) {
         const BnHook bn = {bn_z, mean, invstd, gamma, beta, slope_dev, slope, part};
-        hipLaunchKernelGGL(convt_last_dgrad_kernel<true>, dim3(n * tx * ty), dim3(256), 0, s, dout, V, dprev, n, hc, wc, cin, cin / 4,
+        RD_LAUNCH(convt_last_dgrad_kernel<true>, dim3(n * tx * ty), dim3(256), 0, s, dout, V, dprev, n, hc, wc, cin, cin / 4,
                            tx, ty, bn);
         *rows = n * tx * ty;
     } else {
         const BnHook none = {};
-        hipLaunchKernelGGL(convt_last_dgrad_kernel<false>, dim3(n * tx * ty), dim3(256), 0, s, dout, V, dprev, n, hc, wc, cin, cin / 4,
+        RD_LAUNCH(convt_last_dgrad_kernel<false>, dim3(n * tx * ty), dim3(256), 0, s, dout, V, dprev, n, hc, wc, cin, cin / 4,
                            tx, ty, none);
     }
     RD_LAUNCH_CHECK("convt_last_dgrad");
@@ -2053,11 +2053,11 @@ int tail_t16_launch(const TailSkip& sk, const float* V, float* t16, long pixels,
     const long ntile = (pixels + 15) / 16;
     const int grid = (int)(ntile / 4 < 2048 ? (ntile + 3) / 4 : 2048);
     switch (cin) {
-        case 16: hipLaunchKernelGGL(tail_t16_kernel<4>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
-        case 32: hipLaunchKernelGGL(tail_t16_kernel<8>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
-        case 64: hipLaunchKernelGGL(tail_t16_kernel<16>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
-        case 128: hipLaunchKernelGGL(tail_t16_kernel<32>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
-        default: hipLaunchKernelGGL(tail_t16_kernel<64>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
+        case 16: RD_LAUNCH(tail_t16_kernel<4>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
+        case 32: RD_LAUNCH(tail_t16_kernel<8>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
+        case 64: RD_LAUNCH(tail_t16_kernel<16>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
+        case 128: RD_LAUNCH(tail_t16_kernel<32>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
+        default: RD_LAUNCH(tail_t16_kernel<64>, dim3(grid), dim3(256), 0, s, sk, V, t16, pixels); break;
     }
     RD_LAUNCH_CHECK("tail_t16");
     return RD_OK;
@@ -2067,8 +2067,8 @@ int convt_last_wgrad_launch(const float* x, const TailSkip& sk, const float* dou
                             double* c16, int n, int hc, int wc, int cin, int c0, hipStream_t s) {
     const int tx = cdiv(wc, ET_W), ty = cdiv(hc, ET_H), nb = tail_corr_blocks(n, hc, wc);
     const size_t smem = (2368 + 16384) * sizeof(float);
-    hipLaunchKernelGGL(tail_corr_kernel, dim3(nb), dim3(256), smem, s, x, sk, dout, partial, n, hc, wc, cin, cin / 4, tx, ty, n * tx * ty);
-    hipLaunchKernelGGL(tail_wgrad_finish_kernel, dim3(cin), dim3(256), 0, s, (const double*)partial, nb, wl, dwt, c16, cin, c0);
+    RD_LAUNCH(tail_corr_kernel, dim3(nb), dim3(256), smem, s, x, sk, dout, partial, n, hc, wc, cin, cin / 4, tx, ty, n * tx * ty);
+    RD_LAUNCH(tail_wgrad_finish_kernel, dim3(cin), dim3(256), 0, s, (const double*)partial, nb, wl, dwt, c16, cin, c0);
     RD_LAUNCH_CHECK("convt_last_wgrad");
     return RD_OK;
 }
@@ -2083,7 +2083,7 @@ int conv_last_wgrad_launch(const float* s_in, const float* dout, double* partial
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H);
     const int nb = conv_last_wgrad_blocks(n, h, w, c);
     const size_t smem = (640 + (size_t)(256 / (c / 4)) * 9 * c) * sizeof(float);       // 640 + 9 * 256 * 4 floats = 39.4 KB
-    hipLaunchKernelGGL(conv_last_wgrad_tile_kernel, dim3(nb), dim3(256), smem, s, s_in, dout, partial, n, h, w, c, c / 4, tx, ty,
+    RD_LAUNCH(conv_last_wgrad_tile_kernel, dim3(nb), dim3(256), smem, s, s_in, dout, partial, n, h, w, c, c / 4, tx, ty,
                        n * tx * ty);
     RD_LAUNCH_CHECK("conv_last_wgrad");
     return RD_OK;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void partial_reduce_f32_kernel(const float* __
 }
 
 int reduce_partials_f32(const float* partial, double* sums, int nb, int qc, hipStream_t s) {
-    hipLaunchKernelGGL(partial_reduce_f32_kernel, dim3(cdiv(qc, 16)), dim3(256), 0, s, partial, sums, nb, qc);
+    RD_LAUNCH(partial_reduce_f32_kernel, dim3(cdiv(qc, 16)), dim3(256), 0, s, partial, sums, nb, qc);
     RD_LAUNCH_CHECK("partial_reduce_f32");
     return RD_OK;
 }
@@ -347,10 +347,10 @@ __global__ __launch_bounds__(512) void bn_reduce_finalize_quad_kernel(const floa
 int bn_reduce_finalize(const float* partial, int nb, int c, double count, float eps, float momentum, float* mean, float* invstd,
                        float* rmean, float* rvar, int64_t* nbt, hipStream_t s) {
     if (c % 4 == 0)
-        hipLaunchKernelGGL(bn_reduce_finalize_quad_kernel, dim3(c / 4), dim3(512), 0, s, partial, nb, c, count, eps, momentum, mean,
+        RD_LAUNCH(bn_reduce_finalize_quad_kernel, dim3(c / 4), dim3(512), 0, s, partial, nb, c, count, eps, momentum, mean,
                            invstd, rmean, rvar, nbt);
     else
-        hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(c, 4)), dim3(256), 0, s, partial, nb, c, count, eps, momentum, mean,
+        RD_LAUNCH(bn_reduce_finalize_kernel, dim3(cdiv(c, 4)), dim3(256), 0, s, partial, nb, c, count, eps, momentum, mean,
                            invstd, rmean, rvar, nbt);
     RD_LAUNCH_CHECK("bn_reduce_finalize");
     return RD_OK;
@@ -1260,7 +1260,7 @@ int rd_upsample2x_add_fwd(const float* t, const float* bias, const float* skip, 
     RD_REQUIRE(c > 0 && c % 4 == 0, "rd_upsample2x_add_fwd: C must be a multiple of 4 (got %d)", c);
     const long total = (long)n * 4 * h * w * (c / 4);
     ProfScope ps((hipStream_t)s, "upsample2x_add", 0, 4.0 * ((double)n * h * w * c * (1 + 4 + (skip ? 4 : 0))));
-    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_cap((total + 255) / 256, 16384)), dim3(256), 0, (hipStream_t)s, t, bias, skip, out,
+    RD_LAUNCH(upsample2x_add_kernel, dim3(grid_cap((total + 255) / 256, 16384)), dim3(256), 0, (hipStream_t)s, t, bias, skip, out,
                        total, h, w, c / 4);
     RD_LAUNCH_CHECK("upsample2x_add");
     return RD_OK;
@@ -1271,7 +1271,7 @@ int rd_upsample2x_bwd(const float* g, float* dt, int n, int h, int w, int c, rd_
     RD_REQUIRE(c > 0 && c % 4 == 0, "rd_upsample2x_bwd: C must be a multiple of 4 (got %d)", c);
     const long total = (long)n * h * w * (c / 4);
     ProfScope ps((hipStream_t)s, "upsample2x_bwd", 0, 4.0 * ((double)n * h * w * c * 5));
-    hipLaunchKernelGGL(upsample2x_adj_kernel, dim3(grid_cap((total + 255) / 256, 16384)), dim3(256), 0, (hipStream_t)s, g, dt, total, h, w,
+    RD_LAUNCH(upsample2x_adj_kernel, dim3(grid_cap((total + 255) / 256, 16384)), dim3(256), 0, (hipStream_t)s, g, dt, total, h, w,
                        c / 4);
     RD_LAUNCH_CHECK("upsample2x_bwd");
     return RD_OK;
@@ -1295,11 +1295,11 @@ int rd_channel_sum(const float* g, float* out, long long pixels, int c, void* ws
     ProfScope ps((hipStream_t)s, "channel_sum", 0, 4.0 * pixels * c);
     double* partial = (double*)ws;
     double* sums = partial + (size_t)pl.nb * c;
-    hipLaunchKernelGGL((channel_stats_kernel<false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, g, partial,
+    RD_LAUNCH((channel_stats_kernel<false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, g, partial,
                        (long)pixels, c, pl.CQ, pl.RP, pl.rows_per_block);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(c, 16)), dim3(256), 0, (hipStream_t)s, partial, sums, pl.nb, c, 0,
-                       (float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, (float*)nullptr,
+    RD_LAUNCH(partial_reduce_kernel, dim3(cdiv(c, 16)), dim3(256), 0, (hipStream_t)s, partial, sums, pl.nb, c, 0,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    RD_LAUNCH(bn_param_grad_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, (float*)nullptr,
                        out, c);
     RD_LAUNCH_CHECK("channel_sum");
     return RD_OK;
@@ -1322,10 +1322,10 @@ int rd_bn_stats_partial(const float* z, double* sums, long long pixels, int c, v
         return RD_ERR_WS;
     }
     ProfScope ps((hipStream_t)s, "bn_stats", 0, 4.0 * pixels * c);
-    hipLaunchKernelGGL((channel_stats_kernel<true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, (double*)ws,
+    RD_LAUNCH((channel_stats_kernel<true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, (double*)ws,
                        (long)pixels, c, pl.CQ, pl.RP, pl.rows_per_block);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(2 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
-                       sums, pl.nb, 2 * c, 0, (float*)nullptr, (float*)nullptr);
+    RD_LAUNCH(partial_reduce_kernel, dim3(cdiv(2 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
+                       sums, pl.nb, 2 * c, 0, (float*)nullptr, (float*)nullptr, (float*)nullptr);
     RD_LAUNCH_CHECK("bn_stats");
     return RD_OK;
 }
@@ -1333,7 +1333,7 @@ int rd_bn_stats_partial(const float* z, double* sums, long long pixels, int c, v
 int rd_bn_stats_finalize(const double* sums, double count, float eps, float momentum, float* mean, float* invstd,
                          float* running_mean, float* running_var, int64_t* nbt, int c, rd_stream_t s) {
     RD_REQUIRE(sums && mean && invstd && c > 0 && count > 0, "rd_bn_stats_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, count, eps, momentum,
+    RD_LAUNCH(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, count, eps, momentum,
                        mean, invstd, running_mean, running_var, nbt, c);
     RD_LAUNCH_CHECK("bn_finalize");
     return RD_OK;
@@ -1342,7 +1342,7 @@ int rd_bn_stats_finalize(const double* sums, double count, float eps, float mome
 int rd_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* invstd, int c,
                      rd_stream_t s) {
     RD_REQUIRE(running_mean && running_var && mean && invstd && c > 0, "rd_bn_eval_stats: bad arguments");
-    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, running_mean,
+    RD_LAUNCH(bn_eval_stats_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, running_mean,
                        running_var, eps, mean, invstd, c);
     RD_LAUNCH_CHECK("bn_eval_stats");
     return RD_OK;
@@ -1361,12 +1361,12 @@ int rd_bn_act_pool_fwd(const float* z, const float* mean, const float* invstd, c
         const long rows = pixels / 4;
         ProfScope ps((hipStream_t)s, "bn_act_pool_fwd", 0,
                      4.0 * pixels * c * (a ? 2.25 : 1.25) + 0.25 * pixels * c + (zpool ? 1.0 * pixels * c : 0.0));
-        hipLaunchKernelGGL((bn_act_pool_fwd_kernel<true>), dim3(grid_cap((rows * CQ + 255) / 256, qa.out2 ? 2048 : 8192)), dim3(256), 0,
+        RD_LAUNCH((bn_act_pool_fwd_kernel<true>), dim3(grid_cap((rows * CQ + 255) / 256, 8192)), dim3(256), 0,
                            (hipStream_t)s, z, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, idx, zpool, rows, h, w, c,
                            CQ, (unsigned*)nullptr, qa.out2);
     } else {
         ProfScope ps((hipStream_t)s, "bn_act_fwd", 0, 8.0 * pixels * c);
-        hipLaunchKernelGGL((bn_act_pool_fwd_kernel<false>), dim3(grid_cap((pixels * CQ + 255) / 256, qa.out ? 2048 : 8192)), dim3(256),
+        RD_LAUNCH((bn_act_pool_fwd_kernel<false>), dim3(grid_cap((pixels * CQ + 255) / 256, 8192)), dim3(256),
                            0, (hipStream_t)s, z, mean, invstd, gamma, beta, slope, slope_dev, a, (float*)nullptr,
                            (uint8_t*)nullptr, (float*)nullptr, pixels, h, w, c, CQ, qa.out, (unsigned*)nullptr);
     }
@@ -1399,14 +1399,14 @@ int rd_bn_act_bwd_reduce(const float* z, const float* mean, const float* invstd,
     }
     ProfScope ps((hipStream_t)s, "bn_act_bwd_reduce", 0, 4.0 * pixels * c * (1 + (g_full ? 1 : 0) + (pool ? 0.3 : 0)));
     if (pool)
-        hipLaunchKernelGGL((bn_act_bwd_kernel<true, false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean, invstd,
+        RD_LAUNCH((bn_act_bwd_kernel<true, false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean, invstd,
                            gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
                            (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block, (unsigned*)nullptr);
     else
-        hipLaunchKernelGGL((bn_act_bwd_kernel<false, false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
+        RD_LAUNCH((bn_act_bwd_kernel<false, false>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
                            invstd, gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)ws, (const double*)nullptr, 1.0, 1,
                            (float*)nullptr, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block, (unsigned*)nullptr);
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3(cdiv(4 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
+    RD_LAUNCH(partial_reduce_kernel, dim3(cdiv(4 * c, 16)), dim3(256), 0, (hipStream_t)s, (const double*)ws,
                        sums, pl.nb, 4 * c, c, dbeta, dgamma, dextra);
     RD_LAUNCH_CHECK("bn_act_bwd_reduce");
     return RD_OK;
@@ -1416,7 +1416,7 @@ int rd_bn_bwd_stats_finalize(const float* part_a, int rows_a, const float* part_
                              float* dgamma, float* dbeta, float* dextra, rd_stream_t s) {
     RD_REQUIRE(part_a && rows_a > 0 && sums && c > 0 && c % 4 == 0 && (!part_b || rows_b > 0), "rd_bn_bwd_stats_finalize: bad arguments");
     ProfScope ps((hipStream_t)s, "bn_act_bwd_reduce", 0, 16.0 * c * ((double)rows_a + (part_b ? rows_b : 0)));
-    hipLaunchKernelGGL(bn_bwd_stats_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)s, part_a, rows_a, part_b,
+    RD_LAUNCH(bn_bwd_stats_finalize_kernel, dim3(c), dim3(256), 0, (hipStream_t)s, part_a, rows_a, part_b,
                        part_b ? rows_b : 0, c, sums, dgamma, dbeta, dextra);
     RD_LAUNCH_CHECK("bn_bwd_stats_finalize");
     return RD_OK;
@@ -1441,16 +1441,16 @@ int rd_bn_act_bwd_apply(const float* z, const float* mean, const float* invstd, 
         ProfScope ps((hipStream_t)s, "bn_act_bwd_apply", 0,
                      4.0 * pixels * c * (2 + (g_full ? 1 : 0) + (pool ? 0.3 : 0)));
         if (pool)
-            hipLaunchKernelGGL((bn_act_bwd_kernel<true, true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
+            RD_LAUNCH((bn_act_bwd_kernel<true, true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
                                invstd, gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)nullptr, sums, count,
                                training, dz, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block, qa.out);
         else
-            hipLaunchKernelGGL((bn_act_bwd_kernel<false, true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
+            RD_LAUNCH((bn_act_bwd_kernel<false, true>), dim3(pl.nb), dim3(256), 0, (hipStream_t)s, z, mean,
                                invstd, gamma, beta, slope, slope_dev, g_full, g_pool, idx, (double*)nullptr, sums, count, training,
                                dz, rows, h, w, c, pl.CQ, pl.RP, pl.rows_per_block, qa.out);
     }
     if (dgamma || dbeta)
-        hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, dgamma, dbeta,
+        RD_LAUNCH(bn_param_grad_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)s, sums, dgamma, dbeta,
                            c);
     RD_LAUNCH_CHECK("bn_act_bwd_apply");
     return RD_OK;
@@ -1472,7 +1472,7 @@ static int launch_first(const float* x, const float* wt, float* z, const float* 
     const int CQ = cout / 4, PS = 256 / CQ;
 #define RD_FIRST_CASE(CI)                                                                                              \
     case CI:                                                                                                           \
-        hipLaunchKernelGGL((conv_first_kernel<CI, WGRAD>), dim3(grid), dim3(256), 0, s, x, wt, z, dz, partial, n, h, w, \
+        RD_LAUNCH((conv_first_kernel<CI, WGRAD>), dim3(grid), dim3(256), 0, s, x, wt, z, dz, partial, n, h, w, \
                            cout, CQ, PS, tiles_x, tiles_y, ntiles);                                                    \
         break;
     switch (cin) {
@@ -1608,7 +1608,7 @@ int rd_conv3x3_first_bwd_weight_bn(const float* x, const float* z, const float* 
                  4.0 * n * h * w * ((double)cin + cout * (1.0 + (g_full ? 1.0 : 0.0) + (g_pool ? 0.3 : 0.0))));
     const FirstBnBwd bn = {z, mean, invstd, gamma, beta, slope_dev, slope, g_full, g_pool, idx, sums, count, training, dout, w_last};
     if (int e = conv_first_seg_launch(true, x, nullptr, nullptr, nullptr, (float*)ws, n, h, w, cin, cout, (hipStream_t)s, &bn)) return e;
-    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 16)), dim3(256), 0, (hipStream_t)s, (const float*)ws, dw,
+    RD_LAUNCH(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 16)), dim3(256), 0, (hipStream_t)s, (const float*)ws, dw,
                        grid, cin, cout);
     RD_LAUNCH_CHECK("conv_first_wgrad");
     return RD_OK;
@@ -1632,7 +1632,7 @@ int rd_conv3x3_first_bwd_weight(const float* x, const float* dz, float* dw, int 
                  4.0 * n * h * w * (double)(cin + cout));
     if (seg_blocks) {
         if (int e = conv_first_seg_launch(true, x, nullptr, nullptr, dz, (float*)ws, n, h, w, cin, cout, (hipStream_t)s)) return e;
-        hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 16)), dim3(256), 0, (hipStream_t)s,
+        RD_LAUNCH(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 16)), dim3(256), 0, (hipStream_t)s,
                            (const float*)ws, dw, grid, cin, cout);
         RD_LAUNCH_CHECK("conv_first_wgrad");
         return RD_OK;
@@ -1640,7 +1640,7 @@ int rd_conv3x3_first_bwd_weight(const float* x, const float* dz, float* dw, int 
     if (int e = launch_first<true>(x, nullptr, nullptr, dz, (float*)ws, n, h, w, cin, cout, grid, tx, ty, nt,
                                    (hipStream_t)s))
         return e;
-    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 16)), dim3(256), 0, (hipStream_t)s,
+    RD_LAUNCH(first_wgrad_reduce_kernel, dim3(cdiv(9 * cin * cout, 16)), dim3(256), 0, (hipStream_t)s,
                        (const float*)ws, dw, grid, cin, cout);
     RD_LAUNCH_CHECK("conv_first_wgrad");
     return RD_OK;
@@ -1660,7 +1660,7 @@ int rd_conv3x3_last_fwd(const float* s_in, const float* wt, const float* bias, c
         if (int e = conv_last_fwd_launch(s_in, wt, bias, x_nchw, x_channels, out, n, h, w, c, (hipStream_t)s, &launched)) return e;
         if (launched) return RD_OK;
     }
-    hipLaunchKernelGGL(conv_last_fwd_kernel, dim3(n * tx * ty), dim3(256), 0, (hipStream_t)s, s_in, wt, bias, x_nchw,
+    RD_LAUNCH(conv_last_fwd_kernel, dim3(n * tx * ty), dim3(256), 0, (hipStream_t)s, s_in, wt, bias, x_nchw,
                        x_channels, out, n, h, w, c, tx, ty);
     RD_LAUNCH_CHECK("conv_last_fwd");
     return RD_OK;
@@ -1677,7 +1677,7 @@ int rd_conv3x3_last_bwd_data(const float* dout, const float* wt, float* ds, int 
         if (int e = conv_last_dgrad_launch(dout, wt, ds, n, h, w, c, (hipStream_t)s, &launched)) return e;
         if (launched) return RD_OK;
     }
-    hipLaunchKernelGGL(conv_last_dgrad_kernel, dim3(pl.nb), dim3(256), 0, (hipStream_t)s, dout, wt, ds, (long)n * h * w,
+    RD_LAUNCH(conv_last_dgrad_kernel, dim3(pl.nb), dim3(256), 0, (hipStream_t)s, dout, wt, ds, (long)n * h * w,
                        h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
     RD_LAUNCH_CHECK("conv_last_dgrad");
     return RD_OK;
@@ -1849,14 +1849,14 @@ int rd_conv3x3_last_bwd_weight(const float* s_in, const float* dout, float* dw, 
     ProfScope ps((hipStream_t)s, "conv_last_wgrad", 2.0 * n * h * w * 9.0 * c, 4.0 * n * h * w * (double)(c + 1));
     if (const int nb = conv_last_wgrad_blocks(n, h, w, c)) {
         if (int e = conv_last_wgrad_launch(s_in, dout, (double*)ws, n, h, w, c, (hipStream_t)s)) return e;
-        hipLaunchKernelGGL(last_wgrad_reduce_kernel, dim3(cdiv(9 * c + 1, 16)), dim3(256), 0, (hipStream_t)s,
+        RD_LAUNCH(last_wgrad_reduce_kernel, dim3(cdiv(9 * c + 1, 16)), dim3(256), 0, (hipStream_t)s,
                            (const double*)ws, dw, dbias, nb, c);
         RD_LAUNCH_CHECK("conv_last_wgrad");
         return RD_OK;
     }
-    hipLaunchKernelGGL(conv_last_wgrad_kernel, dim3(pl.nb), dim3(256), 0, (hipStream_t)s, s_in, dout, (double*)ws,
+    RD_LAUNCH(conv_last_wgrad_kernel, dim3(pl.nb), dim3(256), 0, (hipStream_t)s, s_in, dout, (double*)ws,
                        (long)n * h * w, h, w, c, pl.CQ, pl.RP, pl.rows_per_block);
-    hipLaunchKernelGGL(last_wgrad_reduce_kernel, dim3(cdiv(9 * c + 1, 16)), dim3(256), 0, (hipStream_t)s,
+    RD_LAUNCH(last_wgrad_reduce_kernel, dim3(cdiv(9 * c + 1, 16)), dim3(256), 0, (hipStream_t)s,
                        (const double*)ws, dw, dbias, pl.nb, c);
     RD_LAUNCH_CHECK("conv_last_wgrad");
     return RD_OK;
@@ -1877,9 +1877,9 @@ int rd_masked_l1_partial(const float* yp, const float* y, const uint8_t* mask, c
         return RD_ERR_WS;
     }
     ProfScope ps((hipStream_t)s, "masked_l1", 0, 9.0 * total);
-    hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, yp, y, mask, mean, stdv, (double*)ws,
+    RD_LAUNCH(l1_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)s, yp, y, mask, mean, stdv, (double*)ws,
                        total, (long)pps);
-    hipLaunchKernelGGL(l1_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, (const double*)ws, sums, nb);
+    RD_LAUNCH(l1_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, (const double*)ws, sums, nb);
     RD_LAUNCH_CHECK("masked_l1_partial");
     return RD_OK;
 }
@@ -1890,7 +1890,7 @@ int rd_masked_l1_finish(const float* yp, const float* y, const uint8_t* mask, co
     RD_REQUIRE(yp && y && mask && mean && stdv && sums && n > 0 && pps > 0, "rd_masked_l1_finish: bad arguments");
     const long total = (long)n * pps;
     ProfScope ps((hipStream_t)s, "masked_l1", 0, 13.0 * total);
-    hipLaunchKernelGGL(l1_finish_kernel, dim3(dyp ? l1_grid(total) : 1), dim3(256), 0, (hipStream_t)s, yp, y, mask, mean,
+    RD_LAUNCH(l1_finish_kernel, dim3(dyp ? l1_grid(total) : 1), dim3(256), 0, (hipStream_t)s, yp, y, mask, mean,
                        stdv, sums, numel_total, gout, loss, dyp, total, (long)pps);
     RD_LAUNCH_CHECK("masked_l1_finish");
     return RD_OK;
@@ -1901,7 +1901,7 @@ int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, 
                  float weight_decay, float step_size, float bc2_sqrt, float grad_scale, rd_stream_t s) {
     RD_REQUIRE(p && g && m && v && numel > 0, "rd_adam_step: bad arguments");
     ProfScope ps((hipStream_t)s, "adam", 0, 28.0 * numel);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_cap((numel + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v,
+    RD_LAUNCH(adam_kernel, dim3(grid_cap((numel + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v,
                        (long)numel, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, step_size, bc2_sqrt,
                        grad_scale);
     RD_LAUNCH_CHECK("adam");
@@ -1911,7 +1911,7 @@ int rd_adam_step(float* p, const float* g, float* m, float* v, long long numel, 
 int rd_adam_step_dev(float* p, const float* g, float* m, float* v, long long numel, const float* scalars_dev, rd_stream_t s) {
     RD_REQUIRE(p && g && m && v && scalars_dev && numel > 0, "rd_adam_step_dev: bad arguments");
     ProfScope ps((hipStream_t)s, "adam", 0, 28.0 * numel);
-    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_cap((numel + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v,
+    RD_LAUNCH(adam_dev_kernel, dim3(grid_cap((numel + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, p, g, m, v,
                        (long)numel, scalars_dev);
     RD_LAUNCH_CHECK("adam_dev");
     return RD_OK;
@@ -1924,10 +1924,10 @@ int rd_sgd_step(float* p, const float* g, float* momentum_buf, long long numel, 
     ProfScope ps((hipStream_t)s, "sgd", 0, (momentum != 0.f ? 20.0 : 12.0) * numel);
     const dim3 grid(grid_cap((numel + 255) / 256, 8192));
     if (momentum != 0.f)
-        hipLaunchKernelGGL(sgd_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, p, g, momentum_buf, (long)numel, lr, weight_decay,
+        RD_LAUNCH(sgd_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, p, g, momentum_buf, (long)numel, lr, weight_decay,
                            momentum, 1.f - dampening, nesterov, first_step, grad_scale);
     else
-        hipLaunchKernelGGL(sgd_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, p, g, (float*)nullptr, (long)numel, lr,
+        RD_LAUNCH(sgd_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, p, g, (float*)nullptr, (long)numel, lr,
                            weight_decay, 0.f, 1.f, 0, 0, grad_scale);
     RD_LAUNCH_CHECK("sgd");
     return RD_OK;
@@ -1941,14 +1941,14 @@ int rd_blend_accumulate(const float* pred, const float* mean, const float* stdv,
     ProfScope ps((hipStream_t)s, "blend_accumulate", 0, 20.0 * n * tile_size * tile_size);
     if (n <= 64) {      // one launch for the whole batch (owner threads walk the covering tiles in order)
         const long total = (long)n * tile_size * tile_size;
-        hipLaunchKernelGGL(blend_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, pred, mean, stdv,
+        RD_LAUNCH(blend_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, pred, mean, stdv,
                            pos, reg, n, tile_size, stride, raster, rows, cols);
         RD_LAUNCH_CHECK("blend_accumulate");
         return RD_OK;
     }
     const int blocks = cdiv((long)tile_size * tile_size, 256);
     for (int i = 0; i < n; ++i)   // one launch per tile, in order: overlapping tiles never race, order is fixed
-        hipLaunchKernelGGL(blend_tile_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, pred, mean, stdv, pos, reg, i,
+        RD_LAUNCH(blend_tile_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, pred, mean, stdv, pos, reg, i,
                            tile_size, stride, raster, rows, cols);
     RD_LAUNCH_CHECK("blend_accumulate");
     return RD_OK;
@@ -1959,7 +1959,7 @@ int rd_patch_sums(const float* planes, long long plane_stride, const int* plane_
     RD_REQUIRE(planes && plane_idx && pos && sums && n > 0 && tile > 0 && width >= tile && p_per_patch > 0,
                "rd_patch_sums: bad arguments");
     ProfScope ps((hipStream_t)s, "patch_sums", 0, 4.0 * n * p_per_patch * tile * tile);
-    hipLaunchKernelGGL(patch_sums_kernel, dim3(n), dim3(256), 0, (hipStream_t)s, planes, (long)plane_stride, plane_idx,
+    RD_LAUNCH(patch_sums_kernel, dim3(n), dim3(256), 0, (hipStream_t)s, planes, (long)plane_stride, plane_idx,
                        p_per_patch, pos, tile, width, nodata, use_nodata, sums);
     RD_LAUNCH_CHECK("patch_sums");
     return RD_OK;
@@ -1975,7 +1975,7 @@ int rd_assemble_patches(const float* dsm_in, const float* dsm_gt, const float* o
     RD_REQUIRE(!dsm_gt || (target && mask), "rd_assemble_patches: target / mask outputs missing");
     const long total = (long)n * (views + 2) * tile * tile;
     ProfScope ps((hipStream_t)s, "assemble_patches", 0, 8.0 * total);
-    hipLaunchKernelGGL(assemble_patches_kernel, dim3(grid_cap((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s,
+    RD_LAUNCH(assemble_patches_kernel, dim3(grid_cap((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s,
                        dsm_in, dsm_gt, ortho_planes, (long)plane_stride, pair_idx, views, pos, aug, dsm_mean, dsm_std,
                        ortho_mean, ortho_std, nodata, n, tile, width, input, target, mask);
     RD_LAUNCH_CHECK("assemble_patches");
@@ -1985,7 +1985,7 @@ int rd_assemble_patches(const float* dsm_in, const float* dsm_gt, const float* o
 int rd_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s) {
     RD_REQUIRE(src && dst, "rd_nchw_to_nhwc: null pointer");
     const long total = (long)n * c * h * w;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_cap((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, src,
+    RD_LAUNCH(nchw_to_nhwc_kernel, dim3(grid_cap((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, src,
                        dst, n, c, h * w);
     RD_LAUNCH_CHECK("nchw_to_nhwc");
     return RD_OK;
@@ -1994,7 +1994,7 @@ int rd_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, rd
 int rd_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, rd_stream_t s) {
     RD_REQUIRE(src && dst, "rd_nhwc_to_nchw: null pointer");
     const long total = (long)n * c * h * w;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_cap((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, src,
+    RD_LAUNCH(nhwc_to_nchw_kernel, dim3(grid_cap((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)s, src,
                        dst, n, c, h * w);
     RD_LAUNCH_CHECK("nhwc_to_nchw");
     return RD_OK;

@@ -662,8 +662,11 @@ __device__ __forceinline__ void write_split_piece(uint4* out, long n, int nk, in
 // three-product form of a packed operand: follows the six-product form (rows32 * nk * 96 bytes = rows32 * nk * 6 uint4)
 __device__ __forceinline__ uint4* form3_of(uint4* out6, long rows, int nk) { return out6 + rows32_of_dev(rows) * nk * 6; }
 // scale of a weight tensor's three-product form from its magnitude slot (the kernel that filled it ran just before)
-__device__ __forceinline__ float pack_scale(const unsigned* amax) {
+__device__ __forceinline__ float pack_scale(const unsigned* amax) {       // any thread, any tensor
     return __uint_as_float((unsigned)scale_bexp(amax_read(amax)) << 23);
+}
+__device__ __forceinline__ float pack_scale_wave(const unsigned* amax) {  // every lane of the wave asks for the same tensor
+    return __uint_as_float((unsigned)scale_bexp(amax_read_wave(amax)) << 23);
 }
 
 // max |w| of weight tensors into their magnitude slots: block b of an item strides over the item's elements
@@ -684,7 +687,7 @@ __global__ void split_pack_kernel(const float* __restrict__ B, uint4* __restrict
     const long rows32 = (long)((N + 31) / 32) * 32;
     const long total = rows32 * nk * 2;
     uint4* out3 = amax ? form3_of(out, N, nk) : nullptr;
-    const float s3 = amax ? pack_scale(amax) : 1.f;
+    const float s3 = amax ? pack_scale_wave(amax) : 1.f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int g = (int)(e & 1);
         const int kt = (int)((e >> 1) % nk);
@@ -713,7 +716,7 @@ __global__ void split_pack_conv3x3_kernel(const float* __restrict__ w, uint4* __
     const int nkf = 9 * ((cin + SK - 1) / SK), nkd = 9 * ((cout + SK - 1) / SK);
     const long rf = (long)((cout + 31) / 32) * 32, rd_ = (long)((cin + 31) / 32) * 32;
     const long Tf = rf * nkf * 2, Td = outd ? rd_ * nkd * 2 : 0;
-    const float s3 = amax ? pack_scale(amax) : 1.f;
+    const float s3 = amax ? pack_scale_wave(amax) : 1.f;
     for (long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x; e0 < Tf + Td; e0 += (long)gridDim.x * blockDim.x) {
         const bool fwd = e0 < Tf;
         const long e = fwd ? e0 : e0 - Tf;
@@ -849,7 +852,7 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const PackItem* __restr
         const int lt = (int)(T - I.tile_begin);
         float v[8];
         const unsigned* am = reinterpret_cast<const unsigned*>(I.amax);
-        const float s3 = am ? pack_scale(am) : 1.f;
+        const float s3 = am ? pack_scale_wave(am) : 1.f;      // one item per block
         auto put = [&](long long outp, long rows, long n, int nk, int kt) {
             uint4* out = reinterpret_cast<uint4*>(outp);
             write_split_piece(out, n, nk, kt, g, v, am ? form3_of(out, rows, nk) : nullptr, s3);
@@ -939,7 +942,7 @@ static inline size_t packed_bytes(long rows, int taps, int cin) {
 static int grid_for(long total, int block, int cap);
 // max |w| of a weight tensor -> its magnitude slot (zeroed by the caller); row_scale: the folded operand's rows
 static void launch_amax(const float* w, long n, unsigned* slot, const float* row_scale, long row_len, hipStream_t s) {
-    hipLaunchKernelGGL(amax_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, s, w, n, slot, row_scale, row_len);
+    RD_LAUNCH(amax_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, s, w, n, slot, row_scale, row_len);
 }
 
 static int split_pack(const float* b_f32, long rows, int taps, int cin, hipStream_t s, const unsigned* amax = nullptr) {
@@ -948,7 +951,7 @@ static int split_pack(const float* b_f32, long rows, int taps, int cin, hipStrea
     const long total = rows32_of(rows) * nk * 2;
     long g = (total + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(split_pack_kernel, dim3((int)g), dim3(256), 0, s, b_f32, out, (int)rows, taps * cin, cin, taps, nk, amax);
+    RD_LAUNCH(split_pack_kernel, dim3((int)g), dim3(256), 0, s, b_f32, out, (int)rows, taps * cin, cin, taps, nk, amax);
     RD_LAUNCH_CHECK("split_pack");
     return RD_OK;
 }
@@ -1034,7 +1037,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
         char pc8[64];
         snprintf(pc8, sizeof(pc8), "%s|conv3_halo_split<64,w8>", cls);
         ProfScope ps8(s, pc8, (double)flops, bytes, true);
-        hipLaunchKernelGGL((conv3_halo_split_kernel<64, 2, 2, EPI_STORE, 8, 1>), dim3((unsigned)(tiles * p.ksplit)), dim3(256), 0, s, p);
+        RD_LAUNCH((conv3_halo_split_kernel<64, 2, 2, EPI_STORE, 8, 1>), dim3((unsigned)(tiles * p.ksplit)), dim3(256), 0, s, p);
         RD_LAUNCH_CHECK(cls);
         return RD_OK;
     }
@@ -1062,15 +1065,15 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
         if (cfg == 0) {
             p.tiles_n = cdiv(p.N, 128);
             if (tune(TUNE_NT_SKEW) == 0)
-                hipLaunchKernelGGL((conv3_halo_split_kernel<128, 1, 4, EPI_STORE, 0>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
+                RD_LAUNCH((conv3_halo_split_kernel<128, 1, 4, EPI_STORE, 0>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
             else
-                hipLaunchKernelGGL((conv3_halo_split_kernel<128, 1, 4, EPI_STORE>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
+                RD_LAUNCH((conv3_halo_split_kernel<128, 1, 4, EPI_STORE>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
         } else {
             p.tiles_n = cdiv(p.N, 64);
             if (tune(TUNE_NT_SKEW) == 0)
-                hipLaunchKernelGGL((conv3_halo_split_kernel<64, 2, 2, EPI_STORE, 0>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
+                RD_LAUNCH((conv3_halo_split_kernel<64, 2, 2, EPI_STORE, 0>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
             else
-                hipLaunchKernelGGL((conv3_halo_split_kernel<64, 2, 2, EPI_STORE>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
+                RD_LAUNCH((conv3_halo_split_kernel<64, 2, 2, EPI_STORE>), dim3(tiles_m * p.tiles_n), dim3(256), 0, s, p);
         }
         RD_LAUNCH_CHECK(cls);
         return RD_OK;
@@ -1085,13 +1088,13 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     p.direct = EPI == EPI_STORE && tune(TUNE_NT_EPI) != 0 && p.M % bm == 0 && p.N % 32 == 0 && !p.shift && !p.pool_out &&
                (long)bm * p.N * 4 < 0x7fffffffL;
     if (split) {
-        if (cfg == 2) hipLaunchKernelGGL((igemm_nt_split_kernel<64, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
-        else if (cfg == 0) hipLaunchKernelGGL((igemm_nt_split_kernel<128, 128, 1, 4, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((igemm_nt_split_kernel<128, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+        if (cfg == 2) RD_LAUNCH((igemm_nt_split_kernel<64, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+        else if (cfg == 0) RD_LAUNCH((igemm_nt_split_kernel<128, 128, 1, 4, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+        else RD_LAUNCH((igemm_nt_split_kernel<128, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
     } else {
-        if (cfg == 2) hipLaunchKernelGGL((igemm_nt_kernel<64, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
-        else if (cfg == 0) hipLaunchKernelGGL((igemm_nt_kernel<128, 128, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((igemm_nt_kernel<128, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+        if (cfg == 2) RD_LAUNCH((igemm_nt_kernel<64, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+        else if (cfg == 0) RD_LAUNCH((igemm_nt_kernel<128, 128, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
+        else RD_LAUNCH((igemm_nt_kernel<128, 64, 2, 2, AMODE, EPI>), dim3(grid), dim3(256), 0, s, p);
     }
     RD_LAUNCH_CHECK(cls);
     return RD_OK;
@@ -1519,24 +1522,24 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t s, const char* cl
     const int grid = p.tiles_mn * pl.splits;
     if (split) {
         if (pl.bm == 128 && pl.bn == 128)
-            hipLaunchKernelGGL((wgrad_tn_split_kernel<128, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+            RD_LAUNCH((wgrad_tn_split_kernel<128, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
         else if (pl.bm == 128)
-            hipLaunchKernelGGL((wgrad_tn_split_kernel<128, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+            RD_LAUNCH((wgrad_tn_split_kernel<128, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
         else if (pl.bn == 128)
-            hipLaunchKernelGGL((wgrad_tn_split_kernel<64, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+            RD_LAUNCH((wgrad_tn_split_kernel<64, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
         else
-            hipLaunchKernelGGL((wgrad_tn_split_kernel<64, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+            RD_LAUNCH((wgrad_tn_split_kernel<64, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
         RD_LAUNCH_CHECK(cls);
         return RD_OK;
     }
     if (pl.bm == 128 && pl.bn == 128)
-        hipLaunchKernelGGL((wgrad_tn_kernel<128, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+        RD_LAUNCH((wgrad_tn_kernel<128, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
     else if (pl.bm == 128)
-        hipLaunchKernelGGL((wgrad_tn_kernel<128, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+        RD_LAUNCH((wgrad_tn_kernel<128, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
     else if (pl.bn == 128)
-        hipLaunchKernelGGL((wgrad_tn_kernel<64, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+        RD_LAUNCH((wgrad_tn_kernel<64, 128, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((wgrad_tn_kernel<64, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
+        RD_LAUNCH((wgrad_tn_kernel<64, 64, 2, 2, AMODE, BMODE>), dim3(grid), dim3(256), 0, s, p);
     RD_LAUNCH_CHECK(cls);
     return RD_OK;
 }
@@ -1611,11 +1614,11 @@ static void launch_slab_reduce(const float* slab, float* dw, int M, int N, int s
     int spt = 1;
     while (spt < 16 && quads * spt < 262144 && 2 * spt <= splits) spt *= 2;      // ~1024 blocks of work, at most 16 lanes per quad
     const int grid = grid_for(quads * spt, 256, 4096);
-    if (spt == 1) hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
-    else if (spt == 2) hipLaunchKernelGGL(slab_reduce_kernel<2>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
-    else if (spt == 4) hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
-    else if (spt == 8) hipLaunchKernelGGL(slab_reduce_kernel<8>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
-    else hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
+    if (spt == 1) RD_LAUNCH(slab_reduce_kernel<1>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
+    else if (spt == 2) RD_LAUNCH(slab_reduce_kernel<2>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
+    else if (spt == 4) RD_LAUNCH(slab_reduce_kernel<4>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
+    else if (spt == 8) RD_LAUNCH(slab_reduce_kernel<8>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
+    else RD_LAUNCH(slab_reduce_kernel<16>, dim3(grid), dim3(256), 0, s, slab, dw, M, N, splits, mode, Cin, Cout);
 }
 
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd,
@@ -1731,16 +1734,16 @@ int rd_pack_conv3x3_weight(const float* w, float* wf, float* wd, int cout, int c
         const long pieces = rows32_of(cout) * nk16_of(9, cin) * 2 + (wd ? rows32_of(cin) * nk16_of(9, cout) * 2 : 0);
         long g = (pieces + 255) / 256;
         if (g > 8192) g = 8192;
-        hipLaunchKernelGGL(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, od, cout, cin,
+        RD_LAUNCH(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, od, cout, cin,
                            (const float*)nullptr, (const unsigned*)amax);
         RD_LAUNCH_CHECK("pack_conv3x3");
         return RD_OK;
     }
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for((long)cout * cin * 9)), dim3(256), 0, (hipStream_t)s, w, wf,
+    RD_LAUNCH(pack_conv3x3_kernel, dim3(grid_for((long)cout * cin * 9)), dim3(256), 0, (hipStream_t)s, w, wf,
                        (float*)nullptr, cout, cin);
     if (wd) {
         const long tiles = 9L * cdiv(cout, 32) * cdiv(cin, 32);
-        hipLaunchKernelGGL(tiled_transpose_kernel, dim3((int)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)s,
+        RD_LAUNCH(tiled_transpose_kernel, dim3((int)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)s,
                            (const float*)wf, wd, cout, 9, cin, 1);
     }
     RD_LAUNCH_CHECK("pack_conv3x3");
@@ -1759,7 +1762,7 @@ int rd_pack_conv3x3_weight_folded(const float* w, const float* row_scale, float*
     const long pieces = rows32_of(cout) * nk16_of(9, cin) * 2;
     long g = (pieces + 255) / 256;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, (uint4*)nullptr, cout, cin,
+    RD_LAUNCH(split_pack_conv3x3_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, w, of, (uint4*)nullptr, cout, cin,
                        row_scale, (const unsigned*)amax);
     RD_LAUNCH_CHECK("pack_conv3x3_folded");
     return RD_OK;
@@ -1783,16 +1786,16 @@ int rd_pack_weights_fused(const void* items_dev, int n_items, long long total_pi
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 10.0 * 8.0 * (double)total_pieces + 14.0 * 9216.0 * (double)total_tiles);
     // items with a magnitude slot (column 9 of the table; zeroed by the caller) get the three-product form too: first their maxima
     if (mfma_products() == 3)
-        hipLaunchKernelGGL(pack_items_amax_kernel, dim3(32 * n_items), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items);
+        RD_LAUNCH(pack_items_amax_kernel, dim3(32 * n_items), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items);
     if (total_tiles > 0) {
         const long gt = total_tiles < 4096 ? total_tiles : 4096;
-        hipLaunchKernelGGL(pack_tiles_kernel, dim3((int)gt), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items,
+        RD_LAUNCH(pack_tiles_kernel, dim3((int)gt), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items,
                            (long)total_tiles);
     }
     if (total_pieces > 0) {
         long g = (total_pieces + 255) / 256;
         if (g > 16384) g = 16384;
-        hipLaunchKernelGGL(pack_all_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items,
+        RD_LAUNCH(pack_all_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items,
                            (long)total_pieces);
     }
     RD_LAUNCH_CHECK("pack_weights_fused");
@@ -1804,11 +1807,11 @@ int rd_pack_convt2x2_weight(const float* w, float* wtf, float* wtd, int cin, int
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 12.0 * cout * cin * 4);
     unsigned* amax = mfma_products() == 3 ? quant_take().out2 : (quant_take(), nullptr);
     if (amax) launch_amax(w, (long)cout * cin * 4, amax, nullptr, 1, (hipStream_t)s);
-    hipLaunchKernelGGL(pack_convt_kernel, dim3(grid_for((long)cout * cin * 4)), dim3(256), 0, (hipStream_t)s, w, wtf,
+    RD_LAUNCH(pack_convt_kernel, dim3(grid_for((long)cout * cin * 4)), dim3(256), 0, (hipStream_t)s, w, wtf,
                        (float*)nullptr, cin, cout);
     if (wtd) {
         const long tiles = (long)cdiv(4 * cout, 32) * cdiv(cin, 32);
-        hipLaunchKernelGGL(tiled_transpose_kernel, dim3((int)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)s,
+        RD_LAUNCH(tiled_transpose_kernel, dim3((int)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)s,
                            (const float*)wtf, wtd, 4 * cout, 1, cin, 0);
     }
     RD_LAUNCH_CHECK("pack_convt");
@@ -2117,6 +2120,7 @@ int rd_pack_conv1x1_weight(const float* w, float* wf, float* wt, int cout, int c
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 16.0 * cout * cin);
     unsigned* amax = mfma_products() == 3 ? quant_take().out2 : (quant_take(), nullptr);
     if (amax) launch_amax(w, (long)cout * cin, amax, nullptr, 1, (hipStream_t)s);
+    plan_poison((hipStream_t)s, "rd_pack_conv1x1_weight (bilinear up-mode) copies with hipMemcpyAsync");
     if (int e = check_hip(hipMemcpyAsync(wf, w, (size_t)cout * cin * 4, hipMemcpyDeviceToDevice, (hipStream_t)s),
                           "pack_conv1x1 copy"))
         return e;
@@ -2124,7 +2128,7 @@ int rd_pack_conv1x1_weight(const float* w, float* wf, float* wt, int cout, int c
     if (!wt) return RD_OK;
     {
         const long tiles = (long)cdiv(cout, 32) * cdiv(cin, 32);
-        hipLaunchKernelGGL(tiled_transpose_kernel, dim3((int)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)s, w, wt,
+        RD_LAUNCH(tiled_transpose_kernel, dim3((int)(tiles < 8192 ? tiles : 8192)), dim3(256), 0, (hipStream_t)s, w, wt,
                            cout, 1, cin, 0);
     }
     RD_LAUNCH_CHECK("pack_conv1x1");

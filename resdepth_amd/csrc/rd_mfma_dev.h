@@ -54,7 +54,10 @@ constexpr int SROWB3 = 64;  // ... three-product form (2 fp16 terms), which foll
 //          elements are fine: they stay NaN in both terms), sends the launch to the NP = 6 body -- which therefore keeps
 //          fp32's non-finite semantics.
 // =====================================================================================================================
-constexpr int AMAX_WORDS = 16;      // one slot = 16 words: a wave commits to word (its id & 15), spreading same-address atomics
+// one slot = 16 words, each on a 128-byte line of its own (2 KB): a block commits to word (blockIdx & 15).  Device-scope
+// atomics serialise per LINE at ~11 ns each (MI355X_MICROARCH.md "fanin"; measured here: 2048 commits into one line = 22 us
+// behind a 14 us element-wise kernel), sixteen lines take them in parallel
+constexpr int AMAX_WORDS = 16, AMAX_STRIDE = 32;
 
 template <int NP> struct frag_of { typedef bf16x8 type; };
 template <> struct frag_of<3> { typedef f16x8 type; };
@@ -70,14 +73,26 @@ struct Quant {
     float sa, sb;   // operand scales 2^ea, 2^eb (sb only where B is split on the fly: the weight-gradient kernels)
     int dexp;       // -(ea + eb): exponent of the result's scale-back
 };
+// per-thread form (pack kernels whose threads serve different tensors)
 __device__ __forceinline__ unsigned amax_read(const unsigned* __restrict__ slot) {
     unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < AMAX_WORDS; ++i) {
-        const unsigned v = slot[i];
+        const unsigned v = slot[i * AMAX_STRIDE];
         m = v > m ? v : m;
     }
     return m;
+}
+// wave-uniform form: lanes 0..15 fetch one word each (ONE load instruction, sixteen lines in flight), then a cross-lane maximum
+__device__ __forceinline__ unsigned amax_read_wave(const unsigned* __restrict__ slot) {
+    const int lane = threadIdx.x & 63;
+    unsigned m = lane < AMAX_WORDS ? slot[lane * AMAX_STRIDE] : 0u;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)m, o);
+        m = other > m ? other : m;
+    }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
 }
 // biased exponent of the scale that maps a tensor maximum with bits `am` into [2^14, 2^15) (clamped to a finite float)
 __device__ __forceinline__ int scale_bexp(unsigned am) {
@@ -87,8 +102,7 @@ __device__ __forceinline__ int scale_bexp(unsigned am) {
 __device__ __forceinline__ Quant quant_select(const unsigned* a_amax, const unsigned* b_amax) {
     Quant q = {0, 1.f, 1.f, 0};
     if (a_amax == nullptr || b_amax == nullptr) return q;
-    const unsigned am = (unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(a_amax));
-    const unsigned bm = (unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(b_amax));
+    const unsigned am = amax_read_wave(a_amax), bm = amax_read_wave(b_amax);
     if (am >= 0x7f800000u || bm >= 0x7f800000u) return q;        // an infinite element: exact non-finite semantics live in NP = 6
     const int ea = scale_bexp(am), eb = scale_bexp(bm);
     q.use3 = 1;
@@ -106,8 +120,7 @@ __device__ __forceinline__ float amax_acc(float m, float v) {
 // EVERY thread of the block calls this (block-uniform control flow): wave maximum by cross-lane exchange, block maximum through
 // 8 words of LDS, then ONE agent-scope atomic per block.  Measured r06: device-scope atomics on one 128-byte line retire at
 // ~11 ns each whatever word they hit (MI355X_MICROARCH.md "fanin"), so one per WAVE of an 8192-block element-wise kernel cost
-// 0.23 ms per launch (bn_act_pool_fwd 0.27 -> 1.44 ms per step) -- hence one per block, and the element-wise producers cap
-// their grid at 2048 blocks when a slot is asked for (amax_grid_cap).
+// 0.23 ms per launch (bn_act_pool_fwd 0.27 -> 1.44 ms per step) -- hence one per block, spread over the slot's sixteen lines.
 __device__ __forceinline__ void amax_commit(unsigned* slot, float m) {
     __shared__ unsigned amax_red[16];
     unsigned b = __float_as_uint(m);
@@ -121,7 +134,7 @@ __device__ __forceinline__ void amax_commit(unsigned* slot, float m) {
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < nw; ++w) b = amax_red[w] > b ? amax_red[w] : b;
-        __hip_atomic_fetch_max(slot + (blockIdx.x & (AMAX_WORDS - 1)), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(slot + (blockIdx.x & (AMAX_WORDS - 1)) * AMAX_STRIDE, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

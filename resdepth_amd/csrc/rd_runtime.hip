@@ -34,7 +34,7 @@ struct TuneEntry {
 static TuneEntry g_tune[TUNE_COUNT] = {
     {"mfma_f32", 0},   {"nt_tile", -1},      {"nt_halo", -1},    {"nt_skew", 1},     {"tn_tile", -1},     {"tn_blocks", 512}, {"tn_split", -1},
     {"wg_strip", -1},  {"wg_minblocks", 768}, {"wg_blocks", 512}, {"wg_occ", 2}, {"convt_patch", -1}, {"edge_conv", -1}, {"rows_blocks", 512}, {"last_blocks", 2048},
-    {"nt_splitk", -1}, {"nt_epi", -1}, {"mfma_products", 6}, {"d2h_blocks", 0},
+    {"nt_splitk", -1}, {"nt_epi", -1}, {"mfma_products", 3}, {"d2h_blocks", 0},
 };
 static int tune_index(const char* name, size_t len) {
     for (int i = 0; i < TUNE_COUNT; ++i)
@@ -67,6 +67,73 @@ QuantArgs quant_take() {
     const QuantArgs q = t_quant;
     t_quant = {nullptr, nullptr, nullptr, nullptr};
     return q;
+}
+
+// ---- launch plans (rd_plan_*) ----------------------------------------------------------------------------------------------
+// One recording at a time per process (the forward runs on the caller's thread, the backward on an autograd worker: the
+// recorder is keyed by STREAM, not by thread).  A plan = a list of operations in host enqueue order: kernel launches with their
+// argument values, event records / waits between the plan's two streams, and segment ends (where the host acts between
+// replays: a collective, a read-back).
+struct PlanOp {
+    int kind;                 // 0 launch | 1 event record | 2 event wait
+    int role;                 // stream of the op: 0 = main, 1 = side
+    const void* fn;
+    dim3 grid, block;
+    unsigned shmem;
+    int nargs;
+    size_t arg0;              // index of the first argument offset in Plan::arg_off
+    int ev;                   // event index (kinds 1, 2)
+};
+struct Plan {
+    std::vector<PlanOp> ops;
+    std::vector<size_t> arg_off;      // byte offsets into blob
+    std::vector<char> blob;           // argument values, each at its natural alignment
+    std::vector<hipEvent_t> events;
+    std::vector<size_t> seg_end;      // ops index one past each segment
+    hipStream_t rec[2] = {nullptr, nullptr};
+    int n_events = 0, n_launches = 0, dev = -1;
+    bool poisoned = false;
+    std::string why;
+};
+static std::mutex g_plan_mu;
+static Plan* g_rec = nullptr;             // the plan being recorded (nullptr: none)
+static volatile int g_recording = 0;
+
+bool plan_recording() { return g_recording != 0; }
+
+static int plan_role(const Plan* p, hipStream_t s) { return s == p->rec[0] ? 0 : s == p->rec[1] ? 1 : -1; }
+
+void plan_note_launch(const void* fn, dim3 grid, dim3 block, size_t shmem, hipStream_t s, void** args, const size_t* sizes,
+                      const size_t* aligns, int nargs) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    Plan* p = g_rec;
+    if (!p) return;
+    const int role = plan_role(p, s);
+    if (role < 0) return;                 // another stream's work (a prefetcher, another model): not part of this plan
+    if (nargs > 64) {
+        p->poisoned = true;
+        p->why = "a kernel with more than 64 arguments";
+        return;
+    }
+    PlanOp op = {};
+    op.kind = 0; op.role = role; op.fn = fn; op.grid = grid; op.block = block; op.shmem = (unsigned)shmem; op.nargs = nargs;
+    op.arg0 = p->arg_off.size();
+    for (int i = 0; i < nargs; ++i) {
+        size_t off = (p->blob.size() + aligns[i] - 1) / aligns[i] * aligns[i];
+        p->blob.resize(off + sizes[i]);
+        memcpy(p->blob.data() + off, args[i], sizes[i]);
+        p->arg_off.push_back(off);
+    }
+    p->ops.push_back(op);
+    p->n_launches++;
+}
+
+void plan_poison(hipStream_t s, const char* why) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (g_rec && plan_role(g_rec, s) >= 0 && !g_rec->poisoned) {
+        g_rec->poisoned = true;
+        g_rec->why = why;
+    }
 }
 
 // ---- split-K scratch (rd_set_splitk_workspace) --------------------------------------------------------------------
@@ -180,9 +247,150 @@ static void drain_locked() {
 
 extern "C" {
 
-int rd_version(void) { return 105; }      // 101 (r04): rd_set_splitk_workspace keyed by (device, stream); 102 (r05): rd_host_register; 103: rd_mfma_products; 104: rd_adam_step_dev; 105 (r06): rd_quant_next, rd_amax, packed operands carry both split forms
+int rd_version(void) { return 106; }      // 101 (r04): rd_set_splitk_workspace keyed by (device, stream); 102 (r05): rd_host_register; 103: rd_mfma_products; 104: rd_adam_step_dev; 105 (r06): rd_quant_next, rd_amax, packed operands carry both split forms; 106: rd_plan_*
 
 const char* rd_last_error_string(void) { return rd::g_err; }
+
+// ---- launch plans -----------------------------------------------------------------------------------------------------------
+int rd_plan_begin(rd_stream_t main_stream, rd_stream_t side_stream) {
+    using namespace rd;
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (g_rec) {
+        set_error("rd_plan_begin: a plan is already being recorded");
+        return RD_ERR_ARG;
+    }
+    Plan* p = new Plan();
+    p->rec[0] = (hipStream_t)main_stream;
+    p->rec[1] = (hipStream_t)side_stream;
+    (void)hipGetDevice(&p->dev);
+    g_rec = p;
+    g_recording = 1;
+    return RD_OK;
+}
+
+int rd_plan_event_record(rd_stream_t stream) {
+    using namespace rd;
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (!g_rec) return -1;
+    const int role = plan_role(g_rec, (hipStream_t)stream);
+    if (role < 0) return -1;
+    PlanOp op = {};
+    op.kind = 1; op.role = role; op.ev = g_rec->n_events++;
+    g_rec->ops.push_back(op);
+    return op.ev;
+}
+
+int rd_plan_event_wait(rd_stream_t stream, int ev) {
+    using namespace rd;
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (!g_rec) return RD_OK;
+    const int role = plan_role(g_rec, (hipStream_t)stream);
+    if (role < 0 || ev < 0) {
+        // a wait on something the plan did not record (an event of a stream outside it): the replay could not reproduce it
+        if (role >= 0 && !g_rec->poisoned) {
+            g_rec->poisoned = true;
+            g_rec->why = "a plan stream waited for an event recorded outside the plan";
+        }
+        return RD_OK;
+    }
+    PlanOp op = {};
+    op.kind = 2; op.role = role; op.ev = ev;
+    g_rec->ops.push_back(op);
+    return RD_OK;
+}
+
+int rd_plan_segment(void) {
+    using namespace rd;
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (!g_rec) return -1;
+    g_rec->seg_end.push_back(g_rec->ops.size());
+    return (int)g_rec->seg_end.size() - 1;
+}
+
+int rd_plan_poison(const char* why) {
+    using namespace rd;
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (g_rec && !g_rec->poisoned) {
+        g_rec->poisoned = true;
+        g_rec->why = why ? why : "(no reason given)";
+    }
+    return RD_OK;
+}
+
+void* rd_plan_end(int* n_launches, int* n_segments) {
+    using namespace rd;
+    Plan* p;
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        p = g_rec;
+        g_rec = nullptr;
+        g_recording = 0;
+    }
+    if (!p) {
+        set_error("rd_plan_end: no plan is being recorded");
+        return nullptr;
+    }
+    if (p->poisoned) {
+        set_error("rd_plan_end: the recording cannot be replayed: %s", p->why.c_str());
+        delete p;
+        return nullptr;
+    }
+    if (p->seg_end.empty() || p->seg_end.back() != p->ops.size()) p->seg_end.push_back(p->ops.size());
+    p->events.resize(p->n_events);
+    for (int i = 0; i < p->n_events; ++i)
+        if (hipEventCreateWithFlags(&p->events[i], hipEventDisableTiming) != hipSuccess) {
+            set_error("rd_plan_end: hipEventCreate failed");
+            for (int j = 0; j < i; ++j) (void)hipEventDestroy(p->events[j]);
+            delete p;
+            return nullptr;
+        }
+    if (n_launches) *n_launches = p->n_launches;
+    if (n_segments) *n_segments = (int)p->seg_end.size();
+    return p;
+}
+
+int rd_plan_replay(void* plan, int segment, rd_stream_t main_stream, rd_stream_t side_stream) {
+    using namespace rd;
+    Plan* p = (Plan*)plan;
+    RD_REQUIRE(p && segment >= 0 && segment < (int)p->seg_end.size(), "rd_plan_replay: bad plan / segment %d", segment);
+    hipStream_t st[2] = {(hipStream_t)main_stream, (hipStream_t)side_stream};
+    const size_t a = segment ? p->seg_end[segment - 1] : 0, b = p->seg_end[segment];
+    void* argv[64];
+    for (size_t i = a; i < b; ++i) {
+        const PlanOp& op = p->ops[i];
+        if (op.kind == 0) {
+            for (int k = 0; k < op.nargs; ++k) argv[k] = p->blob.data() + p->arg_off[op.arg0 + k];
+            const hipError_t e = hipLaunchKernel(op.fn, op.grid, op.block, argv, op.shmem, st[op.role]);
+            if (e != hipSuccess) return check_hip(e, "rd_plan_replay: launch");
+        } else if (op.kind == 1) {
+            if (int e = check_hip(hipEventRecord(p->events[op.ev], st[op.role]), "rd_plan_replay: event record")) return e;
+        } else {
+            if (int e = check_hip(hipStreamWaitEvent(st[op.role], p->events[op.ev], 0), "rd_plan_replay: event wait")) return e;
+        }
+    }
+    return RD_OK;
+}
+
+int rd_plan_free(void* plan) {
+    rd::Plan* p = (rd::Plan*)plan;
+    if (!p) return RD_OK;
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    delete p;
+    return RD_OK;
+}
+
+// zero a 16-byte aligned range with a kernel of the library (a launch a plan can hold; hipMemsetAsync is not)
+__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+int rd_zero(void* p, size_t bytes, rd_stream_t s) {
+    using namespace rd;
+    RD_REQUIRE(p && bytes % 16 == 0 && ((size_t)p & 15) == 0, "rd_zero: a 16-byte aligned range of whole 16-byte units");
+    if (!bytes) return RD_OK;
+    const size_t n16 = bytes / 16;
+    RD_LAUNCH(zero_kernel, dim3((unsigned)(n16 < 256 * 256 ? (n16 + 255) / 256 : 256)), dim3(256), 0, (hipStream_t)s, (uint4*)p, n16);
+    return check_hip(hipGetLastError(), "rd_zero");
+}
 
 int rd_quant_next(const unsigned* a_amax, const unsigned* b_amax, unsigned* out_amax, unsigned* out2_amax) {
     rd::t_quant = {a_amax, b_amax, out_amax, out2_amax};
@@ -267,6 +475,7 @@ extern "C" int rd_set_splitk_workspace(void* ws, size_t bytes, rd_stream_t strea
             break;
         }
     if (!ws) return RD_OK;                           // un-register
+    plan_poison(s, "rd_set_splitk_workspace inside a recording (register the scratch before)");
     if (int e = check_hip(hipMemsetAsync(ws, 0, kSkTicketBytes, s), "rd_set_splitk_workspace")) return e;
     g_sk.push_back({dev, s, (char*)ws, bytes});
     return RD_OK;
@@ -305,11 +514,12 @@ extern "C" int rd_copy_to_host_async(void* dst_host, const void* src_dev, size_t
         rd::set_error("rd_copy_to_host_async: null pointer");
         return RD_ERR_ARG;
     }
+    rd::plan_poison((hipStream_t)stream, "rd_copy_to_host_async inside a recording");
     const int blocks = rd::tune(rd::TUNE_D2H_BLOCKS);
     void* dmap = nullptr;
     if (blocks > 0 && bytes % 16 == 0 && ((size_t)dst_host % 16) == 0 && ((size_t)src_dev % 16) == 0 &&
         hipHostGetDevicePointer(&dmap, dst_host, 0) == hipSuccess && dmap) {
-        hipLaunchKernelGGL(copy_to_host_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+        RD_LAUNCH(copy_to_host_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<const u32x4*>(src_dev), reinterpret_cast<u32x4*>(dmap), bytes / 16);
         return rd::check_hip(hipGetLastError(), "rd_copy_to_host_async");
     }

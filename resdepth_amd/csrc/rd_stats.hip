@@ -181,20 +181,20 @@ int rd_residual_stats(const double* raster, const float* gt, const uint8_t* mask
     unsigned* hist = (unsigned*)((char*)partial + (size_t)nb * 5 * sizeof(double));
     SelState* st = (SelState*)((char*)hist + 512 * sizeof(unsigned));
     ProfScope ps(s, "residual_stats", 0, 13.0 * n + 24.0 * 9.0 * n);
-    hipLaunchKernelGGL(residual_kernel, dim3(nb), dim3(256), 0, s, raster, gt, mask, (long)n, nodata, threshold, r, valid,
+    RD_LAUNCH(residual_kernel, dim3(nb), dim3(256), 0, s, raster, gt, mask, (long)n, nodata, threshold, r, valid,
                        partial);
-    hipLaunchKernelGGL(moments_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)partial, nb, out, st);
+    RD_LAUNCH(moments_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)partial, nb, out, st);
     // out: 0 count, 1 max, 2 min, 3 MAE, 4 RMSE, 5 absolute_median, 6 median, 7 NMAD
     const int modes[3] = {1, 0, 2};
     const int dst[3] = {5, 6, 7};
     for (int m = 0; m < 3; ++m) {
-        hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, s, st, hist, m == 2 ? (const double*)(out + 5) : nullptr);
+        RD_LAUNCH(select_init_kernel, dim3(1), dim3(256), 0, s, st, hist, m == 2 ? (const double*)(out + 5) : nullptr);
         for (int pass = 7; pass >= 0; --pass) {
-            hipLaunchKernelGGL(select_hist_kernel, dim3(nb), dim3(256), 0, s, (const double*)r, (const uint8_t*)valid,
+            RD_LAUNCH(select_hist_kernel, dim3(nb), dim3(256), 0, s, (const double*)r, (const uint8_t*)valid,
                                (long)n, modes[m], pass, (const SelState*)st, hist);
-            hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, s, st, hist);
+            RD_LAUNCH(select_pick_kernel, dim3(1), dim3(256), 0, s, st, hist);
         }
-        hipLaunchKernelGGL(select_finish_kernel, dim3(1), dim3(64), 0, s, (const SelState*)st, out + dst[m],
+        RD_LAUNCH(select_finish_kernel, dim3(1), dim3(64), 0, s, (const SelState*)st, out + dst[m],
                            m == 2 ? 1.4826 : 1.0);
     }
     RD_LAUNCH_CHECK("residual_stats");

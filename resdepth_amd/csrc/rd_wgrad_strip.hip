@@ -371,12 +371,12 @@ int wgrad_strip_launch(const float* x, const float* dz, float* slab, int n, int 
     // library in r06)
     const dim3 grid(q.tiles_mn * wp.splits);
     const int occ = tune(TUNE_WG_OCC);
-    if (wp.w8 && occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 2, 2, true>), grid, dim3(256), 0, s, q);
-    else if (wp.w8) hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 2, 2, true>), grid, dim3(256), 0, s, q);
-    else if (wp.sq && occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 2, 2>), grid, dim3(256), 0, s, q);
-    else if (wp.sq) hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 2, 2>), grid, dim3(256), 0, s, q);
-    else if (occ == 2) hipLaunchKernelGGL((wgrad_strip_tr_kernel<2, 4, 1>), grid, dim3(256), 0, s, q);
-    else hipLaunchKernelGGL((wgrad_strip_tr_kernel<1, 4, 1>), grid, dim3(256), 0, s, q);
+    if (wp.w8 && occ == 2) RD_LAUNCH((wgrad_strip_tr_kernel<2, 2, 2, true>), grid, dim3(256), 0, s, q);
+    else if (wp.w8) RD_LAUNCH((wgrad_strip_tr_kernel<1, 2, 2, true>), grid, dim3(256), 0, s, q);
+    else if (wp.sq && occ == 2) RD_LAUNCH((wgrad_strip_tr_kernel<2, 2, 2>), grid, dim3(256), 0, s, q);
+    else if (wp.sq) RD_LAUNCH((wgrad_strip_tr_kernel<1, 2, 2>), grid, dim3(256), 0, s, q);
+    else if (occ == 2) RD_LAUNCH((wgrad_strip_tr_kernel<2, 4, 1>), grid, dim3(256), 0, s, q);
+    else RD_LAUNCH((wgrad_strip_tr_kernel<1, 4, 1>), grid, dim3(256), 0, s, q);
     RD_LAUNCH_CHECK("wgrad_strip");
     *splits_out = wp.splits;
     *swapped_out = wp.swapped;

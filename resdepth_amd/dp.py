@@ -29,6 +29,8 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 
 class Probe:
     """Optional per-step timing of the exchange points, for the benchmark's `dist` block (never on by default: it
@@ -134,8 +136,10 @@ class GradSync:
     # ---- small collectives ---------------------------------------------------------------------
     def allreduce_loss_sums(self, sums: torch.Tensor, numel: int) -> int:
         """(sum |d|, #valid) -> global; returns the global element count."""
-        with self._t("loss_norm"):
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
+        def run():
+            with self._t("loss_norm"):
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.pg)
+        _lib.host_action(run)            # (a launch plan re-issues it between its segments: resdepth_amd/plan.py)
         return numel * self.world
 
     def allreduce_stats(self, sums: torch.Tensor, count: int) -> int:
@@ -224,20 +228,26 @@ class GradSync:
     def _launch(self, model, bi):
         b = self._buckets[bi]
         view = model._flat_grad[b["lo"]:b["hi"]]
-        if self.launch_stream is not None and view.is_cuda:
-            # a bucket mixes gradients produced on the main stream (BN / bias) and on the wgrad stream: the collective
-            # is issued from the wgrad stream after it has caught up with the main stream (cheap: main runs ahead)
-            cur = torch.cuda.current_stream()
-            with torch.cuda.stream(self.launch_stream):
-                if cur != self.launch_stream:
-                    self.launch_stream.wait_stream(cur)
+        launch_stream = self.launch_stream
+
+        def issue():
+            if launch_stream is not None and view.is_cuda:
+                # a bucket mixes gradients produced on the main stream (BN / bias) and on the wgrad stream: the collective
+                # is issued from the wgrad stream after it has caught up with the main stream (cheap: main runs ahead)
+                cur = torch.cuda.current_stream()
+                with torch.cuda.stream(launch_stream):
+                    if cur != launch_stream:
+                        launch_stream.wait_stream(cur)
+                    h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            else:
                 h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        else:
-            h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._handles.append(h)
+            self._handles.append(h)
+            if self.probe is not None and view.is_cuda:
+                self.probe.mark_bucket(bi, launch_stream if launch_stream is not None else torch.cuda.current_stream())
+        # eager: issued now; while a launch plan is recorded: the plan's current segment ends here and the replay loop issues
+        # the collective at this point of every iteration (the view is a range of the persistent flat gradient buffer)
+        _lib.host_action(issue)
         self._launched[bi] = True
-        if self.probe is not None and view.is_cuda:
-            self.probe.mark_bucket(bi, self.launch_stream if self.launch_stream is not None else torch.cuda.current_stream())
 
     def params_ready(self, model, indices) -> None:
         """Called by the backward pass after the kernels writing these parameter gradients were enqueued."""
@@ -255,10 +265,12 @@ class GradSync:
         for bi in range(len(self._buckets)):
             if not self._launched[bi]:
                 self._launch(model, bi)
-        with self._t("grad_wait"):
-            for h in self._handles:
-                h.wait()
-        self._handles = []
+        def wait_all():
+            with self._t("grad_wait"):
+                for h in self._handles:
+                    h.wait()
+            self._handles = []
+        _lib.host_action(wait_all)
         self._ready = set()
         self._launched = [False] * len(self._buckets)
 
@@ -279,7 +291,6 @@ def broadcast_parameters(model, src: int = 0, process_group=None) -> None:
     """Rank `src`'s parameters and BN buffers to everyone (start of training / after loading a checkpoint).  The
     parameters go as ONE message when the model keeps them in its flat buffer; the packed GEMM-layout weight copies of
     every rank are invalidated (the broadcast writes through `.data`, which autograd's version counters do not see)."""
-    from . import _lib
     flat = getattr(model, "_flat_param", None)
     params = list(model.parameters())
     lo, hi = (flat.data_ptr(), flat.data_ptr() + flat.numel() * 4) if flat is not None else (0, 0)

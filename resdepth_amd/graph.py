@@ -43,6 +43,7 @@ class GraphedTrainStep:
         self._cap_token = None
         self._stream = None                      # the capture stream, with a split-K scratch of its own (_lib.pin_splitk_workspace)
         self._scratch = None
+        self._one = None
         self.why_eager = None                    # reason the last call ran eagerly (None: it was a replay)
         self.replays = 0
 
@@ -60,6 +61,16 @@ class GraphedTrainStep:
             for p in self.params:
                 p.grad = None
         return loss.detach()
+
+    # ---- hooks of the launch-plan variant (resdepth_amd/plan.py) -----------------------------------------------------------
+    def _record_begin(self):
+        pass
+
+    def _record_end(self):
+        pass
+
+    def _replay(self):
+        self._graph.replay()
 
     def _eligible(self, x):
         if not x.is_cuda:
@@ -108,13 +119,19 @@ class GraphedTrainStep:
             self._stream = torch.cuda.Stream(device=dev)
             self._scratch = _lib.pin_splitk_workspace(self._stream)
         g = torch.cuda.CUDAGraph()
+        if self._one is None or self._one.device != dev:
+            self._one = torch.ones((), device=dev, dtype=torch.float32)      # dL/dL: a persistent tensor instead of autograd's own
         torch.cuda.synchronize(dev)
         with torch.cuda.graph(g, stream=self._stream, capture_error_mode="thread_local"):
-            out = self.model(static[0])
-            loss = masked_l1_loss(out, static[1], static[2], static[3], static[4])
-            loss.backward()
-            self.optimizer.capture_step()
-            sloss = loss.detach()
+            self._record_begin()
+            try:
+                out = self.model(static[0])
+                loss = masked_l1_loss(out, static[1], static[2], static[3], static[4], grad_sync=getattr(self.model, "grad_sync", None))
+                loss.backward(self._one)
+                self.optimizer.capture_step()
+                sloss = loss.detach()
+            finally:
+                self._record_end()
         self._graph, self._static, self._loss = g, static, sloss
         self._grads = [p.grad for p in self.params]
         self._key = self._shape_key(batch)
@@ -165,7 +182,7 @@ class GraphedTrainStep:
                     if s.data_ptr() != t.data_ptr():
                         s.copy_(t, non_blocking=True)
             self.optimizer.advance()
-            self._graph.replay()
+            self._replay()
             self.replays += 1
             self.why_eager = None
             if self.keep_grads:

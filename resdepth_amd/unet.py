@@ -66,7 +66,7 @@ class _Packed:
     def get(self, key):
         ev = self.events.pop(key, None)
         if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            _lib.ev_wait(torch.cuda.current_stream(), ev)
         return self.items[key]
 
 
@@ -138,6 +138,7 @@ class UNet(nn.Module):
         self.composed_tail = True         # last up-convolution's gradients straight from the 1-channel dout (ops.tail_*)
         self.fused_first_wgrad = True     # level 0: BN / activation / pool backward evaluated inside the first conv's weight gradient
         self.fused_first_eval = True      # inference: level 0's BN + activation + max-pool inside the first convolution (no z0)
+        self.fast_eval = False            # inference on the three-product (split2h) bodies: +50 % sweep rate, results then depend on the batch composition in the last bits
         # loss.backward(retain_graph=True) on the reference keeps the saved activations for a second backward.  A custom
         # autograd.Function cannot see that flag, and keeping 137 MB per tile alive until the loss tensor dies would surprise
         # callers that hold on to losses -- so the activations are released by the first backward unless this is set
@@ -195,7 +196,7 @@ class UNet(nn.Module):
         tw = self._twin()
         tw._ensure_flat()
         tw.train(self.training)
-        tw.two_stream_backward, tw.fold_eval_bn = self.two_stream_backward, self.fold_eval_bn
+        tw.two_stream_backward, tw.fold_eval_bn, tw.fast_eval = self.two_stream_backward, self.fold_eval_bn, self.fast_eval
         # data parallel: the twin's engine exchanges ITS statistics and ITS flat gradient buffer (the padding channels carry
         # zeros on every rank); this model's gradients are then corners of already all-reduced tensors
         tw.grad_sync, tw.sync_bn = self.grad_sync, self.sync_bn
@@ -333,14 +334,14 @@ class UNet(nn.Module):
         if self._side_stream is None or self._side_stream.device != dev:
             self._side_stream = torch.cuda.Stream(device=dev)
         side = self._side_stream
-        side.wait_stream(main)                   # the parameters' last writer (optimizer step) ran on the main stream
+        _lib.wait_stream(side, main)             # the parameters' last writer (optimizer step) ran on the main stream
 
         if self.up_mode == "transpose" and _lib.tune_get("mfma_f32") == 0:
             # split-bf16 mode: every operand of the network in ONE launch into persistent buffers (device item table)
             plan = self._pack_plan()
             with torch.cuda.stream(side):
                 if _lib.products() == 3:
-                    plan["wamax"].zero_()        # the layers' magnitude slots: the pack fills them, then writes the fp16 forms
+                    _lib.zero_(plan["wamax"])    # the layers' magnitude slots: the pack fills them, then writes the fp16 forms
                 _lib.check(_lib.load().rd_pack_weights_fused(plan["items"].data_ptr(), plan["n"], plan["total"], plan["tiles"],
                                                              _lib.stream_ptr()), "pack_weights_fused")
                 if self._tail_expected(True):
@@ -349,8 +350,7 @@ class UNet(nn.Module):
                     v_.record_stream(main)
                     b9_.record_stream(main)
                     pk.items["tail"] = (v_, b9_)
-                ev = torch.cuda.Event()
-                ev.record(side)
+                ev = _lib.Ev(side)
             for k, tensors in plan["buffers"].items():
                 pk.items[k], pk.events[k] = tensors, ev
             if "tail" in pk.items:
@@ -362,8 +362,7 @@ class UNet(nn.Module):
             for t_ in tensors:
                 if t_ is not None:
                     t_.record_stream(main)       # allocated under the side stream, consumed on the main stream
-            ev = torch.cuda.Event()
-            ev.record(side)
+            ev = _lib.Ev(side)
             pk.items[k], pk.events[k] = tensors, ev
 
         with torch.cuda.stream(side):
@@ -657,7 +656,11 @@ class UNet(nn.Module):
         a GEMM operand max-accumulates |x| into a slot of it, the tensor carries the slot as `_rd_amax`, and the GEMM that takes
         the tensor reads it -- see ops._gemm_slots.  The pool is kept with the saved activations (the weight gradients of the
         backward read the forward's slots)."""
-        if _lib.products() != 3:
+        # Inference (eval mode, no graph kept) stays on the six-product body unless `fast_eval` is set: a per-TENSOR scale makes a
+        # tile's result depend, in the last bits, on which other tiles share its batch, and the tiled sweep promises the same
+        # raster bits however the tiles are batched or sharded over ranks (tests/test_blend_gpu.py).  Training couples the batch
+        # through BatchNorm anyway.
+        if _lib.products() != 3 or not (training or save or self.fast_eval):
             return self._engine_forward_impl(x, training, save, keep_skips)
         pool = _lib.AmaxPool(x.device)
         with pool:
@@ -885,10 +888,9 @@ class UNet(nn.Module):
                 fn(*args)
                 done(*ready)
                 return
-            ev = torch.cuda.Event()
-            ev.record(main)
+            ev = _lib.Ev(main)
             with torch.cuda.stream(side):
-                side.wait_event(ev)
+                _lib.ev_wait(side, ev)
                 fn(*args, ws_slot=1)
                 for t_ in reads:
                     t_.record_stream(side)
@@ -1090,10 +1092,9 @@ class UNet(nn.Module):
                     if side is None:
                         done(w_)
                         return
-                    ev = torch.cuda.Event()
-                    ev.record(main)
+                    ev = _lib.Ev(main)
                     with torch.cuda.stream(side):      # bucket launches are ordered on the side stream
-                        side.wait_event(ev)
+                        _lib.ev_wait(side, ev)
                         done(w_)
             dz = bn_backward(e, blk, self.act_fn_encoder, skipgrad[i], gp, e["idx"], extra_bias=up.bias,
                              pre=(skipstat[i], gpstat), fuse_into=fuse)
@@ -1110,7 +1111,7 @@ class UNet(nn.Module):
                 wgrad(ops.conv3x3_first_bwd_weight, (dz,), S["x"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
         dx = self._input_grad(S, dz, dout, pk) if want_dx else None
         if side is not None:
-            main.wait_stream(side)           # every weight gradient (and bucket launch) is ordered before what follows
+            _lib.wait_stream(main, side)     # every weight gradient (and bucket launch) is ordered before what follows
         if sync is not None:
             sync.finish(self)
         elif self.grad_sync is not None:
