@@ -315,7 +315,8 @@ class TrainBench:
     def __init__(self, wl, n, dev, rank=0, gs=None, from_rasters=False):
         from resdepth_amd import UNet, FusedAdam, synthetic_batch
         self.wl, self.n, self.gs = wl, n, gs
-        self.graph, self.use_graph = None, False      # resdepth_amd.graph.GraphedTrainStep (attach_optimizer); on for the headline only
+        self.graph, self.use_graph = None, False      # resdepth_amd.graph.GraphedTrainStep (attach_optimizer): --graph
+        self.plan, self.use_plan = None, False        # resdepth_amd.plan.PlannedTrainStep: the default iteration of the headline
         torch.manual_seed(0)
         self.model = UNet(n_input_channels=wl["c"], start_kernel=64, depth=wl["depth"], bias_conv_layer=True).to(dev).train()
         b = synthetic_batch(n, wl["c"], wl["t"], seed=1234 + rank)
@@ -340,7 +341,9 @@ class TrainBench:
         self.opt = FusedAdam(self.model.parameters(), lr=2e-4, weight_decay=1e-5)
         self.params = list(self.model.parameters())
         from resdepth_amd.graph import GraphedTrainStep
+        from resdepth_amd.plan import PlannedTrainStep
         self.graph = GraphedTrainStep(self.model, self.opt, warmup=2)
+        self.plan = PlannedTrainStep(self.model, self.opt, warmup=2)
 
     def step(self):
         from resdepth_amd import masked_l1_loss
@@ -349,6 +352,10 @@ class TrainBench:
             xx, yy, mm, me, sd_ = bb["input"], bb["target"], bb["loss_mask"], bb["dsm_mean"], bb["dsm_std"]
         else:
             xx, yy, mm, me, sd_ = self.x, self.y, self.mask, self.mean, self.std
+        if self.use_plan:
+            loss = self.plan(xx, yy, mm, me, sd_)         # the recorded launch list replayed from C (eager while it warms up)
+            self.losses.append(loss.clone() if self.plan.why_eager is None else loss)
+            return
         if self.use_graph and self.gs is None:
             loss = self.graph(xx, yy, mm, me, sd_)        # one hipGraph launch once captured (eager while it warms up)
             self.losses.append(loss.clone() if self.graph.why_eager is None else loss)
@@ -583,16 +590,18 @@ def split2_measurement():
 
 def graph_small_batch_measurement(dev, wl, n=4, steps=40):
     res = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "plan"):
         t = TrainBench(wl, n, dev)
         t.attach_optimizer()
-        t.use_graph = mode == "graph"
-        for _ in range(4):
+        t.use_graph, t.use_plan = mode == "graph", mode == "plan"
+        for _ in range(5):
             t.step()
         dt, ev = t.timed(steps, 4)
         res[mode] = {"tiles_per_s": round(n * steps / dt, 1), "step_ms_median": round(_median(ev), 3)}
         if mode == "graph":
             res[mode]["replays"] = t.graph.replays
+        if mode == "plan":
+            res[mode]["replays"], res[mode]["rejected"] = t.plan.replays, getattr(t.plan, "plan_rejected", None)
         del t
     res["note"] = (f"cfg-S at batch {n}, fwd+loss+bwd+Adam, {steps} timed steps: the eager iteration is bound by its ~110 launches "
                    "(~3.5 ms of host time per step), resdepth_amd.graph.GraphedTrainStep replays it as one HIP graph (0.35 ms of host "
@@ -882,6 +891,8 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the iteration as one captured HIP graph (resdepth_amd.graph) instead of ~110 eager launches: pays when the "
                          "step is launch-bound (batch <= 6 at cfg-S), costs the two-stream overlap at the benchmark batch")
+    ap.add_argument("--no-plan", action="store_true",
+                    help="enqueue every iteration from Python instead of replaying the recorded launch plan (resdepth_amd/plan.py)")
     ap.add_argument("--separate-bn-stats", action="store_true",
                     help="A/B: BN-backward sums from the stand-alone reduction pass instead of the data-gradient epilogues")
     ap.add_argument("--serial-backward", action="store_true",
@@ -983,12 +994,20 @@ def main():
         torch.cuda.synchronize()
 
     tb.use_graph = args.graph and not use_dist
-    if tb.use_graph:
-        for _ in range(4):                       # two eager warm-up iterations, capture preparation, capture: outside the timed region
-            tb.step()
+    tb.use_plan = not args.no_plan and not tb.use_graph
+    if tb.use_graph or tb.use_plan:
+        for _ in range(5):                       # two eager warm-up iterations, capture preparation, capture (+ the plan's verified
+            tb.step()                            # first replay), one plain replay: outside the timed region
         torch.cuda.synchronize()
     dt, step_ms = tb.timed(args.steps, args.warmup, barrier)
     timed_losses = list(tb.losses)
+    plan_info = {"enabled": bool(tb.use_plan), "replays": tb.plan.replays, "launches": tb.plan.n_launches, "segments": tb.plan.n_segments,
+                 "last_eager_reason": tb.plan.why_eager, "rejected": getattr(tb.plan, "plan_rejected", None),
+                 "note": "the iteration's ~110 kernel launches recorded once (under a graph capture, for its reserved memory) and "
+                         "replayed from C with one hipLaunchKernel each onto the REAL two streams (resdepth_amd/plan.py, rd_plan_*): "
+                         "the eager iteration's kernels, arguments, stream overlap and bits (the first replay is verified bit for bit "
+                         "against an eager iteration; tests/test_plan_gpu.py), without its Python / ctypes enqueue time; under data "
+                         "parallelism the collectives are issued by the host between the plan's segments"}
     graph_info = {"enabled": bool(tb.use_graph), "replays": tb.graph.replays, "last_eager_reason": tb.graph.why_eager,
                   "note": "the whole iteration (weight packing, forward, loss, two-stream backward, Adam) replayed as one captured HIP "
                           "graph per step: the same kernels and arguments as the eager iteration, bit-identical results "
@@ -998,11 +1017,16 @@ def main():
     # ---- diagnostics pass (after the timed region, production two-stream mode): host enqueue time and, with a process
     # group, the exposed part of every exchange point
     diag = diagnostics_pass(tb, gs, args.diag_steps, barrier) if args.diag_steps > 0 else None
-    if tb.use_graph and diag is not None:        # the eager iteration's enqueue time beside the graph launch's
-        tb.use_graph = False
+    eager_info = None
+    if (tb.use_graph or tb.use_plan) and diag is not None:        # the eager iteration beside the replayed one: enqueue time and rate
+        tb.use_graph = tb.use_plan = False
         d2 = diagnostics_pass(tb, gs, args.diag_steps, barrier)
         diag["host_enqueue_ms_eager"] = d2["host_enqueue_ms"]
-    tb.use_graph = False                         # everything below (instrumented passes, arithmetic switches) runs eagerly
+        dte, eve = tb.timed(min(10, args.steps), 2, barrier)
+        eager_info = {"tiles_per_s": round(n * world * min(10, args.steps) / dte, 1), "step_ms_median": round(_median(eve), 3),
+                      "host_enqueue_ms": d2["host_enqueue_ms"],
+                      "note": "the same iteration enqueued from Python (the r01-r05 headline path), measured right after the timed region"}
+    tb.use_graph = tb.use_plan = False           # everything below (instrumented passes, arithmetic switches) runs eagerly
     # ---- per-kernel roofline pass.  In the timed region the weight-gradient kernels run concurrently with the
     # dgrad/BN chain on a second stream, so a kernel's event-to-event duration there includes time shared with another
     # kernel; the roofline numbers therefore come from a SERIALIZED pass of the same step, in this process, right after
@@ -1076,6 +1100,9 @@ def main():
             "loss_first_last": [round(loss_vals[0], 6), round(loss_vals[-1], 6)] if loss_vals else None,
         }
         out["hip_graph"] = graph_info
+        out["launch_plan"] = plan_info
+        if eager_info is not None:
+            out["eager_iteration"] = eager_info
         if dist_info:
             out["dist"] = dist_info
         if diag is not None:

@@ -99,6 +99,7 @@ int rd_plan_poison(const char* why);
 void* rd_plan_end(int* n_launches, int* n_segments);
 int rd_plan_replay(void* plan, int segment, rd_stream_t main_stream, rd_stream_t side_stream);
 int rd_plan_free(void* plan);
+int rd_plan_dump(void* plan);   /* diagnosis: the operations in enqueue order, one line each, to stderr */
 
 /* ---- weight (re)packing: torch layouts -> GEMM operand layouts ------------------- */
 /* Every packed operand B[rows][K = taps*Cin] is ONE opaque caller-owned buffer of

@@ -48,6 +48,7 @@ SIGNATURES = {
     "rd_plan_end": (P, [P, P]),
     "rd_plan_replay": (I, [P, I, P, P]),
     "rd_plan_free": (I, [P]),
+    "rd_plan_dump": (I, [P]),
     "rd_quant_next": (I, [P, P, P, P]),
     "rd_amax": (I, [P, LL, P, P]),
     "rd_zero": (I, [P, SZ, P]),
@@ -407,9 +408,14 @@ def pin_splitk_workspace(stream: "torch.cuda.Stream", nbytes: int = SPLITK_BYTES
     key = (index, stream.cuda_stream)
     with _ws_lock:
         old = _splitk.pop(key, None)
-        buf = old[0] if old is not None and old[0].numel() >= int(nbytes) else \
-            torch.empty(int(nbytes), dtype=torch.uint8, device=torch.device("cuda", index))
-        with torch.cuda.device(index):
+        # allocated UNDER `stream`: the registration zeroes the ticket area with a memset on that stream, and torch's allocator
+        # only hands a stream blocks whose earlier uses are ordered before it on the SAME stream.  (r06: allocated under the
+        # caller's current stream, the block could be one the previous iteration's kernels -- still running there -- had just
+        # given back; they then overwrote the zeroed tickets, and the first split-K launch of the capture's replay went wrong:
+        # found by the launch plan's bit-for-bit verification at batch 32, where the GPU lags the host by several iterations.)
+        with torch.cuda.device(index), torch.cuda.stream(stream):
+            buf = old[0] if old is not None and old[0].numel() >= int(nbytes) else \
+                torch.empty(int(nbytes), dtype=torch.uint8, device=torch.device("cuda", index))
             check(load().rd_set_splitk_workspace(buf.data_ptr(), buf.numel(), stream.cuda_stream), "set_splitk_workspace")
         _splitk[key] = [buf, _PINNED]
     return buf

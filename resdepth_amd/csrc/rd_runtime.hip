@@ -354,6 +354,11 @@ int rd_plan_replay(void* plan, int segment, rd_stream_t main_stream, rd_stream_t
     Plan* p = (Plan*)plan;
     RD_REQUIRE(p && segment >= 0 && segment < (int)p->seg_end.size(), "rd_plan_replay: bad plan / segment %d", segment);
     hipStream_t st[2] = {(hipStream_t)main_stream, (hipStream_t)side_stream};
+    // diagnosis: 1 = synchronise after every launch | 2 = everything on the main stream | 3 / 4 = synchronise after SIDE / main launches
+    static const int dbg = getenv("RD_PLAN_DEBUG") ? atoi(getenv("RD_PLAN_DEBUG")) : 0;
+    if (dbg == 2) st[1] = st[0];
+    static const int dlo = getenv("RD_PLAN_SYNC_LO") ? atoi(getenv("RD_PLAN_SYNC_LO")) : -1;       // 5: synchronise after ops [lo, hi)
+    static const int dhi = getenv("RD_PLAN_SYNC_HI") ? atoi(getenv("RD_PLAN_SYNC_HI")) : -1;
     const size_t a = segment ? p->seg_end[segment - 1] : 0, b = p->seg_end[segment];
     void* argv[64];
     for (size_t i = a; i < b; ++i) {
@@ -362,10 +367,31 @@ int rd_plan_replay(void* plan, int segment, rd_stream_t main_stream, rd_stream_t
             for (int k = 0; k < op.nargs; ++k) argv[k] = p->blob.data() + p->arg_off[op.arg0 + k];
             const hipError_t e = hipLaunchKernel(op.fn, op.grid, op.block, argv, op.shmem, st[op.role]);
             if (e != hipSuccess) return check_hip(e, "rd_plan_replay: launch");
+            if ((dbg == 1 || (dbg == 3 && op.role == 1) || (dbg == 4 && op.role == 0) || (dbg == 5 && (int)i >= dlo && (int)i < dhi)) &&
+                hipDeviceSynchronize() != hipSuccess)
+                return check_hip(hipGetLastError(), "rd_plan_replay: debug sync");
         } else if (op.kind == 1) {
             if (int e = check_hip(hipEventRecord(p->events[op.ev], st[op.role]), "rd_plan_replay: event record")) return e;
         } else {
             if (int e = check_hip(hipStreamWaitEvent(st[op.role], p->events[op.ev], 0), "rd_plan_replay: event wait")) return e;
+        }
+    }
+    return RD_OK;
+}
+
+// diagnosis: the plan's operations in enqueue order, one line each, to stderr
+int rd_plan_dump(void* plan) {
+    rd::Plan* p = (rd::Plan*)plan;
+    if (!p) return RD_ERR_ARG;
+    size_t seg = 0;
+    for (size_t i = 0; i < p->ops.size(); ++i) {
+        const rd::PlanOp& op = p->ops[i];
+        while (seg < p->seg_end.size() && p->seg_end[seg] <= i) fprintf(stderr, "  ---- end of segment %zu\n", seg++);
+        if (op.kind == 0) {
+            const char* nm = hipKernelNameRefByPtr(op.fn, nullptr);
+            fprintf(stderr, "%4zu %s launch %-60.60s grid %u block %u\n", i, op.role ? "SIDE" : "main", nm ? nm : "?", op.grid.x, op.block.x);
+        } else {
+            fprintf(stderr, "%4zu %s %s event %d\n", i, op.role ? "SIDE" : "main", op.kind == 1 ? "RECORD" : "WAIT  ", op.ev);
         }
     }
     return RD_OK;

@@ -202,6 +202,11 @@ class Trainer:
         # (at the benchmark batch the eager two-stream backward is 4-5 % faster).  Ragged batches, validation and
         # multi-rank gradient synchronisation run the eager iteration either way.
         self.hip_graph = bool(_get(args, "hip_graph", False))
+        # launch_plan (r06): replay the training iteration from a recorded launch plan (resdepth_amd.plan.PlannedTrainStep) -- the
+        # same ~110 kernels enqueued from C on the real two streams: the eager iteration's GPU time (two-stream overlap kept,
+        # bit-identical) at a fraction of its host time, and it works under data parallelism (the collectives are issued between
+        # the plan's segments).  Off by default in the Trainer shell (a drop-in loop should not change behaviour silently).
+        self.launch_plan = bool(_get(args, "launch_plan", False))
         self._graphed = None
 
         if self.pretrained_path is not None:
@@ -327,10 +332,14 @@ class Trainer:
         for p in params:
             p.grad = None
         graphed = None
-        if phase == "train" and self.hip_graph and self.device.type == "cuda":
+        if phase == "train" and (self.hip_graph or self.launch_plan) and self.device.type == "cuda":
             if self._graphed is None or self._graphed.model is not self.model or self._graphed.optimizer is not self.optimizer:
-                from .graph import GraphedTrainStep
-                self._graphed = GraphedTrainStep(self.model, self.optimizer)
+                if self.launch_plan:
+                    from .plan import PlannedTrainStep
+                    self._graphed = PlannedTrainStep(self.model, self.optimizer)
+                else:
+                    from .graph import GraphedTrainStep
+                    self._graphed = GraphedTrainStep(self.model, self.optimizer)
             graphed = self._graphed
             self.model.train()
         for c_iter, batch in enumerate(loader):

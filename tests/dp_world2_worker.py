@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--arch", default="S", choices=["S", "odd"])
     ap.add_argument("--tune", default="", help="RD_TUNE string (kernel-selection knobs), applied before the library loads")
     ap.add_argument("--ragged", type=int, default=0)
+    ap.add_argument("--plan", type=int, default=0, help="mode plan: 1 = replay the iteration from a launch plan, 0 = eager")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     if a.tune:
@@ -193,6 +194,31 @@ def main():
                 losses.append(float(loss))
             torch.cuda.synchronize()
             torch.save({"losses": losses, "y0": y0, "grads0": grads0, "bufs0": bufs0, "n_buckets": n_buckets, "dec0": dec0,
+                        "state": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}, a.out)
+        elif a.mode == "plan":
+            # the iteration through resdepth_amd.plan.PlannedTrainStep (--plan 1) or its eager path (--plan 0): local BatchNorm,
+            # bucketed gradient all-reduce issued between the plan's segments
+            from resdepth_amd.plan import PlannedTrainStep
+            torch.manual_seed(100 + a.rank)
+            model = UNet(**ARCH[a.arch]).to(dev).train()
+            gs = dp.attach(model, sync_bn=False, bucket_bytes=a.bucket_mb << 20)
+            dp.broadcast_parameters(model, 0)
+            opt = FusedAdam(model.parameters(), lr=2e-4, weight_decay=1e-5)
+            step_fn = PlannedTrainStep(model, opt, warmup=1 if a.plan else 1 << 60)
+            shards = []
+            for k in range(2):
+                b = dp.shard_batch(make_batch(a.batch, k, a.tile, ARCH[a.arch]["n_input_channels"]), a.rank, a.world)
+                shards.append((b["input"].to(dev), b["target"].to(dev), b["loss_mask"].to(dev), b["dsm_mean"].float().to(dev),
+                               b["dsm_std"].float().to(dev)))
+            losses, how = [], []
+            for step in range(a.steps):
+                losses.append(step_fn(*shards[step % 2]).clone())
+                how.append(step_fn.why_eager)
+            torch.cuda.synchronize()
+            torch.save({"losses": torch.stack(losses).cpu(), "how": how, "replays": step_fn.replays, "segments": step_fn.n_segments,
+                        "launches": step_fn.n_launches, "rejected": getattr(step_fn, "plan_rejected", None),
+                        "n_buckets": len(gs._buckets) if gs._buckets else 0,
+                        "opt_step": float(next(iter(opt.state_dict()["state"].values()))["step"]),
                         "state": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}}, a.out)
         elif a.mode == "infer":
             from torch.utils.data import DataLoader
