@@ -39,23 +39,33 @@ if ROOT not in sys.path:
 FLOP_PER_TILE = 59.33e9        # fwd+bwd, cfg-S (SURVEY.md 8d / BASELINE.md section 2)
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: f32-input MFMA = fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA (2495 measured)
-# split-bf16 kernels (DESIGN.md "split-bf16 MFMA"): every fp32 multiply-add costs six bf16 MFMA products, so the matrix
-# pipe bounds them at 2500/6 fp32-equivalent TFLOP/s
+# split kernels: every fp32 multiply-add costs `products` 16-bit MFMA products -- 3 in the default split2h
+# arithmetic (two fp16 terms), 6 in split3 (three bf16 terms) -- so the matrix pipe bounds them at 2500 / products
+# fp32-equivalent TFLOP/s
+def peak_split_tflops(products):
+    return PEAK_BF16_TFLOPS / float(products)
+
+
 PEAK_SPLIT_TFLOPS = PEAK_BF16_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0
 # measured bounds: scripts/split_numerics.py / tests/test_split_numerics_gpu.py
-ARITHMETIC = ("fp32 storage and accumulation; MFMA-class kernels multiply exactly-split operands (x = x1+x2+x3, bf16 terms by "
-              "truncation) on v_mfma_f32_32x32x16_bf16, 6 of the 9 term products per multiply -- the three dropped products are "
-              "below 2^-21 |ab| (worst case); the leading product a1*b1 and the five low-order products accumulate in separate "
-              "fp32 accumulators merged once per output (measured on all-positive operands at K = 4608: 5.9 u rms / 27 u max, "
-              "u = 2^-24, vs 16 u / 75 u for the exact-f32 MFMA chain; tests/test_split_numerics_gpu.py); +-Inf / NaN operands "
-              "propagate exactly like fp32 in the forward / data-gradient kernels (weight gradients: same set of non-finite "
-              "outputs, an Inf may surface as NaN); RD_MFMA=f32 selects the exact-f32 MFMA kernels")
-ARITHMETIC_SPLIT2 = ("RD_MFMA=split2 (libresdepth_hip_split2.so, OPT-IN, not the headline arithmetic): fp32 storage and accumulation; MFMA-class "
-                     "kernels multiply two-term operands (x ~ x1+x2, round-to-nearest bf16 terms, |x - x1 - x2| <= 2^-16 |x|) with three "
-                     "products per multiply (a1 b1, a1 b2, a2 b1): |error| <= 3 * 2^-16 |ab| per product, ~17 significant bits; whole net "
-                     "on cfg-S: forward 7e-6, gradients <= 4e-5 rel-L2 against the fp64 oracle (tests/test_split2_gpu.py)")
-MFMA_RANDOM_OPERAND_TFLOPS = 1850.0     # measured, scripts/ubench/mfma_order.hip: register-only MFMA loop on split terms (hi/mid/lo) of N(0,1) floats
+# measured bounds: tests/test_split2h_gpu.py, tests/test_split_numerics_gpu.py
+ARITHMETIC_SPLIT2H = ("fp32 storage and accumulation; MFMA-class kernels multiply every operand as TWO fp16 terms of s*x (s = a power of "
+                      "two per operand tensor from the tensor's maximum, which the producing kernel's epilogue leaves in a device slot: "
+                      "order-independent integer max, bit-reproducible) with THREE products per multiply (a1 b1 | a1 b2, a2 b1 in a "
+                      "second fp32 accumulator) on v_mfma_f32_32x32x16_f16, scaled back exactly: <= 3 * 2^-22 |ab| per product; per op "
+                      "against fp64 the error is BELOW the exact-f32 MFMA chain's on every operand flavour (0.17-0.23 u rms vs 0.34-0.47 "
+                      "on N(0,1) data at K = 4608, u = 2^-24; tests/test_split2h_gpu.py), every whole-net parity bar of tests/ holds; a "
+                      "launch whose operand has no slot or an infinite element runs the six-product split3 body (decided on the device): "
+                      "fp32's non-finite semantics.  Inference keeps split3 (results independent of the batch a tile is in). "
+                      "RD_MFMA=split3 / f32 select the other arithmetics")
+ARITHMETIC_SPLIT3 = ("RD_MFMA=split3: fp32 storage and accumulation; MFMA-class kernels multiply exactly-split operands (x = x1+x2+x3, bf16 "
+                     "terms by truncation) on v_mfma_f32_32x32x16_bf16, 6 of the 9 term products per multiply -- the three dropped products "
+                     "are below 2^-21 |ab| (worst case); hi / lo fp32 accumulators merged once per output; +-Inf / NaN operands propagate "
+                     "exactly like fp32 in the forward / data-gradient kernels")
+ARITHMETIC = ARITHMETIC_SPLIT2H
+MFMA_RANDOM_OPERAND_TFLOPS = 1850.0     # measured, scripts/ubench/mfma_order.hip: register-only bf16 MFMA loop on split terms (hi/mid/lo) of N(0,1) floats
+MFMA_F16_SPLIT_OPERAND_TFLOPS = 1717.0  # measured r06, scripts/ubench/mfma_f16.hip: the same loop on the two fp16 terms of scaled N(0,1) floats (profiles/r06_mfma_f16.txt)
 MFMA_CLASSES = ("conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "convt2x2_fwd", "convt2x2_dgrad", "convt2x2_wgrad")
 
 
@@ -237,6 +247,8 @@ def infer_main(args, world, rank, dev):
     torch.manual_seed(0)
     model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).eval()
     model.fold_eval_bn = not args.no_fold
+    model.fast_eval = bool(args.fast_eval)       # three-product bodies in the sweep (results then depend on the batch a tile is in)
+    model_fast_eval = model.fast_eval and _lib.products() == 3
     ds = SyntheticRasterTiles(args.raster, args.raster, 3, tile_size=256, seed=1, shard=(rank, world))
     # tiles are staged on the device once (the metric excludes host->device staging, as for training)
     batches = []
@@ -287,14 +299,16 @@ def infer_main(args, world, rank, dev):
             "metric": "DSM tiles/sec forward-only tiled inference + linear blend (256x256, 3-ch, depth-5 U-Net)",
             "value": round(tiles_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32" if _lib.mfma_mode() != "split2" else "f32 storage / bf16x2 multiplies (RD_MFMA=split2)",
+            "vs_baseline": None, "dtype": "f32", "arithmetic_mode": ("split2h" if model_fast_eval else "split3") if _lib.mfma_mode() != "f32" else "f32",
             "data": "synthetic raster",
             "config": {"workload": f"cfg-G: {args.raster}x{args.raster} raster, {n_tiles_global} tiles of 256x256 at stride 128, "
                                    f"eval-mode BN, batch {args.batch}",
                        "parallelism": f"tiles sharded over {world} GPU(s)" + (" (ranks SHARE one GPU: code-path check)" if args.share_gpu else "")},
             "e2e": {"tflops": round(tiles_s / world * fwd_flop / 1e12, 2),
                     "frac_f32_peak": round(tiles_s / world * fwd_flop / 1e12 / PEAK_F32_TFLOPS, 4)},
-            "roofline": build_roofline(kern, 1, PMC_SUMMARIES["G"], "HIP events, one instrumented sweep right after the timed "
+            "roofline": build_roofline(kern, 1, PMC_SUMMARIES["G"], products=3 if model_fast_eval else 6,
+                                       mode=("split2h" if model_fast_eval else "split3") if _lib.mfma_mode() != "f32" else "f32",
+                                       measured="HIP events, one instrumented sweep right after the timed "
                                        "sweeps (this rank's shard of the tiles)", per="sweep"),
             "raster_checksum": checksum, "dist": dist_info, "sweep": sweep_info,
             "kernels": kernel_rows(kern, 1, per="sweep")}
@@ -390,8 +404,7 @@ class TrainBench:
 
 # committed rocprofv3 PMC summaries (scripts/profile.sh + scripts/summarize_prof.py) per workload, newest first: the source
 # of `roofline.traffic` / `roofline.pmc` -- counters are never collected by bench.py itself
-PMC_SUMMARIES = {"S": ("r05_summary.json", "r05a_summary.json", "r04_summary.json", "r03_summary.json", "r02_summary.json", "r01_summary.json"),
-                 "M": ("r05_cfgM_summary.json", "r04_cfgM_summary.json"), "G": ("r05_cfgG_summary.json", "r04_cfgG_summary.json")}
+PMC_SUMMARIES = {"S": ("r06_summary.json",), "M": ("r06_cfgM_summary.json",), "G": ("r06_cfgG_summary.json",)}
 
 
 def kernel_rows(kern, prof_steps, per="step"):
@@ -414,7 +427,7 @@ def kernel_rows(kern, prof_steps, per="step"):
     return rows
 
 
-def build_roofline(kern, prof_steps, summaries, measured, per="step"):
+def build_roofline(kern, prof_steps, summaries, measured, per="step", products=None, mode=None):
     """`roofline` of the dominant KERNEL (= one kernel symbol as rocprofv3 reports it; e.g. the conv3x3 forward and
     data-gradient launches are the same conv3_halo_split instantiation): algorithmic FLOP per launch / average launch
     duration from the HIP events of rd_prof_*, against the pipe that bounds it."""
@@ -434,7 +447,16 @@ def build_roofline(kern, prof_steps, summaries, measured, per="step"):
         # of this same command (scripts/profile.sh + scripts/summarize_prof.py; FETCH_SIZE doubled per the guide)
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                rec = json.load(f)["kernels"][sym]
+                whole = json.load(f)
+            from resdepth_amd import _lib as _l3
+            have = (_l3.load().rd_version(), mode or _l3.mfma_mode())
+            if (whole.get("rd_version"), whole.get("arithmetic_mode")) != have:
+                # a summary of another library / arithmetic: its bytes and pipe figures describe other kernels under the same
+                # symbol names -- no traffic rather than someone else's (r05 verdict, evidence defect 16)
+                traffic_src = (f"profiles/{name} was taken with library version {whole.get('rd_version')} / mode "
+                               f"{whole.get('arithmetic_mode')}, this run is {have[0]} / {have[1]}: traffic not quoted")
+                continue
+            rec = whole["kernels"][sym]
             traffic = rec["hbm_bytes_per_launch"]
             # same passes: MFMA pipe busy fraction IN CYCLES and the effective clock (power-limited DVFS) -- the
             # product of the two, relative to 2.4 GHz, is what `frac` sees
@@ -445,18 +467,26 @@ def build_roofline(kern, prof_steps, summaries, measured, per="step"):
         except Exception:       # noqa: BLE001
             continue
     is_split = any(tag in sym for tag in ("split", "strip", "convt_"))
-    peak = PEAK_SPLIT_TFLOPS if is_split else PEAK_F32_TFLOPS
+    if products is None:
+        from resdepth_amd import _lib as _l2
+        products = _l2.products()           # 3: split2h (training default), 6: split3
+    peak = peak_split_tflops(products) if is_split else PEAK_F32_TFLOPS
+    power_peak = (MFMA_F16_SPLIT_OPERAND_TFLOPS if products == 3 else MFMA_RANDOM_OPERAND_TFLOPS) / products
     return {"kernel": sym, "ops": sorted(dom["ops"]), "bound": "mfma", "achieved": round(ach, 2),
             "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "peak_note": ("fp32-equivalent FLOP/s; bound = dense bf16 MFMA peak (2500 TF) / 6 products per fp32 "
-                          "multiply-add of the exact 3-term split" if is_split else "f32-input MFMA peak"),
+            "peak_note": (f"fp32-equivalent FLOP/s; bound = dense 16-bit MFMA peak (2500 TF) / {products} products per fp32 "
+                          "multiply-add (" + ("two fp16 terms, split2h" if products == 3 else "three bf16 terms, split3") + ")"
+                          if is_split else "f32-input MFMA peak"),
+            "products_per_multiply": products if is_split else 1,
             "frac_of_f32_mfma_peak": round(ach / PEAK_F32_TFLOPS, 4),
             # scripts/ubench/mfma_power.hip / mfma_order.hip (profiles/r03_notes.md section 9): a register-only loop of
             # back-to-back v_mfma_f32_32x32x16_bf16 (pipe 100 % busy, no memory traffic) sustains 2486 TFLOP/s on constant
             # operands, 1684-1724 on random bits and 1850 on what these kernels feed it (the three split terms of
             # N(0,1) floats) -- the power limit (effective clock 1.78 GHz).  Against THAT ceiling / 6 products:
-            "power_limited_peak": round(MFMA_RANDOM_OPERAND_TFLOPS / 6.0, 1) if is_split else None,
-            "frac_of_power_limited_peak": round(ach / (MFMA_RANDOM_OPERAND_TFLOPS / 6.0), 4) if is_split else None,
+            # (r06: the fp16 split terms draw more power per MFMA than the bf16 ones -- 1545-1717 vs 1836-1907 TFLOP/s in the same
+            # loop, profiles/r06_mfma_f16.txt)
+            "power_limited_peak": round(power_peak, 1) if is_split else None,
+            "frac_of_power_limited_peak": round(ach / power_peak, 4) if is_split else None,
             "traffic": traffic, "traffic_source": traffic_src, "pmc": pmc, "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
             "alg_flop_per_launch": dom["flops"] / dom["launches"],
             f"launches_per_{per}": dom["launches"] / prof_steps,
@@ -569,20 +599,16 @@ def eval_stats_measurement(dev, side=8192):
                     "(f64) + ground truth (f32) + mask (u8) per call"}
 
 
-def split2_measurement():
-    """RD_MFMA=split2 in a child process (train step of cfg-S and the cfg-G sweep), never `value`."""
+def split3_measurement():
+    """RD_MFMA=split3 (six products everywhere) in a child process: the r01-r05 headline arithmetic on the same workloads."""
     env = {k: v for k, v in os.environ.items() if k != "RESDEPTH_HIP_LIB"}
-    env["RD_MFMA"] = "split2"
+    env["RD_MFMA"] = "split3"
     base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-secondary", "--no-prof"]
     r = subprocess.run(base + ["--steps", "20", "--warmup", "5"], env=env, capture_output=True, text=True, timeout=600)
     d = json.loads(r.stdout.strip().splitlines()[-1])
-    out = {"tiles_per_s": d["value"], "step_ms_median": d["step_ms_median"], "arithmetic": d["arithmetic"],
-           "note": "python bench.py under RD_MFMA=split2 in a child process, 20 timed steps of the same cfg-S workload; an opt-in "
-                   "precision mode, NOT the headline arithmetic"}
-    r = subprocess.run(base + ["--infer", "--raster", "8192", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
-                       timeout=600)
-    g = json.loads(r.stdout.strip().splitlines()[-1])
-    out["cfg_G_tiles_per_s"] = g["value"]
+    out = {"tiles_per_s": d["value"], "step_ms_median": d["step_ms_median"],
+           "note": "python bench.py under RD_MFMA=split3 in a child process, 20 timed steps of the same cfg-S workload: three bf16 "
+                   "terms / six products per multiply in every MFMA-class kernel (the default arithmetic of r01-r05)"}
     r = subprocess.run(base + ["--workload", "M", "--steps", "3", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=600)
     out["cfg_M_tiles_per_s"] = json.loads(r.stdout.strip().splitlines()[-1])["value"]
     return out
@@ -640,10 +666,10 @@ def secondary_measurements(args, dev, tb):
         _lib.tune_set("mfma_f32", 0)
         tb.model.invalidate_packed()
         _lib.prof_enable(0)
-    try:        # the opt-in two-term / three-product build on the same workload (its library is chosen per process: child run)
-        out["split2"] = split2_measurement()
+    try:        # the six-product arithmetic on the same workloads (the library reads RD_MFMA once, at load time: child run)
+        out["split3"] = split3_measurement()
     except Exception as e:      # noqa: BLE001
-        out["split2"] = {"error": repr(e)[:300]}
+        out["split3"] = {"error": repr(e)[:300]}
     try:        # the launch-bound regime: the same iteration at batch 4, eager (~110 launches) vs one captured HIP graph per step
         out["hip_graph_small_batch"] = graph_small_batch_measurement(dev, tb.wl)
     except Exception as e:      # noqa: BLE001
@@ -915,9 +941,12 @@ def main():
     ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; gloo for --rendezvous-only on CPU)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="CODE-PATH CHECK, never a measurement: every rank uses cuda:0 (RCCL refuses two ranks on one device, so "
-                         "this needs --backend gloo; device collectives go through tests/host_staged_collectives.py).  Lets a "
+                         "this needs --backend gloo, which takes device tensors natively in this torch build).  Lets a "
                          "one-GPU box execute `bench.py --gpus N` end to end: launcher, broadcast, bucketed all-reduce, "
                          "max-over-ranks timing, rank-0 line")
+    ap.add_argument("--fast-eval", action="store_true",
+                    help="--infer: UNet.fast_eval = True, the sweep's convolutions on the three-product split2h bodies (default: split3, "
+                         "so that a tile's result does not depend on the batch it is in)")
     ap.add_argument("--no-fold", action="store_true", help="--infer: keep eval-mode BN as separate kernels (A/B of the folded path)")
     ap.add_argument("--prof-all", action="store_true", help="(kept for scripts) same as the default full breakdown")
     ap.add_argument("--force-dist", action="store_true",
@@ -1076,8 +1105,8 @@ def main():
                       "DSM tiles/sec fwd+bwd (512x512, 2-ch, depth-6 U-Net)", "value": round(tiles_s, 2),
             "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if mode != "split2" else "f32 storage / bf16x2 multiplies (RD_MFMA=split2)",
-            "arithmetic": ARITHMETIC if mode != "split2" else ARITHMETIC_SPLIT2,
+            "dtype": "f32", "arithmetic_mode": mode,
+            "arithmetic": ARITHMETIC_SPLIT2H if mode == "split2h" else ARITHMETIC_SPLIT3 if mode == "split3" else "RD_MFMA=f32: v_mfma_f32_32x32x2_f32, exact",
             "data": ("synthetic rasters resident in HBM, a fresh augmented batch assembled on the GPU every step"
                      if args.from_rasters else "synthetic (randn tiles resident in HBM, default-initialised weights)"),
             "config": {"workload": wl["name"] + ", fwd+loss+bwd+Adam",
@@ -1092,7 +1121,7 @@ def main():
                            "pair per step on the launch stream (rank 0)",
             "e2e": {"tflops": round(per_gpu * wl["flop"] / 1e12, 2),
                     "frac_f32_peak": round(per_gpu * wl["flop"] / 1e12 / PEAK_F32_TFLOPS, 4),
-                    "frac_split_mfma_bound": round(per_gpu * wl["flop"] / 1e12 / (PEAK_SPLIT_TFLOPS * (2 if mode == "split2" else 1)), 4),
+                    "frac_split_mfma_bound": round(per_gpu * wl["flop"] / 1e12 / peak_split_tflops(3 if mode == "split2h" else 6), 4),
                     "hbm_frac": round(per_gpu * wl["bytes_a"] / (PEAK_HBM_GBS * 1e9), 4),
                     "hbm_frac_note": "tiles/s/GPU x op-level compulsory bytes per tile (SURVEY 8d model A) / 8 TB/s"},
             "roofline": roof,

@@ -77,6 +77,21 @@ out = {"note": "FETCH_SIZE/WRITE_SIZE are KiB counters; fetch is doubled (gfx950
                "GRBM_GUI_ACTIVE is summed over the 8 XCDs (clock = GUI/8/duration). MFMA pipe utilisation = "
                "SQ_VALU_MFMA_BUSY_CYCLES / (GUI/8 * 1024 SIMDs).",
        "kernels": {}}
+# the library and the arithmetic the passes ran with (bench.py quotes `traffic` / `pmc` from a summary only when both match
+# the run that reads it): from the bench line captured under the kernel trace, else from the library as it loads here
+try:
+    line = json.loads(open(os.path.join(SRC, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+    out["arithmetic_mode"] = line.get("arithmetic_mode")
+except Exception:       # noqa: BLE001
+    out["arithmetic_mode"] = None
+try:
+    sys.path.insert(0, ROOT)
+    from resdepth_amd import _lib
+    out["rd_version"] = _lib.load().rd_version()
+    if out["arithmetic_mode"] is None:
+        out["arithmetic_mode"] = _lib.mfma_mode()
+except Exception:       # noqa: BLE001
+    out["rd_version"] = None
 for k, st in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"]):
     e = dict(st)
     if k in fetch and k in write:

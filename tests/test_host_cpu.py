@@ -287,3 +287,26 @@ def test_flat_buffer_layout_follows_gradient_completion_order(kw):
     assert launched == list(range(len(buckets)))
     last_stage = [max(stage(i) for i in b["params"]) for b in buckets]
     assert last_stage == sorted(last_stage)
+
+
+def test_bench_quotes_pmc_traffic_only_from_a_summary_of_the_same_library_and_arithmetic(tmp_path, monkeypatch):
+    """r05 verdict, evidence defect 16: `roofline.traffic` / `pmc` come from committed rocprofv3 summaries; one taken with
+    another library version or arithmetic mode describes other kernels under the same symbol names -> traffic null + reason."""
+    import importlib
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from resdepth_amd import _lib
+    ver, mode = _lib.load().rd_version(), _lib.mfma_mode()
+    (tmp_path / "profiles").mkdir()
+    kern = [{"name": "conv3x3_fwd|conv3_halo_split<128>", "ms": 1.0, "flops": 3e11, "bytes": 1e8, "launches": 2}]
+    rec = {"kernels": {"conv3_halo_split<128>": {"hbm_bytes_per_launch": 123.0, "mfma_pipe_util": 0.5}}}
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    for stamp, want in (({"rd_version": ver, "arithmetic_mode": mode}, 123.0), ({"rd_version": ver - 1, "arithmetic_mode": mode}, None),
+                        ({"rd_version": ver, "arithmetic_mode": "split3" if mode != "split3" else "split2h"}, None), ({}, None)):
+        json.dump(dict(rec, **stamp), open(tmp_path / "profiles" / "x_summary.json", "w"))
+        roof = bench.build_roofline(kern, 1, ("x_summary.json",), "test")
+        assert roof["traffic"] == want, (stamp, roof["traffic"], roof["traffic_source"])
+        if want is None:
+            assert roof["pmc"] is None and "not quoted" in roof["traffic_source"]
