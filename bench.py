@@ -782,6 +782,66 @@ def diagnostics_pass(tb, gs, steps, barrier):
     return out
 
 
+def dist_tuning_pass(tb, gs, args, barrier, steps):
+    """What the FIRST multi-GPU run needs to tune itself (r05 verdict, next 3) -- after the timed region, never part of `value`,
+    eager iteration (a launch plan is recorded for ONE bucket plan):
+      * bucket sweep: the diagnostics pass again with 4 / 8 / 16 MB gradient buckets -> step time, exposed all-reduce (main stream
+        blocked in GradSync.finish), bucket count, when each bucket was issued;
+      * CU contention: the MFMA-class kernels' own time per step (HIP events around each launch, rd_prof level 1) WITH the
+        collectives in flight and WITHOUT them (grad_sync detached: the same kernels, no RCCL kernels co-resident) -- RCCL's
+        channels occupy CUs and LDS the convolution kernels would use;
+      * RCCL facts: library version and the channel-count environment (--rccl-channels sets NCCL_MIN / MAX_NCHANNELS)."""
+    from resdepth_amd import _lib
+    out = {"bucket_sweep": [], "note": "eager iteration, diagnostics only"}
+    keep = gs.bucket_bytes
+    for mb in (4, 8, 16):
+        gs.bucket_bytes = mb << 20
+        gs._model_key = None                              # re-plan the buckets at the next backward
+        for _ in range(2):
+            tb.step()
+        d = diagnostics_pass(tb, gs, steps, barrier)
+        out["bucket_sweep"].append({"bucket_mb": mb, "step_ms": d.get("step_ms_under_probe"),
+                                    "exposed_grad_allreduce_ms": (d.get("grad_wait") or {}).get("device_ms_per_step"),
+                                    "n_buckets": (d.get("plan") or {}).get("n_buckets"),
+                                    "bucket_issue_ms_after_step_start": d.get("bucket_issue_ms_after_step_start")})
+    gs.bucket_bytes = keep
+    gs._model_key = None
+
+    def mfma_ms():
+        for _ in range(2):
+            tb.step()
+        barrier()
+        _lib.prof_reset()
+        _lib.prof_enable(1)
+        for _ in range(steps):
+            tb.step()
+        torch.cuda.synchronize()
+        _lib.prof_enable(0)
+        return round(sum(k["ms"] for k in _lib.prof_collect()) / steps, 3)
+    with_c = mfma_ms()
+    model_gs, tb_gs = tb.model.grad_sync, tb.gs
+    tb.model.grad_sync = tb.gs = None                     # the same kernels without any collective (local loss normaliser)
+    try:
+        without_c = mfma_ms()
+    finally:
+        tb.model.grad_sync, tb.gs = model_gs, tb_gs
+    for _ in range(2):
+        tb.step()
+    barrier()
+    out["mfma_kernel_ms_per_step"] = {"with_collectives_in_flight": with_c, "without_collectives": without_c,
+                                      "note": "sum of the MFMA-class kernels' HIP-event durations per step (two-stream backward: "
+                                              "overlapping kernels each count their own elapsed time); the difference is what RCCL's "
+                                              "co-resident channels cost the convolution kernels"}
+    try:
+        ver = torch.cuda.nccl.version()
+    except Exception:       # noqa: BLE001
+        ver = None
+    out["rccl"] = {"version": ver, "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
+                   "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"), "NCCL_ALGO": os.environ.get("NCCL_ALGO"),
+                   "NCCL_PROTO": os.environ.get("NCCL_PROTO"), "rccl_channels_flag": args.rccl_channels}
+    return out
+
+
 def summarize_ranks(per_rank_ms, diags, args):
     """rank 0: the per-rank diagnostics -> the `dist` fields (DESIGN.md section 6 says how to read each one)."""
     def col(key, sub=None):
@@ -803,6 +863,16 @@ def summarize_ranks(per_rank_ms, diags, args):
            "loss_normaliser_allreduce_ms_per_rank": col("loss_norm", "device_ms_per_step"),
            "affinity_per_rank": col("affinity")}
     d0 = diags[0] or {}
+    if "tuning" in d0:
+        t0 = d0["tuning"]
+        out["bucket_sweep_rank0"] = t0.get("bucket_sweep")
+        out["rccl"] = t0.get("rccl")
+        out["mfma_kernel_ms_per_step_per_rank"] = [((d or {}).get("tuning") or {}).get("mfma_kernel_ms_per_step") for d in diags]
+        sweep = [b for b in (t0.get("bucket_sweep") or []) if b.get("step_ms") is not None]
+        if sweep:
+            best = min(sweep, key=lambda b: b["step_ms"])
+            out["bucket_sweep_best"] = {"bucket_mb": best["bucket_mb"], "step_ms": best["step_ms"],
+                                        "note": "fastest of the swept bucket sizes on rank 0 (re-run with --bucket-mb to adopt it)"}
     if "plan" in d0:
         out["gradient_buckets"] = d0["plan"]
     if "bucket_issue_ms_after_step_start" in d0:
@@ -880,6 +950,8 @@ def init_dist(args):
     collectives take device tensors in this torch build (staged through the host by the backend itself; nothing from
     tests/ is imported here)."""
     import torch.distributed as dist
+    if getattr(args, "rccl_channels", 0) > 0:
+        os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
     dist.init_process_group(args.backend or "nccl")
 
 
@@ -949,6 +1021,10 @@ def main():
                          "so that a tile's result does not depend on the batch it is in)")
     ap.add_argument("--no-fold", action="store_true", help="--infer: keep eval-mode BN as separate kernels (A/B of the folded path)")
     ap.add_argument("--prof-all", action="store_true", help="(kept for scripts) same as the default full breakdown")
+    ap.add_argument("--rccl-channels", type=int, default=0,
+                    help="set NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS = N before the process group is created (0: RCCL's own choice); "
+                         "fewer channels leave more CUs / LDS to the convolution kernels the all-reduce overlaps")
+    ap.add_argument("--no-tuning", action="store_true", help="skip the bucket-size sweep / CU-contention passes of a multi-rank run")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the data-parallel code path (RCCL process group, bucketed all-reduce) even at world size 1")
     ap.add_argument("--no-pin", action="store_true",
@@ -1056,6 +1132,8 @@ def main():
                       "host_enqueue_ms": d2["host_enqueue_ms"],
                       "note": "the same iteration enqueued from Python (the r01-r05 headline path), measured right after the timed region"}
     tb.use_graph = tb.use_plan = False           # everything below (instrumented passes, arithmetic switches) runs eagerly
+    if use_dist and gs is not None and diag is not None and not args.no_tuning:
+        diag["tuning"] = dist_tuning_pass(tb, gs, args, barrier, max(2, min(args.diag_steps, 4)))
     # ---- per-kernel roofline pass.  In the timed region the weight-gradient kernels run concurrently with the
     # dgrad/BN chain on a second stream, so a kernel's event-to-event duration there includes time shared with another
     # kernel; the roofline numbers therefore come from a SERIALIZED pass of the same step, in this process, right after

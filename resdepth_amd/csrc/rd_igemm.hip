@@ -818,16 +818,25 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackItem* __restric
 }
 
 
-// magnitude slots of every item of a fused pack (first pass of rd_pack_weights_fused in three-product mode): 32 blocks per item
+// magnitude slots of every item of a fused pack (first pass of rd_pack_weights_fused in three-product mode): AMAX_PARTS blocks per
+// item, four elements per thread and trip in flight (r06: 32 blocks per item took 126 us -- a 9.4 MB layer over 32 blocks is
+// latency-bound -- ahead of the pack itself on the stream the first 3 x 3 convolution waits for)
+constexpr int AMAX_PARTS = 256;
 __global__ __launch_bounds__(256) void pack_items_amax_kernel(const PackItem* __restrict__ items, int n_items) {
-    const int it = blockIdx.x >> 5, part = blockIdx.x & 31;
+    const int it = blockIdx.x / AMAX_PARTS, part = blockIdx.x % AMAX_PARTS;
     const PackItem I = items[it];
     if (!I.amax) return;
     const float* __restrict__ w = reinterpret_cast<const float*>(I.w);
     const long n = (long)I.cout * I.cin * (I.kind == 0 ? 9 : 4);
-    float m = 0.f;
-    for (long e = (long)part * 256 + threadIdx.x; e < n; e += 32 * 256) m = amax_acc(m, w[e]);
-    amax_commit(reinterpret_cast<unsigned*>(I.amax), m);
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    const long stride = (long)AMAX_PARTS * 256;
+    long e = (long)part * 256 + threadIdx.x;
+    for (; e + 3 * stride < n; e += 4 * stride) {
+        const float a = w[e], b = w[e + stride], c = w[e + 2 * stride], d = w[e + 3 * stride];
+        m0 = amax_acc(m0, a); m1 = amax_acc(m1, b); m2 = amax_acc(m2, c); m3 = amax_acc(m3, d);
+    }
+    for (; e < n; e += stride) m0 = amax_acc(m0, w[e]);
+    amax_commit(reinterpret_cast<unsigned*>(I.amax), fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
 }
 
 // ---- tile packer: layers whose channel counts are multiples of 32 (every MFMA layer of cfg-S / cfg-M) -----------------------
@@ -1786,7 +1795,7 @@ int rd_pack_weights_fused(const void* items_dev, int n_items, long long total_pi
     ProfScope ps((hipStream_t)s, "pack_weights", 0, 10.0 * 8.0 * (double)total_pieces + 14.0 * 9216.0 * (double)total_tiles);
     // items with a magnitude slot (column 9 of the table; zeroed by the caller) get the three-product form too: first their maxima
     if (mfma_products() == 3)
-        RD_LAUNCH(pack_items_amax_kernel, dim3(32 * n_items), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items);
+        RD_LAUNCH(pack_items_amax_kernel, dim3(AMAX_PARTS * n_items), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items);
     if (total_tiles > 0) {
         const long gt = total_tiles < 4096 ? total_tiles : 4096;
         RD_LAUNCH(pack_tiles_kernel, dim3((int)gt), dim3(256), 0, (hipStream_t)s, (const PackItem*)items_dev, n_items,

@@ -45,3 +45,40 @@ def test_weights_are_a_partition_of_unity():
         for (y, x), (uly, ulx, lry, lrx) in zip(pos, reg):
             acc[y:y + t, x:x + t] += B.blend_weights(t, s, ulx, uly, lrx, lry)
         np.testing.assert_allclose(acc, 1.0, rtol=0, atol=1e-12)
+
+
+def test_world8_band_sweep_assembles_the_unsharded_raster():
+    """cfg-G's multi-rank sweep at WORLD 8 (tiling.band_shards + the exchange of resdepth_amd/inference.py:_exchange_overlaps),
+    executed rank by rank in one process with the oracle's accumulate: every rank blends its tiles into its private band
+    [lo, hi), rows of its extent that another rank owns travel to their owner and are added there in ascending sender order,
+    every rank delivers the rows it owns -- the assembled raster equals the unsharded sweep (same additions per pixel up to
+    their order: 1e-12), on a two-area raster whose bands share rows with one and with two neighbours."""
+    from resdepth_amd.tiling import band_shards, regular_grid
+    rows, cols, t, s = 1400, 300, 64, 32
+    areas_x, areas_y = [(0, 199), (80, 299)], [(0, 799), (600, 1399)]
+    pos, reg = regular_grid(areas_x, areas_y, t, s)
+    rng = np.random.default_rng(5)
+    pred = rng.standard_normal((len(pos), 1, t, t))
+    means, stds = rng.standard_normal(len(pos)) * 10 + 400, np.full(len(pos), 3.0)
+    full = B.accumulate(np.zeros((rows, cols)), pred, means, stds, pos, reg, t, s)
+    for world in (8, 5):
+        plan = band_shards(pos, t, rows, world)
+        assert plan[0]["monotonic"] and plan[0]["c0"] == 0 and plan[-1]["c1"] == rows
+        private = []
+        for r, me in enumerate(plan):                       # every rank's sweep of its own tiles into its band-sized raster
+            band = np.zeros((max(me["hi"] - me["lo"], 0), cols))
+            i0, i1 = me["i0"], me["i1"]
+            shifted = [(y - me["lo"], x) for (y, x) in pos[i0:i1]]
+            private.append(B.accumulate(band, pred[i0:i1], means[i0:i1], stds[i0:i1], shifted, reg[i0:i1], t, s) if i1 > i0 else band)
+        out = np.full((rows, cols), np.nan)
+        for r, me in enumerate(plan):
+            own = private[r][me["c0"] - me["lo"]:me["c1"] - me["lo"]].copy()
+            for q, o in enumerate(plan):                    # ascending sender order, as the exchange adds them
+                if q == r or o["y0"] is None:
+                    continue
+                a, b = max(o["y0"], me["c0"]), min(o["y1"], me["c1"])
+                if b > a:
+                    own[a - me["c0"]:b - me["c0"]] += private[q][a - o["lo"]:b - o["lo"]]
+            out[me["c0"]:me["c1"]] = own
+        assert not np.isnan(out).any()
+        np.testing.assert_allclose(out, full, rtol=1e-12, atol=1e-9)

@@ -279,3 +279,102 @@ def test_four_rank_gloo_syncbn_uneven_bucket_order_matches_single_device():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in results), results
+
+
+def _worker8(rank, world, port, q, sync_bn):
+    """world 8, one tile per rank: the protocol of the 8-GPU node (BASELINE configs[2]) executed end to end on CPU -- global loss
+    normaliser, bucketed gradient all-reduce with the geometric tail (three pieces), SyncBN on (== one process at the global
+    batch) or off (== the sum of the eight shards' local-BN gradients under the global normaliser)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        import torch.nn.functional as F
+        g = torch.Generator().manual_seed(21)
+        w1 = torch.randn(8, 2, 3, 3, generator=g) * 0.3
+        gamma, beta = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g) * 0.1
+        w2 = torch.randn(8, 8, 3, 3, generator=g) * 0.2
+        w3 = torch.randn(1, 8, 3, 3, generator=g) * 0.3
+        b3 = torch.randn(1, generator=g)
+        base = (w1, gamma, beta, w2, w3, b3)
+        full = O.synthetic_batch(world, 2, 16, seed=19)
+        full["dsm_std"] = torch.linspace(0.5, 3.0, world)
+
+        def net(x, p, bn):
+            a = torch.relu(bn(F.conv2d(x, p[0], None, 1, 1), p[1], p[2]))
+            a = torch.relu(F.conv2d(a, p[3], None, 1, 1))
+            return x[:, 0:1] + F.conv2d(a, p[4], p[5], 1, 1)
+
+        def loss_num(yp, b):
+            return (((yp - b["target"]) * b["dsm_std"].view(-1, 1, 1, 1)).abs() * b["loss_mask"]).sum()
+
+        local_bn = lambda z, ga, be: F.batch_norm(z, None, None, ga, be, True, 0.1, 1e-5)      # noqa: E731
+        cnt_all = full["loss_mask"].sum()
+        if sync_bn:          # reference: one process, the whole batch
+            pr = [t.clone().requires_grad_(True) for t in base]
+            ref = torch.autograd.grad(loss_num(net(full["input"], pr, local_bn), full) / cnt_all, pr)
+        else:                # reference: every shard on its own statistics, gradients summed
+            ref = None
+            for r in range(world):
+                sh = dp.shard_batch(full, r, world)
+                pr = [t.clone().requires_grad_(True) for t in base]
+                # one tile per rank: 256 values per channel, batch_norm is happy
+                gr = torch.autograd.grad(loss_num(net(sh["input"], pr, local_bn), sh) / cnt_all, pr)
+                ref = [x.double() for x in gr] if ref is None else [a + x.double() for a, x in zip(ref, gr)]
+        # 64-byte buckets, 32-byte geometric tail: the leftover bucket is cut again (tests/test_dp_cpu.py::test_plan_buckets...)
+        gs = dp.GradSync(bucket_bytes=2048, tail_bytes=64)
+        local = dp.shard_batch(full, rank, world)
+        pl = [t.clone().requires_grad_(True) for t in base]
+        bn = (lambda z, ga, be: _SyncBN.apply(z, ga, be, gs)) if sync_bn else local_bn
+        num = loss_num(net(local["input"], pl, bn), local)
+        sums = torch.stack([num.detach().double(), local["loss_mask"].sum().double()])
+        assert gs.allreduce_loss_sums(sums, local["target"].numel()) == full["target"].numel()
+        assert float(sums[1]) == float(cnt_all)
+        gl = torch.autograd.grad(num / sums[1].float(), pl)
+        model = FlatModel([tuple(t.shape) for t in pl])
+        for i, gr in enumerate(gl):
+            o = model._offsets[i]
+            model._flat_grad[o:o + gr.numel()] = gr.flatten()
+        for i in reversed(range(len(pl))):
+            gs.params_ready(model, [i])
+        n_b = len(gs._buckets)
+        assert n_b >= 3 and sum(gs._launched) >= n_b - 1, (n_b, gs._launched)
+        sizes = [b["hi"] - b["lo"] for b in gs._buckets]
+        # [b3, w3, w2] fill the first bucket; the leftover [w1, gamma, beta] is cut again: [gamma, beta] goes out before the
+        # last (whole-tensor) piece w1
+        assert sizes == [649, 16, 144] and sum(sizes) == sum(t.numel() for t in pl), sizes
+        gs.finish(model)
+        for i, gr in enumerate(ref):
+            o = model._offsets[i]
+            got = model._flat_grad[o:o + gr.numel()].view(gr.shape)
+            err = float((got.double() - gr.double()).norm() / (gr.double().norm() + 1e-30))
+            assert err < 3e-5, (i, err)
+        gs.check_equal_across_ranks(3, "len(loader)")
+        lin = torch.nn.Linear(3, 2)
+        with torch.no_grad():
+            lin.weight.fill_(float(rank + 1))
+        dp.broadcast_parameters(lin, src=0)
+        assert float(lin.weight[0, 0]) == 1.0
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sync_bn", [True, False])
+def test_eight_rank_gloo_protocol_matches_single_device(sync_bn):
+    """r05 verdict, missing item 4: a world-8 execution of the DP protocol (the collectives, not only the plans)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q, sync_bn)) for r in range(8)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in results), results

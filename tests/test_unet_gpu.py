@@ -630,6 +630,18 @@ def test_bench_gpus_2_runs_end_to_end_without_a_launcher_on_one_gpu():
     assert len(d["bucket_issue_ms_after_step_start_rank0"]) == plan["n_buckets"]
     assert all(isinstance(a, dict) and "pinned" in a for a in d["affinity_per_rank"])
     assert o["host_enqueue_ms"] > 0
+    # r06: the headline iteration is the recorded launch plan, also under data parallelism (collectives between its segments)
+    lp = o["launch_plan"]
+    assert lp["enabled"] and lp["rejected"] is None and lp["replays"] >= 3 and lp["segments"] >= 2 + plan["n_buckets"], lp
+    assert o["host_enqueue_ms"] < o["host_enqueue_ms_eager"]
+    # ... and the first multi-rank run tunes itself: bucket-size sweep, RCCL facts, MFMA-kernel time with / without collectives
+    sweep = d["bucket_sweep_rank0"]
+    assert [b["bucket_mb"] for b in sweep] == [4, 8, 16] and all(b["step_ms"] > 0 and b["n_buckets"] >= 2 for b in sweep)
+    assert sweep[0]["n_buckets"] > sweep[2]["n_buckets"] and all(b["exposed_grad_allreduce_ms"] is not None for b in sweep)
+    assert d["bucket_sweep_best"]["bucket_mb"] in (4, 8, 16)
+    assert "version" in d["rccl"] and "NCCL_MAX_NCHANNELS" in d["rccl"]
+    mk = d["mfma_kernel_ms_per_step_per_rank"]
+    assert len(mk) == 2 and all(m["with_collectives_in_flight"] > 0 and m["without_collectives"] > 0 for m in mk)
     r = subprocess.run(common + ["--infer", "--raster", "1024", "--batch", "8", "--steps", "1", "--warmup", "1"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
