@@ -498,7 +498,7 @@ def _median(v):
     return v[len(v) // 2] if v else None
 
 
-def infer_sweep(dev, raster, batch, sweeps, warm=1, host_batches=False):
+def infer_sweep(dev, raster, batch, sweeps, warm=1, host_batches=False, fast_eval=False):
     """cfg-G on one GPU: `sweeps` full sweeps of a raster x raster synthetic DSM -> (tiles/s, n_tiles).  Tiles resident in HBM
     (the metric's convention: staging excluded), or host_batches=True: pinned HOST batch dicts, what a DataLoader(pin_memory=True)
     hands lib/evaluation.py:486-498 -- every tile crosses PCIe inside the timed sweep."""
@@ -506,6 +506,7 @@ def infer_sweep(dev, raster, batch, sweeps, warm=1, host_batches=False):
     from resdepth_amd import UNet, SyntheticRasterTiles, predict_linear_blend
     torch.manual_seed(0)
     model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).eval()
+    model.fast_eval = bool(fast_eval)
     ds = SyntheticRasterTiles(raster, raster, 3, tile_size=256, seed=1)
     move = (lambda v: v.pin_memory()) if host_batches else (lambda v: v.to(dev))
     batches = [{k: (move(v) if torch.is_tensor(v) else v) for k, v in b.items()} for b in DataLoader(ds, batch_size=batch, shuffle=False)]
@@ -728,9 +729,14 @@ def secondary_measurements(args, dev, tb):
         ts, nt = infer_sweep(dev, 8192, 32, 2)
         out["cfg_G"] = {"tiles_per_s": round(ts, 1), "tiles": nt, "tflops": round(ts * 19.80e9 / 1e12, 1),
                         "workload": "cfg-G on one GPU (SURVEY 8d size): 8192x8192 raster, 3969 tiles of 256x256 at stride 128, "
-                                    "eval-mode BN folded, batch 32, forward + linear blend, 2 timed sweeps"}
+                                    "eval-mode BN folded, batch 32, forward + linear blend, 2 timed sweeps; six-product split3 "
+                                    "arithmetic (the inference default: a tile's result does not depend on its batch)"}
+        tf, _ = infer_sweep(dev, 8192, 32, 2, fast_eval=True)
+        out["cfg_G"]["fast_eval_tiles_per_s"] = round(tf, 1)
+        out["cfg_G"]["fast_eval_note"] = ("UNet.fast_eval = True: the sweep's convolutions on the three-product split2h bodies (results "
+                                          "then depend, in the last bits, on which tiles share a batch)")
     except Exception as e:      # noqa: BLE001
-        out["cfg_G"] = {"error": repr(e)[:200]}
+        out["cfg_G"] = dict(out.get("cfg_G") or {}, error=repr(e)[:200])
     try:        # the same sweep fed from HOST batches (the drop-in call: a DataLoader's pinned batch dicts), 4096^2 raster
         res, _ = infer_sweep(dev, 4096, 32, 2)
         hst, nt = infer_sweep(dev, 4096, 32, 2, host_batches=True)
