@@ -124,7 +124,16 @@ class PlannedTrainStep(GraphedTrainStep):
 
     def _capture(self, batch):
         self._plan_error = None
-        super()._capture(batch)
+        try:
+            super()._capture(batch)
+        except _PlanUnavailable:
+            raise
+        except Exception as e:      # noqa: BLE001 -- whatever a capture can throw (a torch op that refuses to be captured, an
+            # allocator or runtime error): the recording executed nothing, so the eager iteration can take this call
+            _lib._plan_rec = None
+            self.invalidate()
+            self.warmup = 1 << 62
+            raise _PlanUnavailable(f"the recording raised {type(e).__name__}: {str(e)[:200]}") from e
         if self._plan is None:
             # the iteration holds something a plan cannot: stay eager from now on (the hipGraph of the capture is dropped too)
             why = self._plan_error
