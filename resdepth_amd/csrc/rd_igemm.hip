@@ -503,6 +503,27 @@ __device__ __forceinline__ void conv3_halo_split_body(const NtParams& p, float* 
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i][q] = *reinterpret_cast<const FR*>(nstage + a_rd[i] + NEXT + q * 8);
         };
+#if RD_TAP_FINE
+        if constexpr (NP == 3) {
+            // every fragment is re-read for the next tap right after ITS last use, pinned by scheduling fences
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                lo[i] = mfma16<NP>(af[i][1], bf[0], lo[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                af[i][1] = *reinterpret_cast<const FR*>(nstage + a_rd[i] + NEXT + 8);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) lo[i] = mfma16<NP>(af[i][0], bf[1], lo[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                acc[i][0] = mfma16<NP>(af[i][0], bf[0], acc[i][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                af[i][0] = *reinterpret_cast<const FR*>(nstage + a_rd[i] + NEXT);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
+#endif
         if constexpr (NP == 3) {
             // three products (a2 b1, a1 b2, a1 b1): term 2 does not exist
 #pragma unroll

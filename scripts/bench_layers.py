@@ -13,6 +13,7 @@ layers = [  # name, H, Cin, Cout
 convt = [("up0", 8, 512), ("up1", 16, 512), ("up2", 32, 256), ("up3", 64, 128), ("up4", 128, 64)]
 which = os.environ.get("BL_WHICH", "fwd,dgrad,wgrad,convt").split(",")
 reps = 5
+TAG = os.environ.get("BL_TAG", "1") == "1"      # BL_TAG=0: untagged operands -> six-product fallback bodies
 
 
 def timed(fn):
@@ -38,6 +39,8 @@ for name, h, cin, cout in layers:
     elif os.environ.get("BL_DATA") == "one":         # exact bf16 values: the mid / lo split terms are all zero
         x.fill_(1.0); dz.fill_(1.0); w.fill_(0.5)
     wf, wd = ops.pack_conv3x3_weight(w)
+    if TAG:
+        x, dz = ops.amax_of(x), ops.amax_of(dz)       # magnitude slots: the launches take the three-product bodies
     row = f"{name:5s} M={N*h*h:7d} Cin={cin:3d} Cout={cout:3d} "
     if "fwd" in which:
         ms, tf = timed(lambda: ops.conv3x3_fwd(x, wf)); row += f"| fwd {ms:6.3f} ms {tf:6.1f} TF "; tot["fwd"] = tot.get("fwd", 0) + ms
@@ -56,6 +59,8 @@ if "convt" in which:
         if os.environ.get("BL_DATA") == "zero":
             x.zero_(); do.zero_(); skip.zero_(); w.zero_(); b.zero_()
         wtf, wtd = ops.pack_convt2x2_weight(w)
+        if TAG:
+            x, do = ops.amax_of(x), ops.amax_of(do)
         row = f"{name:5s} M={N*h*h:7d} C={c:3d}          "
         ms, tf = timed(lambda: ops.convt2x2_fwd(x, wtf, b, skip)); row += f"| fwd {ms:6.3f} ms {tf:6.1f} TF "; tot["tfwd"] = tot.get("tfwd", 0) + ms
         ms, tf = timed(lambda: ops.convt2x2_bwd_data(do, wtd)); row += f"| dgrad {ms:6.3f} ms {tf:6.1f} TF "; tot["tdgrad"] = tot.get("tdgrad", 0) + ms
