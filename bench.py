@@ -879,6 +879,8 @@ def summarize_ranks(per_rank_ms, diags, args):
             best = min(sweep, key=lambda b: b["step_ms"])
             out["bucket_sweep_best"] = {"bucket_mb": best["bucket_mb"], "step_ms": best["step_ms"],
                                         "note": "fastest of the swept bucket sizes on rank 0 (re-run with --bucket-mb to adopt it)"}
+    if any((d or {}).get("tuning_error") for d in diags):
+        out["tuning_error_per_rank"] = col("tuning_error")
     if "plan" in d0:
         out["gradient_buckets"] = d0["plan"]
     if "bucket_issue_ms_after_step_start" in d0:
@@ -1139,7 +1141,13 @@ def main():
                       "note": "the same iteration enqueued from Python (the r01-r05 headline path), measured right after the timed region"}
     tb.use_graph = tb.use_plan = False           # everything below (instrumented passes, arithmetic switches) runs eagerly
     if use_dist and gs is not None and diag is not None and not args.no_tuning:
-        diag["tuning"] = dist_tuning_pass(tb, gs, args, barrier, max(2, min(args.diag_steps, 4)))
+        try:
+            diag["tuning"] = dist_tuning_pass(tb, gs, args, barrier, max(2, min(args.diag_steps, 4)))
+        except Exception as e:      # noqa: BLE001 -- diagnostics of the first multi-GPU run must never cost it its headline line
+            # (every rank runs the same code on the same shapes, so a failure here is the same failure everywhere)
+            diag["tuning_error"] = f"{type(e).__name__}: {str(e)[:300]}"
+            tb.model.grad_sync, tb.gs = gs, gs
+            gs.probe = None
     # ---- per-kernel roofline pass.  In the timed region the weight-gradient kernels run concurrently with the
     # dgrad/BN chain on a second stream, so a kernel's event-to-event duration there includes time shared with another
     # kernel; the roofline numbers therefore come from a SERIALIZED pass of the same step, in this process, right after

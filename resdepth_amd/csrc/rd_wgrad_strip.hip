@@ -204,6 +204,9 @@ __device__ __forceinline__ void wgrad_strip_tr_body(const WsParams& p, float* sm
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             if (dy < 2) read_b(dy + 1, bf[(dy + 1) & 1]);
+#if RD_WG_FENCE
+            if constexpr (NP == 3) __builtin_amdgcn_sched_barrier(0);      // the next group's fragment reads stay AHEAD of this group's MFMAs
+#endif
 #pragma unroll
             for (int t6 = lo0<NP>(); t6 < 6; ++t6)
 #pragma unroll
