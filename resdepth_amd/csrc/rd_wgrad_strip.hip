@@ -271,14 +271,236 @@ __device__ __forceinline__ void wgrad_strip_tr_body(const WsParams& p, float* sm
     }
 }
 
+// ---- three-product form with the x fragments ROTATING through registers (r06) ---------------------------------------------------
+// In wgrad_strip_tr_body every K-step (image row y) reads the fragments of the three x halo rows y-1, y, y+1 from LDS: 36 of its
+// 40 fragment reads, each row three steps in a row, and each group of reads sits right in front of the MFMAs that need it (hipcc
+// sinks them there whatever the source order; the wave then waits out the LDS latency three times per step: MFMA pipe 0.58 at
+// 1.96 GHz in profiles/r06_summary.json -- stall-bound, not power-bound like the halo kernel).  With two fp16 terms per operand a
+// row's fragments are 24 registers, so two rows stay in registers across steps:
+//     step y:   set P = x row y-1, set Q = x row y, af = dz row y     (all read during EARLIER steps)
+//               MFMAs of dy = 0 on P  ->  P <- x row y+1, af' <- dz row y+1 (16 reads, behind 18 MFMAs of cover)
+//               MFMAs of dy = 1 on Q,  MFMAs of dy = 2 on P,  barrier;  step y+1 runs with (Q, P, af') in the roles of (P, Q, af).
+// 16 fragment reads per step instead of 40, none of them waited for.  Staging runs one row further ahead (task T(k) = dz row k+2
+// and x halo row k+2), so LDS holds four dz stages and only TWO halo rows (the one being read and the one being written).  Per
+// accumulator the MFMAs arrive in the same order as in wgrad_strip_tr_body<3>: bit-identical results.
+template <int NCO, int NCI, bool W8>
+__device__ __forceinline__ void wgrad_strip_rot_body(const WsParams& p, float* smem, const Quant qz) {
+    typedef f16x8 FR;
+    static_assert(NCO * NCI == 4, "four waves");
+    constexpr int TA = 64 * NCO, TB = 64 * NCI;
+    constexpr int APX = 3 * TA + (NCO == 4 ? 64 : NCO == 2 ? 64 : 0), BPX = 3 * TB + (NCI == 2 ? 64 : 0);   // pixel strides of the
+    constexpr int HPX = W8 ? 20 : 18;                                                                      // six-product layout: same banks
+    constexpr int ASTAGE = 16 * APX, BSLOT = HPX * BPX;
+    constexpr int RINGB = 4 * ASTAGE;                          // four dz stages, then two halo-row slots
+    constexpr int AQ = 8 * NCO, BQ = 8 * NCI;
+    constexpr int AI = 16 * AQ / 256, BI = (HPX * BQ + 255) / 256;
+
+    const int gb = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = gb / p.tiles_mn;
+    const int lb = gb - split * p.tiles_mn;
+    const int tile_ci = lb % p.tiles_ci, tile_m = lb / p.tiles_ci;
+    const int m0 = tile_m * (32 * NCO), ci0 = tile_ci * (32 * NCI);
+    int img = 0, x0 = 0, ya = 0, yb = 0;
+    const int H = p.H, W = p.W;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cw = wave / NCI, cb = wave % NCI;
+
+    int a_wr[AI], b_wr[BI];
+    int a_px[AI], a_ch[AI], b_hp[BI], b_ch[BI];
+    bool b_act[BI];
+#pragma unroll
+    for (int k = 0; k < AI; ++k) {
+        const int e = t + 256 * k, cq = e % AQ, px = e / AQ;
+        a_px[k] = px;
+        a_ch[k] = m0 + cq * 4 < p.Cout ? m0 + cq * 4 : -1;
+        a_wr[k] = px * APX + cq * 8;
+    }
+#pragma unroll
+    for (int k = 0; k < BI; ++k) {
+        const int e = t + 256 * k, cq = e % BQ, hp = e / BQ;
+        b_act[k] = e < HPX * BQ;
+        b_hp[k] = hp;
+        b_ch[k] = (b_act[k] && ci0 + cq * 4 < p.Cin) ? ci0 + cq * 4 : -1;
+        b_wr[k] = hp * BPX + cq * 8;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.dz, p.a_bytes), rsB = make_rsrc(p.x, p.b_bytes);
+    const unsigned rowA = (unsigned)W * p.Cout * 4, rowB = (unsigned)W * p.Cin * 4;
+    unsigned baseA = 0, baseB = 0, voffA[AI], voffB[BI];
+    auto set_strip = [&](int sid) {
+        const int sx = sid % p.strips_x;
+        const int cy = (sid / p.strips_x) % p.chunks_y;
+        img = sid / (p.strips_x * p.chunks_y);
+        x0 = sx * 16;
+        ya = cy * p.rows_per_chunk;
+        yb = ya + p.rows_per_chunk;
+        if (W8) img *= 2;
+        baseA = (unsigned)img * H * rowA;
+        baseB = (unsigned)img * H * rowB;
+        if (W8) {
+            const bool two = img + 1 < p.n_img;
+#pragma unroll
+            for (int k = 0; k < AI; ++k) {
+                const int sub = a_px[k] >> 3, xx = a_px[k] & 7;
+                voffA[k] = (a_ch[k] >= 0 && (sub == 0 || two)) ? (unsigned)(((sub * 64 + xx) * p.Cout + a_ch[k]) * 4) : kOOB;
+            }
+#pragma unroll
+            for (int k = 0; k < BI; ++k) {
+                const int sub = b_hp[k] >= 10 ? 1 : 0, px = b_hp[k] - 10 * sub - 1;
+                voffB[k] = (b_ch[k] >= 0 && (unsigned)px < 8u && (sub == 0 || two)) ? (unsigned)(((sub * 64 + px) * p.Cin + b_ch[k]) * 4) : kOOB;
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < AI; ++k) voffA[k] = a_ch[k] >= 0 ? (unsigned)(((x0 + a_px[k]) * p.Cout + a_ch[k]) * 4) : kOOB;
+#pragma unroll
+        for (int k = 0; k < BI; ++k) {
+            const int px = x0 - 1 + b_hp[k];
+            voffB[k] = (b_ch[k] >= 0 && (unsigned)px < (unsigned)W) ? (unsigned)((px * p.Cin + b_ch[k]) * 4) : kOOB;
+        }
+    };
+    // task T(k) = { dz row k+2, x halo row k+2 }: loaded two steps before it is stored, stored during step k, read during step k+1
+    auto load_task = [&](int k, float4 (&v)[AI + BI]) {
+        const int r = k + 2;
+        const bool oka = r >= ya && r < yb, okb = r >= 0 && r < H && r <= yb;
+        const unsigned sa = (unsigned)__builtin_amdgcn_readfirstlane(oka ? (int)(baseA + (unsigned)r * rowA) : 0);
+        const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane(okb ? (int)(baseB + (unsigned)r * rowB) : 0);
+#pragma unroll
+        for (int i = 0; i < AI; ++i) v[i] = buf_load4(rsA, oka ? voffA[i] : kOOB, sa);
+#pragma unroll
+        for (int i = 0; i < BI; ++i) v[AI + i] = buf_load4(rsB, okb ? voffB[i] : kOOB, sb);
+    };
+    auto put = [&](char* dst, int tstride, const float4 x, float qs) {
+        uint2 ph, pm, pl;
+        split_pack4v<3, false>(x.x, x.y, x.z, x.w, qs, ph, pm, pl);
+        *reinterpret_cast<uint2*>(dst) = ph;
+        *reinterpret_cast<uint2*>(dst + tstride) = pm;
+    };
+    auto store_task = [&](int k, const float4 (&v)[AI + BI]) {
+        char* sa = reinterpret_cast<char*>(smem) + ((k + 2) & 3) * ASTAGE;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) put(sa + a_wr[i], TA, v[i], qz.sa);
+        char* sb = reinterpret_cast<char*>(smem) + RINGB + ((k + 2) & 1) * BSLOT;
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+            if (b_act[i]) put(sb + b_wr[i], TB, v[AI + i], qz.sb);
+    };
+
+    const int li = lane & 15, lg = lane >> 4, nb = lg & 1, hk = lg >> 1;
+    const int a_rd = (8 * hk + (li >> 2)) * APX + (32 * cw + 16 * nb + 4 * (li & 3)) * 2;
+    const int b_rd = (8 * hk + (li >> 2) + (W8 ? 2 * hk : 0)) * BPX + (32 * cb + 16 * nb + 4 * (li & 3)) * 2;
+    const int lrow = lane & 31, half = lane >> 5;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+    auto read_x = [&](int row, FR (&dst)[3][2]) {              // fragments of x halo row `row` (three horizontal shifts x two terms)
+        const int slot = RINGB + (row & 1) * BSLOT;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) dst[d][q] = lds_tr2<FR>(smem, slot + b_rd + d * BPX + q * TB, 4 * BPX);
+    };
+    auto read_dz = [&](int row, FR (&dst)[2]) {
+        const int stage = (row & 3) * ASTAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) dst[q] = lds_tr2<FR>(smem, stage + a_rd + q * TA, 4 * APX);
+    };
+    // the nine MFMAs of one vertical tap row: a2 b1, a1 b2, a1 b1 for the three horizontal shifts (order of wgrad_strip_tr_body<3>)
+    auto group = [&](int dy, const FR (&af)[2], const FR (&xf)[3][2]) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[dy * 3 + d] = mfma16<3>(af[1], xf[d][0], acc[dy * 3 + d]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[dy * 3 + d] = mfma16<3>(af[0], xf[d][1], acc[dy * 3 + d]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[dy * 3 + d] = mfma16<3>(af[0], xf[d][0], acc[dy * 3 + d]);
+    };
+    // one K-step (image row y): P holds x row y-1, Q x row y, af dz row y; leaves x row y+1 in P and dz row y+1 in afn
+    auto step = [&](int y, const FR (&af)[2], FR (&afn)[2], FR (&P)[3][2], const FR (&Q)[3][2]) {
+        group(0, af, P);
+        __builtin_amdgcn_sched_barrier(0);                      // the sixteen reads go out HERE, behind eighteen MFMAs of cover
+        read_x(y + 1, P);
+        read_dz(y + 1, afn);
+        __builtin_amdgcn_sched_barrier(0);
+        group(1, af, Q);
+        __builtin_amdgcn_sched_barrier(0);                      // (hipcc would pull the a2 products of dy = 2 -- which wait for P -- forward)
+        group(2, af, P);
+        __builtin_amdgcn_sched_barrier(0);                      // the step's barrier stays BEHIND its MFMAs (hipcc hoists it -- and the
+    };                                                          // wait for all sixteen reads with it -- to right behind the reads)
+
+    float4 v0[AI + BI], v1[AI + BI];
+    FR xa[3][2], xb[3][2], af0[2], af1[2];
+    for (int rep = 0; rep < p.reps; ++rep) {
+        set_strip(split * p.reps + rep);
+        // warm-up: x rows ya-1, ya and dz row ya into registers, T(ya-1) into LDS, T(ya) / T(ya+1) in flight
+        load_task(ya - 3, v0);
+        load_task(ya - 2, v1);
+        store_task(ya - 3, v0);
+        load_task(ya - 1, v0);
+        store_task(ya - 2, v1);
+        load_task(ya, v1);
+        __syncthreads();
+        read_x(ya - 1, xa);
+        read_x(ya, xb);
+        read_dz(ya, af0);
+        __syncthreads();                                        // (the compiler waits for the reads before the barrier) slot of row ya-1 is free
+        store_task(ya - 1, v0);
+        load_task(ya + 1, v0);
+        __syncthreads();
+        for (int yy = ya; yy < yb; yy += 2) {                   // rows_per_chunk is even
+            store_task(yy, v1);
+            load_task(yy + 2, v1);
+            step(yy, af0, af1, xa, xb);
+            __syncthreads();
+            store_task(yy + 1, v0);
+            load_task(yy + 3, v0);
+            step(yy + 1, af1, af0, xb, xa);
+            __syncthreads();
+        }
+    }
+
+    float* out = p.slab + (long)split * p.M * p.N;
+    const int cwu = __builtin_amdgcn_readfirstlane(cw), cbu = __builtin_amdgcn_readfirstlane(cb);
+    if (m0 + 32 * NCO <= p.M && (long)(32 * NCO) * p.N * 4 < 0x7fffffffL) {
+        const __amdgpu_buffer_rsrc_t rsO = make_rsrc(out + (long)m0 * p.N + ci0, (unsigned)((long)(32 * NCO) * p.N * 4));
+        const unsigned lane_off = (unsigned)(((4 * half) * p.N + lrow) * 4);
+        const int rowN = __builtin_amdgcn_readfirstlane(p.N * 4);
+        const int base = (cwu * 32) * rowN + cbu * 128;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int tapo = base + tp * p.Cin * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(scale_q<3>(acc[tp][r], qz.dexp)), rsO, lane_off, (unsigned)(tapo + ((r & 3) + 8 * (r >> 2)) * rowN), 0);
+        }
+        return;
+    }
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        const int n = tp * p.Cin + ci0 + cb * 32 + lrow;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < p.M) out[(long)m * p.N + n] = scale_q<3>(acc[tp][r], qz.dexp);
+        }
+    }
+}
+
 template <int OCC, int NCO, int NCI, bool W8 = false>
 __global__ __launch_bounds__(256, OCC) void wgrad_strip_tr_kernel(WsParams p) {
     constexpr int TA = 64 * NCO, TB = 64 * NCI;
     constexpr int APX = 3 * TA + (NCO == 4 ? 64 : NCO == 2 ? 64 : 0), BPX = 3 * TB + (NCI == 2 ? 64 : 0);
     constexpr int HPX = W8 ? 20 : 18, ASTAGE = 16 * APX, BSLOT = HPX * BPX;
-    __shared__ __attribute__((aligned(16))) float smem[(2 * ASTAGE + 4 * BSLOT) / 4];
+    constexpr int SM6 = 2 * ASTAGE + 4 * BSLOT, SM3 = 4 * ASTAGE + 2 * BSLOT;      // six-product ring | rotating three-product form
+    __shared__ __attribute__((aligned(16))) float smem[(SM6 > SM3 ? SM6 : SM3) / 4];
     const Quant qz = quant_select(p.a_amax, p.b_amax);
+#if RD_WG_NOROT
     if (qz.use3) wgrad_strip_tr_body<3, NCO, NCI, W8>(p, smem, qz);
+#else
+    if (qz.use3) wgrad_strip_rot_body<NCO, NCI, W8>(p, smem, qz);
+#endif
     else wgrad_strip_tr_body<6, NCO, NCI, W8>(p, smem, qz);
 }
 
