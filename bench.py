@@ -247,8 +247,10 @@ def infer_main(args, world, rank, dev):
     torch.manual_seed(0)
     model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).eval()
     model.fold_eval_bn = not args.no_fold
-    model.fast_eval = bool(args.fast_eval)       # three-product bodies in the sweep (results then depend on the batch a tile is in)
-    model_fast_eval = model.fast_eval and _lib.products() == 3
+    model.fast_eval = bool(args.fast_eval)       # one scale per TENSOR in the sweep (results then depend on the batch a tile is in)
+    model.eval_per_image = not args.eval_six     # default: three-product bodies with one scale per IMAGE (a tile depends on itself alone)
+    model_fast_eval = (model.fast_eval or model.eval_per_image) and _lib.products() == 3
+    eval_scales = None if not model_fast_eval else "one per tensor (fast_eval)" if model.fast_eval else "one per image (rd_quant_next_img)"
     ds = SyntheticRasterTiles(args.raster, args.raster, 3, tile_size=256, seed=1, shard=(rank, world))
     # tiles are staged on the device once (the metric excludes host->device staging, as for training)
     batches = []
@@ -300,6 +302,7 @@ def infer_main(args, world, rank, dev):
             "value": round(tiles_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "arithmetic_mode": ("split2h" if model_fast_eval else "split3") if _lib.mfma_mode() != "f32" else "f32",
+            "eval_scales": eval_scales,
             "data": "synthetic raster",
             "config": {"workload": f"cfg-G: {args.raster}x{args.raster} raster, {n_tiles_global} tiles of 256x256 at stride 128, "
                                    f"eval-mode BN, batch {args.batch}",
@@ -498,7 +501,7 @@ def _median(v):
     return v[len(v) // 2] if v else None
 
 
-def infer_sweep(dev, raster, batch, sweeps, warm=1, host_batches=False, fast_eval=False):
+def infer_sweep(dev, raster, batch, sweeps, warm=1, host_batches=False, fast_eval=False, per_image=True):
     """cfg-G on one GPU: `sweeps` full sweeps of a raster x raster synthetic DSM -> (tiles/s, n_tiles).  Tiles resident in HBM
     (the metric's convention: staging excluded), or host_batches=True: pinned HOST batch dicts, what a DataLoader(pin_memory=True)
     hands lib/evaluation.py:486-498 -- every tile crosses PCIe inside the timed sweep."""
@@ -506,7 +509,7 @@ def infer_sweep(dev, raster, batch, sweeps, warm=1, host_batches=False, fast_eva
     from resdepth_amd import UNet, SyntheticRasterTiles, predict_linear_blend
     torch.manual_seed(0)
     model = UNet(n_input_channels=3, start_kernel=64, depth=5, bias_conv_layer=True).to(dev).eval()
-    model.fast_eval = bool(fast_eval)
+    model.fast_eval, model.eval_per_image = bool(fast_eval), bool(per_image)
     ds = SyntheticRasterTiles(raster, raster, 3, tile_size=256, seed=1)
     move = (lambda v: v.pin_memory()) if host_batches else (lambda v: v.to(dev))
     batches = [{k: (move(v) if torch.is_tensor(v) else v) for k, v in b.items()} for b in DataLoader(ds, batch_size=batch, shuffle=False)]
@@ -729,12 +732,16 @@ def secondary_measurements(args, dev, tb):
         ts, nt = infer_sweep(dev, 8192, 32, 2)
         out["cfg_G"] = {"tiles_per_s": round(ts, 1), "tiles": nt, "tflops": round(ts * 19.80e9 / 1e12, 1),
                         "workload": "cfg-G on one GPU (SURVEY 8d size): 8192x8192 raster, 3969 tiles of 256x256 at stride 128, "
-                                    "eval-mode BN folded, batch 32, forward + linear blend, 2 timed sweeps; six-product split3 "
-                                    "arithmetic (the inference default: a tile's result does not depend on its batch)"}
+                                    "eval-mode BN folded, batch 32, forward + linear blend, 2 timed sweeps; three-product split2h "
+                                    "arithmetic with one magnitude slot per IMAGE (the inference default since r06: a tile's result "
+                                    "does not depend on its batch; the 8 x 8 level and its up-convolution stay on six products)"}
+        t6, _ = infer_sweep(dev, 8192, 32, 2, per_image=False)
+        out["cfg_G"]["six_product_tiles_per_s"] = round(t6, 1)
+        out["cfg_G"]["six_product_note"] = "UNet.eval_per_image = False: the split3 bodies of r01-r05 (same property, twice the matrix instructions)"
         tf, _ = infer_sweep(dev, 8192, 32, 2, fast_eval=True)
         out["cfg_G"]["fast_eval_tiles_per_s"] = round(tf, 1)
-        out["cfg_G"]["fast_eval_note"] = ("UNet.fast_eval = True: the sweep's convolutions on the three-product split2h bodies (results "
-                                          "then depend, in the last bits, on which tiles share a batch)")
+        out["cfg_G"]["fast_eval_note"] = ("UNet.fast_eval = True: one scale per operand TENSOR, as in training (results then depend, in "
+                                          "the last bits, on which tiles share a batch)")
     except Exception as e:      # noqa: BLE001
         out["cfg_G"] = dict(out.get("cfg_G") or {}, error=repr(e)[:200])
     try:        # the same sweep fed from HOST batches (the drop-in call: a DataLoader's pinned batch dicts), 4096^2 raster
@@ -1025,8 +1032,10 @@ def main():
                          "one-GPU box execute `bench.py --gpus N` end to end: launcher, broadcast, bucketed all-reduce, "
                          "max-over-ranks timing, rank-0 line")
     ap.add_argument("--fast-eval", action="store_true",
-                    help="--infer: UNet.fast_eval = True, the sweep's convolutions on the three-product split2h bodies (default: split3, "
-                         "so that a tile's result does not depend on the batch it is in)")
+                    help="--infer: UNet.fast_eval = True, one scale per operand TENSOR as in training (default: one per IMAGE, so that a "
+                         "tile's result does not depend on the batch it is in)")
+    ap.add_argument("--eval-six", action="store_true",
+                    help="--infer: UNet.eval_per_image = False, the six-product split3 bodies of r01-r05")
     ap.add_argument("--no-fold", action="store_true", help="--infer: keep eval-mode BN as separate kernels (A/B of the folded path)")
     ap.add_argument("--prof-all", action="store_true", help="(kept for scripts) same as the default full breakdown")
     ap.add_argument("--rccl-channels", type=int, default=0,

@@ -40,7 +40,7 @@ typedef void* rd_stream_t; /* hipStream_t */
 #define RD_ERR_WS 2
 #define RD_ERR_HIP 3
 
-int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream); 102: rd_host_register & co; 103: rd_mfma_products; 104: rd_adam_step_dev; 105 (r06): rd_quant_next / rd_amax, packed operands hold both split forms; 106: rd_plan_* */
+int rd_version(void); /* 100: r01-r03; 101: rd_set_splitk_workspace registrations belong to (current device, stream); 102: rd_host_register & co; 103: rd_mfma_products; 104: rd_adam_step_dev; 105 (r06): rd_quant_next / rd_amax, packed operands hold both split forms; 106: rd_plan_*; 107: rd_quant_next_img */
 /* Arithmetic of the split MFMA kernels -- ONE library, chosen per launch (csrc/rd_mfma_dev.h):
  *   6  "split3"   x = x1 + x2 + x3 (three bf16 terms, exact), six products per multiply on v_mfma_f32_32x32x16_bf16.  No
  *                 assumption about the operands; what every launch falls back to.
@@ -66,6 +66,16 @@ int rd_mfma_products(void);
  *     slot, which the call fills itself before it writes the three-product form of the operand.
  *   rd_amax(x, n, slot): max |x[0..n)| into a (zeroed) slot: operands that no producer of this library wrote. */
 int rd_quant_next(const unsigned* a_amax, const unsigned* b_amax, unsigned* out_amax, unsigned* out2_amax);
+/* Per-IMAGE slots (inference, r06): a, out and out2 are arrays of slots, one per image of the batch, `img_stride_words` 32-bit
+ * words apart (a multiple of 32, >= RD_AMAX_SLOT_BYTES / 4); b (the packed weight) stays one slot.  A block of a consumer scales
+ * its activation operand by ITS image's maximum, a block of a producer commits to its image's slot: a tile's result then depends
+ * on that tile alone -- not on the tiles that share its batch, as with one scale per tensor -- which the tiled sweep of
+ * lib/evaluation.py:460-567 promises (same raster however the tiles are batched or sharded).  Taken by rd_conv3x3_fwd_act
+ * (its patch kernels; the 8 x 8 level, whose patches hold two images, and any launch that falls to a generic row-tile kernel
+ * run the six-product body and commit nothing), rd_convt2x2_fwd / rd_convt2x2_fwd_bnskip (tiles inside one image, else the
+ * same) and rd_conv3x3_first_fwd_act (out2); every other entry point ignores slots set this way.  A slot nobody wrote reads as
+ * zero = "magnitude unknown": the consumer runs the six-product body (so does an all-zero operand, in either slot form). */
+int rd_quant_next_img(const unsigned* a_amax, const unsigned* b_amax, unsigned* out_amax, unsigned* out2_amax, int img_stride_words);
 int rd_amax(const float* x, long long n, unsigned* slot, rd_stream_t s);
 /* zero `bytes` (a multiple of 16, 16-byte aligned) with a kernel launch -- which a launch plan records, unlike a memset node */
 int rd_zero(void* p, size_t bytes, rd_stream_t s);

@@ -50,6 +50,7 @@ SIGNATURES = {
     "rd_plan_free": (I, [P]),
     "rd_plan_dump": (I, [P]),
     "rd_quant_next": (I, [P, P, P, P]),
+    "rd_quant_next_img": (I, [P, P, P, P, I]),
     "rd_amax": (I, [P, LL, P, P]),
     "rd_zero": (I, [P, SZ, P]),
     "rd_last_error_string": (C.c_char_p, []),
@@ -205,16 +206,22 @@ _tls = threading.local()
 
 
 class AmaxPool:
-    """A zeroed block of magnitude slots for one pass (forward or backward) of one model: one torch.zeros per pass."""
+    """A zeroed block of magnitude slots for one pass (forward or backward) of one model: one torch.zeros per pass.
+    per_image = n > 0 (inference): every take() is an ARRAY of n slots, one per image of the batch (rd_quant_next_img) -- the
+    view carries `_rd_img = n`."""
 
-    def __init__(self, device, slots: int = 64):
-        self.buf = zeros_i32(slots * AMAX_WORDS, device)
+    def __init__(self, device, slots: int = 64, per_image: int = 0):
+        self.img = int(per_image)
+        self.words = AMAX_WORDS * max(1, self.img)
+        self.buf = zeros_i32(slots * self.words, device)
         self.n, self.cap = 0, slots
 
     def take(self):
         if self.n >= self.cap:
             return None                      # more producers than planned: the tensor goes without (six-product consumer)
-        v = self.buf[self.n * AMAX_WORDS:(self.n + 1) * AMAX_WORDS]
+        v = self.buf[self.n * self.words:(self.n + 1) * self.words]
+        if self.img:
+            v._rd_img = self.img
         self.n += 1
         return v
 
@@ -276,10 +283,13 @@ def host_action(fn) -> None:
         _plan_rec.add_action(fn)
 
 
-def amax_slot():
-    """A fresh slot from the active pool, or None (no pool / six-product mode)."""
+def amax_slot(img_ok: bool = False):
+    """A fresh slot from the active pool, or None (no pool / six-product mode).  A per-image pool serves only the producers that
+    commit per image (img_ok: the three entry points of the folded inference path); everyone else's output goes without."""
     pool = getattr(_tls, "pool", None)
-    return pool.take() if pool is not None else None
+    if pool is None or (pool.img and not img_ok):
+        return None
+    return pool.take()
 
 
 def slot_of(t):
@@ -293,11 +303,16 @@ def tag(t, slot):
 
 
 def quant_next(a=None, b=None, out=None, out2=None):
-    """rd_quant_next with tensors (None -> NULL): only worth a call when something is set."""
+    """rd_quant_next with tensors (None -> NULL): only worth a call when something is set.  Slot ARRAYS (views of a per-image
+    pool, `_rd_img`) go through rd_quant_next_img -- the caller has made sure a, out, out2 are all of that kind."""
     if a is None and b is None and out is None and out2 is None:
         return
-    load().rd_quant_next(a.data_ptr() if a is not None else None, b.data_ptr() if b is not None else None,
-                         out.data_ptr() if out is not None else None, out2.data_ptr() if out2 is not None else None)
+    args = (a.data_ptr() if a is not None else None, b.data_ptr() if b is not None else None,
+            out.data_ptr() if out is not None else None, out2.data_ptr() if out2 is not None else None)
+    if any(getattr(t, "_rd_img", 0) for t in (a, out, out2) if t is not None):
+        check(load().rd_quant_next_img(*args, AMAX_WORDS), "quant_next_img")
+    else:
+        load().rd_quant_next(*args)
 
 
 def check(rc: int, what: str = ""):

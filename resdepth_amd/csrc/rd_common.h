@@ -73,8 +73,14 @@ struct QuantArgs {
     const unsigned* b;     // operand B (packed weights; the second activation operand of a weight gradient)
     unsigned* out;         // receives max |output|
     unsigned* out2;        // second output of the call (pooled tensor), or the weight slot a pack call fills
+    int img_stride;        // 0: one slot per tensor | > 0 (rd_quant_next_img): a, out, out2 are ARRAYS of slots, one per image of the
+                           // batch, this many words apart (inference: a tile's scale then depends on that tile alone); b stays per tensor
 };
+// the slots of the next call.  quant_take(): entry points that know nothing of per-image slots -- they get NO slots when the
+// caller set per-image ones (six-product body, nothing committed: an untouched slot reads as "magnitude unknown", quant_select).
+// quant_take_img(): the entry points of the inference path that index the arrays by image.
 QuantArgs quant_take();
+QuantArgs quant_take_img();
 // conv3x3 weight-gradient strip kernel (rd_wgrad_strip.hip): number of split-K slabs it will write for this shape
 // (0 = shape not handled, use the TN kernel), and its launcher (*splits_out = 0 when it did not run; *swapped_out = 1
 // when the slab is the mirrored transpose [Cin][(8 - tap) * Cout + co], see plan_strip)
@@ -158,7 +164,7 @@ struct FirstBnBwd {
 };
 int conv_first_fwd_act_launch(const float* x, const float* wt, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, float slope, const float* slope_dev, float* a, float* pooled, int n, int h, int w,
-                              int cin, int cout, hipStream_t s, unsigned* p_amax = nullptr);
+                              int cin, int cout, hipStream_t s, unsigned* p_amax = nullptr, int amax_img_stride = 0);
 int conv_first_seg_launch(bool wgrad, const float* x, const float* wt, float* z, const float* dz, float* partial, int n, int h,
                           int w, int cin, int cout, hipStream_t s, const FirstBnBwd* bn = nullptr);
 int conv_last_wgrad_launch(const float* s_in, const float* dout, double* partial, int n, int h, int w, int c, hipStream_t s);

@@ -46,6 +46,9 @@ struct CtParams {
     const void* wsplit3;
     unsigned w_bytes3;
     unsigned* out_amax;
+    // per-image slots (rd_quant_next_img): a_amax / out_amax are arrays, amax_img_stride words per image, and a tile's rows lie
+    // inside one image of img_rows stacked rows (the launcher checks TR | H); 0 = one slot per tensor
+    int amax_img_stride, img_rows;
 };
 
 __device__ __forceinline__ float ct_act(float y, float slope) { return y > 0.f ? y : y * slope; }
@@ -60,7 +63,7 @@ __device__ __forceinline__ float ct_act(float y, float slope) { return y > 0.f ?
 __device__ __forceinline__ int stage_row(int idx) { return (idx & ~7) | ((idx & 3) << 1) | ((idx >> 2) & 1); }
 
 template <int NP, int TM>
-__device__ __forceinline__ void convt_fwd_body(const CtParams& p, float* smem, const Quant qz) {
+__device__ __forceinline__ void convt_fwd_body(const CtParams& p, float* smem, const Quant qz, const int amax_off) {
     typedef typename frag_of<NP>::type FR;
     constexpr int NT = NP == 3 ? 2 : 3;
     constexpr int BM = 32 * TM, RS = 28;                  // LDS row = 3 terms x 16 bf16 + 16 B pad (conflict-free b128 reads)
@@ -236,7 +239,7 @@ __device__ __forceinline__ void convt_fwd_body(const CtParams& p, float* smem, c
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(o), rsO, voff(i, r), soffd(i, r), 0);
                     if (FULL || rowok(i, r)) omax = amax_acc(omax, o);
                 }
-            if (p.out_amax) amax_commit(p.out_amax, omax);
+            if (p.out_amax) amax_commit(p.out_amax + amax_off, omax);
         };
         if (p.sk_mean) {
             if (rows_left >= p.TR) emit(std::true_type(), std::true_type());
@@ -310,7 +313,7 @@ __device__ __forceinline__ void convt_fwd_body(const CtParams& p, float* smem, c
         }
         __syncthreads();
     }
-    if (p.out_amax) amax_commit(p.out_amax, omax);
+    if (p.out_amax) amax_commit(p.out_amax + amax_off, omax);
 }
 
 template <int TM>
@@ -318,9 +321,15 @@ __global__ __launch_bounds__(256, 2) void convt_fwd_kernel(CtParams p) {
     constexpr int STAGE = 32 * TM * 28, EPI_WORDS = 32 * (128 + 4);
     constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
-    const Quant qz = quant_select(p.a_amax, p.b_amax);
-    if (qz.use3) convt_fwd_body<3, TM>(p, smem, qz);
-    else convt_fwd_body<6, TM>(p, smem, qz);
+    int amax_off = 0;
+    if (p.amax_img_stride) {                                  // this block's image (the body's tile -> row map)
+        const int lb = xcd_remap(blockIdx.x, gridDim.x);
+        const int ty = (lb / p.ngroups) / p.tiles_x;
+        amax_off = ((ty * p.TR) / p.img_rows) * p.amax_img_stride;
+    }
+    const Quant qz = quant_select(p.a_amax ? p.a_amax + amax_off : nullptr, p.b_amax);
+    if (qz.use3) convt_fwd_body<3, TM>(p, smem, qz, amax_off);
+    else convt_fwd_body<6, TM>(p, smem, qz, amax_off);
 }
 
 // ---- data gradient:  dx[p][ci] = sum_{a,b,co} dout[2g+a][2x+b][co] * W[ci][co][a][b]   (p = (g, x), g = n*H + y) --------
@@ -824,6 +833,12 @@ int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, co
     p.w_bytes3 = (unsigned)(wsplit_bytes / SROWB * SROWB3);
     p.out_amax = qa.out;
     if (mfma_products() == 3 && qa.a && qa.b) { p.a_amax = qa.a; p.b_amax = qa.b; }
+    if (qa.img_stride) {
+        // per-image slots: a tile (TR stacked rows) must lie inside one image; otherwise the launch goes without (six products,
+        // nothing committed -- the untouched slots read as "unknown" downstream)
+        if (h % p.TR == 0) { p.amax_img_stride = qa.img_stride; p.img_rows = h; }
+        else { p.a_amax = p.b_amax = nullptr; p.out_amax = nullptr; }
+    }
     const long tiles_y = (G + p.TR - 1) / p.TR;
     const long grid = tiles_y * p.tiles_x * p.ngroups;
     if (grid >= (1L << 31)) return RD_OK;

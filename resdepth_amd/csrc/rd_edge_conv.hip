@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_act_seg_kernel(const fl
                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                      float slope_val, const float* __restrict__ slope_dev,
                                                                      float* __restrict__ a, float* __restrict__ pooled, int N, int H,
-                                                                     int W, int tiles_x, int tiles_y, unsigned* p_amax) {
+                                                                     int W, int tiles_x, int tiles_y, unsigned* p_amax, int amax_img_stride) {
     constexpr int Cout = CQ * 4, SLOTS = 256 / CQ, NSEG = (ET_H * ET_W / 8) / SLOTS;
     static_assert(NSEG % 2 == 0 && SLOTS % 4 == 0, "row pairs per thread");
     float pmx = 0.f;        // p_amax (nullable): magnitude slot of `pooled`, the operand of the next level's three-product GEMM
@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_act_seg_kernel(const fl
             }
         }
     }
-    if (p_amax) amax_commit(p_amax, pmx);
+    if (p_amax) amax_commit(p_amax + n * amax_img_stride, pmx);       // (per-image slots: stride > 0, rd_quant_next_img)
 }
 
 // FUSED: there is no dz tensor.  The first block's BN + activation + pool backward (bn_act_bwd_kernel<true, true> in
@@ -1738,16 +1738,16 @@ int conv_first_seg_launch(bool wgrad, const float* x, const float* wt, float* z,
 template <int CIN>
 static int launch_first_act(const float* x, const float* wt, const float* mean, const float* invstd, const float* gamma,
                             const float* beta, float slope, const float* slope_dev, float* a, float* pooled, int n, int h, int w,
-                            int cout, hipStream_t s, unsigned* p_amax) {
+                            int cout, hipStream_t s, unsigned* p_amax, int amax_img_stride) {
     const int tx = cdiv(w, ET_W), ty = cdiv(h, ET_H), nt = n * tx * ty;
     if (first_mfma_ok(cout)) {      // (opt-in A/B variant: no magnitude slot -- the next level then runs the six-product body)
         launch_first_mfma<CIN, 1>(x, wt, a, pooled, mean, invstd, gamma, beta, slope, slope_dev, n, h, w, cout, s);
         RD_LAUNCH_CHECK("conv_first_fwd_act");
         return RD_OK;
     }
-    if (cout == 64) RD_LAUNCH((conv_first_fwd_act_seg_kernel<CIN, 16>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax);
-    else if (cout == 32) RD_LAUNCH((conv_first_fwd_act_seg_kernel<CIN, 8>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax);
-    else RD_LAUNCH((conv_first_fwd_act_seg_kernel<CIN, 32>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax);
+    if (cout == 64) RD_LAUNCH((conv_first_fwd_act_seg_kernel<CIN, 16>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax, amax_img_stride);
+    else if (cout == 32) RD_LAUNCH((conv_first_fwd_act_seg_kernel<CIN, 8>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax, amax_img_stride);
+    else RD_LAUNCH((conv_first_fwd_act_seg_kernel<CIN, 32>), dim3(nt), dim3(256), 0, s, x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, tx, ty, p_amax, amax_img_stride);
     RD_LAUNCH_CHECK("conv_first_fwd_act");
     return RD_OK;
 }
@@ -1755,12 +1755,12 @@ static int launch_first_act(const float* x, const float* wt, const float* mean, 
 // inference: convolution + BN (given mean / invstd) + activation (+ 2x2 max-pool) in one kernel; shapes of conv_first_seg_tiles
 int conv_first_fwd_act_launch(const float* x, const float* wt, const float* mean, const float* invstd, const float* gamma,
                               const float* beta, float slope, const float* slope_dev, float* a, float* pooled, int n, int h, int w,
-                              int cin, int cout, hipStream_t s, unsigned* p_amax) {
+                              int cin, int cout, hipStream_t s, unsigned* p_amax, int amax_img_stride) {
     switch (cin) {
-        case 1: return launch_first_act<1>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s, p_amax);
-        case 2: return launch_first_act<2>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s, p_amax);
-        case 3: return launch_first_act<3>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s, p_amax);
-        default: return launch_first_act<4>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s, p_amax);
+        case 1: return launch_first_act<1>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s, p_amax, amax_img_stride);
+        case 2: return launch_first_act<2>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s, p_amax, amax_img_stride);
+        case 3: return launch_first_act<3>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s, p_amax, amax_img_stride);
+        default: return launch_first_act<4>(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cout, s, p_amax, amax_img_stride);
     }
 }
 

@@ -1509,8 +1509,9 @@ int rd_conv3x3_first_fwd_act(const float* x, const float* wt, const float* mean,
                "rd_conv3x3_first_fwd_act: shape not covered (1-4 input channels, 32 / 64 / 128 output channels, even H and W)");
     ProfScope ps((hipStream_t)s, "conv_first_fwd", 2.0 * n * h * w * cout * 9.0 * cin,
                  4.0 * n * h * w * (double)(cin + cout * (pooled ? 1.25 : 1.0)));
+    const QuantArgs qa = quant_take_img();     // out2: slot of `pooled` -- or, with a stride, one slot per image
     return conv_first_fwd_act_launch(x, wt, mean, invstd, gamma, beta, slope, slope_dev, a, pooled, n, h, w, cin, cout, (hipStream_t)s,
-                                     quant_take().out2);
+                                     qa.out2, qa.img_stride);
 }
 
 size_t rd_conv3x3_first_fwd_stats_ws_bytes(int n, int h, int w, int cin, int cout) {

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void igemm_nt_split_kernel(NtParams p) {
 // ranges, p.chunks_per = 8): the blocks park their range in a scratch slab and draw a ticket, the last one adds the ranges in
 // the same order and runs the epilogue (statistics, BN-backward hook) on the finished tile -- the same bits as the unsplit form.
 template <int NP, int BN, int WM, int WN, int EPI, int SKEW, int W8>
-__device__ __forceinline__ void conv3_halo_split_body(const NtParams& p, float* smem, int& sk_last, const Quant qz) {
+__device__ __forceinline__ void conv3_halo_split_body(const NtParams& p, float* smem, int& sk_last, const Quant qz, const int amax_off) {
     typedef typename frag_of<NP>::type FR;
     constexpr int NT = NP == 3 ? 2 : 3;               // split terms per operand
     constexpr int BM = 128, PH = 8, PW = 16, HW_ = W8 ? 20 : PW + 2, HROWS = (PH + 2) * HW_;   // 180 (200) halo pixels
@@ -639,7 +639,7 @@ __device__ __forceinline__ void conv3_halo_split_body(const NtParams& p, float* 
     }
     const int m0 = ((img * H + y0) * W) + x0;
     const long pool_base = ((long)img * (H >> 1) + (y0 >> 1)) * (W >> 1) + (x0 >> 1);
-    nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m, pool_base);
+    nt_epilogue<BM, BN, WM, WN, EPI, SMEM, 1>(acc, smem, p, m0, n0, tile_m, pool_base, amax_off);
 }
 
 template <int BN, int WM, int WN, int EPI, int SKEW = 8, int W8 = 0>
@@ -648,9 +648,17 @@ __global__ __launch_bounds__(256) void conv3_halo_split_kernel(NtParams p) {
     constexpr int SMEM = 2 * STAGE > EPI_WORDS ? 2 * STAGE : EPI_WORDS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     __shared__ int sk_last;
-    const Quant qz = quant_select(p.a_amax, p.b_amax);
-    if (qz.use3) conv3_halo_split_body<3, BN, WM, WN, EPI, SKEW, W8>(p, smem, sk_last, qz);
-    else conv3_halo_split_body<6, BN, WM, WN, EPI, SKEW, W8>(p, smem, sk_last, qz);
+    // per-image magnitude slots (inference; never with W8, whose patches hold two images: launch_nt): this block's image, as the
+    // body derives it from the block index
+    int amax_off = 0;
+    if (!W8 && p.amax_img_stride) {
+        const int lb = xcd_remap(blockIdx.x, gridDim.x);
+        const int tile_m = lb / p.tiles_n;
+        amax_off = (tile_m / ((p.W >> 4) * (p.H >> 3))) * p.amax_img_stride;
+    }
+    const Quant qz = quant_select(p.a_amax ? p.a_amax + amax_off : nullptr, p.b_amax);
+    if (qz.use3) conv3_halo_split_body<3, BN, WM, WN, EPI, SKEW, W8>(p, smem, sk_last, qz, amax_off);
+    else conv3_halo_split_body<6, BN, WM, WN, EPI, SKEW, W8>(p, smem, sk_last, qz, amax_off);
 }
 
 // one 16-byte fragment piece per term of row n, K-step kt, k-half g: the six-product form (three bf16 terms) at `out`, and --
@@ -987,7 +995,12 @@ static int split_pack(const float* b_f32, long rows, int taps, int cin, hipStrea
 }
 
 static inline void set_quant(NtParams& p, const QuantArgs& q) {
-    p.a_amax = q.a; p.b_amax = q.b; p.out_amax = q.out; p.pool_amax = q.out2;
+    p.a_amax = q.a; p.b_amax = q.b; p.out_amax = q.out; p.pool_amax = q.out2; p.amax_img_stride = q.img_stride;
+}
+// per-image slots reach a kernel that cannot index them (generic row tiles, the two-images-per-patch form): the launch goes
+// without -- six-product body, nothing committed (the untouched slots read as "unknown" downstream)
+static inline void drop_img_quant(NtParams& p) {
+    if (p.amax_img_stride) { p.a_amax = p.b_amax = nullptr; p.out_amax = p.pool_amax = nullptr; p.amax_img_stride = 0; }
 }
 
 template <int AMODE, int EPI>
@@ -1061,6 +1074,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
             p.sk_ticket = tickets;
         }
         p.patch = 2;
+        drop_img_quant(p);
         p.direct = tune(TUNE_NT_EPI) != 0 && p.N % 32 == 0;
         p.tiles_n = tiles_n;
         if (tiles_m_out) *tiles_m_out = tiles_m;
@@ -1075,6 +1089,7 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
         set_error("%s: the pooling epilogue exists in the patch (halo) kernels only", cls);
         return RD_ERR_ARG;
     }
+    if (!halo) drop_img_quant(p);
     char pcls[64];   // "<operation>|<kernel symbol>": the kernel symbol is what rocprofv3 reports
     if (halo)
         snprintf(pcls, sizeof(pcls), "%s|conv3_halo_split<%d>", cls, cfg == 0 ? 128 : 64);
@@ -1911,7 +1926,7 @@ int rd_conv3x3_fwd_act(const float* x, const float* wf_folded, const float* shif
     RD_REQUIRE(!pooled || (w % 16 == 0 && h % 8 == 0),
                "rd_conv3x3_fwd_act: the pooling epilogue needs W a multiple of 16 and H a multiple of 8 (got %dx%d)", h, w);
     NtParams p = {};
-    set_quant(p, quant_take());
+    set_quant(p, quant_take_img());
     p.A = x; p.B = wf_folded; p.C = a;
     p.M = n * h * w; p.N = cout; p.K = 9 * cin; p.Cin = cin;
     p.H = h; p.W = w; p.pd = make_pixdiv(h, w);
@@ -2012,7 +2027,7 @@ int rd_convt2x2_fwd(const float* x, const float* wtf, const float* bias, const f
     if (int e = check_conv_args(n, h, w, cin, cout)) return e;
     RD_REQUIRE(x && wtf && out, "rd_convt2x2_fwd: null pointer");
     RD_REQUIRE(cin % 4 == 0, "rd_convt2x2_fwd: Cin must be a multiple of 4 (got %d)", cin);
-    const QuantArgs qa = quant_take();
+    const QuantArgs qa = quant_take_img();
     {
         int launched = 0;
         const size_t sb = (size_t)rows32_of(4L * cout) * nk16_of(1, cin) * SROWB;
@@ -2035,7 +2050,7 @@ int rd_convt2x2_fwd_bnskip(const float* x, const float* wtf, const float* bias, 
     if (int e = check_conv_args(n, h, w, cin, cout)) return e;
     RD_REQUIRE(x && wtf && out && z_skip && mean && invstd && gamma && beta, "rd_convt2x2_fwd_bnskip: null pointer");
     RD_REQUIRE(cin % 4 == 0, "rd_convt2x2_fwd_bnskip: Cin must be a multiple of 4 (got %d)", cin);
-    const QuantArgs qa = quant_take();
+    const QuantArgs qa = quant_take_img();
     {
         int launched = 0;
         const size_t sb = (size_t)rows32_of(4L * cout) * nk16_of(1, cin) * SROWB;

@@ -104,6 +104,7 @@ __device__ __forceinline__ Quant quant_select(const unsigned* a_amax, const unsi
     if (a_amax == nullptr || b_amax == nullptr) return q;
     const unsigned am = amax_read_wave(a_amax), bm = amax_read_wave(b_amax);
     if (am >= 0x7f800000u || bm >= 0x7f800000u) return q;        // an infinite element: exact non-finite semantics live in NP = 6
+    if (am == 0u || bm == 0u) return q;                          // a slot nobody wrote (or an all-zero operand): magnitude unknown
     const int ea = scale_bexp(am), eb = scale_bexp(bm);
     q.use3 = 1;
     q.sa = __uint_as_float((unsigned)ea << 23);

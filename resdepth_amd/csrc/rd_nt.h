@@ -80,6 +80,9 @@ struct NtParams {
     unsigned b_bytes3;
     unsigned* out_amax;
     unsigned* pool_amax;
+    // per-image slots (rd_quant_next_img; patch kernels with one image per patch only): a_amax, out_amax, pool_amax are arrays,
+    // this many words per image; 0 = one slot per tensor
+    int amax_img_stride;
 };
 
 // transposed-convolution data gradient (rd_convt.hip); *launched = 0 when the shape is left to the generic NT kernel
@@ -105,7 +108,7 @@ __device__ __forceinline__ float skip_act(float y, float slope) { return y > 0.f
 // image, only the second image of a two-image patch (patch == 2) can be absent.
 template <int BM, int BN, int WM, int WN, int SMEM_WORDS>
 __device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem, const NtParams& p,
-                                                   int m0, int n0, int tile_m, long pool_base) {
+                                                   int m0, int n0, int tile_m, long pool_base, int amax_off = 0) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -189,7 +192,7 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][B
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(mx), rsP, ncol0 + j * 32 < N ? lane_off_p + j * 128 : kOOB, so, 0);
                         pmax = amax_acc(pmax, mx);
                     }
-            if (p.pool_amax) amax_commit(p.pool_amax, pmax);
+            if (p.pool_amax) amax_commit(p.pool_amax + amax_off, pmax);
         }
     }
     // ---- C
@@ -209,7 +212,7 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][B
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (img2_ok || !((r >> 2) & 1)) cmax = amax_acc(cmax, acc[i][j][r]);
-        amax_commit(p.out_amax, cmax);
+        amax_commit(p.out_amax + amax_off, cmax);
     }
     // ---- forward BatchNorm statistics: per-(tile_m) column sums / sums of squares [tiles_m][2][N]
     if (st_on) {
@@ -331,11 +334,11 @@ __device__ __forceinline__ void nt_epilogue_direct(f32x16 (&acc)[BM / WM / 32][B
 // map is the same for the f32 and the bf16 MFMA shapes).
 template <int BM, int BN, int WM, int WN, int EPI, int SMEM_WORDS, int EB = BM / WM / 32>
 __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem, const NtParams& p,
-                                            int m0, int n0, int tile_m, long pool_base = -1) {
+                                            int m0, int n0, int tile_m, long pool_base = -1, int amax_off = 0) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     if constexpr (EPI == EPI_STORE) {
         if (p.direct) {
-            nt_epilogue_direct<BM, BN, WM, WN, SMEM_WORDS>(acc, smem, p, m0, n0, tile_m, pool_base);
+            nt_epilogue_direct<BM, BN, WM, WN, SMEM_WORDS>(acc, smem, p, m0, n0, tile_m, pool_base, amax_off);
             return;
         }
     }
@@ -547,8 +550,8 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
             }
         }
     }
-    if (p.out_amax) amax_commit(p.out_amax, cmax);
-    if (EPI == EPI_STORE && p.pool_amax && p.pool_out) amax_commit(p.pool_amax, pmax);
+    if (p.out_amax) amax_commit(p.out_amax + amax_off, cmax);
+    if (EPI == EPI_STORE && p.pool_amax && p.pool_out) amax_commit(p.pool_amax + amax_off, pmax);
     if (EPI == EPI_STORE && p.stats && t < BN && n0 + t < p.N) {
         float* out = p.stats + (long)tile_m * 2 * p.N;
         out[n0 + t] = tot_s;

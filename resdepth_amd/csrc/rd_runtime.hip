@@ -62,10 +62,16 @@ static const int g_tune_env = [] {      // RD_TUNE="name=value,..." and the RD_M
 int tune(int key) { return g_tune[key].value; }
 
 // ---- magnitude slots of the next call (rd_quant_next) ---------------------------------------------------------------
-static thread_local QuantArgs t_quant = {nullptr, nullptr, nullptr, nullptr};
-QuantArgs quant_take() {
+static thread_local QuantArgs t_quant = {nullptr, nullptr, nullptr, nullptr, 0};
+QuantArgs quant_take_img() {
     const QuantArgs q = t_quant;
-    t_quant = {nullptr, nullptr, nullptr, nullptr};
+    t_quant = {nullptr, nullptr, nullptr, nullptr, 0};
+    return q;
+}
+QuantArgs quant_take() {
+    QuantArgs q = t_quant;
+    t_quant = {nullptr, nullptr, nullptr, nullptr, 0};
+    if (q.img_stride) q = {nullptr, nullptr, nullptr, nullptr, 0};
     return q;
 }
 
@@ -247,7 +253,7 @@ static void drain_locked() {
 
 extern "C" {
 
-int rd_version(void) { return 106; }      // 101 (r04): rd_set_splitk_workspace keyed by (device, stream); 102 (r05): rd_host_register; 103: rd_mfma_products; 104: rd_adam_step_dev; 105 (r06): rd_quant_next, rd_amax, packed operands carry both split forms; 106: rd_plan_*
+int rd_version(void) { return 107; }      // 101 (r04): rd_set_splitk_workspace keyed by (device, stream); 102 (r05): rd_host_register; 103: rd_mfma_products; 104: rd_adam_step_dev; 105 (r06): rd_quant_next, rd_amax, packed operands carry both split forms; 106: rd_plan_*; 107: rd_quant_next_img (per-image magnitude slots)
 
 const char* rd_last_error_string(void) { return rd::g_err; }
 
@@ -419,7 +425,14 @@ int rd_zero(void* p, size_t bytes, rd_stream_t s) {
 }
 
 int rd_quant_next(const unsigned* a_amax, const unsigned* b_amax, unsigned* out_amax, unsigned* out2_amax) {
-    rd::t_quant = {a_amax, b_amax, out_amax, out2_amax};
+    rd::t_quant = {a_amax, b_amax, out_amax, out2_amax, 0};
+    return RD_OK;
+}
+
+int rd_quant_next_img(const unsigned* a_amax, const unsigned* b_amax, unsigned* out_amax, unsigned* out2_amax, int img_stride_words) {
+    RD_REQUIRE(img_stride_words >= RD_AMAX_SLOT_BYTES / 4 && img_stride_words % 32 == 0,
+               "rd_quant_next_img: the per-image stride must be a whole number of 128-byte lines and hold a slot (got %d words)", img_stride_words);
+    rd::t_quant = {a_amax, b_amax, out_amax, out2_amax, img_stride_words};
     return RD_OK;
 }
 

@@ -24,18 +24,25 @@ def _f32(t, name):
     return t
 
 
-def _gemm_slots(x, w, out=None, out2=None):
+def _gemm_slots(x, w, out=None, out2=None, img_ok=False):
     """rd_quant_next for a GEMM launch: the magnitude slots of its two operands (both or neither: an operand without a slot
-    sends the launch to the six-product body) and of its outputs."""
+    sends the launch to the six-product body) and of its outputs.  Per-image slot arrays (inference, _lib.AmaxPool(per_image=))
+    only go to the entry points that index them (img_ok), and never mixed with per-tensor slots of an activation."""
     a, b = slot_of(x), slot_of(w)
     if a is None or b is None or _lib.products() != 3:
         a = b = None
+    kinds = {bool(getattr(t, "_rd_img", 0)) for t in (a, out, out2) if t is not None}
+    if True in kinds:
+        if not img_ok:
+            return                                              # (amax_slot hands no per-image slot to such a caller: a is the only one)
+        if False in kinds:
+            a = b = None                                        # a per-tensor activation slot beside per-image outputs: six products
     quant_next(a, b, out, out2)
 
 
-def _out_slot():
+def _out_slot(img_ok=False):
     """slot for a tensor this launch produces, when a pool is active (the engine's forward / backward in split2h mode)"""
-    return amax_slot() if _lib.products() == 3 else None
+    return amax_slot(img_ok) if _lib.products() == 3 else None
 
 
 def _weight_slot(device):
@@ -119,8 +126,8 @@ def conv3x3_fwd_act(x, wf_folded, shift, slope, pool=False):
     cout = wf_folded.shape[0]
     a = torch.empty(n, h, w, cout, device=x.device, dtype=torch.float32)
     pooled = torch.empty(n, h // 2, w // 2, cout, device=x.device, dtype=torch.float32) if pool else None
-    sa, sp = _out_slot(), (_out_slot() if pool else None)
-    _gemm_slots(x, wf_folded, sa, sp)
+    sa, sp = _out_slot(True), (_out_slot(True) if pool else None)
+    _gemm_slots(x, wf_folded, sa, sp, img_ok=True)
     check(load().rd_conv3x3_fwd_act(ptr(_f32(x, "x")), ptr(wf_folded), ptr(shift), float(slope), ptr(a), ptr(pooled), n, h, w,
                                     cin, cout, stream_ptr()), "conv3x3_fwd_act")
     return tag(a, sa), tag(pooled, sp)
@@ -244,7 +251,7 @@ def conv3x3_first_fwd_act(x_nchw, w, mean, invstd, gamma, beta, slope, slope_dev
     cout = w.shape[0]
     a = torch.empty(n, h, wd, cout, device=x_nchw.device, dtype=torch.float32)
     pooled = torch.empty(n, h // 2, wd // 2, cout, device=x_nchw.device, dtype=torch.float32) if pool else None
-    sp = _out_slot() if pool else None
+    sp = _out_slot(True) if pool else None
     quant_next(out2=sp)
     tag(pooled, sp)
     check(load().rd_conv3x3_first_fwd_act(ptr(_f32(x_nchw, "x")), ptr(w.detach()), ptr(mean), ptr(invstd), ptr(gamma.detach()),
@@ -475,8 +482,8 @@ def convt2x2_fwd(x, wtf, bias, skip):
     n, h, w, cin = x.shape
     cout = wtf.shape[0] // 4
     out = torch.empty(n, 2 * h, 2 * w, cout, device=x.device, dtype=torch.float32)
-    so = _out_slot()
-    _gemm_slots(x, wtf, so)
+    so = _out_slot(True)
+    _gemm_slots(x, wtf, so, img_ok=True)
     check(load().rd_convt2x2_fwd(ptr(x), ptr(wtf), ptr(bias.detach() if bias is not None else None), ptr(skip),
                                  ptr(out), n, h, w, cin, cout, stream_ptr()), "convt2x2_fwd")
     return tag(out, so)
@@ -488,9 +495,9 @@ def convt2x2_fwd_bnskip(x, wtf, bias, z_skip, mean, invstd, gamma, beta, slope, 
     n, h, w, cin = x.shape
     cout = wtf.shape[0] // 4
     out = torch.empty(n, 2 * h, 2 * w, cout, device=x.device, dtype=torch.float32)
-    so = _out_slot()
+    so = _out_slot(True)
     tag(out, so)
-    _gemm_slots(x, wtf, so)
+    _gemm_slots(x, wtf, so, img_ok=True)
     check(load().rd_convt2x2_fwd_bnskip(ptr(x), ptr(wtf), ptr(bias.detach() if bias is not None else None), ptr(z_skip),
                                         ptr(mean), ptr(invstd), ptr(gamma.detach()), ptr(beta.detach()), float(slope),
                                         ptr(slope_dev), ptr(out), n, h, w, cin, cout, stream_ptr()), "convt2x2_fwd_bnskip")

@@ -138,7 +138,8 @@ class UNet(nn.Module):
         self.composed_tail = True         # last up-convolution's gradients straight from the 1-channel dout (ops.tail_*)
         self.fused_first_wgrad = True     # level 0: BN / activation / pool backward evaluated inside the first conv's weight gradient
         self.fused_first_eval = True      # inference: level 0's BN + activation + max-pool inside the first convolution (no z0)
-        self.fast_eval = False            # inference on the three-product (split2h) bodies: +50 % sweep rate, results then depend on the batch composition in the last bits
+        self.fast_eval = False            # inference with ONE scale per tensor (as in training): results then depend on the batch composition in the last bits
+        self.eval_per_image = True        # inference on the three-product (split2h) bodies with one scale per IMAGE: a tile's result depends on that tile alone (False: six-product bodies, r01-r05)
         # loss.backward(retain_graph=True) on the reference keeps the saved activations for a second backward.  A custom
         # autograd.Function cannot see that flag, and keeping 137 MB per tile alive until the loss tensor dies would surprise
         # callers that hold on to losses -- so the activations are released by the first backward unless this is set
@@ -197,6 +198,7 @@ class UNet(nn.Module):
         tw._ensure_flat()
         tw.train(self.training)
         tw.two_stream_backward, tw.fold_eval_bn, tw.fast_eval = self.two_stream_backward, self.fold_eval_bn, self.fast_eval
+        tw.eval_per_image = self.eval_per_image
         # data parallel: the twin's engine exchanges ITS statistics and ITS flat gradient buffer (the padding channels carry
         # zeros on every rank); this model's gradients are then corners of already all-reduced tensors
         tw.grad_sync, tw.sync_bn = self.grad_sync, self.sync_bn
@@ -656,12 +658,18 @@ class UNet(nn.Module):
         a GEMM operand max-accumulates |x| into a slot of it, the tensor carries the slot as `_rd_amax`, and the GEMM that takes
         the tensor reads it -- see ops._gemm_slots.  The pool is kept with the saved activations (the weight gradients of the
         backward read the forward's slots)."""
-        # Inference (eval mode, no graph kept) stays on the six-product body unless `fast_eval` is set: a per-TENSOR scale makes a
-        # tile's result depend, in the last bits, on which other tiles share its batch, and the tiled sweep promises the same
-        # raster bits however the tiles are batched or sharded over ranks (tests/test_blend_gpu.py).  Training couples the batch
-        # through BatchNorm anyway.
-        if _lib.products() != 3 or not (training or save or self.fast_eval):
+        # Inference (eval mode, no graph kept): a per-TENSOR scale would make a tile's result depend, in the last bits, on which
+        # other tiles share its batch, and the tiled sweep promises the same raster bits however the tiles are batched or sharded
+        # over ranks (tests/test_blend_gpu.py).  So the folded inference path runs under a pool of per-IMAGE slot arrays
+        # (rd_quant_next_img: a block scales its operand by its own image's maximum); `fast_eval` asks for per-tensor scales
+        # anyway, `eval_per_image = False` for the six-product bodies of r01-r05.  Training couples the batch through BatchNorm.
+        if _lib.products() != 3:
             return self._engine_forward_impl(x, training, save, keep_skips)
+        if not (training or save or self.fast_eval):
+            if not (self.eval_per_image and self._can_fold()):
+                return self._engine_forward_impl(x, training, save, keep_skips)
+            with _lib.AmaxPool(x.device, slots=32, per_image=int(x.shape[0])):
+                return self._engine_forward_impl(x, training, save, keep_skips)
         pool = _lib.AmaxPool(x.device)
         with pool:
             out, S = self._engine_forward_impl(x, training, save, keep_skips)
