@@ -815,7 +815,11 @@ int convt_fwd_launch(const float* x, const void* wsplit, size_t wsplit_bytes, co
     // 8^2 -> 16^2 level: 0.038 -> 0.032 ms).  Everywhere else they measured +3 % alone but -0.3 % end to end (r03 notes);
     // convt_patch = 4 forces them wherever Cin % 64 == 0
     const long blocks128 = ((G + 128 / (w < 16 ? w : 16) - 1) / (128 / (w < 16 ? w : 16))) * (w / (w < 16 ? w : 16)) * (4L * cout / 128);
-    const int tm = (cin % 64 == 0 && (tune(TUNE_CONVT_PATCH) == 4 || blocks128 < 512)) ? 2 : 4;
+    int tm = (cin % 64 == 0 && (tune(TUNE_CONVT_PATCH) == 4 || blocks128 < 512)) ? 2 : 4;
+    // per-image magnitude slots: a tile must lie inside one image, and whether it does must follow from the layer's SHAPE alone
+    // (never from the batch size that picks the tile height above): images too small for 128-row tiles take the 64-row ones
+    const int pw_ = w < 16 ? w : 16;
+    if (qa.img_stride && h % (128 / pw_) != 0 && cin % 64 == 0) tm = 2;
     CtParams p = {};
     p.x = x; p.wsplit = wsplit; p.bias = bias; p.skip = skip; p.out = out;
     p.sk_mean = sk_mean; p.sk_invstd = sk_invstd; p.sk_gamma = sk_gamma; p.sk_beta = sk_beta; p.sk_slope = sk_slope;

@@ -1032,8 +1032,10 @@ static int launch_nt(NtParams p, hipStream_t s, const char* cls, int* tiles_m_ou
     if (split) {
         // split kernel: two 128x128 blocks (57 KB LDS each) per CU; measured per layer with scripts/bench_layers.py
         const bool halo_shape = AMODE == A_CONV3 && EPI == EPI_STORE && p.W % 16 == 0 && p.H % 8 == 0;
-        // (the pooling epilogue exists in the patch kernels only: small batches take them too)
-        if (halo_shape && (tiles_128x64 >= 512 || p.pool_out)) cfg = (p.N >= 128 && tiles_128x64 >= 1024) ? 0 : 1;   // 16x16 levels: 128x64 patches
+        // (the pooling epilogue exists in the patch kernels only: small batches take them too.  So do launches with per-image
+        // magnitude slots, which only the patch kernels index: whether a layer runs on three or six products must follow from
+        // its SHAPE alone -- a ragged last batch of a sweep must not change a tile's bits)
+        if (halo_shape && (tiles_128x64 >= 512 || p.pool_out || p.amax_img_stride)) cfg = (p.N >= 128 && tiles_128x64 >= 1024) ? 0 : 1;   // 16x16 levels: 128x64 patches
         else if (p.M < 128 || tiles_128x64 < 1024) cfg = 2;
         else if (EPI == EPI_CONVT && p.K <= 256) cfg = 2;   // scatter epilogue dominates: small tiles keep more in flight
         else if (p.N >= 128) cfg = AMODE == A_UP2 ? 1 : 0;  // gathered operand (convT data gradient): 128x64 runs two waves per SIMD (0.130 -> 0.116 ms)
@@ -1655,6 +1657,11 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 static void launch_slab_reduce(const float* slab, float* dw, int M, int N, int splits, int mode, int Cin, int Cout, hipStream_t s) {
+#if RD_DIAG_SLAB_READ_DIV
+    // DIAGNOSIS BUILD (wrong results): the reduction reads only every RD_DIAG_SLAB_READ_DIV-th slab -- the upper bound of what a
+    // grouped fix-up inside the weight-gradient kernels could take off the reduce (r05 verdict item 5; profiles/r06_notes.md)
+    splits = (splits + RD_DIAG_SLAB_READ_DIV - 1) / RD_DIAG_SLAB_READ_DIV;
+#endif
     const long quads = (long)M * N / 4;
     int spt = 1;
     while (spt < 16 && quads * spt < 262144 && 2 * spt <= splits) spt *= 2;      // ~1024 blocks of work, at most 16 lanes per quad

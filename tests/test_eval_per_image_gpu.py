@@ -49,6 +49,11 @@ def test_a_tile_does_not_depend_on_its_batch_mates_and_takes_the_three_product_b
     # ... wherever it sits in the batch
     out_c = _fwd(m, torch.cat([mates_b[:3], t0, mates_a[:4]]))
     assert torch.equal(out_a[0], out_c[3])
+    # ... and whatever the batch size (the ragged last batch of a sweep): three or six products is decided by the layer's shape
+    more = torch.cat([mates_b, mates_a * 0.01, mates_a[:2] * 7.0])
+    for nb in (1, 3, 17):
+        out_n = _fwd(m, torch.cat([t0, more[:nb - 1]]) if nb > 1 else t0)
+        assert torch.equal(out_a[0], out_n[0]), nb
     # the six-product form of r01-r05 computes the same forward: close, and NOT the same bits (the three-product bodies did run)
     six = _fwd(m, torch.cat([t0, mates_a]), eval_per_image=False)
     assert not torch.equal(six, out_a)
@@ -61,18 +66,16 @@ def test_a_tile_does_not_depend_on_its_batch_mates_and_takes_the_three_product_b
     assert not torch.equal(fa[0], fb[0])
 
 
-def test_per_image_forward_against_the_fp64_reference_of_the_same_network():
-    """Eval forward of a depth-4 net on 128 x 128 tiles against torch's own modules in fp64 on the CPU (same state_dict)."""
-    import resdepth_amd
+def test_per_image_forward_against_the_fp64_oracle_of_the_same_network():
+    """Eval forward of a depth-4 net on 128 x 128 tiles against the oracle (oracle/unet_oracle.py, lib/UNet.py:196-246) in fp64."""
+    from oracle import unet_oracle as O
     m = _model(seed=5, depth=4)
     x = torch.randn(4, 3, 128, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
     out = _fwd(m, x)
     six = _fwd(m, x, eval_per_image=False)
-    ref_m = resdepth_amd.UNet(n_input_channels=3, start_kernel=64, depth=4)
-    ref_m.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
-    ref_m = ref_m.double().eval()
+    sd64 = {k: (v.double().cpu() if v.is_floating_point() else v.cpu()) for k, v in m.state_dict().items()}
     with torch.no_grad():
-        ref = ref_m(x.double().cpu())
+        ref = O.forward(sd64, x.double().cpu(), O.Spec(n_input_channels=3, start_kernel=64, depth=4), training=False)
     scale = float(ref.abs().max())
     e3, e6 = float((out.double().cpu() - ref).abs().max()) / scale, float((six.double().cpu() - ref).abs().max()) / scale
     assert e3 <= 2e-5 and e6 <= 2e-5, (e3, e6)

@@ -576,14 +576,23 @@ def test_inference_level0_in_one_kernel_is_bit_identical(kw, t):
     m.eval()
     x = torch.randn(3, kw["n_input_channels"], t, t, generator=g).to(DEV)
     with torch.no_grad():
+        # (six-product bodies for the bit-for-bit claim: with per-image magnitude slots -- the r06 inference default -- the fused
+        #  kernel hands the next level a slot array and that level runs three products, the two-kernel route's pooled tensor comes
+        #  without one and it runs six: same forward, different rounding)
+        m.eval_per_image = False
         m.fused_first_eval = False
         y0 = m(x)
         m.fused_first_eval = True
         y1 = m(x)
         m.fold_eval_bn = False                   # the unfolded eval path (training kernels with running statistics)
         y2 = m(x)
+        m.fold_eval_bn, m.eval_per_image = True, True
+        y3 = m(x)                                # the default inference arithmetic on the same route as y1
+        m.fused_first_eval = False
+        y4 = m(x)
     assert torch.equal(y0, y1)
     assert float((y2 - y1).abs().max()) <= 1e-4
+    assert float((y3 - y1).abs().max()) <= 2e-5 * float(y1.abs().max()) and float((y4 - y1).abs().max()) <= 2e-5 * float(y1.abs().max())
 
 
 def test_bench_gpus_2_runs_end_to_end_without_a_launcher_on_one_gpu():
