@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -133,6 +135,7 @@ class UNet(nn.Module):
         self.grad_sync = None        # optional resdepth_amd.dp.GradSync (data-parallel hooks)
         self.sync_bn = False
         self.two_stream_backward = True   # weight gradients on a second HIP stream, overlapping the dgrad/BN chain
+        self.defer_wgrad_levels = int(os.environ.get("RD_DEFER_WGRAD", "1"))    # encoder levels 1..n launch their weight gradient behind their data gradient (see _engine_backward_impl)
         self.fold_eval_bn = True          # inference: eval-mode BN folded into the packed conv weights + epilogue activation
         self.fused_bn_bwd_stats = True    # BN-backward sums from the epilogues of the kernels producing the gradient operands
         self.composed_tail = True         # last up-convolution's gradients straight from the 1-channel dout (ops.tail_*)
@@ -198,7 +201,7 @@ class UNet(nn.Module):
         tw._ensure_flat()
         tw.train(self.training)
         tw.two_stream_backward, tw.fold_eval_bn, tw.fast_eval = self.two_stream_backward, self.fold_eval_bn, self.fast_eval
-        tw.eval_per_image = self.eval_per_image
+        tw.eval_per_image, tw.defer_wgrad_levels = self.eval_per_image, self.defer_wgrad_levels
         # data parallel: the twin's engine exchanges ITS statistics and ITS flat gradient buffer (the padding channels carry
         # zeros on every rank); this model's gradients are then corners of already all-reduced tensors
         tw.grad_sync, tw.sync_bn = self.grad_sync, self.sync_bn
@@ -1110,9 +1113,18 @@ class UNet(nn.Module):
             if dz is None:
                 continue
             if i > 0:
-                wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][i - 1]["p"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
+                # The last `defer_wgrad_levels` encoder levels launch their weight gradient BEHIND their data gradient (the side
+                # stream's event is recorded after it): the data gradient then has the chip to itself -- it is the critical path --
+                # and the strip kernel runs beside what follows on the main stream, which at level 1 is the fused first-convolution
+                # weight gradient: an HBM / VALU-class kernel that otherwise ends the step alone (profiles/r06_notes.md section 12).
+                # Two MFMA-class kernels side by side only share one power budget; an MFMA-class one beside an HBM-class one overlaps.
+                late = side is not None and i <= self.defer_wgrad_levels
+                if not late:
+                    wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][i - 1]["p"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
                 gp, gpstat = with_stats(ops.conv3x3_bwd_data, dz, pk.get(("enc", i - 1))[1],
                                         bn=hook(S["enc"][i - 1], self.encoder[i - 1][0], self.act_fn_encoder, mode=2))
+                if late:
+                    wgrad(ops.conv3x3_bwd_weight, (dz,), S["enc"][i - 1]["p"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
             elif self._first_generic():
                 wgrad(ops.conv3x3_bwd_weight, (dz,), S["xh"], dz, gv(blk[0].weight), ready=(blk[0].weight,))
             else:
