@@ -79,6 +79,9 @@ int rd_quant_next_img(const unsigned* a_amax, const unsigned* b_amax, unsigned* 
 int rd_amax(const float* x, long long n, unsigned* slot, rd_stream_t s);
 /* zero `bytes` (a multiple of 16, 16-byte aligned) with a kernel launch -- which a launch plan records, unlike a memset node */
 int rd_zero(void* p, size_t bytes, rd_stream_t s);
+/* n <= 8 device-to-device copies (16-byte aligned ranges of whole 16-byte units) in ONE launch: a batch's tensors into the static
+ * input buffers of a captured / planned iteration (lib/Trainer.py:212-215 hands the step a new batch every iteration) */
+int rd_copy_segments(void* const* dst, const void* const* src, const size_t* bytes, int n, rd_stream_t s);
 #define RD_AMAX_SLOT_BYTES 2048
 const char* rd_last_error_string(void);
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "rd_quant_next_img": (I, [P, P, P, P, I]),
     "rd_amax": (I, [P, LL, P, P]),
     "rd_zero": (I, [P, SZ, P]),
+    "rd_copy_segments": (I, [P, P, P, I, P]),
     "rd_last_error_string": (C.c_char_p, []),
     "rd_pack_conv3x3_weight": (I, [P, P, P, I, I, P]),
     "rd_pack_item_pieces": (LL, [I, I, I, I]),
@@ -240,6 +241,27 @@ def zeros_i32(n: int, device) -> torch.Tensor:
     t = torch.empty(n, dtype=torch.int32, device=device)
     zero_(t)
     return t
+
+
+def copy_segments(pairs) -> None:
+    """dst.copy_(src) for up to eight (dst, src) pairs of same-shaped contiguous device tensors in ONE launch on the current
+    stream (rd_copy_segments); pairs the kernel cannot take (alignment, odd sizes, dtype / layout differences) go through torch."""
+    fast = []
+    for d, s in pairs:
+        nb = d.numel() * d.element_size()
+        if (d.is_cuda and s.is_cuda and d.dtype == s.dtype and d.shape == s.shape and d.is_contiguous() and s.is_contiguous()
+                and nb % 16 == 0 and d.data_ptr() % 16 == 0 and s.data_ptr() % 16 == 0 and len(fast) < 8):
+            fast.append((d, s, nb))
+        else:
+            d.copy_(s, non_blocking=True)
+    if not fast:
+        return
+    n = len(fast)
+    dst = (C.c_void_p * n)(*[d.data_ptr() for d, _, _ in fast])
+    src = (C.c_void_p * n)(*[s.data_ptr() for _, s, _ in fast])
+    nbs = (C.c_size_t * n)(*[nb for _, _, nb in fast])
+    with device_of(fast[0][0]):
+        check(load().rd_copy_segments(dst, src, nbs, n, stream_ptr()), "copy_segments")
 
 
 def zero_(t: torch.Tensor) -> torch.Tensor:

@@ -424,6 +424,42 @@ int rd_zero(void* p, size_t bytes, rd_stream_t s) {
     return check_hip(hipGetLastError(), "rd_zero");
 }
 
+// up to eight device-to-device copies in ONE launch (the five tensors of a batch into the static input buffers of a captured /
+// planned iteration: five hipMemcpyAsync blit kernels were 55 us at the head of every step, serialized before the first convolution)
+struct CopySegs {
+    const uint4* src[8];
+    uint4* dst[8];
+    unsigned long long start[9];      // prefix sums of the segment lengths in 16-byte units
+    int n;
+};
+__global__ __launch_bounds__(256) void copy_segments_kernel(CopySegs s) {
+    const unsigned long long total = s.start[s.n];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) k += (j < s.n && i >= s.start[j]) ? 1 : 0;
+        s.dst[k][i - s.start[k]] = s.src[k][i - s.start[k]];
+    }
+}
+int rd_copy_segments(void* const* dst, const void* const* src, const size_t* bytes, int n, rd_stream_t st) {
+    using namespace rd;
+    RD_REQUIRE(dst && src && bytes && n >= 1 && n <= 8, "rd_copy_segments: 1..8 segments");
+    CopySegs s = {};
+    s.n = n;
+    for (int k = 0; k < n; ++k) {
+        RD_REQUIRE(dst[k] && src[k] && bytes[k] % 16 == 0 && (((size_t)dst[k] | (size_t)src[k]) & 15) == 0,
+                   "rd_copy_segments: segment %d is not a 16-byte aligned range of whole 16-byte units", k);
+        s.src[k] = (const uint4*)src[k];
+        s.dst[k] = (uint4*)dst[k];
+        s.start[k + 1] = s.start[k] + bytes[k] / 16;
+    }
+    const unsigned long long total = s.start[n];
+    if (!total) return RD_OK;
+    const unsigned grid = (unsigned)(total < 2048ull * 256 ? (total + 255) / 256 : 2048);
+    RD_LAUNCH(copy_segments_kernel, dim3(grid), dim3(256), 0, (hipStream_t)st, s);
+    return check_hip(hipGetLastError(), "rd_copy_segments");
+}
+
 int rd_quant_next(const unsigned* a_amax, const unsigned* b_amax, unsigned* out_amax, unsigned* out2_amax) {
     rd::t_quant = {a_amax, b_amax, out_amax, out2_amax, 0};
     return RD_OK;

@@ -194,3 +194,21 @@ def test_trainer_loop_with_hip_graph_equals_the_eager_loop(tmp_path, prefetch):
     for k, v in le["model_state_dict"].items():
         assert torch.equal(v.cpu(), lg["model_state_dict"][k].cpu()), k
     _same_state(te.model, te.optimizer, tg.model, tg.optimizer)
+
+
+def test_copy_segments_moves_a_batch_in_one_launch_and_falls_back_for_what_it_cannot_take():
+    """rd_copy_segments (the new batch -> the static input buffers of a captured / planned iteration, lib/Trainer.py:212-215): up to
+    eight aligned ranges in one launch; odd sizes, other dtypes' layouts or a ninth pair go through torch -- same result."""
+    from resdepth_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(1)
+    shapes = [(32, 3, 256, 256), (32, 1, 256, 256), (32, 1, 256, 256), (32,), (32,), (7, 3), (5,), (4, 4), (16, 16), (3, 5, 7)]
+    src = [torch.randn(s, device="cuda", generator=g) for s in shapes]
+    src[2] = src[2] > 0                                      # a bool mask: one byte per element, still whole 16-byte units
+    src.append(torch.randn(40, device="cuda", generator=g)[1:33])          # misaligned view: torch's copy
+    dst = [torch.empty_like(s) for s in src]
+    _lib.copy_segments(list(zip(dst, src)))
+    torch.cuda.synchronize()
+    for d, s in zip(dst, src):
+        assert torch.equal(d, s)
+    with pytest.raises(RuntimeError, match="1..8 segments"):
+        _lib.check(_lib.load().rd_copy_segments(None, None, None, 0, None), "copy_segments")
