@@ -1,4 +1,5 @@
 // Error reporting, version and the event-based kernel profiler of libresdepth_hip.so.
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -343,8 +344,10 @@ void* rd_plan_end(int* n_launches, int* n_segments) {
     }
     if (p->seg_end.empty() || p->seg_end.back() != p->ops.size()) p->seg_end.push_back(p->ops.size());
     p->events.resize(p->n_events);
+    // stream-to-stream ordering on ONE device: no timing, and no system-scope fence when the event fires (RD_PLAN_SYSFENCE=1 keeps it)
+    static const int sysfence = getenv("RD_PLAN_SYSFENCE") ? atoi(getenv("RD_PLAN_SYSFENCE")) : 0;
     for (int i = 0; i < p->n_events; ++i)
-        if (hipEventCreateWithFlags(&p->events[i], hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreateWithFlags(&p->events[i], hipEventDisableTiming | (sysfence ? 0 : hipEventDisableSystemFence)) != hipSuccess) {
             set_error("rd_plan_end: hipEventCreate failed");
             for (int j = 0; j < i; ++j) (void)hipEventDestroy(p->events[j]);
             delete p;
@@ -367,11 +370,21 @@ int rd_plan_replay(void* plan, int segment, rd_stream_t main_stream, rd_stream_t
     static const int dhi = getenv("RD_PLAN_SYNC_HI") ? atoi(getenv("RD_PLAN_SYNC_HI")) : -1;
     const size_t a = segment ? p->seg_end[segment - 1] : 0, b = p->seg_end[segment];
     void* argv[64];
+    // A launch followed by an event record on its stream: the event rides on the kernel's own completion signal
+    // (hipExtLaunchKernel's stop event) instead of a marker packet of its own, which the NEXT kernel of the stream would wait
+    // for -- ~6 us in front of every data-gradient launch of the backward (RD_PLAN_EXT=0: separate records, for A/B runs)
+    static const int ext = getenv("RD_PLAN_EXT") ? atoi(getenv("RD_PLAN_EXT")) : 1;
     for (size_t i = a; i < b; ++i) {
         const PlanOp& op = p->ops[i];
         if (op.kind == 0) {
             for (int k = 0; k < op.nargs; ++k) argv[k] = p->blob.data() + p->arg_off[op.arg0 + k];
-            const hipError_t e = hipLaunchKernel(op.fn, op.grid, op.block, argv, op.shmem, st[op.role]);
+            hipError_t e;
+            if (ext && i + 1 < b && p->ops[i + 1].kind == 1 && p->ops[i + 1].role == op.role) {
+                e = hipExtLaunchKernel(op.fn, op.grid, op.block, argv, op.shmem, st[op.role], nullptr, p->events[p->ops[i + 1].ev], 0);
+                ++i;                                   // the record is done
+            } else {
+                e = hipLaunchKernel(op.fn, op.grid, op.block, argv, op.shmem, st[op.role]);
+            }
             if (e != hipSuccess) return check_hip(e, "rd_plan_replay: launch");
             if ((dbg == 1 || (dbg == 3 && op.role == 1) || (dbg == 4 && op.role == 0) || (dbg == 5 && (int)i >= dlo && (int)i < dhi)) &&
                 hipDeviceSynchronize() != hipSuccess)

@@ -64,11 +64,19 @@ class _Packed:
 
     def __init__(self):
         self.items, self.events = {}, {}
+        self._waited = set()             # (event, stream) pairs already ordered: the fused pack marks EVERY layer with one event
 
     def get(self, key):
         ev = self.events.pop(key, None)
         if ev is not None:
-            _lib.ev_wait(torch.cuda.current_stream(), ev)
+            cur = torch.cuda.current_stream()
+            mark = (id(ev), cur.cuda_stream)
+            if mark not in self._waited:
+                # one wait per (event, stream): a wait on an event that has long fired still costs the queue a barrier packet --
+                # ~6 us in front of every convolution of the forward pass (kernel trace, profiles/r06_notes.md section 13)
+                self._waited.add(mark)
+                self._keep = getattr(self, "_keep", []) + [ev]       # ids stay unique while the marks live
+                _lib.ev_wait(cur, ev)
         return self.items[key]
 
 
