@@ -1108,7 +1108,7 @@ class UNet(nn.Module):
                 def fuse(z_, mean_, invstd_, gamma_, beta_, slope_, gf_, gp_, idx_, sums_, count_, training_, sdev_, w_=blk[0].weight):
                     ops.conv3x3_first_bwd_weight_bn(S["x"], z_, mean_, invstd_, gamma_, beta_, slope_, gf_, gp_, idx_, sums_, count_,
                                                     training=training_, slope_dev=sdev_, out=gv(w_))
-                    if side is None:
+                    if side is None or sync is None:     # (the event below only orders a bucket launch: nothing to order without one)
                         done(w_)
                         return
                     ev = _lib.Ev(main)
