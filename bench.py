@@ -543,7 +543,7 @@ class _CyclingLoader:
             yield self.batches[i % len(self.batches)]
 
 
-def trainer_loop_measurement(dev, wl, n, iters=24, prefetch=1):
+def trainer_loop_measurement(dev, wl, n, iters=24, prefetch=1, launch_plan=False):
     """tiles/s of the drop-in loop itself -- resdepth_amd.Trainer.inference_one_epoch('train') over `iters` host-resident
     pinned batches (lib/Trainer.py:159-222 driven as train.py does) -- next to the bare resident-batch step of `value`."""
     import tempfile
@@ -562,11 +562,11 @@ def trainer_loop_measurement(dev, wl, n, iters=24, prefetch=1):
                               trainloader=mk(iters), valloader=None, n_epochs=1, evaluate_rate=1, save_model_rate=10 ** 9,
                               freq_average_train_loss=10 ** 9, save_dir=tmp, log_file=None,
                               checkpoint_dir=os.path.join(tmp, "ck"), tboard_log_dir=os.path.join(tmp, "tb"),
-                              pretrained_path=None, prefetch_batches=prefetch)
+                              pretrained_path=None, prefetch_batches=prefetch, launch_plan=launch_plan)
     tr = Trainer(a)
     tr.logger.handlers.clear()
-    tr.loader["train"] = mk(6)
-    tr.inference_one_epoch(0, "train")               # warm-up epoch (allocator, pinned staging, packed weights)
+    tr.loader["train"] = mk(8 if launch_plan else 6)
+    tr.inference_one_epoch(0, "train")               # warm-up epoch (allocator, pinned staging, packed weights; the plan's recording)
     torch.cuda.synchronize()
     tr.loader["train"] = mk(iters)
     t0 = time.perf_counter()
@@ -684,7 +684,14 @@ def secondary_measurements(args, dev, tb):
         out["trainer_loop"] = dict(on, without_prefetch_tiles_per_s=off["tiles_per_s"],
                                    note="resdepth_amd.Trainer.inference_one_epoch('train'): 4 distinct pinned host batches cycled, "
                                         "every iteration copies its batch host->device (DevicePrefetcher: next batch staged on a "
-                                        "copy stream under the current step); deferred loss read-back, FusedAdam")
+                                        "copy stream under the current step); deferred loss read-back, FusedAdam; eager enqueue "
+                                        "(the Trainer shell's default)")
+        try:        # the same loop with Trainer(launch_plan=True): the iteration replayed from its recorded launch plan
+            pl = trainer_loop_measurement(dev, tb.wl, tb.n, prefetch=1, launch_plan=True)
+            out["trainer_loop"]["launch_plan_tiles_per_s"] = pl["tiles_per_s"]
+            out["trainer_loop"]["launch_plan_loss_avg"] = pl["loss_avg"]
+        except Exception as e:      # noqa: BLE001
+            out["trainer_loop"]["launch_plan_error"] = repr(e)[:200]
     except Exception as e:      # noqa: BLE001
         out["trainer_loop"] = {"error": repr(e)[:300]}
     try:        # sample assembly on the GPU inside every step
